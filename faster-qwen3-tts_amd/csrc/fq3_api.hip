@@ -1,0 +1,636 @@
+// libfq3hip.so: context, weight binding, launch orchestration and hipGraph capture for the decode path.
+// C ABI declared in include/fq3hip.h (which cites the reference interface each entry replaces).
+#include "../../include/fq3hip.h"
+#include "decode_kernels.cuh"
+#include "sampler.cuh"
+#include "sampler_wave.cuh"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+using namespace fq3;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& m) { g_err = m; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(FQ3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+extern "C" const char* fq3_last_error(void) { return g_err.c_str(); }
+extern "C" int fq3_abi_version(void) { return FQ3_ABI_VERSION; }
+
+struct StackBufs {
+    std::vector<void*> k, v;          // per layer [n_kv][max_seq][128]
+    int max_seq = 0, workers = 1;
+};
+
+struct fq3_ctx {
+    fq3_config cfg{};
+    int esz = 2;
+    std::vector<fq3_layer_weights> tl, pl;
+    fq3_weight_table wt{};
+    std::vector<const void*> pemb, lmh;
+    const void** d_pemb = nullptr;    // device array of the 15 predictor embedding tables
+    bool bound = false;
+    StackBufs tk, pk;
+    // scratch (device)
+    void *h = nullptr, *xin = nullptr, *qkv = nullptr, *act = nullptr, *logits = nullptr, *past_hidden = nullptr;
+    void *pred_in = nullptr, *pred_x = nullptr, *pred_next = nullptr, *plogits = nullptr, *tmp_hidden = nullptr;
+    float* part = nullptr;
+    float* rope_now = nullptr;
+    unsigned char* seen_api = nullptr;
+    DecodeState* st = nullptr;
+    unsigned char* seen = nullptr;
+    int* codes = nullptr;
+    int64_t* ids64 = nullptr;
+    int n_pad = 0, rope_delta = 0;
+    bool talker_wave = true;      // talker sampler variant baked into the captured graph
+    fq3_sampling pred_sampling{0.9f, 50, 1.0f, 1, 1.0f};
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    std::vector<void*> allocs;
+};
+
+static int dmalloc(fq3_ctx* c, void** p, size_t bytes) {
+    HIPCHK(hipMalloc(p, bytes));
+    HIPCHK(hipMemset(*p, 0, bytes));
+    c->allocs.push_back(*p);
+    return 0;
+}
+
+static bool dims_ok(const fq3_stack_dims& d) {
+    return d.head_dim == kHeadDim && d.hidden % 8 == 0 && d.inter % 8 == 0 && d.n_heads % d.n_kv_heads == 0 &&
+           (d.n_heads / d.n_kv_heads == 1 || d.n_heads / d.n_kv_heads == 2 || d.n_heads / d.n_kv_heads == 4) &&
+           d.vocab <= kMaxVocab && d.hidden <= 8192 && d.inter <= 8192 * 3;
+}
+
+extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
+    if (!cfg || !out) return fail(FQ3_EINVAL, "null argument");
+    if (cfg->dtype != FQ3_BF16 && cfg->dtype != FQ3_F32) return fail(FQ3_EINVAL, "dtype must be FQ3_BF16 or FQ3_F32");
+    if (!dims_ok(cfg->talker) || !dims_ok(cfg->predictor))
+        return fail(FQ3_EUNSUPPORTED, "unsupported dims (need head_dim 128, GQA ratio 1/2/4, vocab <= 4096)");
+    if (cfg->num_code_groups < 2 || cfg->num_code_groups > 64) return fail(FQ3_EINVAL, "num_code_groups");
+    if (cfg->max_seq_len < 8) return fail(FQ3_EINVAL, "max_seq_len");
+    fq3_ctx* c = new fq3_ctx();
+    c->cfg = *cfg;
+    c->esz = cfg->dtype == FQ3_BF16 ? 2 : 4;
+    const fq3_stack_dims &t = cfg->talker, &p = cfg->predictor;
+    const int pred_seq = cfg->num_code_groups + 1;          // 2 + 15 (predictor_graph.py:46)
+    auto alloc_stack = [&](StackBufs& b, const fq3_stack_dims& d, int max_seq) -> int {
+        b.max_seq = max_seq;
+        b.workers = std::min(kMaxWorkers, (max_seq + kKeysPerTile - 1) / kKeysPerTile);
+        b.k.resize(d.n_layers); b.v.resize(d.n_layers);
+        const size_t bytes = (size_t)d.n_kv_heads * max_seq * kHeadDim * c->esz;
+        for (int i = 0; i < d.n_layers; ++i) {
+            if (int r = dmalloc(c, &b.k[i], bytes)) return r;
+            if (int r = dmalloc(c, &b.v[i], bytes)) return r;
+        }
+        return 0;
+    };
+    int r;
+    if ((r = alloc_stack(c->tk, t, cfg->max_seq_len))) return r;
+    if ((r = alloc_stack(c->pk, p, pred_seq))) return r;
+    const int Hm = std::max(t.hidden, p.hidden), Im = std::max(t.inter, p.inter);
+    const int qkvm = std::max(t.n_heads + 2 * t.n_kv_heads, p.n_heads + 2 * p.n_kv_heads) * kHeadDim;
+    const int Vm = std::max(t.vocab, p.vocab);
+    const int G = cfg->num_code_groups;
+    const int frames = cfg->max_frames > 0 ? cfg->max_frames : 4096;
+    c->cfg.max_frames = frames;
+    if ((r = dmalloc(c, &c->h, (size_t)Hm * c->esz))) return r;
+    if ((r = dmalloc(c, &c->xin, (size_t)Hm * c->esz))) return r;
+    if ((r = dmalloc(c, &c->tmp_hidden, (size_t)Hm * c->esz))) return r;
+    if ((r = dmalloc(c, &c->qkv, (size_t)qkvm * c->esz))) return r;
+    if ((r = dmalloc(c, &c->act, (size_t)Im * c->esz))) return r;
+    if ((r = dmalloc(c, &c->logits, (size_t)Vm * c->esz))) return r;
+    if ((r = dmalloc(c, &c->past_hidden, (size_t)t.hidden * c->esz))) return r;
+    if ((r = dmalloc(c, &c->pred_in, (size_t)2 * t.hidden * c->esz))) return r;
+    if ((r = dmalloc(c, &c->pred_next, (size_t)t.hidden * c->esz))) return r;
+    if ((r = dmalloc(c, &c->pred_x, (size_t)p.hidden * c->esz))) return r;
+    if ((r = dmalloc(c, &c->plogits, (size_t)(G - 1) * p.vocab * c->esz))) return r;
+    const int maxkv = std::max(t.n_kv_heads, p.n_kv_heads);
+    if ((r = dmalloc(c, (void**)&c->part, (size_t)maxkv * kMaxWorkers * 4 * kPartStride * sizeof(float)))) return r;
+    if ((r = dmalloc(c, (void**)&c->rope_now, 2 * 64 * sizeof(float)))) return r;
+    if ((r = dmalloc(c, (void**)&c->seen_api, kMaxVocab))) return r;
+    if ((r = dmalloc(c, (void**)&c->st, sizeof(DecodeState)))) return r;
+    if ((r = dmalloc(c, (void**)&c->seen, kMaxVocab))) return r;
+    if ((r = dmalloc(c, (void**)&c->codes, (size_t)(frames + 1) * G * sizeof(int)))) return r;
+    if ((r = dmalloc(c, (void**)&c->ids64, (size_t)64 * sizeof(int64_t)))) return r;
+    if ((r = dmalloc(c, (void**)&c->d_pemb, (size_t)64 * sizeof(void*)))) return r;
+    HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    *out = c;
+    return FQ3_OK;
+}
+
+extern "C" int fq3_graph_reset(fq3_ctx* c) {
+    if (!c) return fail(FQ3_EINVAL, "null ctx");
+    if (c->exec) { (void)hipGraphExecDestroy(c->exec); c->exec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    return FQ3_OK;
+}
+
+extern "C" int fq3_ctx_destroy(fq3_ctx* c) {
+    if (!c) return FQ3_OK;
+    (void)hipDeviceSynchronize();
+    fq3_graph_reset(c);
+    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    for (void* p : c->allocs) (void)hipFree(p);
+    delete c;
+    return FQ3_OK;
+}
+
+extern "C" int fq3_bind_weights(fq3_ctx* c, const fq3_weight_table* w) {
+    if (!c || !w) return fail(FQ3_EINVAL, "null argument");
+    const int G = c->cfg.num_code_groups;
+    if (!w->talker_layers || !w->predictor_layers || !w->codec_embedding || !w->codec_head || !w->talker_final_norm ||
+        !w->predictor_final_norm || !w->predictor_embeddings || !w->lm_heads || !w->talker_cos || !w->talker_sin ||
+        !w->pred_cos || !w->pred_sin)
+        return fail(FQ3_EINVAL, "weight table has null entries");
+    if (c->cfg.has_projection && !w->proj_w) return fail(FQ3_EINVAL, "has_projection set but proj_w is null");
+    if (w->talker_rope_len < c->cfg.max_seq_len || w->pred_rope_len < G + 1)
+        return fail(FQ3_EINVAL, "rope tables shorter than the caches");
+    c->wt = *w;
+    c->tl.assign(w->talker_layers, w->talker_layers + c->cfg.talker.n_layers);
+    c->pl.assign(w->predictor_layers, w->predictor_layers + c->cfg.predictor.n_layers);
+    c->pemb.assign(w->predictor_embeddings, w->predictor_embeddings + (G - 1));
+    c->lmh.assign(w->lm_heads, w->lm_heads + (G - 1));
+    for (auto& l : c->tl) if (!l.qkv || !l.o || !l.gate_up || !l.down || !l.input_norm || !l.post_norm || !l.q_norm || !l.k_norm)
+        return fail(FQ3_EINVAL, "talker layer has null weights");
+    for (auto& l : c->pl) if (!l.qkv || !l.o || !l.gate_up || !l.down || !l.input_norm || !l.post_norm || !l.q_norm || !l.k_norm)
+        return fail(FQ3_EINVAL, "predictor layer has null weights");
+    HIPCHK(hipMemcpy(c->d_pemb, c->pemb.data(), (G - 1) * sizeof(void*), hipMemcpyHostToDevice));
+    c->bound = true;
+    fq3_graph_reset(c);
+    return FQ3_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// GEMV dispatch
+// -------------------------------------------------------------------------------------------------
+template <typename T, int NCH, int PRO, int EPI, bool NT>
+static void launch_gemv_n(GemvArgs a, hipStream_t s) {
+    constexpr int NR = EPI == EPI_SWIGLU ? 2 : 1;
+    constexpr int RB = (RowsInFlight<NCH>::v / NR) > 0 ? (RowsInFlight<NCH>::v / NR) : 1;
+    int R = (a.N + 1023) / 1024;            // aim at >= 256 workgroups of 4 waves
+    if (R < 1) R = 1;
+    if (R > RB) R = RB;
+    a.R = R;
+    const int grid = (a.N + 4 * R - 1) / (4 * R);
+    const size_t shm = PRO == PRO_COMBINE ? (size_t)a.K * sizeof(float) : 0;
+    hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT>), dim3(grid), dim3(256), shm, s, a);
+}
+template <typename T, int PRO, int EPI, bool NT>
+static int launch_gemv_t(const GemvArgs& a, hipStream_t s) {
+    const int need = (a.K + 511) / 512;
+    if (need <= 1) launch_gemv_n<T, 1, PRO, EPI, NT>(a, s);
+    else if (need <= 2) launch_gemv_n<T, 2, PRO, EPI, NT>(a, s);
+    else if (need <= 4) launch_gemv_n<T, 4, PRO, EPI, NT>(a, s);
+    else if (need <= 6) launch_gemv_n<T, 6, PRO, EPI, NT>(a, s);
+    else if (need <= 12) launch_gemv_n<T, 12, PRO, EPI, NT>(a, s);
+    else return fail(FQ3_EUNSUPPORTED, "GEMV inner dimension above 6144");
+    return 0;
+}
+template <int PRO, int EPI>
+static int launch_gemv(const fq3_ctx* c, const GemvArgs& a, bool nt, hipStream_t s) {
+    if (c->cfg.dtype == FQ3_BF16)
+        return nt ? launch_gemv_t<bf16_t, PRO, EPI, true>(a, s) : launch_gemv_t<bf16_t, PRO, EPI, false>(a, s);
+    return nt ? launch_gemv_t<float, PRO, EPI, true>(a, s) : launch_gemv_t<float, PRO, EPI, false>(a, s);
+}
+
+template <typename T>
+static void launch_attn_t(const AttnArgs& a, int rep, int workers, hipStream_t s) {
+    dim3 grid(a.n_kv, workers);
+    if (rep == 1) hipLaunchKernelGGL((attn_decode_kernel<T, 1>), grid, dim3(256), 0, s, a);
+    else if (rep == 2) hipLaunchKernelGGL((attn_decode_kernel<T, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<T, 4>), grid, dim3(256), 0, s, a);
+}
+
+// One token through every layer of a stack (no final norm).  Layer 0 reads its input (and its
+// residual) from x0 [+ (*x0_idx) * hidden]; later layers work in place on c->h.
+struct StepSrc { const void* x0; const int* pos_ptr; int pos_imm; };
+
+static int run_stack(fq3_ctx* c, bool talker, const StepSrc& src, hipStream_t s) {
+    const fq3_stack_dims& d = talker ? c->cfg.talker : c->cfg.predictor;
+    const std::vector<fq3_layer_weights>& L = talker ? c->tl : c->pl;
+    StackBufs& kv = talker ? c->tk : c->pk;
+    const int rep = d.n_heads / d.n_kv_heads;
+    const int q_dim = d.n_heads * kHeadDim, kv_dim = d.n_kv_heads * kHeadDim;
+    const bool nt = talker;     // talker weights stream once per frame; predictor weights are re-read 16x
+    // RoPE row: immediate position -> table row chosen on the host; device position -> the row the
+    // frame's embed_sum kernel staged in rope_now
+    const float *cos_row, *sin_row;
+    if (src.pos_ptr) { cos_row = c->rope_now; sin_row = c->rope_now + 64; }
+    else {
+        const int rl = talker ? c->wt.talker_rope_len : c->wt.pred_rope_len;
+        int rp = src.pos_imm + (talker ? c->rope_delta : 0);
+        rp = rp < 0 ? 0 : (rp >= rl ? rl - 1 : rp);
+        cos_row = (talker ? c->wt.talker_cos : c->wt.pred_cos) + (size_t)rp * 64;
+        sin_row = (talker ? c->wt.talker_sin : c->wt.pred_sin) + (size_t)rp * 64;
+    }
+    for (int i = 0; i < d.n_layers; ++i) {
+        const fq3_layer_weights& w = L[i];
+        const void* xin = i == 0 ? src.x0 : c->h;
+        GemvArgs g{};
+        g.eps = d.rms_eps;
+        // 1. norm + qkv
+        g.W = w.qkv; g.N = q_dim + 2 * kv_dim; g.K = d.hidden; g.x = xin;
+        g.norm_w = w.input_norm; g.y = c->qkv;
+        if (int r = launch_gemv<PRO_NORM, EPI_STORE>(c, g, nt, s)) return r;
+        // 2. attention
+        AttnArgs a{};
+        a.qkv = c->qkv; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm; a.eps = d.rms_eps;
+        a.cos_row = cos_row; a.sin_row = sin_row;
+        a.kcache = kv.k[i]; a.vcache = kv.v[i]; a.max_seq = kv.max_seq;
+        a.pos_ptr = src.pos_ptr; a.pos_imm = src.pos_imm;
+        a.n_pad = talker ? c->n_pad : 0;
+        a.n_kv = d.n_kv_heads; a.part = c->part;
+        a.scale = 1.0f / sqrtf((float)kHeadDim);
+        if (c->cfg.dtype == FQ3_BF16) launch_attn_t<bf16_t>(a, rep, kv.workers, s);
+        else launch_attn_t<float>(a, rep, kv.workers, s);
+        // 3. combine + o_proj + residual
+        GemvArgs o{};
+        o.W = w.o; o.N = d.hidden; o.K = q_dim; o.y = c->h; o.res = xin;
+        o.part = c->part; o.n_part = kv.workers; o.rep = rep;
+        if (int r = launch_gemv<PRO_COMBINE, EPI_RESIDUAL>(c, o, nt, s)) return r;
+        // 4. norm + gate/up + SwiGLU
+        GemvArgs m{};
+        m.eps = d.rms_eps; m.W = w.gate_up; m.N = d.inter; m.K = d.hidden; m.x = c->h;
+        m.norm_w = w.post_norm; m.y = c->act; m.up_off = d.inter;
+        if (int r = launch_gemv<PRO_NORM, EPI_SWIGLU>(c, m, nt, s)) return r;
+        // 5. down + residual
+        GemvArgs dn{};
+        dn.W = w.down; dn.N = d.hidden; dn.K = d.inter; dn.x = c->act; dn.y = c->h; dn.res = c->h;
+        if (int r = launch_gemv<PRO_PLAIN, EPI_RESIDUAL>(c, dn, nt, s)) return r;
+    }
+    return 0;
+}
+
+#define NEED_BOUND(c) do { if (!(c)) return fail(FQ3_EINVAL, "null ctx"); if (!(c)->bound) return fail(FQ3_ESTATE, "weights not bound"); } while (0)
+#define LAUNCH_CHECK() HIPCHK(hipGetLastError())
+
+extern "C" int fq3_set_generation_state(fq3_ctx* c, int n_pad, int rope_delta) {
+    if (!c) return fail(FQ3_EINVAL, "null ctx");
+    if (n_pad < 0 || n_pad >= c->cfg.max_seq_len) return fail(FQ3_EINVAL, "n_pad out of range");
+    if (c->n_pad != n_pad || c->rope_delta != rope_delta) fq3_graph_reset(c);   // baked into captured launches
+    c->n_pad = n_pad; c->rope_delta = rope_delta;
+    return FQ3_OK;
+}
+
+template <typename T>
+static void kv_copy(void* dst, const void* src, int n_kv, int L, int dst_stride, int src_stride, hipStream_t s) {
+    const int n = n_kv * L * kHeadDim;
+    hipLaunchKernelGGL((kv_copy_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, (T*)dst, (const T*)src, L,
+                       dst_stride, src_stride, n);
+}
+
+extern "C" int fq3_kv_import(fq3_ctx* c, int layer, const void* k, const void* v, int L, void* stream) {
+    if (!c || !k || !v) return fail(FQ3_EINVAL, "null argument");
+    if (layer < 0 || layer >= c->cfg.talker.n_layers) return fail(FQ3_EINVAL, "layer out of range");
+    if (L > c->cfg.max_seq_len) {
+        char b[256];
+        snprintf(b, sizeof b, "Input is too long: prefill has %d tokens but max_seq_len=%d. Use shorter text or shorter reference audio.",
+                 L, c->cfg.max_seq_len);
+        return fail(FQ3_ETOOLONG, b);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int nk = c->cfg.talker.n_kv_heads, ms = c->tk.max_seq * kHeadDim, ls = L * kHeadDim;
+    if (c->cfg.dtype == FQ3_BF16) { kv_copy<bf16_t>(c->tk.k[layer], k, nk, L, ms, ls, s); kv_copy<bf16_t>(c->tk.v[layer], v, nk, L, ms, ls, s); }
+    else { kv_copy<float>(c->tk.k[layer], k, nk, L, ms, ls, s); kv_copy<float>(c->tk.v[layer], v, nk, L, ms, ls, s); }
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
+extern "C" int fq3_kv_export(fq3_ctx* c, int layer, void* k, void* v, int L, void* stream) {
+    if (!c || !k || !v) return fail(FQ3_EINVAL, "null argument");
+    if (layer < 0 || layer >= c->cfg.talker.n_layers || L > c->cfg.max_seq_len) return fail(FQ3_EINVAL, "range");
+    hipStream_t s = (hipStream_t)stream;
+    const int nk = c->cfg.talker.n_kv_heads, ms = c->tk.max_seq * kHeadDim, ls = L * kHeadDim;
+    if (c->cfg.dtype == FQ3_BF16) { kv_copy<bf16_t>(k, c->tk.k[layer], nk, L, ls, ms, s); kv_copy<bf16_t>(v, c->tk.v[layer], nk, L, ls, ms, s); }
+    else { kv_copy<float>(k, c->tk.k[layer], nk, L, ls, ms, s); kv_copy<float>(v, c->tk.v[layer], nk, L, ls, ms, s); }
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
+static int final_norm(fq3_ctx* c, bool talker, const void* x, void* y, hipStream_t s) {
+    const fq3_stack_dims& d = talker ? c->cfg.talker : c->cfg.predictor;
+    const void* w = talker ? c->wt.talker_final_norm : c->wt.predictor_final_norm;
+    if (c->cfg.dtype == FQ3_BF16)
+        hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(1), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, d.hidden, d.rms_eps);
+    else
+        hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(1), dim3(256), 0, s, (const float*)x, (const float*)w, (float*)y, d.hidden, d.rms_eps);
+    return 0;
+}
+
+extern "C" int fq3_talker_step(fq3_ctx* c, const void* embeds, int position, void* out_hidden, void* stream) {
+    NEED_BOUND(c);
+    if (!embeds || !out_hidden) return fail(FQ3_EINVAL, "null argument");
+    if (position < 0 || position >= c->cfg.max_seq_len) return fail(FQ3_EINVAL, "position outside the static cache");
+    hipStream_t s = (hipStream_t)stream;
+    StepSrc src{embeds, nullptr, position};
+    if (int r = run_stack(c, true, src, s)) return r;
+    final_norm(c, true, c->h, out_hidden, s);
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
+extern "C" int fq3_codec_head(fq3_ctx* c, const void* hidden, void* out_logits, void* stream) {
+    NEED_BOUND(c);
+    if (!hidden || !out_logits) return fail(FQ3_EINVAL, "null argument");
+    GemvArgs g{};
+    g.W = c->wt.codec_head; g.N = c->cfg.talker.vocab; g.K = c->cfg.talker.hidden; g.x = hidden; g.y = out_logits;
+    if (int r = launch_gemv<PRO_PLAIN, EPI_STORE>(c, g, true, (hipStream_t)stream)) return r;
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
+// Round-1 prefill: the prompt is walked token by token through the decode-step kernels (exactly the
+// arithmetic the decode parity tests pin).  The MFMA GEMM prefill replaces this in csrc/prefill.hip.
+extern "C" int fq3_prefill(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits, void* out_hidden,
+                           void* stream) {
+    NEED_BOUND(c);
+    if (!embeds || L <= 0) return fail(FQ3_EINVAL, "bad prompt");
+    if (L > c->cfg.max_seq_len) {
+        char b[256];
+        snprintf(b, sizeof b, "Input is too long: prefill has %d tokens but max_seq_len=%d. Use shorter text or shorter reference audio.",
+                 L, c->cfg.max_seq_len);
+        return fail(FQ3_ETOOLONG, b);
+    }
+    if (n_pad < 0 || n_pad >= L) return fail(FQ3_EINVAL, "n_pad");
+    if (int r = fq3_set_generation_state(c, n_pad, -n_pad)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rowb = (size_t)c->cfg.talker.hidden * c->esz;
+    for (int i = n_pad; i < L; ++i) {
+        StepSrc src{(const char*)embeds + rowb * i, nullptr, i};
+        if (int r = run_stack(c, true, src, s)) return r;
+    }
+    void* hid = out_hidden ? out_hidden : c->tmp_hidden;
+    final_norm(c, true, c->h, hid, s);
+    if (out_logits) {
+        GemvArgs g{};
+        g.W = c->wt.codec_head; g.N = c->cfg.talker.vocab; g.K = c->cfg.talker.hidden; g.x = hid; g.y = out_logits;
+        if (int r = launch_gemv<PRO_PLAIN, EPI_STORE>(c, g, true, s)) return r;
+    }
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// Sampler dispatch: single-wave kernels when top_p >= 1 (default), workgroup kernel otherwise
+// -------------------------------------------------------------------------------------------------
+__global__ void build_seen_kernel(const int64_t* history, int n, unsigned char* seen, int V) {
+    for (int i = threadIdx.x; i < V; i += blockDim.x) seen[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const int id = (int)history[i]; if (id >= 0 && id < V) seen[id] = 1; }
+}
+template <typename F>
+static void dispatch_nc(int V, F&& f) {
+    const int nc = (V + 511) / 512;
+    if (nc <= 1) f(std::integral_constant<int, 1>{});
+    else if (nc <= 2) f(std::integral_constant<int, 2>{});
+    else if (nc <= 3) f(std::integral_constant<int, 3>{});
+    else if (nc <= 4) f(std::integral_constant<int, 4>{});
+    else if (nc <= 6) f(std::integral_constant<int, 6>{});
+    else f(std::integral_constant<int, 8>{});
+}
+
+template <typename T>
+static void launch_sample_pred(const DecodeState* st, const T* lg, int V, int cb, const SampleCfg& cfg, const T* nz,
+                               int* codes, int G, int64_t* out64, const T* next_emb, T* next_in, int H, bool wave,
+                               hipStream_t s) {
+    if (wave) dispatch_nc(V, [&](auto nc) {
+        constexpr int NC = decltype(nc)::value;
+        hipLaunchKernelGGL((sample_pred_wave_kernel<T, NC>), dim3(1), dim3(64), 0, s, st, lg, V, cb, cfg, nz, codes, G,
+                           out64, next_emb, next_in, H);
+    });
+    else hipLaunchKernelGGL((sample_pred_kernel<T>), dim3(1), dim3(256), 0, s, st, lg, V, cb, cfg, nz, codes, G, out64,
+                            next_emb, next_in, H);
+}
+template <typename T>
+static void launch_sample_talker(DecodeState* st, const T* lg, int V, const unsigned char* seen, bool wave, hipStream_t s) {
+    if (wave) dispatch_nc(V, [&](auto nc) {
+        constexpr int NC = decltype(nc)::value;
+        hipLaunchKernelGGL((sample_talker_wave_kernel<T, NC>), dim3(1), dim3(64), 0, s, st, lg, V, seen);
+    });
+    else hipLaunchKernelGGL((sample_talker_kernel<T>), dim3(1), dim3(256), 0, s, st, lg, V, seen);
+}
+template <typename T>
+static void launch_sample_api(fq3_ctx* c, const T* lg, int V, const SampleCfg& cfg, const int64_t* history, int n_hist,
+                              const T* noise, int64_t* out, hipStream_t s) {
+    if (cfg.top_p >= 1.0f) {
+        const unsigned char* seen = nullptr;
+        if (n_hist > 0) {
+            hipLaunchKernelGGL(build_seen_kernel, dim3(1), dim3(256), 0, s, history, n_hist, c->seen_api, V);
+            seen = c->seen_api;
+        }
+        dispatch_nc(V, [&](auto nc) {
+            constexpr int NC = decltype(nc)::value;
+            hipLaunchKernelGGL((sample_api_wave_kernel<T, NC>), dim3(1), dim3(64), 0, s, lg, V, cfg, seen, noise, out);
+        });
+    } else {
+        hipLaunchKernelGGL((sample_api_kernel<T>), dim3(1), dim3(256), 0, s, lg, V, cfg, history, n_hist, noise, out);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Sampler
+// -------------------------------------------------------------------------------------------------
+static SampleCfg to_cfg(const fq3_sampling& s) {
+    SampleCfg c{};
+    c.temperature = s.temperature; c.top_k = s.top_k; c.top_p = s.top_p; c.do_sample = s.do_sample;
+    c.rep_penalty = s.repetition_penalty; c.sup_lo = 0; c.sup_hi = 0; c.keep_id = -1; c.sup_extra = -1;
+    return c;
+}
+
+extern "C" int fq3_sample(fq3_ctx* c, const void* logits, int V, const fq3_sampling* sp, const int64_t* history,
+                          int n_hist, int sup_lo, int sup_hi, int keep_id, int suppress_eos, const void* noise,
+                          int64_t* out_token, void* stream) {
+    if (!c || !logits || !sp || !out_token) return fail(FQ3_EINVAL, "null argument");
+    if (V <= 0 || V > kMaxVocab) return fail(FQ3_EUNSUPPORTED, "vocab above 4096");
+    if (sp->do_sample && !noise) return fail(FQ3_EINVAL, "do_sample needs a noise vector");
+    if (sp->do_sample && !(sp->temperature > 0.f)) return fail(FQ3_EINVAL, "temperature must be > 0");
+    SampleCfg cfg = to_cfg(*sp);
+    cfg.sup_lo = sup_lo; cfg.sup_hi = sup_hi; cfg.keep_id = keep_id;
+    cfg.sup_extra = suppress_eos ? c->cfg.codec_eos_token_id : -1;
+    hipStream_t s = (hipStream_t)stream;
+    if (c->cfg.dtype == FQ3_BF16)
+        launch_sample_api<bf16_t>(c, (const bf16_t*)logits, V, cfg, history, history ? n_hist : 0, (const bf16_t*)noise, out_token, s);
+    else
+        launch_sample_api<float>(c, (const float*)logits, V, cfg, history, history ? n_hist : 0, (const float*)noise, out_token, s);
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
+extern "C" int fq3_set_predictor_sampling(fq3_ctx* c, const fq3_sampling* s) {
+    if (!c || !s) return fail(FQ3_EINVAL, "null argument");
+    if (s->do_sample && !(s->temperature > 0.f)) return fail(FQ3_EINVAL, "temperature must be > 0");
+    if ((s->top_p >= 1.0f) != (c->pred_sampling.top_p >= 1.0f)) fq3_graph_reset(c);
+    c->pred_sampling = *s;
+    return FQ3_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Predictor loop (predictor_graph.py:115-167).  `st` == nullptr: immediate mode (API call);
+// otherwise sampling policy, noise row and output slot come from the on-device loop state.
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+static int predictor_passes_t(fq3_ctx* c, const DecodeState* st_dev, const void* pred_input, const void* noise_imm,
+                              int64_t* out64, void* out_logits, hipStream_t s) {
+    const fq3_stack_dims &p = c->cfg.predictor, &t = c->cfg.talker;
+    const int G = c->cfg.num_code_groups, Vp = p.vocab, Ht = t.hidden;
+    SampleCfg scfg = to_cfg(c->pred_sampling);
+    // pass schedule: token A (past_hidden, pos 0), token B (embed(tok0), pos 1), then 14 single-token passes
+    for (int pass = 0; pass < G; ++pass) {              // G = 16 token passes
+        const T* x_talker = pass < 2 ? (const T*)pred_input + (size_t)pass * Ht : (const T*)c->pred_next;
+        const void* x0 = x_talker;
+        if (c->cfg.has_projection) {                    // small_to_mtp_projection (predictor_graph.py:118,145)
+            GemvArgs g{};
+            g.W = c->wt.proj_w; g.bias = c->wt.proj_b; g.N = p.hidden; g.K = Ht; g.x = x_talker; g.y = c->pred_x;
+            if (int r = launch_gemv<PRO_PLAIN, EPI_STORE>(c, g, false, s)) return r;
+            x0 = c->pred_x;
+        }
+        StepSrc src{x0, nullptr, pass};
+        if (int r = run_stack(c, false, src, s)) return r;
+        if (pass == 0) continue;                        // first prefill token: only its K/V are needed
+        const int cb = pass - 1;                        // codebook produced by this pass
+        T* lg = out_logits ? (T*)out_logits + (size_t)cb * Vp : (T*)c->plogits + (size_t)cb * Vp;
+        GemvArgs hgm{};
+        hgm.eps = p.rms_eps; hgm.W = c->lmh[cb]; hgm.N = Vp; hgm.K = p.hidden; hgm.x = c->h;
+        hgm.norm_w = c->wt.predictor_final_norm; hgm.y = lg;
+        if (int r = launch_gemv<PRO_NORM, EPI_STORE>(c, hgm, false, s)) return r;
+        const T* nz = noise_imm ? (const T*)noise_imm + (size_t)cb * Vp : nullptr;
+        const T* next_emb = cb + 1 < G - 1 ? (const T*)c->pemb[cb] : nullptr;     // codec_embeds[cb](tok) feeds pass cb+1
+        launch_sample_pred<T>(st_dev, (const T*)lg, Vp, cb, scfg, nz, st_dev ? c->codes : nullptr, G, out64, next_emb,
+                              (T*)c->pred_next, Ht, c->pred_sampling.top_p >= 1.0f, s);
+    }
+    return 0;
+}
+
+extern "C" int fq3_predictor_loop(fq3_ctx* c, const void* pred_input, const void* noise, int64_t* out_ids,
+                                  void* out_logits, void* stream) {
+    NEED_BOUND(c);
+    if (!pred_input || !out_ids) return fail(FQ3_EINVAL, "null argument");
+    if (c->pred_sampling.do_sample && !noise) return fail(FQ3_EINVAL, "predictor sampling enabled but no noise given");
+    hipStream_t s = (hipStream_t)stream;
+    int r = c->cfg.dtype == FQ3_BF16 ? predictor_passes_t<bf16_t>(c, nullptr, pred_input, noise, out_ids, out_logits, s)
+                                     : predictor_passes_t<float>(c, nullptr, pred_input, noise, out_ids, out_logits, s);
+    if (r) return r;
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Fused on-device decode loop
+// -------------------------------------------------------------------------------------------------
+extern "C" int fq3_decode_begin(fq3_ctx* c, const fq3_decode_params* p, void* stream) {
+    NEED_BOUND(c);
+    if (!p || !p->past_hidden || !p->tts_pad_embed) return fail(FQ3_EINVAL, "null argument");
+    if (p->trailing_len > 0 && !p->trailing_text) return fail(FQ3_EINVAL, "trailing_text");
+    if (p->talker.do_sample && (!p->talker_noise || p->noise_frames <= 0)) return fail(FQ3_EINVAL, "talker sampling needs a noise ring");
+    if (c->pred_sampling.do_sample && (!p->pred_noise || p->noise_frames <= 0)) return fail(FQ3_EINVAL, "predictor sampling needs a noise ring");
+    if (p->talker.do_sample && !(p->talker.temperature > 0.f)) return fail(FQ3_EINVAL, "temperature must be > 0");
+    if (p->max_new_tokens > c->cfg.max_frames) return fail(FQ3_EINVAL, "max_new_tokens exceeds the context's max_frames");
+    if (p->prefill_len <= 0 || p->prefill_len > c->cfg.max_seq_len) return fail(FQ3_EINVAL, "prefill_len");
+    const bool wave = p->talker.top_p >= 1.0f;
+    if (wave != c->talker_wave) { fq3_graph_reset(c); c->talker_wave = wave; }
+    hipStream_t s = (hipStream_t)stream;
+    DecodeState h{};
+    h.token = p->first_token; h.frame = 0; h.pos = p->prefill_len; h.gen_step = p->gen_step; h.done = 0;
+    h.min_new = p->min_new_tokens; h.max_new = p->max_new_tokens; h.trailing_len = p->trailing_len;
+    h.noise_frames = p->noise_frames > 0 ? p->noise_frames : 1;
+    h.eos_id = c->cfg.codec_eos_token_id; h.max_seq = c->cfg.max_seq_len;
+    h.sup_lo = c->cfg.talker.vocab - 1024 > 0 ? c->cfg.talker.vocab - 1024 : 0; h.sup_hi = c->cfg.talker.vocab;
+    h.t_temperature = p->talker.temperature; h.t_top_k = p->talker.top_k; h.t_top_p = p->talker.top_p;
+    h.t_do_sample = p->talker.do_sample; h.t_rep_penalty = p->talker.repetition_penalty;
+    h.p_temperature = c->pred_sampling.temperature; h.p_top_k = c->pred_sampling.top_k; h.p_top_p = c->pred_sampling.top_p;
+    h.p_do_sample = c->pred_sampling.do_sample;
+    h.trailing_text = p->trailing_text; h.tts_pad = p->tts_pad_embed; h.talker_noise = p->talker_noise; h.pred_noise = p->pred_noise;
+    HIPCHK(hipMemcpyAsync(c->st, &h, sizeof h, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->seen, 0, kMaxVocab, s));
+    HIPCHK(hipMemcpyAsync(c->past_hidden, p->past_hidden, (size_t)c->cfg.talker.hidden * c->esz, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));     // `h` lives on this stack frame
+    return FQ3_OK;
+}
+
+template <typename T>
+static int enqueue_frame_t(fq3_ctx* c, hipStream_t s) {
+    const fq3_stack_dims& t = c->cfg.talker;
+    const int G = c->cfg.num_code_groups, H = t.hidden;
+    DecodeState* st = c->st;
+    hipLaunchKernelGGL((frame_begin_kernel<T>), dim3(1), dim3(256), 0, s, st, (const T*)c->wt.codec_embedding,
+                       (const T*)c->past_hidden, (T*)c->pred_in, c->codes, c->seen, H, G);
+    if (int r = predictor_passes_t<T>(c, st, c->pred_in, nullptr, nullptr, nullptr, s)) return r;
+    EmbTables tabs{};
+    tabs.t[0] = c->wt.codec_embedding;
+    for (int i = 1; i < G; ++i) tabs.t[i] = c->pemb[i - 1];
+    if (G != 16) return fail(FQ3_EUNSUPPORTED, "the fused loop is built for 16 code groups");
+    hipLaunchKernelGGL((embed_sum_kernel<T, 16>), dim3(1), dim3(256), 0, s, st, tabs, c->codes, (T*)c->xin, H,
+                       c->wt.talker_cos, c->wt.talker_sin, c->wt.talker_rope_len, c->rope_delta, c->rope_now);
+    StepSrc src{c->xin, &st->pos, 0};
+    if (int r = run_stack(c, true, src, s)) return r;
+    // final norm fused into the codec_head GEMV; block 0 also stores the normed hidden = next frame's past_hidden
+    GemvArgs g{};
+    g.eps = t.rms_eps; g.W = c->wt.codec_head; g.N = t.vocab; g.K = H; g.x = c->h;
+    g.norm_w = c->wt.talker_final_norm; g.y = c->logits; g.xn_out = c->past_hidden;
+    if (int r = launch_gemv<PRO_NORM, EPI_STORE>(c, g, true, s)) return r;
+    launch_sample_talker<T>(st, (const T*)c->logits, t.vocab, c->seen, c->talker_wave, s);
+    return 0;
+}
+static int enqueue_frame(fq3_ctx* c, hipStream_t s) {
+    return c->cfg.dtype == FQ3_BF16 ? enqueue_frame_t<bf16_t>(c, s) : enqueue_frame_t<float>(c, s);
+}
+
+extern "C" int fq3_graph_capture(fq3_ctx* c, void* stream) {
+    NEED_BOUND(c);
+    if (c->exec) return FQ3_OK;
+    (void)stream;
+    hipStream_t cs = c->cap_stream;
+    HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    int r = enqueue_frame(c, cs);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(cs, &g);
+    if (r) { if (g) (void)hipGraphDestroy(g); return r; }
+    if (e != hipSuccess) return fail(FQ3_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    c->graph = g;
+    HIPCHK(hipGraphInstantiate(&c->exec, c->graph, nullptr, nullptr, 0));
+    return FQ3_OK;
+}
+
+extern "C" int fq3_decode_frames(fq3_ctx* c, int n_frames, void* stream) {
+    NEED_BOUND(c);
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < n_frames; ++i) {
+        if (c->exec) { HIPCHK(hipGraphLaunch(c->exec, s)); }
+        else if (int r = enqueue_frame(c, s)) return r;
+    }
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
+extern "C" int fq3_decode_poll(fq3_ctx* c, int* n_frames_total, int* done, void* stream) {
+    if (!c) return fail(FQ3_EINVAL, "null ctx");
+    hipStream_t s = (hipStream_t)stream;
+    DecodeState h;
+    HIPCHK(hipMemcpyAsync(&h, c->st, sizeof h, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (n_frames_total) *n_frames_total = h.frame;
+    if (done) *done = h.done || h.token == h.eos_id;
+    return FQ3_OK;
+}
+
+__global__ void codes_to_i64_kernel(const int* src, int64_t* dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+extern "C" int fq3_decode_codes(fq3_ctx* c, int from, int count, int64_t* out, void* stream) {
+    if (!c || !out) return fail(FQ3_EINVAL, "null argument");
+    if (from < 0 || count < 0 || from + count > c->cfg.max_frames) return fail(FQ3_EINVAL, "range");
+    const int G = c->cfg.num_code_groups, n = count * G;
+    if (n == 0) return FQ3_OK;
+    hipLaunchKernelGGL(codes_to_i64_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       c->codes + (size_t)from * G, out, n);
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}

@@ -1,0 +1,261 @@
+"""Host-side owner of one ``fq3_ctx``: weight packing, RoPE tables, and typed wrappers over the C ABI.
+
+PyTorch is plumbing here (device memory for weights / activations, the stream handle); every
+arithmetic step of the decode path runs in ``libfq3hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+from .config import TTSConfig, StackConfig
+
+Weights = Dict[str, torch.Tensor]
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def rope_tables(head_dim: int, theta: float, n_pos: int, dtype: torch.dtype):
+    """cos/sin [n_pos, head_dim/2] as fp32 images of the activation-dtype values, computed with the
+    same Torch ops as the upstream rotary module (inv_freq in fp32, fp32 angle, cast to dtype) so the
+    kernels see bit-identical tables.  (transformers modeling_qwen3_omni_moe.py:2414-2436.)"""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+    ang = torch.arange(n_pos, dtype=torch.float32)[:, None] * inv[None, :]
+    return ang.cos().to(dtype).float().contiguous(), ang.sin().to(dtype).float().contiguous()
+
+
+class Fq3Engine:
+    """One decode context (talker + predictor static state) on one GPU.  Not re-entrant."""
+
+    def __init__(self, cfg: TTSConfig, weights: Weights, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
+                 max_seq_len: int = 2048, max_frames: int = 4096):
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("fq3hip supports torch.bfloat16 and torch.float32")
+        self.lib = L.load()
+        self.cfg, self.dtype, self.max_seq_len = cfg, dtype, int(max_seq_len)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("fq3hip needs a ROCm GPU device ('cuda' in PyTorch-ROCm)")
+        self.max_frames = int(max_frames)
+        self._keep = []          # tensors whose storage the context borrows
+        self.ctx = L.vp()
+        c = L.Config()
+        c.dtype = L.FQ3_BF16 if dtype == torch.bfloat16 else L.FQ3_F32
+        for dst, src in ((c.talker, cfg.talker), (c.predictor, cfg.predictor)):
+            dst.hidden, dst.inter, dst.n_layers = src.hidden_size, src.intermediate_size, src.num_hidden_layers
+            dst.n_heads, dst.n_kv_heads, dst.head_dim = src.num_attention_heads, src.num_key_value_heads, src.head_dim
+            dst.vocab, dst.rms_eps = src.vocab_size, src.rms_norm_eps
+        c.num_code_groups = cfg.num_code_groups
+        c.max_seq_len = self.max_seq_len
+        c.codec_eos_token_id = cfg.codec_eos_token_id
+        c.has_projection = 1 if "talker.code_predictor.small_to_mtp_projection.weight" in weights else 0
+        c.max_frames = self.max_frames
+        with torch.cuda.device(self.device):
+            L.check(self.lib.fq3_ctx_create(C.byref(c), C.byref(self.ctx)))
+            self._bind(weights)
+        self.weights = weights
+        self._pred_sampling = dict(do_sample=True, top_k=50, top_p=1.0, temperature=0.9)
+
+    # ------------------------------------------------------------------------------------------
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.to(device=self.device, dtype=self.dtype).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _layers(self, W: Weights, prefix: str, sc: StackConfig):
+        arr = (L.LayerWeights * sc.num_hidden_layers)()
+        for i in range(sc.num_hidden_layers):
+            p = f"{prefix}.layers.{i}"
+            qkv = self._dev(torch.cat([W[f"{p}.self_attn.q_proj.weight"], W[f"{p}.self_attn.k_proj.weight"],
+                                       W[f"{p}.self_attn.v_proj.weight"]], 0))
+            gu = self._dev(torch.cat([W[f"{p}.mlp.gate_proj.weight"], W[f"{p}.mlp.up_proj.weight"]], 0))
+            lw = arr[i]
+            lw.input_norm = _ptr(self._dev(W[f"{p}.input_layernorm.weight"]))
+            lw.qkv = _ptr(qkv)
+            lw.q_norm = _ptr(self._dev(W[f"{p}.self_attn.q_norm.weight"]))
+            lw.k_norm = _ptr(self._dev(W[f"{p}.self_attn.k_norm.weight"]))
+            lw.o = _ptr(self._dev(W[f"{p}.self_attn.o_proj.weight"]))
+            lw.post_norm = _ptr(self._dev(W[f"{p}.post_attention_layernorm.weight"]))
+            lw.gate_up = _ptr(gu)
+            lw.down = _ptr(self._dev(W[f"{p}.mlp.down_proj.weight"]))
+        return arr
+
+    def _bind(self, W: Weights):
+        cfg = self.cfg
+        t = L.WeightTable()
+        self._tl = self._layers(W, "talker.model", cfg.talker)
+        self._pl = self._layers(W, "talker.code_predictor.model", cfg.predictor)
+        t.talker_layers, t.predictor_layers = self._tl, self._pl
+        self.codec_embedding = self._dev(W["talker.model.codec_embedding.weight"])
+        self.codec_head_w = self._dev(W["talker.codec_head.weight"])
+        t.talker_final_norm = _ptr(self._dev(W["talker.model.norm.weight"]))
+        t.codec_embedding = _ptr(self.codec_embedding)
+        t.codec_head = _ptr(self.codec_head_w)
+        pre = "talker.code_predictor"
+        t.predictor_final_norm = _ptr(self._dev(W[f"{pre}.model.norm.weight"]))
+        pw = W.get(f"{pre}.small_to_mtp_projection.weight")
+        pb = W.get(f"{pre}.small_to_mtp_projection.bias")
+        t.proj_w = _ptr(self._dev(pw)) if pw is not None else None
+        t.proj_b = _ptr(self._dev(pb)) if pb is not None else None
+        n = cfg.num_code_groups - 1
+        self.predictor_embeddings = [self._dev(W[f"{pre}.model.codec_embedding.{j}.weight"]) for j in range(n)]
+        self._pe = (L.vp * n)(*[e.data_ptr() for e in self.predictor_embeddings])
+        self._lh = (L.vp * n)(*[self._dev(W[f"{pre}.lm_head.{j}.weight"]).data_ptr() for j in range(n)])
+        t.predictor_embeddings = self._pe
+        t.lm_heads = self._lh
+        tc, ts = rope_tables(cfg.talker.head_dim, cfg.talker.rope_theta, self.max_seq_len, self.dtype)
+        pc, ps = rope_tables(cfg.predictor.head_dim, cfg.predictor.rope_theta, cfg.num_code_groups + 1, self.dtype)
+        self._rope = [x.to(self.device) for x in (tc, ts, pc, ps)]
+        t.talker_cos, t.talker_sin, t.talker_rope_len = self._rope[0].data_ptr(), self._rope[1].data_ptr(), self.max_seq_len
+        t.pred_cos, t.pred_sin, t.pred_rope_len = self._rope[2].data_ptr(), self._rope[3].data_ptr(), cfg.num_code_groups + 1
+        self._table = t
+        L.check(self.lib.fq3_bind_weights(self.ctx, C.byref(t)))
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _chk(self, t: torch.Tensor, n: int, what: str):
+        if t.device != self.device and not (t.device.type == "cuda" and self.device.index in (None, t.device.index)):
+            raise ValueError(f"{what}: tensor is on {t.device}, context on {self.device}")
+        if t.dtype != self.dtype or not t.is_contiguous() or t.numel() != n:
+            raise ValueError(f"{what}: need contiguous {self.dtype} tensor with {n} elements, got {t.dtype} {tuple(t.shape)}")
+
+    def new(self, *shape, dtype=None) -> torch.Tensor:
+        return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
+
+    # ---- talker ----
+    def set_generation_state(self, n_pad: int, rope_delta: int):
+        L.check(self.lib.fq3_set_generation_state(self.ctx, int(n_pad), int(rope_delta)))
+
+    def kv_import(self, layer: int, k: torch.Tensor, v: torch.Tensor):
+        Lk = k.shape[-2]
+        k = k.to(self.dtype).contiguous(); v = v.to(self.dtype).contiguous()
+        L.check(self.lib.fq3_kv_import(self.ctx, layer, k.data_ptr(), v.data_ptr(), int(Lk), self._stream()))
+
+    def kv_export(self, layer: int, Lk: int):
+        nk, d = self.cfg.talker.num_key_value_heads, self.cfg.talker.head_dim
+        k, v = self.new(nk, Lk, d), self.new(nk, Lk, d)
+        L.check(self.lib.fq3_kv_export(self.ctx, layer, k.data_ptr(), v.data_ptr(), int(Lk), self._stream()))
+        return k, v
+
+    def talker_step(self, embeds: torch.Tensor, position: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        H = self.cfg.talker.hidden_size
+        self._chk(embeds, H, "talker_step embeds")
+        out = out if out is not None else self.new(H)
+        L.check(self.lib.fq3_talker_step(self.ctx, embeds.data_ptr(), int(position), out.data_ptr(), self._stream()))
+        return out
+
+    def prefill(self, embeds: torch.Tensor, n_pad: int = 0):
+        """embeds [L, H] -> (logits [V], hidden [H])."""
+        Lp, H = embeds.shape
+        self._chk(embeds, Lp * H, "prefill embeds")
+        logits, hid = self.new(self.cfg.talker.vocab_size), self.new(H)
+        L.check(self.lib.fq3_prefill(self.ctx, embeds.data_ptr(), int(Lp), int(n_pad), logits.data_ptr(),
+                                     hid.data_ptr(), self._stream()))
+        return logits, hid
+
+    def codec_head(self, hidden: torch.Tensor) -> torch.Tensor:
+        self._chk(hidden, self.cfg.talker.hidden_size, "codec_head hidden")
+        out = self.new(self.cfg.talker.vocab_size)
+        L.check(self.lib.fq3_codec_head(self.ctx, hidden.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    # ---- predictor ----
+    def set_predictor_sampling(self, *, do_sample: bool, top_k: int, top_p: float, temperature: float):
+        s = L.Sampling(float(temperature), int(top_k), float(top_p), int(bool(do_sample)), 1.0)
+        L.check(self.lib.fq3_set_predictor_sampling(self.ctx, C.byref(s)))
+        self._pred_sampling = dict(do_sample=bool(do_sample), top_k=int(top_k), top_p=float(top_p),
+                                   temperature=float(temperature))
+
+    def predictor_loop(self, pred_input: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                       want_logits: bool = False):
+        H, n, Vp = self.cfg.talker.hidden_size, self.cfg.num_code_groups - 1, self.cfg.predictor.vocab_size
+        self._chk(pred_input, 2 * H, "predictor_loop pred_input")
+        if noise is not None:
+            self._chk(noise, n * Vp, "predictor_loop noise")
+        ids = torch.empty(n, dtype=torch.long, device=self.device)
+        lg = self.new(n, Vp) if want_logits else None
+        L.check(self.lib.fq3_predictor_loop(self.ctx, pred_input.data_ptr(), _ptr(noise), ids.data_ptr(), _ptr(lg),
+                                            self._stream()))
+        return (ids, lg) if want_logits else ids
+
+    # ---- sampler ----
+    def sample(self, logits: torch.Tensor, *, temperature: float, top_k: int, top_p: float, do_sample: bool,
+               repetition_penalty: float = 1.0, history: Optional[torch.Tensor] = None, sup_lo: int = 0,
+               sup_hi: int = 0, keep_id: int = -1, suppress_eos: bool = False,
+               noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        V = logits.numel()
+        self._chk(logits, V, "sample logits")
+        if noise is not None:
+            self._chk(noise, V, "sample noise")
+        s = L.Sampling(float(temperature), int(top_k), float(top_p), int(bool(do_sample)), float(repetition_penalty))
+        out = torch.empty(1, dtype=torch.long, device=self.device)
+        nh = 0
+        if history is not None and history.numel() > 0:
+            history = history.to(device=self.device, dtype=torch.long).contiguous()
+            nh = history.numel()
+        else:
+            history = None
+        L.check(self.lib.fq3_sample(self.ctx, logits.data_ptr(), int(V), C.byref(s), _ptr(history), nh, int(sup_lo),
+                                    int(sup_hi), int(keep_id), int(bool(suppress_eos)), _ptr(noise), out.data_ptr(),
+                                    self._stream()))
+        return out
+
+    # ---- fused on-device loop ----
+    def decode_begin(self, *, first_token: int, prefill_len: int, gen_step: int, past_hidden: torch.Tensor,
+                     trailing_text: torch.Tensor, tts_pad_embed: torch.Tensor, temperature: float, top_k: int,
+                     top_p: float, do_sample: bool, repetition_penalty: float, min_new_tokens: int,
+                     max_new_tokens: int, talker_noise: Optional[torch.Tensor] = None,
+                     pred_noise: Optional[torch.Tensor] = None, noise_frames: int = 0):
+        H = self.cfg.talker.hidden_size
+        self._chk(past_hidden, H, "past_hidden")
+        self._chk(tts_pad_embed, H, "tts_pad_embed")
+        tl = trailing_text.shape[-2] if trailing_text is not None and trailing_text.numel() else 0
+        if tl:
+            self._chk(trailing_text, tl * H, "trailing_text")
+        p = L.DecodeParams()
+        p.talker = L.Sampling(float(temperature), int(top_k), float(top_p), int(bool(do_sample)), float(repetition_penalty))
+        p.min_new_tokens, p.max_new_tokens = int(min_new_tokens), int(max_new_tokens)
+        p.prefill_len, p.gen_step, p.first_token = int(prefill_len), int(gen_step), int(first_token)
+        p.past_hidden, p.trailing_text, p.trailing_len = past_hidden.data_ptr(), _ptr(trailing_text) if tl else None, tl
+        p.tts_pad_embed = tts_pad_embed.data_ptr()
+        p.talker_noise, p.pred_noise, p.noise_frames = _ptr(talker_noise), _ptr(pred_noise), int(noise_frames)
+        self._loop_keep = (past_hidden, trailing_text, tts_pad_embed, talker_noise, pred_noise)
+        L.check(self.lib.fq3_decode_begin(self.ctx, C.byref(p), self._stream()))
+
+    def graph_capture(self):
+        L.check(self.lib.fq3_graph_capture(self.ctx, self._stream()))
+
+    def graph_reset(self):
+        L.check(self.lib.fq3_graph_reset(self.ctx))
+
+    def decode_frames(self, n: int):
+        L.check(self.lib.fq3_decode_frames(self.ctx, int(n), self._stream()))
+
+    def decode_poll(self):
+        n, d = C.c_int(0), C.c_int(0)
+        L.check(self.lib.fq3_decode_poll(self.ctx, C.byref(n), C.byref(d), self._stream()))
+        return n.value, bool(d.value)
+
+    def decode_codes(self, start: int, count: int) -> torch.Tensor:
+        out = torch.empty(count, self.cfg.num_code_groups, dtype=torch.long, device=self.device)
+        if count:
+            L.check(self.lib.fq3_decode_codes(self.ctx, int(start), int(count), out.data_ptr(), self._stream()))
+        return out
+
+    def close(self):
+        if getattr(self, "ctx", None) and self.ctx.value:
+            self.lib.fq3_ctx_destroy(self.ctx)
+            self.ctx = L.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,207 @@
+/*
+ * fq3hip.h -- C ABI of libfq3hip.so: the MI355X (gfx950) fast decode path for Qwen3-TTS.
+ *
+ * This is the drop-in boundary.  Every entry point is extern "C", takes plain device pointers,
+ * sizes and a hipStream_t passed as void*; there are no torch types in any signature.  Python binds
+ * it with ctypes (faster-qwen3-tts_amd/fq3hip/_lib.py); INTEGRATION.md shows the stub a reference
+ * maintainer would add.  The precedent for a ctypes-bound native runtime in the reference is the
+ * libqwen adapter, /root/reference/faster_qwen3_tts/ggml_backend.py:31-39.
+ *
+ * Each function cites the reference interface it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - return 0 on success, a negative FQ3_E* code on failure; fq3_last_error() gives the message.
+ *     Nothing throws across the ABI.
+ *   - all work is enqueued on the stream argument and is asynchronous to the host unless stated.
+ *   - a context is bound to one device and is NOT re-entrant (static buffers), exactly like the
+ *     reference's graph objects (examples/openai_server.py:71 serialises callers with a lock).
+ *   - "T" below is the context dtype: bf16 (FQ3_BF16) or fp32 (FQ3_F32).  Weights, activations, KV
+ *     cache, logits and sampling noise are all T; accumulation is fp32.
+ *   - weight pointers are BORROWED: the caller keeps the allocations alive for the context lifetime.
+ */
+#ifndef FQ3HIP_H
+#define FQ3HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQ3_ABI_VERSION 1
+
+enum { FQ3_BF16 = 0, FQ3_F32 = 1 };
+enum { FQ3_OK = 0, FQ3_EINVAL = -1, FQ3_EHIP = -2, FQ3_ESTATE = -3, FQ3_ETOOLONG = -4, FQ3_EUNSUPPORTED = -5 };
+
+typedef struct fq3_stack_dims {
+    int32_t hidden, inter, n_layers, n_heads, n_kv_heads, head_dim, vocab;
+    float rms_eps;
+} fq3_stack_dims;
+
+typedef struct fq3_config {
+    int32_t dtype;              /* FQ3_BF16 | FQ3_F32 */
+    fq3_stack_dims talker;      /* talker_graph.py:36-37 */
+    fq3_stack_dims predictor;   /* predictor_graph.py:42-46 */
+    int32_t num_code_groups;    /* 16: generate.py:42 */
+    int32_t max_seq_len;        /* static talker KV length: model.py:113, talker_graph.py:43 */
+    int32_t codec_eos_token_id; /* generate.py:41 */
+    int32_t has_projection;     /* small_to_mtp_projection present: predictor_graph.py:54 */
+    int32_t max_frames;         /* capacity of the on-device code buffer (>= max_new_tokens) */
+} fq3_config;
+
+/* One pre-norm GQA decoder layer.  qkv = rows [q | k | v] of the three projections concatenated,
+ * gate_up = rows [gate | up].  All row-major [out, in], no biases (Appendix D of SURVEY.md). */
+typedef struct fq3_layer_weights {
+    const void* input_norm;  /* [H] */
+    const void* qkv;         /* [q_dim + 2*kv_dim, H] */
+    const void* q_norm;      /* [head_dim] */
+    const void* k_norm;      /* [head_dim] */
+    const void* o;           /* [H, q_dim] */
+    const void* post_norm;   /* [H] */
+    const void* gate_up;     /* [2*I, H] */
+    const void* down;        /* [H, I] */
+} fq3_layer_weights;
+
+typedef struct fq3_weight_table {
+    const fq3_layer_weights* talker_layers;     /* talker.n_layers entries (host array) */
+    const void* talker_final_norm;              /* [H] */
+    const void* codec_embedding;                /* [V, H]   talker.get_input_embeddings(), generate.py:100 */
+    const void* codec_head;                     /* [V, H]   generate.py:101 */
+    const fq3_layer_weights* predictor_layers;  /* predictor.n_layers entries */
+    const void* predictor_final_norm;           /* [Hp] */
+    const void* proj_w;                         /* [Hp, H] or NULL (identity)  predictor_graph.py:54 */
+    const void* proj_b;                         /* [Hp] or NULL */
+    const void* const* predictor_embeddings;    /* 15 x [Vp, H]   predictor_graph.py:57 */
+    const void* const* lm_heads;                /* 15 x [Vp, Hp]  predictor_graph.py:56 */
+    /* RoPE tables, fp32 values already rounded through T, [n_pos, head_dim/2] each.  Built by the
+     * host with the same torch ops as the upstream rotary module so they are bit-identical to it. */
+    const float* talker_cos;  const float* talker_sin;  int32_t talker_rope_len;
+    const float* pred_cos;    const float* pred_sin;    int32_t pred_rope_len;
+} fq3_weight_table;
+
+/* Sampling policy (sampling.py:32-41 keyword arguments + generate.py:26-30). */
+typedef struct fq3_sampling {
+    float temperature;
+    int32_t top_k;
+    float top_p;
+    int32_t do_sample;
+    float repetition_penalty;
+} fq3_sampling;
+
+typedef struct fq3_ctx fq3_ctx;
+
+const char* fq3_last_error(void);
+int fq3_abi_version(void);
+
+/* Replaces TalkerGraph.__init__ + PredictorGraph.__init__ (talker_graph.py:27-58,
+ * predictor_graph.py:34-76): allocates static KV caches, I/O buffers and scratch on the current device. */
+int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out);
+int fq3_ctx_destroy(fq3_ctx* ctx);
+
+/* Replaces the module references the graph objects keep (predictor_graph.py:52-58, talker_graph.py:40). */
+int fq3_bind_weights(fq3_ctx* ctx, const fq3_weight_table* table);
+
+/* ---- talker -------------------------------------------------------------------------------- */
+
+/* TalkerGraph.prefill_kv (talker_graph.py:153-170): copy one layer of an externally computed prefill
+ * cache, k and v laid out [n_kv_heads, L, head_dim] (the HF [1, kvh, L, d] tensor), into static slots
+ * [0, L).  FQ3_ETOOLONG if L > max_seq_len (the reference raises RuntimeError, :163-167). */
+int fq3_kv_import(fq3_ctx* ctx, int layer, const void* k, const void* v, int L, void* stream);
+/* Test hook: copy static KV slots [0, L) of one layer back out in the same layout. */
+int fq3_kv_export(fq3_ctx* ctx, int layer, void* k, void* v, int L, void* stream);
+
+/* TalkerGraph.set_generation_state (talker_graph.py:172-196): left-pad count of the prompt mask and
+ * the rope delta; replaces the 2048-row additive mask table with two integers. */
+int fq3_set_generation_state(fq3_ctx* ctx, int n_pad, int rope_delta);
+
+/* TalkerGraph.run (talker_graph.py:198-214): one token through all talker layers + final norm.
+ * embeds T[H]; position = static cache slot; out_hidden T[H] (post-norm). */
+int fq3_talker_step(fq3_ctx* ctx, const void* embeds, int position, void* out_hidden, void* stream);
+
+/* Prefill (generate.py:107-122): L prompt embeddings T[L,H] through the talker, KV written to slots
+ * [0,L); outputs last-position logits T[V] and post-norm hidden T[H].  n_pad = left padding. */
+int fq3_prefill(fq3_ctx* ctx, const void* embeds, int L, int n_pad, void* out_logits, void* out_hidden,
+                void* stream);
+
+/* talker.codec_head (generate.py:182): logits T[V] = codec_head(hidden T[H]) (hidden is post-norm). */
+int fq3_codec_head(fq3_ctx* ctx, const void* hidden, void* out_logits, void* stream);
+
+/* ---- predictor ----------------------------------------------------------------------------- */
+
+/* Construction-time predictor sampling policy (model.py:209-218, predictor_graph.py:47-50). */
+int fq3_set_predictor_sampling(fq3_ctx* ctx, const fq3_sampling* s);
+
+/* PredictorGraph.run (predictor_graph.py:204-214 = _full_loop :115-167): pred_input T[2,H_talker];
+ * noise T[15, Vp] of Exp(1) variates or NULL when greedy; out_ids int64[15]; optional out_logits
+ * T[15, Vp] (may be NULL) for parity tests. */
+int fq3_predictor_loop(fq3_ctx* ctx, const void* pred_input, const void* noise, int64_t* out_ids,
+                       void* out_logits, void* stream);
+
+/* ---- sampler ------------------------------------------------------------------------------- */
+
+/* sample_logits + apply_repetition_penalty (sampling.py:10-66): logits T[V] (not modified);
+ * history int64[n_hist] of previous first-codebook ids (may be NULL); suppress range [sup_lo, sup_hi)
+ * except keep_id (generate.py:46-50), plus eos when suppress_eos (generate.py:125,188);
+ * noise T[V] Exp(1) (NULL when !do_sample); out_token int64[1]. */
+int fq3_sample(fq3_ctx* ctx, const void* logits, int V, const fq3_sampling* s, const int64_t* history,
+               int n_hist, int sup_lo, int sup_hi, int keep_id, int suppress_eos, const void* noise,
+               int64_t* out_token, void* stream);
+
+/* ---- fused on-device decode loop (generate.py:149-199 / streaming.py:106-154) -------------- */
+
+typedef struct fq3_decode_params {
+    fq3_sampling talker;         /* per-call sampling arguments */
+    int32_t min_new_tokens;
+    int32_t max_new_tokens;
+    int32_t prefill_len;         /* talker_graph.prefill_kv return value */
+    int32_t gen_step;            /* out.generation_step of the prefill (generate.py:122) */
+    int32_t first_token;         /* token sampled from the prefill logits (generate.py:124-134) */
+    const void* past_hidden;     /* T[H]: out.past_hidden (generate.py:121) */
+    const void* trailing_text;   /* T[trailing_len, H] (generate.py:168-169) */
+    int32_t trailing_len;
+    const void* tts_pad_embed;   /* T[H] (generate.py:171) */
+    const void* talker_noise;    /* T[noise_frames, V] or NULL */
+    const void* pred_noise;      /* T[noise_frames, 15, Vp] or NULL */
+    int32_t noise_frames;        /* rows in the noise rings; frame f reads row f % noise_frames */
+} fq3_decode_params;
+
+/* Arms the on-device loop state (token, position, history bitmap, counters). */
+int fq3_decode_begin(fq3_ctx* ctx, const fq3_decode_params* p, void* stream);
+/* Enqueue n_frames iterations of the loop body; each is one hipGraph replay once
+ * fq3_graph_capture() has run (talker_graph.py:109-147, predictor_graph.py:169-202), otherwise the
+ * same kernels are launched directly.  Frames after EOS / limits are no-ops on device. */
+int fq3_decode_frames(fq3_ctx* ctx, int n_frames, void* stream);
+/* Synchronises the stream and reports: frames emitted so far, done flag; copies codes
+ * int64[n, 16] for frames [from, n_frames_total) into out_codes (host or device memory visible to host). */
+int fq3_decode_poll(fq3_ctx* ctx, int* n_frames_total, int* done, void* stream);
+int fq3_decode_codes(fq3_ctx* ctx, int from, int count, int64_t* out_codes_dev, void* stream);
+/* Capture the loop body into a hipGraph (no-op if already captured). */
+int fq3_graph_capture(fq3_ctx* ctx, void* stream);
+int fq3_graph_reset(fq3_ctx* ctx);
+
+/* ---- 12 Hz codec decoder (speech_tokenizer.decode, model.py:924) ---------------------------- */
+typedef struct fq3_codec fq3_codec;
+typedef struct fq3_codec_config {
+    int32_t dtype;
+    int32_t codebook_size, codebook_dim, rvq_dim, num_quantizers, num_semantic;
+    int32_t latent_dim, hidden, inter, n_layers, n_heads, head_dim, sliding_window;
+    float rms_eps;
+    int32_t n_upsample;  int32_t upsampling_ratios[4];
+    int32_t n_rates;     int32_t upsample_rates[8];
+    int32_t decoder_dim;
+    int32_t max_frames;
+} fq3_codec_config;
+int fq3_codec_create(const fq3_codec_config* cfg, fq3_codec** out);
+int fq3_codec_destroy(fq3_codec* c);
+/* name -> device pointer binding; names are the checkpoint tensor names under "decoder." */
+int fq3_codec_bind(fq3_codec* c, const char* name, const void* ptr, int64_t numel);
+int fq3_codec_finalize(fq3_codec* c, void* stream);
+/* number of PCM samples produced for T frames (the causal transposed convs trim, so < 1920*T) */
+int64_t fq3_codec_num_samples(const fq3_codec* c, int T);
+/* codes int64[T,16] (device) -> pcm float32[num_samples] (device), clamped to [-1,1]. */
+int fq3_codec_decode(fq3_codec* c, const int64_t* codes, int T, float* pcm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FQ3HIP_H */

@@ -250,6 +250,7 @@ def golden_decode(gen, stream):
             metas = [(t["chunk_index"], t["chunk_steps"], t["total_steps_so_far"], int(t["is_final"])) for _, t in chunks]
             out[f"codes_{tag}_{case}"] = ref_codes.numpy()
             out[f"margins_{tag}_{case}"] = np.array(orc2.margins, dtype=np.float32)
+            out[f"pred_margins_{tag}_{case}"] = np.array(orc2.pred_margins, dtype=np.float32).reshape(-1, 15)
             out[f"chunks_{tag}_{case}"] = np.array(metas, dtype=np.int64)
             out[f"params_{tag}_{case}"] = np.array([plen, tlen, maxnew, minnew, rp], dtype=np.float64)
             print(f"  decode {tag} case {case}: {ref_codes.shape[0]} frames, min margin {min(orc2.margins):.4g}, "

@@ -126,6 +126,9 @@ def stack_forward(W: Weights, prefix: str, c, x: torch.Tensor, start: int, cache
     qpos = torch.arange(start, start + n)[:, None]
     kpos = torch.arange(nk)[None, :]
     mask = (kpos <= qpos) & (kpos >= n_pad)
+    # left-pad query rows see no real key; let them see themselves so their (discarded, never attended)
+    # rows stay finite -- the additive finfo.min mask of the upstream eager path has the same effect
+    mask = mask | ((kpos == qpos) & (qpos < n_pad))
     if window is not None:
         mask = mask & (kpos > qpos - window)
     scale = d ** -0.5
@@ -245,7 +248,8 @@ class OracleTTS:
         self.rope_delta = 0.0
         # predictor sampling policy is construction-time state (model.py:209-218)
         self.pred_sampling = dict(do_sample=True, top_k=50, top_p=1.0, temperature=0.9)
-        self.margins: List[float] = []
+        self.margins: List[float] = []        # top-2 logit gap of every first-codebook decision
+        self.pred_margins: List[float] = []   # same for every predictor decision (15 per frame)
 
     # ---- talker ----------------------------------------------------------------------
     def prefill(self, embeds: torch.Tensor, attention_mask: torch.Tensor):
@@ -294,6 +298,7 @@ class OracleTTS:
         toks, all_logits = [], []
         logits = F.linear(h[-1:], self.W[f"{pre}.lm_head.0.weight"])       # [1, Vp]
         all_logits.append(logits[0])
+        self.pred_margins.append(self._margin(logits))
         tok = sample_logits(logits, noise=None if noise is None else noise[0], **self.pred_sampling)
         toks.append(tok[0])
         for cb in range(1, nc):
@@ -303,6 +308,7 @@ class OracleTTS:
                               torch.tensor([1.0 + cb]))
             logits = F.linear(h[-1:], self.W[f"{pre}.lm_head.{cb}.weight"])
             all_logits.append(logits[0])
+            self.pred_margins.append(self._margin(logits))
             tok = sample_logits(logits, noise=None if noise is None else noise[cb], **self.pred_sampling)
             toks.append(tok[0])
         out = torch.stack(toks).to(torch.long)
@@ -330,6 +336,7 @@ class OracleTTS:
         kw = dict(temperature=sp.temperature, top_k=sp.top_k, top_p=sp.top_p, do_sample=sp.do_sample)
         logits, past_hidden, gen_step, prefill_len = self.prefill(tie, tam)
         self.margins = []
+        self.pred_margins = []
         if record_margins:
             self._record_margin(logits, sm, [eos] if sp.min_new_tokens > 0 else None)
         token = sample_logits(logits.view(1, -1), suppress_mask=sm,
@@ -362,6 +369,11 @@ class OracleTTS:
             past_hidden = hidden.clone()
             gen_step += 1
         return torch.stack(codes) if codes else None
+
+    @staticmethod
+    def _margin(logits) -> float:
+        t = torch.topk(logits.detach().float().view(-1), 2)[0]
+        return float(t[0] - t[1])
 
     def _record_margin(self, logits, sm, sup):
         l = logits.detach().float().view(-1).clone()

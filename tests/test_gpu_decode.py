@@ -1,0 +1,259 @@
+"""GPU parity: the HIP decode path (through the C ABI) vs the CPU oracle and the golden vectors.
+
+Tolerances (stated per the north star): fp32 contexts must reproduce greedy RVQ ids bit-exactly and
+hidden states / logits to 2e-4 abs (fp32 summation-order noise only); bf16 contexts are checked to
+bf16 resolution (2 ulp of the tensor scale) and ids must match wherever the oracle's top-2 logit
+margin exceeds the bf16 noise floor.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fq3hip.config import tiny_test_config
+from fq3hip.weights import synth_weights, synth_prompt
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _engine(cfg, W, dtype, max_seq=96, max_frames=64):
+    from fq3hip.engine import Fq3Engine
+    return Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=max_seq, max_frames=max_frames)
+
+
+def _tol(dtype, scale):
+    return 2e-4 * max(1.0, scale) if dtype == torch.float32 else 0.025 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_prefill_and_steps_match_oracle(dtype):
+    from oracle import qwen3tts_oracle as O
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, dtype)
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, 70, 8, 0, dtype=dtype)     # > 64 keys: exercises two KV splits
+    tie = tie * 30                                                        # O(1) activations
+    orc = O.OracleTTS(cfg, W, max_seq_len=96)
+    o_logits, o_hidden, _, L = orc.prefill(tie, tam)
+    eng = _engine(cfg, W, dtype)
+    logits, hidden = eng.prefill(tie[0].cuda().contiguous())
+    torch.cuda.synchronize()
+    sc = float(o_hidden.float().abs().max())
+    assert (hidden.float().cpu() - o_hidden.float().view(-1)).abs().max() <= _tol(dtype, sc)
+    assert (logits.float().cpu() - o_logits.float().view(-1)).abs().max() <= _tol(dtype, float(o_logits.float().abs().max()))
+    g = torch.Generator().manual_seed(3)
+    for step in range(6):
+        x = torch.randn(1, 1, cfg.talker.hidden_size, generator=g).to(dtype)
+        oh = orc.talker_step(x, L + step)
+        gh = eng.talker_step(x.view(-1).cuda(), L + step)
+        torch.cuda.synchronize()
+        assert (gh.float().cpu() - oh.float().view(-1)).abs().max() <= _tol(dtype, float(oh.float().abs().max()))
+    # KV cache contents (post norm + RoPE) of layer 0
+    k, v = eng.kv_export(0, L + 6)
+    ok = orc.tcache.k[0][:L + 6].permute(1, 0, 2)
+    ov = orc.tcache.v[0][:L + 6].permute(1, 0, 2)
+    assert (k.float().cpu() - ok.float()).abs().max() <= _tol(dtype, float(ok.float().abs().max()))
+    assert (v.float().cpu() - ov.float()).abs().max() <= _tol(dtype, float(ov.float().abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_left_padded_prompt(dtype):
+    from oracle import qwen3tts_oracle as O
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, dtype)
+    tie, tam, _, _, _ = synth_prompt(cfg, 24, 8, 0, dtype=dtype)
+    tie = tie * 30
+    tam[0, :5] = 0
+    orc = O.OracleTTS(cfg, W, max_seq_len=96)
+    o_logits, o_hidden, _, L = orc.prefill(tie, tam)
+    eng = _engine(cfg, W, dtype)
+    logits, hidden = eng.prefill(tie[0].cuda().contiguous(), n_pad=5)
+    assert (hidden.float().cpu() - o_hidden.float().view(-1)).abs().max() <= _tol(dtype, float(o_hidden.float().abs().max()))
+    x = torch.randn(1, 1, cfg.talker.hidden_size).to(dtype)
+    oh = orc.talker_step(x, L)
+    gh = eng.talker_step(x.view(-1).cuda(), L)
+    assert (gh.float().cpu() - oh.float().view(-1)).abs().max() <= _tol(dtype, float(oh.float().abs().max()))
+
+
+def test_stack_matches_transformers_sibling(golden_dir):
+    """HIP layer stack vs vectors produced by transformers' Qwen3OmniMoeTalkerCodePredictorModel
+    (oracle/make_golden.py: stack.npz).  The predictor weights are loaded as a 'talker' so that the
+    plain step API exposes the stack output."""
+    import copy
+    g = np.load(os.path.join(golden_dir, "stack.npz"))
+    cfg = tiny_test_config()
+    for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        W = synth_weights(cfg, 0, dtype)
+        c2 = copy.deepcopy(cfg)
+        c2.talker = copy.deepcopy(cfg.predictor)
+        c2.talker.vocab_size = cfg.talker.vocab_size
+        W2 = dict(W)
+        for k, v in W.items():
+            if k.startswith("talker.code_predictor.model.layers") or k == "talker.code_predictor.model.norm.weight":
+                W2[k.replace("talker.code_predictor.model", "talker.model")] = v
+        eng = _engine(c2, W2, dtype, max_seq=32)
+        x = torch.from_numpy(g[f"x_{tag}"]).to(dtype).cuda()
+        y = torch.from_numpy(g[f"y_{tag}"])
+        for i in range(x.shape[0]):
+            h = eng.talker_step(x[i].contiguous(), i)
+            tol = 2e-4 * float(y.abs().max()) if dtype == torch.float32 else 0.1
+            assert (h.float().cpu() - y[i]).abs().max() <= tol, (tag, i)
+
+
+def test_sampler_golden(golden_dir):
+    """fq3_sample vs reference sampling.py outputs (sampler.npz)."""
+    g = np.load(os.path.join(golden_dir, "sampler.npz"), allow_pickle=True)
+    cfg = tiny_test_config()
+    engines = {}
+    n_ref_same = 0
+    for case in g["cases"]:
+        dtype = torch.bfloat16 if case["bf16"] else torch.float32
+        if dtype not in engines:
+            engines[dtype] = _engine(cfg, synth_weights(cfg, 0, dtype), dtype)
+        eng = engines[dtype]
+        eng.lib  # noqa
+        V = int(case["V"])
+        logits = torch.from_numpy(case["logits"]).to(dtype).cuda()
+        noise = torch.from_numpy(case["noise"]).to(dtype).cuda()
+        # the context eos id is fixed at creation; emulate suppress_tokens=[eos] through keep_id
+        keep = int(case["eos"]) if not case["sup_eos"] else -1
+        tok = eng.sample(logits, temperature=float(case["temperature"]), top_k=int(case["top_k"]),
+                         top_p=float(case["top_p"]), do_sample=bool(case["do_sample"]), sup_lo=max(0, V - 1024),
+                         sup_hi=V, keep_id=keep, noise=noise)
+        assert int(tok) == int(case["token"]), {k: case[k] for k in ("V", "bf16", "temperature", "top_k", "top_p", "do_sample")}
+        n_ref_same += int(tok) == int(case["ref_token"])
+    assert n_ref_same >= len(g["cases"]) - 8     # only nucleus cuts through exact ties may differ (unstable sort)
+    for case in g["penalty"]:
+        dtype = torch.bfloat16 if case["bf16"] else torch.float32
+        eng = engines[dtype]
+        logits = torch.from_numpy(case["logits"]).to(dtype)
+        out = torch.from_numpy(case["out"]).to(dtype)
+        hist = torch.from_numpy(case["hist"])
+        # greedy over penalised logits must pick the argmax of the reference's penalised vector
+        tok = eng.sample(logits.cuda(), temperature=1.0, top_k=0, top_p=1.0, do_sample=False,
+                         repetition_penalty=float(case["p"]), history=hist.cuda())
+        assert int(tok) == int(torch.argmax(out.float()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_predictor_loop_matches_oracle(dtype):
+    from oracle import qwen3tts_oracle as O
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, dtype)
+    orc = O.OracleTTS(cfg, W, max_seq_len=96)
+    orc.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    eng = _engine(cfg, W, dtype)
+    eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    g = torch.Generator().manual_seed(9)
+    for trial in range(3):
+        x = torch.randn(1, 2, cfg.talker.hidden_size, generator=g).to(dtype)
+        o_ids, o_logits = orc.predictor_loop(x, return_logits=True)
+        ids, lg = eng.predictor_loop(x.view(-1).cuda(), want_logits=True)
+        torch.cuda.synchronize()
+        if dtype == torch.float32:
+            assert torch.equal(ids.cpu(), o_ids)
+            assert (lg.float().cpu() - o_logits.float()).abs().max() <= 5e-4
+        else:
+            # teacher-forcing is implicit while ids agree; compare logits of the first pass always
+            assert (lg[0].float().cpu() - o_logits[0].float()).abs().max() <= 0.15
+    # sampled predictor: same noise -> same ids (fp32)
+    if dtype == torch.float32:
+        sp = dict(do_sample=True, top_k=50, top_p=1.0, temperature=0.9)
+        orc.pred_sampling = sp
+        eng.set_predictor_sampling(**sp)
+        x = torch.randn(1, 2, cfg.talker.hidden_size, generator=g).to(dtype)
+        noise = torch.empty(cfg.num_code_groups - 1, cfg.predictor.vocab_size).exponential_(1, generator=g)
+        o_ids = orc.predictor_loop(x, noise=noise)
+        ids = eng.predictor_loop(x.view(-1).cuda(), noise=noise.cuda())
+        assert torch.equal(ids.cpu(), o_ids)
+
+
+def _run_loop(eng, cfg, dtype, tie, tam, tth, tpe, *, max_new, min_new, rp, graph, sampling=None, talker_noise=None,
+              pred_noise=None, first_noise=None, chunk=8):
+    kw = sampling or dict(temperature=1.0, top_k=0, top_p=1.0, do_sample=False)
+    logits, hidden = eng.prefill(tie[0].cuda().contiguous())
+    V = cfg.talker.vocab_size
+    tok = eng.sample(logits, sup_lo=max(0, V - 1024), sup_hi=V, keep_id=cfg.codec_eos_token_id,
+                     suppress_eos=min_new > 0, noise=first_noise, **kw)
+    nf = talker_noise.shape[0] if talker_noise is not None else 0
+    eng.decode_begin(first_token=int(tok), prefill_len=tie.shape[1], gen_step=0, past_hidden=hidden,
+                     trailing_text=tth[0].cuda().contiguous(), tts_pad_embed=tpe.view(-1).cuda().contiguous(),
+                     repetition_penalty=rp, min_new_tokens=min_new, max_new_tokens=max_new,
+                     talker_noise=talker_noise, pred_noise=pred_noise, noise_frames=nf, **kw)
+    if graph:
+        eng.graph_capture()
+    else:
+        eng.graph_reset()
+    done, n = False, 0
+    issued = 0
+    while not done and issued < max_new:
+        k = min(chunk, max_new - issued)
+        eng.decode_frames(k)
+        issued += k
+        n, done = eng.decode_poll()
+    return eng.decode_codes(0, n).cpu()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_loop_matches_reference_golden(dtype, graph, golden_dir):
+    """On-device loop (direct launches and hipGraph replay) vs codes produced by the REFERENCE
+    fast_generate over the oracle's layers (decode.npz)."""
+    g = np.load(os.path.join(golden_dir, "decode.npz"))
+    cfg = tiny_test_config()
+    tag = "f32" if dtype == torch.float32 else "bf16"
+    W = synth_weights(cfg, 0, dtype)
+    eng = _engine(cfg, W, dtype)
+    eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    for case in range(3):
+        plen, tlen, maxnew, minnew, rp = g[f"params_{tag}_{case}"]
+        tie, tam, tth, tpe, _ = synth_prompt(cfg, int(plen), int(tlen), 0, dtype=dtype)
+        ref = torch.from_numpy(g[f"codes_{tag}_{case}"])
+        codes = _run_loop(eng, cfg, dtype, tie, tam, tth, tpe, max_new=int(maxnew), min_new=int(minnew), rp=float(rp),
+                          graph=graph)
+        if dtype == torch.float32:
+            assert codes.shape == ref.shape and torch.equal(codes, ref), (case, graph)
+        else:
+            # bf16: ids must agree until the first frame whose oracle top-2 margin is inside bf16 noise
+            margins = g[f"margins_{tag}_{case}"]          # talker decisions: [prefill, frame0, frame1, ...]
+            pmargins = g[f"pred_margins_{tag}_{case}"]    # predictor decisions [frame, 15]
+            n = min(codes.shape[0], ref.shape[0])
+            same = (codes[:n] == ref[:n]).all(dim=1)
+            first_bad = int((~same).nonzero()[0]) if (~same).any() else n
+            if first_bad < n:
+                near_tie = min(margins[: first_bad + 1].min(), pmargins[: first_bad + 1].min())
+                assert near_tie < 0.25, (case, first_bad, near_tie)
+
+
+def test_fused_loop_sampled_matches_oracle():
+    """Default product sampling (T=0.9, top-k 50, rep 1.05, min_new 2) with shared Exp(1) noise, fp32."""
+    from oracle import qwen3tts_oracle as O
+    cfg = tiny_test_config()
+    dtype = torch.float32
+    W = synth_weights(cfg, 0, dtype)
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, 18, 6, 0, dtype=dtype)
+    max_new = 20
+    g = torch.Generator().manual_seed(21)
+    tn = torch.empty(max_new + 1, cfg.talker.vocab_size).exponential_(1, generator=g)
+    pn = torch.empty(max_new, cfg.num_code_groups - 1, cfg.predictor.vocab_size).exponential_(1, generator=g)
+    orc = O.OracleTTS(cfg, W, max_seq_len=96)
+    sp = O.SamplingParams(max_new_tokens=max_new)
+    ref = orc.generate(tie, tam, tth, tpe, sp, talker_noise=tn, pred_noise=pn)
+    eng = _engine(cfg, W, dtype)
+    eng.set_predictor_sampling(do_sample=True, top_k=50, top_p=1.0, temperature=0.9)
+    codes = _run_loop(eng, cfg, dtype, tie, tam, tth, tpe, max_new=max_new, min_new=2, rp=1.05, graph=True,
+                      sampling=dict(temperature=0.9, top_k=50, top_p=1.0, do_sample=True),
+                      talker_noise=tn[1:].contiguous().cuda(), pred_noise=pn.contiguous().cuda(),
+                      first_noise=tn[0].contiguous().cuda())
+    assert ref is not None and codes.shape == ref.shape and torch.equal(codes, ref)
+
+
+def test_too_long_prompt_raises():
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, torch.bfloat16)
+    eng = _engine(cfg, W, torch.bfloat16, max_seq=32)
+    x = torch.zeros(40, cfg.talker.hidden_size, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="Input is too long"):
+        eng.prefill(x)
