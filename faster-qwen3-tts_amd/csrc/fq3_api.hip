@@ -18,6 +18,7 @@ static int fail(int code, const std::string& m) { g_err = m; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(FQ3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 extern "C" const char* fq3_last_error(void) { return g_err.c_str(); }
+extern "C" void fq3_set_error_(const char* msg) { g_err = msg ? msg : ""; }   // used by the codec TU
 extern "C" int fq3_abi_version(void) { return FQ3_ABI_VERSION; }
 
 struct StackBufs {

@@ -1,0 +1,131 @@
+"""HIP 12 Hz codec decoder behind the upstream ``speech_tokenizer`` duck type.
+
+The reference calls ``speech_tokenizer.decode({"audio_codes": LongTensor[B, T, 16]}) ->
+(list[1-D float waveform], sample_rate)`` (``faster_qwen3_tts/model.py:924``; payload shape pinned by the
+reference's ``tests/test_sample_rate.py:53-75``) and reads ``.sample_rate``.  This class keeps that
+surface and runs the whole decoder in ``libfq3hip.so``; weights are re-laid-out once at load time
+into the GEMM-ready layouts documented in ``csrc/fq3_codec.hip``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List
+
+import torch
+
+from . import _lib as L
+from .config import CodecConfig
+from .engine import rope_tables
+
+Weights = Dict[str, torch.Tensor]
+
+
+def pack_codec_weights(W: Weights, c: CodecConfig) -> Weights:
+    """checkpoint layout -> kernel layout (host glue, runs once)."""
+    out: Weights = {}
+    p = "decoder"
+    conv = lambda w: w.permute(0, 2, 1).contiguous()                      # [Cout, Cin, k] -> [Cout, k, Cin]
+
+    def convT(w, s):                                                      # [Cin, Cout, k] -> [q*Cout+co, tap, Cin]
+        cin, cout, k = w.shape
+        taps = k // s
+        w5 = w.reshape(cin, cout, taps, s)                                # k = tap*s + q
+        return w5.permute(3, 1, 2, 0).reshape(s * cout, taps, cin).contiguous()
+
+    for k, v in W.items():
+        if not k.startswith(p + "."):
+            continue
+        out[k] = v
+    out[f"{p}.pre_conv.conv.weight"] = conv(W[f"{p}.pre_conv.conv.weight"])
+    for name in ("rvq_first", "rvq_rest"):
+        out[f"{p}.quantizer.{name}.output_proj.weight"] = W[f"{p}.quantizer.{name}.output_proj.weight"].squeeze(-1).contiguous()
+    t = f"{p}.pre_transformer"
+    for i in range(c.num_hidden_layers):
+        q = f"{t}.layers.{i}"
+        out[f"{q}.self_attn.qkv.weight"] = torch.cat([W[f"{q}.self_attn.q_proj.weight"], W[f"{q}.self_attn.k_proj.weight"],
+                                                      W[f"{q}.self_attn.v_proj.weight"]], 0).contiguous()
+        out[f"{q}.mlp.gate_up.weight"] = torch.cat([W[f"{q}.mlp.gate_proj.weight"], W[f"{q}.mlp.up_proj.weight"]], 0).contiguous()
+    for i, f in enumerate(c.upsampling_ratios):
+        u = f"{p}.upsample.{i}"
+        out[f"{u}.0.conv.weight"] = convT(W[f"{u}.0.conv.weight"], f)
+        out[f"{u}.1.dwconv.conv.weight"] = W[f"{u}.1.dwconv.conv.weight"].reshape(-1, 7).contiguous()
+    d = f"{p}.decoder"
+    out[f"{d}.0.conv.weight"] = conv(W[f"{d}.0.conv.weight"])
+    for i, r in enumerate(c.upsample_rates):
+        b = f"{d}.{i + 1}.block"
+        out[f"{b}.1.conv.weight"] = convT(W[f"{b}.1.conv.weight"], r)
+        for j in (2, 3, 4):
+            out[f"{b}.{j}.conv1.conv.weight"] = conv(W[f"{b}.{j}.conv1.conv.weight"])
+            out[f"{b}.{j}.conv2.conv.weight"] = conv(W[f"{b}.{j}.conv2.conv.weight"])
+    n = len(c.upsample_rates)
+    out[f"{d}.{n + 2}.conv.weight"] = W[f"{d}.{n + 2}.conv.weight"][0].transpose(0, 1).contiguous()   # [C,7] -> [7,C]
+    return out
+
+
+class HipSpeechTokenizer:
+    """``speech_tokenizer`` replacement whose ``decode`` runs on the HIP codec kernels."""
+
+    def __init__(self, cfg: CodecConfig, weights: Weights, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
+                 max_frames: int = 1024):
+        self.lib = L.load()
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.sample_rate = int(cfg.sample_rate)
+        self.max_frames = int(max_frames)
+        cc = L.CodecConfig()
+        cc.dtype = L.FQ3_BF16 if dtype == torch.bfloat16 else L.FQ3_F32
+        cc.codebook_size, cc.codebook_dim, cc.rvq_dim = cfg.codebook_size, cfg.codebook_dim, cfg.rvq_dim
+        cc.num_quantizers, cc.num_semantic = cfg.num_quantizers, cfg.num_semantic_quantizers
+        cc.latent_dim, cc.hidden, cc.inter = cfg.latent_dim, cfg.hidden_size, cfg.intermediate_size
+        cc.n_layers, cc.n_heads, cc.head_dim = cfg.num_hidden_layers, cfg.num_attention_heads, cfg.head_dim
+        cc.sliding_window, cc.rms_eps = cfg.sliding_window, cfg.rms_norm_eps
+        cc.n_upsample = len(cfg.upsampling_ratios)
+        for i, v in enumerate(cfg.upsampling_ratios):
+            cc.upsampling_ratios[i] = v
+        cc.n_rates = len(cfg.upsample_rates)
+        for i, v in enumerate(cfg.upsample_rates):
+            cc.upsample_rates[i] = v
+        cc.decoder_dim, cc.max_frames = cfg.decoder_dim, self.max_frames
+        self.h = L.vp()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.fq3_codec_create(C.byref(cc), C.byref(self.h)))
+        self._keep: List[torch.Tensor] = []
+        packed = pack_codec_weights(weights, cfg)
+        for name, t in packed.items():
+            t = t.to(device=self.device, dtype=dtype).contiguous()
+            self._keep.append(t)
+            L.check(self.lib.fq3_codec_bind(self.h, name.encode(), t.data_ptr(), t.numel()))
+        cs, sn = rope_tables(cfg.head_dim, cfg.rope_theta, self.max_frames, dtype)
+        for name, t in (("rope.cos", cs), ("rope.sin", sn)):
+            t = t.to(self.device).contiguous()
+            self._keep.append(t)
+            L.check(self.lib.fq3_codec_bind(self.h, name.encode(), t.data_ptr(), t.numel()))
+        L.check(self.lib.fq3_codec_finalize(self.h, None))
+
+    def num_samples(self, n_frames: int) -> int:
+        return int(self.lib.fq3_codec_num_samples(self.h, int(n_frames)))
+
+    def decode_tensor(self, codes: torch.Tensor) -> torch.Tensor:
+        """codes LongTensor[T, 16] -> float32 waveform tensor on the device."""
+        codes = codes.to(device=self.device, dtype=torch.long).contiguous()
+        Tn = codes.shape[0]
+        pcm = torch.empty(self.num_samples(Tn), dtype=torch.float32, device=self.device)
+        L.check(self.lib.fq3_codec_decode(self.h, codes.data_ptr(), int(Tn), pcm.data_ptr(),
+                                          torch.cuda.current_stream(self.device).cuda_stream))
+        return pcm
+
+    def decode(self, payload):
+        codes = payload["audio_codes"]
+        if codes.dim() != 3:
+            raise ValueError("audio_codes must be [B, T, num_quantizers]")
+        return [self.decode_tensor(codes[b]) for b in range(codes.shape[0])], self.sample_rate
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.fq3_codec_destroy(self.h)
+            self.h = L.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

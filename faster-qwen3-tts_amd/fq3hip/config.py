@@ -136,7 +136,7 @@ def tiny_test_config(hidden: int = 256, layers: int = 2, pred_layers: int = 2,
                               num_attention_heads=heads, num_key_value_heads=kv_heads, vocab_size=256),
         codec=CodecConfig(codebook_size=256, codebook_dim=64, rvq_dim=32, latent_dim=128, hidden_size=64,
                           intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, head_dim=32,
-                          sliding_window=8, decoder_dim=192),
+                          sliding_window=8, decoder_dim=512),
         codec_eos_token_id=vocab - 1024 + 102,
         codec_pad_id=vocab - 1024 + 100, codec_bos_id=vocab - 1024 + 101,
         codec_think_id=vocab - 1024 + 106, codec_nothink_id=vocab - 1024 + 107,
