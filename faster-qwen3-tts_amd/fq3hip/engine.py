@@ -61,6 +61,31 @@ class Fq3Engine:
         self.weights = weights
         self._pred_sampling = dict(do_sample=True, top_k=50, top_p=1.0, temperature=0.9)
 
+    @classmethod
+    def sampler_only(cls, device, dtype: torch.dtype) -> "Fq3Engine":
+        """Weight-less context (minimal dims) for callers that only need ``sample`` (fq3hip.sampling)."""
+        from .config import StackConfig
+        self = cls.__new__(cls)
+        self.lib = L.load()
+        self.cfg = TTSConfig(talker=StackConfig(hidden_size=64, intermediate_size=64, num_hidden_layers=1,
+                                                num_attention_heads=1, num_key_value_heads=1, vocab_size=4096),
+                             predictor=StackConfig(hidden_size=64, intermediate_size=64, num_hidden_layers=1,
+                                                   num_attention_heads=1, num_key_value_heads=1, vocab_size=4096),
+                             codec_eos_token_id=-1)
+        self.dtype, self.max_seq_len, self.max_frames = dtype, 8, 8
+        self.device = torch.device(device)
+        self._keep, self.weights = [], {}
+        self.ctx = L.vp()
+        c = L.Config()
+        c.dtype = L.FQ3_BF16 if dtype == torch.bfloat16 else L.FQ3_F32
+        for dst in (c.talker, c.predictor):
+            dst.hidden, dst.inter, dst.n_layers, dst.n_heads, dst.n_kv_heads, dst.head_dim = 64, 64, 1, 1, 1, 128
+            dst.vocab, dst.rms_eps = 4096, 1e-6
+        c.num_code_groups, c.max_seq_len, c.codec_eos_token_id, c.has_projection, c.max_frames = 16, 8, -1, 0, 8
+        with torch.cuda.device(self.device):
+            L.check(self.lib.fq3_ctx_create(C.byref(c), C.byref(self.ctx)))
+        return self
+
     # ------------------------------------------------------------------------------------------
     def _dev(self, t: torch.Tensor) -> torch.Tensor:
         t = t.to(device=self.device, dtype=self.dtype).contiguous()

@@ -1,0 +1,543 @@
+"""``FasterQwen3TTS``: the reference's public API (``faster_qwen3_tts/model.py``) over the MI355X HIP path.
+
+Same constructor arguments, method names, argument order, defaults, return types and error
+behaviour as the reference wrapper (pinned there by ``tests/test_voice_clone_prompt_api.py`` and
+``tests/test_sample_rate.py``; mirrored here by ``tests/test_api_contract.py``), so callers switch by
+changing the import.  What changed underneath: ``predictor_graph`` / ``talker_graph`` are HIP-backed
+objects sharing one ``libfq3hip`` context, ``speech_tokenizer`` is the HIP codec decoder, and the
+decode loop state lives on the GPU.
+"""
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+from typing import Any, Dict, Generator, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+logger = logging.getLogger(__name__)
+
+_GGML_ONLY = ("ref_spk", "ref_rvq", "ref_spk_emb", "ref_codes")
+
+
+def _to_numpy(a) -> np.ndarray:
+    if hasattr(a, "cpu"):
+        return a.flatten().float().cpu().numpy()
+    return a.flatten() if hasattr(a, "flatten") else a
+
+
+class FasterQwen3TTS:
+    """Qwen3-TTS with a hipGraph-captured, hand-written HIP decode path (drop-in for the CUDA-graph wrapper)."""
+
+    def __init__(self, base_model, predictor_graph, talker_graph, device: str = "cuda",
+                 dtype: torch.dtype = torch.bfloat16, max_seq_len: int = 2048):
+        self.model = base_model
+        self.predictor_graph = predictor_graph
+        self.talker_graph = talker_graph
+        self.device = device
+        self.dtype = dtype
+        self.max_seq_len = max_seq_len
+        self.sample_rate = self._infer_sample_rate(base_model)
+        self._warmed_up = False
+        self._voice_prompt_cache: Dict[Any, Any] = {}
+
+    # ---- small helpers pinned by the reference's unit tests ------------------------------------------------
+    @staticmethod
+    def _get_speech_tokenizer(base_model):
+        return getattr(getattr(base_model, "model", None), "speech_tokenizer", None)
+
+    @property
+    def speech_tokenizer(self):
+        tok = self._get_speech_tokenizer(self.model)
+        if tok is None:
+            raise AttributeError("Underlying model does not expose a speech_tokenizer")
+        return tok
+
+    @staticmethod
+    def _infer_sample_rate(base_model) -> int:
+        """speech_tokenizer.sample_rate, then base_model.sample_rate, then 24000 (model.py:59-84)."""
+        rate = None
+        tok = FasterQwen3TTS._get_speech_tokenizer(base_model)
+        if tok is not None:
+            rate = getattr(tok, "sample_rate", None)
+        if rate is None:
+            rate = getattr(base_model, "sample_rate", None)
+        if rate is None:
+            logger.warning("Could not infer sample rate from base model; defaulting to 24000 Hz.")
+            return 24000
+        return int(rate)
+
+    @staticmethod
+    def _resolve_non_streaming_mode(non_streaming_mode: Optional[bool], *, default: bool) -> bool:
+        return default if non_streaming_mode is None else non_streaming_mode
+
+    @staticmethod
+    def _reject_ggml_cached_reference_args(ref_spk=None, ref_rvq=None, ref_spk_emb=None, ref_codes=None) -> None:
+        if any(v is not None for v in (ref_spk, ref_rvq, ref_spk_emb, ref_codes)):
+            raise NotImplementedError(
+                "ref_spk/ref_rvq cached qwentts.cpp references require backend='ggml'. "
+                "Use voice_clone_prompt for precomputed prompts with the torch backend.")
+
+    # ---- construction ---------------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, model_name: str, device: str = "cuda", dtype: Union[str, torch.dtype] = torch.bfloat16,
+                        attn_implementation: str = "sdpa", max_seq_len: int = 2048, backend: str = "torch",
+                        quant: str = "BF16", gguf_talker_path: Optional[Union[str, Path]] = None,
+                        gguf_codec_path: Optional[Union[str, Path]] = None,
+                        qwentts_library_path: Optional[Union[str, Path]] = None, qwentts_use_fa: bool = True,
+                        qwentts_clamp_fp16: bool = False, qwentts_ref_cache_dir: Optional[Union[str, Path]] = None,
+                        cache_dir: Optional[Union[str, Path]] = None, local_files_only: bool = False):
+        """Load a local Qwen3-TTS checkpoint directory and build the HIP decode context.
+
+        ``backend`` keeps the reference's vocabulary: ``"torch"`` (the default) selects the graph-captured
+        fast path -- here the HIP one; ``"ggml"``/``"qwentts"`` name the external qwentts.cpp runtime, which
+        has no ROCm build in this repository.  ``attn_implementation`` is accepted for compatibility (the
+        HIP attention kernel is the only implementation)."""
+        if backend not in ("torch", "ggml", "qwentts"):
+            raise ValueError(f"Unsupported backend {backend!r}. Expected 'torch', 'ggml', or 'qwentts'.")
+        if backend in ("ggml", "qwentts"):
+            raise NotImplementedError("the qwentts.cpp (GGML) backend is not part of the MI355X build; use backend='torch'")
+        if isinstance(dtype, str):
+            dtype = getattr(torch, dtype)
+        if not device.startswith("cuda") or not torch.cuda.is_available():
+            raise ValueError("CUDA graphs require CUDA device")       # same message as the reference (model.py:181-182)
+        from .weights import load_hf_checkpoint
+        import os
+        path = str(model_name)
+        if not os.path.isdir(path):
+            raise FileNotFoundError(
+                f"{model_name!r} is not a local checkpoint directory; this build has no network access "
+                "(HF_HUB_OFFLINE) -- download the model and pass its path.")
+        cfg, weights = load_hf_checkpoint(path, dtype=dtype, device="cpu")
+        tokenizer = None
+        try:
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(path, local_files_only=True)
+        except Exception as e:      # tokenizer files are optional for code-only workflows
+            logger.warning("no text tokenizer loaded from %s (%s)", path, e)
+        return cls.from_weights(cfg, weights, device=device, dtype=dtype, max_seq_len=max_seq_len, tokenizer=tokenizer)
+
+    @classmethod
+    def from_weights(cls, cfg, weights, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
+                     max_seq_len: int = 2048, tokenizer=None, codec_max_frames: int = 1024, max_frames: int = 2048):
+        """Build from an in-memory weight table (real or seeded synthetic, ``fq3hip.weights``)."""
+        if not str(device).startswith("cuda") or not torch.cuda.is_available():
+            raise ValueError("CUDA graphs require CUDA device")
+        from .native_model import NativeQwen3TTS
+        from .predictor_graph import PredictorGraph
+        from .talker_graph import TalkerGraph
+        base = NativeQwen3TTS(cfg, weights, device=device, dtype=dtype, max_seq_len=max_seq_len, tokenizer=tokenizer,
+                              codec_max_frames=codec_max_frames, max_frames=max_frames)
+        pg = PredictorGraph(base.engine, do_sample=True, top_k=50, temperature=0.9)      # model.py:209-218
+        tg = TalkerGraph(base.engine)
+        return cls(base_model=base, predictor_graph=pg, talker_graph=tg, device=device, dtype=dtype,
+                   max_seq_len=max_seq_len)
+
+    def warmup(self, prefill_len: int = 100) -> None:
+        """Capture the decode hipGraph once (idempotent, model.py:239-252)."""
+        if self._warmed_up:
+            return
+        self.predictor_graph.capture(num_warmup=3)
+        self.talker_graph.capture(prefill_len=prefill_len, num_warmup=3)
+        self._warmed_up = True
+
+    def _warmup(self, prefill_len: int) -> None:
+        self.warmup(prefill_len=prefill_len)
+
+    def generate(self, text: str, language: str = "English", max_new_tokens: int = 2048, temperature: float = 0.9,
+                 top_k: int = 50, do_sample: bool = True, repetition_penalty: float = 1.05) -> Tuple[list, int]:
+        raise NotImplementedError("Default voice generation not yet implemented. "
+                                  "Use generate_voice_clone() with reference audio.")
+
+    # ---- voice-clone prompt resolution (model.py:295-463) -------------------------------------------------------
+    def _resolve_voice_clone_prompt(self, input_ids, ref_audio, ref_text: str, xvec_only: bool, append_silence: bool,
+                                    voice_clone_prompt):
+        if voice_clone_prompt is not None:
+            return self._resolve_precomputed_voice_clone_prompt(input_ids=input_ids, ref_text=ref_text,
+                                                                voice_clone_prompt=voice_clone_prompt)
+        if ref_audio is None:
+            raise ValueError("ref_audio is required when voice_clone_prompt is not provided")
+        return self._resolve_voice_clone_prompt_from_reference(input_ids=input_ids, ref_audio=ref_audio,
+                                                               ref_text=ref_text, xvec_only=xvec_only,
+                                                               append_silence=append_silence)
+
+    def _ref_ids(self, text: str):
+        return self.model._tokenize_texts([self.model._build_ref_text(text)])[0]
+
+    def _resolve_precomputed_voice_clone_prompt(self, input_ids, ref_text: str, voice_clone_prompt):
+        n = len(input_ids)
+        if isinstance(voice_clone_prompt, list):
+            if len(voice_clone_prompt) != n:
+                raise ValueError(f"voice_clone_prompt must have length {n}, got {len(voice_clone_prompt)}")
+            vcp = self.model._prompt_items_to_voice_clone_prompt(voice_clone_prompt)
+            ref_ids = []
+            for item in voice_clone_prompt:
+                if bool(item.icl_mode):
+                    text = item.ref_text if item.ref_text else ref_text
+                    if not text:
+                        raise ValueError("ref_text is required when voice_clone_prompt uses ICL mode.")
+                    ref_ids.append(self._ref_ids(text))
+                else:
+                    ref_ids.append(None)
+            return vcp, ref_ids, any(vcp["icl_mode"])
+        missing = [k for k in ("ref_spk_embedding",) if k not in voice_clone_prompt]
+        if missing:
+            raise ValueError(f"voice_clone_prompt missing required keys: {missing}. Expected keys: ['ref_spk_embedding']")
+        for key in ("ref_spk_embedding", "x_vector_only_mode", "icl_mode", "ref_code"):
+            if key in voice_clone_prompt:
+                v = voice_clone_prompt[key]
+                if not isinstance(v, list) or len(v) != n:
+                    raise ValueError(f"voice_clone_prompt[{key!r}] must be a list with length {n}")
+        xvec = voice_clone_prompt.get("x_vector_only_mode", [True] * n)
+        if "icl_mode" in voice_clone_prompt:
+            icl = [bool(v) for v in voice_clone_prompt["icl_mode"]]
+            for i, (a, b) in enumerate(zip(xvec, icl)):
+                if bool(a) == bool(b):
+                    raise ValueError(f"voice_clone_prompt has inconsistent mode flags at index {i}: "
+                                     "x_vector_only_mode and icl_mode must be opposites")
+        else:
+            icl = [not bool(v) for v in xvec]
+        codes = voice_clone_prompt.get("ref_code", [None] * n)
+        for i, (a, b, c) in enumerate(zip(xvec, icl, codes)):
+            if bool(a) and c is not None:
+                raise ValueError(f"voice_clone_prompt index {i}: ref_code must be None in x_vector_only mode")
+            if bool(b) and c is None:
+                raise ValueError(f"voice_clone_prompt index {i}: ref_code is required in ICL mode")
+        vcp = dict(ref_code=codes, ref_spk_embedding=voice_clone_prompt["ref_spk_embedding"],
+                   x_vector_only_mode=[bool(v) for v in xvec], icl_mode=[bool(v) for v in icl])
+        using_icl = any(vcp["icl_mode"])
+        if using_icl:
+            if not ref_text:
+                raise ValueError("ref_text is required when voice_clone_prompt uses ICL mode.")
+            rid = self._ref_ids(ref_text)
+            ref_ids = [rid if f else None for f in vcp["icl_mode"]]
+        else:
+            ref_ids = [None] * n
+        return vcp, ref_ids, using_icl
+
+    def _load_ref_audio_with_silence(self, ref_audio, silence_secs: float = 0.5):
+        """model.py:278-293 (needs ``soundfile``; only reached when raw reference audio is analysed)."""
+        import soundfile as sf
+        audio, sr = sf.read(str(ref_audio), dtype="float32", always_2d=False)
+        if audio.ndim > 1:
+            audio = audio.mean(axis=1)
+        if silence_secs > 0:
+            audio = np.concatenate([audio, np.zeros(int(silence_secs * sr), dtype=np.float32)])
+        return audio, sr
+
+    def _resolve_voice_clone_prompt_from_reference(self, input_ids, ref_audio, ref_text: str, xvec_only: bool,
+                                                   append_silence: bool):
+        using_icl = not xvec_only
+        key = (str(ref_audio), ref_text, xvec_only, append_silence)
+        if key in self._voice_prompt_cache:
+            vcp, ref_ids = self._voice_prompt_cache[key]
+            return vcp, ref_ids, using_icl
+        if xvec_only:
+            items = self.model.create_voice_clone_prompt(ref_audio=str(ref_audio), ref_text="", x_vector_only_mode=True)
+            vcp = dict(ref_code=[None], ref_spk_embedding=[items[0].ref_spk_embedding], x_vector_only_mode=[True],
+                       icl_mode=[False])
+            ref_ids = [None] * len(input_ids)
+        else:
+            audio = self._load_ref_audio_with_silence(ref_audio, silence_secs=0.5 if append_silence else 0.0)
+            items = self.model.create_voice_clone_prompt(ref_audio=audio, ref_text=ref_text)
+            vcp = self.model._prompt_items_to_voice_clone_prompt(items)
+            rt = items[0].ref_text
+            ref_ids = [self._ref_ids(rt) if rt else None]
+        self._voice_prompt_cache[key] = (vcp, ref_ids)
+        return vcp, ref_ids, using_icl
+
+    # ---- prompt assembly (host glue; layout = SURVEY.md Appendix B / model.py:583-805) --------------------------
+    def _build_talker_inputs_local(self, m, input_ids, ref_ids, voice_clone_prompt, languages, speakers,
+                                   non_streaming_mode: bool, instruct_ids=None):
+        tk, tc, mc = m.talker, m.config.talker_config, m.config
+        dev = tk.device
+        emb_c = tk.get_input_embeddings()
+        text = lambda ids: tk.text_projection(tk.get_text_embeddings()(ids))
+        ids_t = lambda rows: torch.tensor(rows, device=dev, dtype=torch.long)
+        spk_embeds = m.generate_speaker_prompt(voice_clone_prompt) if voice_clone_prompt is not None else None
+        speakers = speakers if speakers is not None else [None] * len(input_ids)
+        seqs, trailing, pad = [], [], None
+        for i, (iid, lang, spk) in enumerate(zip(input_ids, languages, speakers)):
+            parts = []
+            if instruct_ids is not None and instruct_ids[i] is not None:
+                parts.append(text(instruct_ids[i]))
+            if spk_embeds is not None:
+                use = voice_clone_prompt["x_vector_only_mode"][i] or voice_clone_prompt["icl_mode"][i]
+                spk_e = spk_embeds[i] if use else None
+            elif spk in ("", None):
+                spk_e = None
+            else:
+                if spk.lower() not in tc.spk_id:
+                    raise NotImplementedError(f"Speaker {spk} not implemented")
+                spk_e = emb_c(ids_t(tc.spk_id[spk.lower()]))
+            assert lang is not None
+            if lang.lower() == "auto":
+                lang_id = None
+            else:
+                if lang.lower() not in tc.codec_language_id:
+                    raise NotImplementedError(f"Language {lang} not implemented")
+                lang_id = tc.codec_language_id[lang.lower()]
+            if lang.lower() in ("chinese", "auto") and spk not in ("", None) and tc.spk_is_dialect.get(spk.lower()):
+                lang_id = tc.codec_language_id[tc.spk_is_dialect[spk.lower()]]
+            bos, eos, pad = text(ids_t([[mc.tts_bos_token_id, mc.tts_eos_token_id, mc.tts_pad_token_id]])).chunk(3, dim=1)
+            prefix = ([tc.codec_nothink_id, tc.codec_think_bos_id, tc.codec_think_eos_id] if lang_id is None else
+                      [tc.codec_think_id, tc.codec_think_bos_id, lang_id, tc.codec_think_eos_id])
+            cod = [emb_c(ids_t([prefix]))]
+            if spk_e is not None:
+                cod.append(spk_e.view(1, 1, -1))
+            cod.append(emb_c(ids_t([[tc.codec_pad_id, tc.codec_bos_id]])))
+            cod = torch.cat(cod, dim=1)                                   # [..., codec_pad, codec_bos]
+            role = text(iid[:, :3])
+            head = torch.cat((pad.expand(-1, cod.shape[1] - 2, -1), bos), dim=1) + cod[:, :-1]
+            parts += [role, head]
+            icl = (voice_clone_prompt is not None and voice_clone_prompt.get("ref_code", None) is not None
+                   and voice_clone_prompt["icl_mode"][i])
+            if icl:
+                icl_embed, trail = m.generate_icl_prompt(
+                    text_id=iid[:, 3:-5], ref_id=ref_ids[i][:, 3:-2],
+                    ref_code=torch.as_tensor(voice_clone_prompt["ref_code"][i]).to(dev).clone(),
+                    tts_pad_embed=pad, tts_eos_embed=eos, non_streaming_mode=non_streaming_mode)
+                parts.append(icl_embed)
+            elif non_streaming_mode:
+                body = iid[:, 3:-5]
+                parts.append(torch.cat((text(body), eos), dim=1) + emb_c(ids_t([[tc.codec_pad_id] * (body.shape[1] + 1)])))
+                parts.append(pad + emb_c(ids_t([[tc.codec_bos_id]])))
+                trail = pad
+            else:
+                parts.append(text(iid[:, 3:4]) + cod[:, -1:])
+                trail = torch.cat((text(iid[:, 4:-5]), eos), dim=1)
+            seqs.append(torch.cat(parts, dim=1).squeeze(0))
+            trailing.append(trail.squeeze(0))
+        # left-pad the batch (B is always 1 through the public API)
+        L = max(s.shape[0] for s in seqs)
+        H = seqs[0].shape[1]
+        embeds = torch.zeros(len(seqs), L, H, dtype=seqs[0].dtype, device=dev)
+        mask = torch.zeros(len(seqs), L, dtype=torch.long, device=dev)
+        for b, s in enumerate(seqs):
+            embeds[b, L - s.shape[0]:] = s
+            mask[b, L - s.shape[0]:] = 1
+        Tt = max(t.shape[0] for t in trailing)
+        tth = pad.squeeze(0).expand(len(seqs), Tt, H).clone()
+        for b, t in enumerate(trailing):
+            tth[b, : t.shape[0]] = t
+        return embeds, mask, tth, pad
+
+    def _after_prepare(self, m, tie):
+        if not self._warmed_up:
+            self.warmup(tie.shape[1])
+        m.talker.rope_deltas = None
+        return m.talker, m.config.talker_config
+
+    def _prepare_generation(self, text: str, ref_audio=None, ref_text: str = "", language: str = "English",
+                            xvec_only: bool = False, non_streaming_mode: bool = False, append_silence: bool = True,
+                            voice_clone_prompt=None, instruct: Optional[str] = None):
+        input_ids = self.model._tokenize_texts([self.model._build_assistant_text(text)])
+        instruct_ids = [None]
+        if instruct:
+            instruct_ids = [self.model._tokenize_texts([self.model._build_instruct_text(instruct)])[0]]
+        vcp, ref_ids, using_icl = self._resolve_voice_clone_prompt(
+            input_ids=input_ids, ref_audio=ref_audio, ref_text=ref_text, xvec_only=xvec_only,
+            append_silence=append_silence, voice_clone_prompt=voice_clone_prompt)
+        if instruct and not using_icl:
+            logger.warning("Base-model instruct with x-vector-only voice cloning is experimental; prefer xvec_only=False.")
+        m = self.model.model
+        tie, tam, tth, tpe = self._build_talker_inputs_local(
+            m=m, input_ids=input_ids, ref_ids=ref_ids, voice_clone_prompt=vcp,
+            languages=[language] if language is not None else ["Auto"], speakers=None,
+            non_streaming_mode=non_streaming_mode, instruct_ids=instruct_ids)
+        talker, config = self._after_prepare(m, tie)
+        ref_codes = None
+        if using_icl and vcp.get("ref_code") and vcp["ref_code"][0] is not None:
+            ref_codes = torch.as_tensor(vcp["ref_code"][0])
+        return m, talker, config, tie, tam, tth, tpe, ref_codes
+
+    def _prepare_generation_custom(self, text: str, language: str, speaker: Optional[str],
+                                   instruct: Optional[str] = None, non_streaming_mode: bool = True):
+        input_ids = self.model._tokenize_texts([self.model._build_assistant_text(text)])
+        instruct_ids = [None if not instruct else
+                        self.model._tokenize_texts([self.model._build_instruct_text(instruct)])[0]]
+        m = self.model.model
+        tie, tam, tth, tpe = self._build_talker_inputs_local(
+            m=m, input_ids=input_ids, ref_ids=[None], voice_clone_prompt=None,
+            languages=[language] if language is not None else ["Auto"], speakers=[speaker],
+            non_streaming_mode=non_streaming_mode, instruct_ids=instruct_ids)
+        talker, config = self._after_prepare(m, tie)
+        return m, talker, config, tie, tam, tth, tpe
+
+    # ---- shared back halves -------------------------------------------------------------------------------------
+    def _run_full(self, m, talker, config, tie, tam, tth, tpe, ref_codes, gen_kwargs) -> Tuple[list, int]:
+        from .generate import fast_generate
+        codec_ids, timing = fast_generate(talker=talker, talker_input_embeds=tie, attention_mask=tam,
+                                          trailing_text_hiddens=tth, tts_pad_embed=tpe, config=config,
+                                          predictor_graph=self.predictor_graph, talker_graph=self.talker_graph,
+                                          **gen_kwargs)
+        if codec_ids is None:
+            logger.warning("Generation returned no tokens")
+            return [np.zeros(1, dtype=np.float32)], self.sample_rate
+        # ICL: the reference codes go in front so the decoder has acoustic context (model.py:919-937)
+        codes = torch.cat([ref_codes.to(codec_ids.device), codec_ids], dim=0) if ref_codes is not None else codec_ids
+        audio_list, sr = m.speech_tokenizer.decode({"audio_codes": codes.unsqueeze(0)})
+        ref_len = ref_codes.shape[0] if ref_codes is not None else 0
+        out = []
+        for a in audio_list:
+            a = _to_numpy(a)
+            if ref_len > 0:
+                a = a[int(ref_len / max(codes.shape[0], 1) * len(a)):]
+            out.append(a)
+        n = timing["steps"]
+        total = timing["prefill_ms"] / 1000 + timing["decode_s"]
+        logger.info("Generated %.2fs audio in %.2fs (%.1fms/step, RTF: %.2f)", n / 12.5, total, timing["ms_per_step"],
+                    (n / 12.5) / total if total > 0 else 0)
+        return out, sr
+
+    def _run_streaming(self, m, talker, config, tie, tam, tth, tpe, ref_codes, gen_kwargs, chunk_size: int,
+                       parity_mode: bool = False):
+        """model.py:1048-1137: phase 1 re-decodes everything until >= max(25, chunk) frames exist and
+        calibrates samples/frame; phase 2 decodes [25 context frames + new chunk] and drops the context."""
+        from .streaming import fast_generate_streaming, parity_generate_streaming
+        tok = m.speech_tokenizer
+        context_frames = 25
+        min_cal = max(context_frames, chunk_size)
+        all_codes: List[torch.Tensor] = []
+        prev_len, spf = 0, None
+        fn = parity_generate_streaming if parity_mode else fast_generate_streaming
+        stream = fn(talker=talker, talker_input_embeds=tie, attention_mask=tam, trailing_text_hiddens=tth,
+                    tts_pad_embed=tpe, config=config, predictor_graph=self.predictor_graph,
+                    talker_graph=self.talker_graph, chunk_size=chunk_size, **gen_kwargs)
+        for chunk, timing in stream:
+            all_codes.append(chunk)
+            n_new = chunk.shape[0]
+            flat = torch.cat(all_codes, dim=0)
+            n_total = flat.shape[0]
+            if spf is None:
+                inp = torch.cat([ref_codes.to(flat.device), flat], dim=0) if ref_codes is not None else flat
+                audio_list, sr = tok.decode({"audio_codes": inp.unsqueeze(0)})
+                audio = _to_numpy(audio_list[0])
+                if ref_codes is not None:
+                    audio = audio[int(ref_codes.shape[0] / max(inp.shape[0], 1) * len(audio)):]
+                new_audio = audio[prev_len:]
+                prev_len = len(audio)
+                if n_total >= min_cal:
+                    spf = len(audio) / n_total
+            else:
+                start = max(0, n_total - n_new - context_frames)
+                window = flat[start:]
+                n_ctx = window.shape[0] - n_new
+                audio_list, sr = tok.decode({"audio_codes": window.unsqueeze(0)})
+                audio = _to_numpy(audio_list[0])
+                new_audio = audio[int(round(n_ctx * spf)):] if n_ctx > 0 else audio
+            yield new_audio, sr, timing
+
+    @staticmethod
+    def _gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty):
+        return dict(max_new_tokens=max_new_tokens, min_new_tokens=min_new_tokens, temperature=temperature,
+                    top_k=top_k, top_p=top_p, do_sample=do_sample, repetition_penalty=repetition_penalty)
+
+    # ---- public generation entry points ----------------------------------------------------------------------------
+    @torch.inference_mode()
+    def generate_voice_clone(self, text: str, language: str, ref_audio: Optional[Union[str, Path]] = None,
+                             ref_text: str = "", max_new_tokens: int = 2048, min_new_tokens: int = 2,
+                             temperature: float = 0.9, top_k: int = 50, top_p: float = 1.0, do_sample: bool = True,
+                             repetition_penalty: float = 1.05, xvec_only: bool = False,
+                             non_streaming_mode: Optional[bool] = None, append_silence: bool = True,
+                             instruct: Optional[str] = None, ref_spk: Optional[Union[str, Path]] = None,
+                             ref_rvq: Optional[Union[str, Path]] = None, ref_spk_emb: Optional[np.ndarray] = None,
+                             ref_codes: Optional[np.ndarray] = None,
+                             voice_clone_prompt: Optional[Union[Dict[str, Any], List[Any]]] = None) -> Tuple[list, int]:
+        """Voice cloning; returns ``([np.float32 waveform], sample_rate)``."""
+        self._reject_ggml_cached_reference_args(ref_spk=ref_spk, ref_rvq=ref_rvq, ref_spk_emb=ref_spk_emb,
+                                                ref_codes=ref_codes)
+        nsm = self._resolve_non_streaming_mode(non_streaming_mode, default=False)
+        m, talker, config, tie, tam, tth, tpe, rc = self._prepare_generation(
+            text=text, language=language, ref_audio=ref_audio, ref_text=ref_text, xvec_only=xvec_only,
+            non_streaming_mode=nsm, append_silence=append_silence, voice_clone_prompt=voice_clone_prompt,
+            instruct=instruct)
+        return self._run_full(m, talker, config, tie, tam, tth, tpe, rc,
+                              self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample,
+                                               repetition_penalty))
+
+    @torch.inference_mode()
+    def generate_voice_clone_streaming(self, text: str, language: str, ref_audio: Optional[Union[str, Path]] = None,
+                                       ref_text: str = "", max_new_tokens: int = 2048, min_new_tokens: int = 2,
+                                       temperature: float = 0.9, top_k: int = 50, top_p: float = 1.0,
+                                       do_sample: bool = True, repetition_penalty: float = 1.05, chunk_size: int = 12,
+                                       xvec_only: bool = False, non_streaming_mode: Optional[bool] = None,
+                                       append_silence: bool = True, parity_mode: bool = False,
+                                       instruct: Optional[str] = None, ref_spk: Optional[Union[str, Path]] = None,
+                                       ref_rvq: Optional[Union[str, Path]] = None,
+                                       ref_spk_emb: Optional[np.ndarray] = None, ref_codes: Optional[np.ndarray] = None,
+                                       voice_clone_prompt: Optional[Union[Dict[str, Any], List[Any]]] = None,
+                                       ) -> Generator[Tuple[np.ndarray, int, dict], None, None]:
+        """Yields ``(audio_chunk, sample_rate, timing)`` every ``chunk_size`` codec frames."""
+        self._reject_ggml_cached_reference_args(ref_spk=ref_spk, ref_rvq=ref_rvq, ref_spk_emb=ref_spk_emb,
+                                                ref_codes=ref_codes)
+        nsm = self._resolve_non_streaming_mode(non_streaming_mode, default=False)
+        m, talker, config, tie, tam, tth, tpe, rc = self._prepare_generation(
+            text=text, language=language, ref_audio=ref_audio, ref_text=ref_text, xvec_only=xvec_only,
+            non_streaming_mode=nsm, append_silence=append_silence, voice_clone_prompt=voice_clone_prompt,
+            instruct=instruct)
+        yield from self._run_streaming(m, talker, config, tie, tam, tth, tpe, rc,
+                                       self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p,
+                                                        do_sample, repetition_penalty), chunk_size, parity_mode)
+
+    def _custom_prepare(self, text, speaker, language, instruct, non_streaming_mode):
+        if self.model.model.tts_model_type != "custom_voice":
+            raise ValueError("Loaded model does not support custom voice generation")
+        self.model._validate_languages([language])
+        self.model._validate_speakers([speaker])
+        nsm = self._resolve_non_streaming_mode(non_streaming_mode, default=True)
+        if self.model.model.tts_model_size in "0b6":        # 0.6B CustomVoice ignores instruct (model.py:1166-1167)
+            instruct = None
+        return self._prepare_generation_custom(text=text, language=language, speaker=speaker, instruct=instruct,
+                                               non_streaming_mode=nsm)
+
+    @torch.inference_mode()
+    def generate_custom_voice(self, text: str, speaker: str, language: str, instruct: Optional[str] = None,
+                              non_streaming_mode: Optional[bool] = None, max_new_tokens: int = 2048,
+                              min_new_tokens: int = 2, temperature: float = 0.9, top_k: int = 50, top_p: float = 1.0,
+                              do_sample: bool = True, repetition_penalty: float = 1.05) -> Tuple[list, int]:
+        m, talker, config, tie, tam, tth, tpe = self._custom_prepare(text, speaker, language, instruct, non_streaming_mode)
+        return self._run_full(m, talker, config, tie, tam, tth, tpe, None,
+                              self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample,
+                                               repetition_penalty))
+
+    @torch.inference_mode()
+    def generate_custom_voice_streaming(self, text: str, speaker: str, language: str, instruct: Optional[str] = None,
+                                        non_streaming_mode: Optional[bool] = None, max_new_tokens: int = 2048,
+                                        min_new_tokens: int = 2, temperature: float = 0.9, top_k: int = 50,
+                                        top_p: float = 1.0, do_sample: bool = True, repetition_penalty: float = 1.05,
+                                        chunk_size: int = 12) -> Generator[Tuple[np.ndarray, int, dict], None, None]:
+        m, talker, config, tie, tam, tth, tpe = self._custom_prepare(text, speaker, language, instruct, non_streaming_mode)
+        yield from self._run_streaming(m, talker, config, tie, tam, tth, tpe, None,
+                                       self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p,
+                                                        do_sample, repetition_penalty), chunk_size)
+
+    def _design_prepare(self, text, instruct, language, non_streaming_mode):
+        if self.model.model.tts_model_type != "voice_design":
+            raise ValueError("Loaded model does not support voice design generation")
+        self.model._validate_languages([language])
+        nsm = self._resolve_non_streaming_mode(non_streaming_mode, default=True)
+        return self._prepare_generation_custom(text=text, language=language, speaker=None, instruct=instruct,
+                                               non_streaming_mode=nsm)
+
+    @torch.inference_mode()
+    def generate_voice_design(self, text: str, instruct: str, language: str, non_streaming_mode: Optional[bool] = None,
+                              max_new_tokens: int = 2048, min_new_tokens: int = 2, temperature: float = 0.9,
+                              top_k: int = 50, top_p: float = 1.0, do_sample: bool = True,
+                              repetition_penalty: float = 1.05) -> Tuple[list, int]:
+        m, talker, config, tie, tam, tth, tpe = self._design_prepare(text, instruct, language, non_streaming_mode)
+        return self._run_full(m, talker, config, tie, tam, tth, tpe, None,
+                              self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample,
+                                               repetition_penalty))
+
+    @torch.inference_mode()
+    def generate_voice_design_streaming(self, text: str, instruct: str, language: str,
+                                        non_streaming_mode: Optional[bool] = None, max_new_tokens: int = 2048,
+                                        min_new_tokens: int = 2, temperature: float = 0.9, top_k: int = 50,
+                                        top_p: float = 1.0, do_sample: bool = True, repetition_penalty: float = 1.05,
+                                        chunk_size: int = 12) -> Generator[Tuple[np.ndarray, int, dict], None, None]:
+        m, talker, config, tie, tam, tth, tpe = self._design_prepare(text, instruct, language, non_streaming_mode)
+        yield from self._run_streaming(m, talker, config, tie, tam, tth, tpe, None,
+                                       self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p,
+                                                        do_sample, repetition_penalty), chunk_size)

@@ -1,0 +1,58 @@
+"""Utterance sharding over the GPUs of one node.
+
+The path shards by independent units: every rank holds a full replica of the weights and its own
+decode context, utterance i goes to rank ``i % world``, and nothing of one utterance is shared with
+another.  The ONLY collectives are the result gather (lengths ``all_gather`` then padded payload
+``all_gather``) -- RCCL over xGMI on GPUs (backend "nccl"), gloo in the CPU tests.  The reference has
+no multi-GPU code at all (requests are serialised by a lock, examples/openai_server.py:71).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Round-robin assignment: item i -> rank i % world."""
+    return list(range(rank, n_items, world))
+
+
+def gather_arrays(local: np.ndarray, device="cpu") -> List[np.ndarray]:
+    """All ranks contribute one 1-D array (ragged); every rank gets the list ordered by rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [np.asarray(local)]
+    world = dist.get_world_size()
+    t = torch.as_tensor(np.ascontiguousarray(local)).to(device)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=device)
+    lens = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(lens, n)
+    lens = [int(x) for x in lens]
+    mx = max(max(lens), 1)
+    pad = torch.zeros(mx, dtype=t.dtype, device=device)
+    pad[: t.numel()] = t.reshape(-1)
+    bufs = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return [b[:l].cpu().numpy() for b, l in zip(bufs, lens)]
+
+
+def run_sharded(items: Sequence, fn: Callable, device="cpu"):
+    """Run ``fn(item) -> 1-D np.ndarray`` on this rank's shard and gather every result to every rank,
+    returned in the original item order."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    mine = shard_indices(len(items), rank, world)
+    results = {i: np.asarray(fn(items[i])) for i in mine}
+    out: List = [None] * len(items)
+    rounds = (len(items) + world - 1) // world
+    for r in range(rounds):
+        idx = r * world + rank
+        local = results[idx] if idx < len(items) else np.zeros(0, dtype=np.float32)
+        gathered = gather_arrays(local, device)
+        for rk, g in enumerate(gathered):
+            j = r * world + rk
+            if j < len(items):
+                out[j] = g
+    return out

@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library loads and exports every symbol include/fq3hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "faster-qwen3-tts_amd", "lib", "libfq3hip.so")
+HDR = os.path.join(ROOT, "include", "fq3hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__ as g
+        g.build()
+    return ctypes.CDLL(LIB)
+
+
+def _declared():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fq3_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    names = _declared()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_binding_table_matches_header():
+    from fq3hip import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_abi_version_and_error_string(lib):
+    lib.fq3_abi_version.restype = ctypes.c_int
+    assert lib.fq3_abi_version() == 1
+    lib.fq3_last_error.restype = ctypes.c_char_p
+    assert isinstance(lib.fq3_last_error(), bytes)
+
+
+def test_null_arguments_are_errors_not_crashes(lib):
+    # argument validation happens before any HIP call, so this is safe without a GPU
+    lib.fq3_ctx_create.restype = ctypes.c_int
+    assert lib.fq3_ctx_create(None, None) == -1
+    lib.fq3_bind_weights.restype = ctypes.c_int
+    assert lib.fq3_bind_weights(None, None) == -1
+    lib.fq3_codec_create.restype = ctypes.c_int
+    assert lib.fq3_codec_create(None, None) == -1
+    lib.fq3_codec_num_samples.restype = ctypes.c_int64
+    assert lib.fq3_codec_num_samples(None, 10) == -1
+
+
+def test_struct_layout_matches_header_sizes():
+    from fq3hip import _lib as L
+    assert ctypes.sizeof(L.StackDims) == 32
+    assert ctypes.sizeof(L.Config) == 4 + 32 + 32 + 5 * 4
+    assert ctypes.sizeof(L.LayerWeights) == 8 * 8
+    assert ctypes.sizeof(L.Sampling) == 20
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not reference oracle/ (only tests, smoke() and bench's cpu leg may)."""
+    pkg = os.path.join(ROOT, "faster-qwen3-tts_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h")):
+                txt = open(os.path.join(d, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(d, f)

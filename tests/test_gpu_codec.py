@@ -21,7 +21,7 @@ def _rms(x):
     return float(np.sqrt(np.mean(np.square(x.astype(np.float64)))))
 
 
-@pytest.mark.parametrize("dtype,tag,tol", [(torch.float32, "f32", 1e-4), (torch.bfloat16, "bf16", 1e-2)])
+@pytest.mark.parametrize("dtype,tag,tol", [(torch.float32, "f32", 1e-4), (torch.bfloat16, "bf16", 2e-2)])
 def test_codec_decode_golden(dtype, tag, tol, golden_dir):
     from fq3hip.codec import HipSpeechTokenizer
     g = np.load(os.path.join(golden_dir, "codec.npz"))
