@@ -107,27 +107,45 @@ def measure_frame_graph(model, prompt, n=64):
     return ms, p_mid
 
 
-def cpu_baseline(cfg, frames=16):
+def cpu_baseline(cfg, frames=6, budget_s=45.0):
     """CPU oracle ("port") on the host cores: same shapes, fp32 (bf16 matmuls are not accelerated on this
-    host), same prompt, `frames` generated frames + their vocoding; RTF with the same definition."""
+    host), same prompt; a BOUNDED sample: 200-token prefill + up to `frames` generated frames + their
+    vocoding, cut short when `budget_s` is exceeded.  RTF with the same definition as the GPU line."""
     from fq3hip.weights import synth_weights, synth_prompt
     from oracle import qwen3tts_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)        # batch-1 matvecs stop scaling (and regress) beyond ~16 threads
     torch.set_num_threads(cores)
     W = synth_weights(cfg, 0, torch.float32, parts=("talker", "predictor", "codec"))
     tie, tam, tth, tpe, ref = synth_prompt(cfg, PROMPT_LEN, 32, REF_FRAMES, dtype=torch.float32)
     orc = O.OracleTTS(cfg, W, max_seq_len=512)
-    sp = O.SamplingParams(max_new_tokens=frames, min_new_tokens=frames)
     t0 = time.perf_counter()
     with torch.inference_mode():
+        # frame-by-frame so the budget can stop the sample: first a 1-frame run (prefill + frame), then more
+        sp = O.SamplingParams(max_new_tokens=1, min_new_tokens=1)
         codes = orc.generate(tie, tam, tth, tpe, sp)
-        t_codes = time.perf_counter() - t0
+        t1 = time.perf_counter() - t0
+        per_frame_est = None
+        if t1 < budget_s / 3:
+            n_more = frames
+            t2 = time.perf_counter()
+            sp = O.SamplingParams(max_new_tokens=2, min_new_tokens=2)
+            orc.generate(tie, tam, tth, tpe, sp)
+            per_frame_est = max(time.perf_counter() - t2 - t1, 1e-3)      # one extra frame beyond the prefill+1 run
+            n_more = int(max(1, min(frames, (budget_s - (time.perf_counter() - t0)) / (per_frame_est + 1e-9) / 2)))
+            sp = O.SamplingParams(max_new_tokens=n_more, min_new_tokens=n_more)
+            t3 = time.perf_counter()
+            codes = orc.generate(tie, tam, tth, tpe, sp)
+            t_codes = time.perf_counter() - t3
+        else:
+            t_codes = t1
+        tv = time.perf_counter()
         wav = O.codec_decode(codes % cfg.codec.codebook_size, W, cfg.codec)
-    wall = time.perf_counter() - t0
+        t_voc = time.perf_counter() - tv
     n = codes.shape[0]
+    wall = t_codes + t_voc
     return {"value": round(n * FRAME_S / wall, 5), "unit": "x real-time (audio s / wall s)", "cores": cores, "kind": "port",
-            "sample": f"oracle/qwen3tts_oracle.py fp32, 0.6B shapes, {PROMPT_LEN}-token prefill + {n} frames "
-                      f"(+ vocoding of those frames, no reference-code re-decode); {t_codes:.1f}s decode, {wall:.1f}s total",
+            "sample": f"oracle/qwen3tts_oracle.py fp32 eager Torch, 0.6B shapes, {PROMPT_LEN}-token prefill + {n} frames "
+                      f"+ vocoding of those frames ({t_codes:.1f}s + {t_voc:.1f}s); host has {os.cpu_count()} cores, {cores} threads used",
             "ms_per_frame": round(1000 * t_codes / n, 1)}
 
 
