@@ -1,7 +1,6 @@
 // libfq3hip.so: context, weight binding, launch orchestration and hipGraph capture for the decode path.
 // C ABI declared in include/fq3hip.h (which cites the reference interface each entry replaces).
-#include "../../include/fq3hip.h"
-#include "decode_kernels.cuh"
+#include "fq3_ctx.h"
 #include "sampler.cuh"
 #include "sampler_wave.cuh"
 
@@ -15,44 +14,12 @@ using namespace fq3;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& m) { g_err = m; return code; }
+int fq3_fail_(int code, const std::string& m) { return fail(code, m); }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(FQ3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 extern "C" const char* fq3_last_error(void) { return g_err.c_str(); }
 extern "C" void fq3_set_error_(const char* msg) { g_err = msg ? msg : ""; }   // used by the codec TU
 extern "C" int fq3_abi_version(void) { return FQ3_ABI_VERSION; }
-
-struct StackBufs {
-    std::vector<void*> k, v;          // per layer [n_kv][max_seq][128]
-    int max_seq = 0, workers = 1;
-};
-
-struct fq3_ctx {
-    fq3_config cfg{};
-    int esz = 2;
-    std::vector<fq3_layer_weights> tl, pl;
-    fq3_weight_table wt{};
-    std::vector<const void*> pemb, lmh;
-    const void** d_pemb = nullptr;    // device array of the 15 predictor embedding tables
-    bool bound = false;
-    StackBufs tk, pk;
-    // scratch (device)
-    void *h = nullptr, *xin = nullptr, *qkv = nullptr, *act = nullptr, *logits = nullptr, *past_hidden = nullptr;
-    void *pred_in = nullptr, *pred_x = nullptr, *pred_next = nullptr, *plogits = nullptr, *tmp_hidden = nullptr;
-    float* part = nullptr;
-    float* rope_now = nullptr;
-    unsigned char* seen_api = nullptr;
-    DecodeState* st = nullptr;
-    unsigned char* seen = nullptr;
-    int* codes = nullptr;
-    int64_t* ids64 = nullptr;
-    int n_pad = 0, rope_delta = 0;
-    bool talker_wave = true;      // talker sampler variant baked into the captured graph
-    fq3_sampling pred_sampling{0.9f, 50, 1.0f, 1, 1.0f};
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipStream_t cap_stream = nullptr;
-    std::vector<void*> allocs;
-};
 
 static int dmalloc(fq3_ctx* c, void** p, size_t bytes) {
     HIPCHK(hipMalloc(p, bytes));
@@ -60,6 +27,7 @@ static int dmalloc(fq3_ctx* c, void** p, size_t bytes) {
     c->allocs.push_back(*p);
     return 0;
 }
+int fq3_dmalloc_(fq3_ctx* c, void** p, size_t bytes) { return dmalloc(c, p, bytes); }
 
 static bool dims_ok(const fq3_stack_dims& d) {
     return d.head_dim == kHeadDim && d.hidden % 8 == 0 && d.inter % 8 == 0 && d.n_heads % d.n_kv_heads == 0 &&
@@ -360,12 +328,18 @@ extern "C" int fq3_prefill(fq3_ctx* c, const void* embeds, int L, int n_pad, voi
     if (n_pad < 0 || n_pad >= L) return fail(FQ3_EINVAL, "n_pad");
     if (int r = fq3_set_generation_state(c, n_pad, -n_pad)) return r;
     hipStream_t s = (hipStream_t)stream;
+    void* hid = out_hidden ? out_hidden : c->tmp_hidden;
+    if (c->prefill_mode != 1 && L - n_pad >= 4) {
+        // matrix-core prefill: GEMMs over all prompt rows, causal attention, KV written straight to the cache
+        if (int r = fq3_prefill_mfma_(c, embeds, L, n_pad, out_logits, hid, s)) return r;
+        LAUNCH_CHECK();
+        return FQ3_OK;
+    }
     const size_t rowb = (size_t)c->cfg.talker.hidden * c->esz;
     for (int i = n_pad; i < L; ++i) {
         StepSrc src{(const char*)embeds + rowb * i, nullptr, i};
         if (int r = run_stack(c, true, src, s)) return r;
     }
-    void* hid = out_hidden ? out_hidden : c->tmp_hidden;
     final_norm(c, true, c->h, hid, s);
     if (out_logits) {
         GemvArgs g{};
@@ -376,6 +350,18 @@ extern "C" int fq3_prefill(fq3_ctx* c, const void* embeds, int L, int n_pad, voi
     return FQ3_OK;
 }
 
+int fq3_codec_head_launch_(fq3_ctx* c, const void* hidden, void* out_logits, hipStream_t s) {
+    GemvArgs g{};
+    g.W = c->wt.codec_head; g.N = c->cfg.talker.vocab; g.K = c->cfg.talker.hidden; g.x = hidden; g.y = out_logits;
+    return launch_gemv<PRO_PLAIN, EPI_STORE>(c, g, true, s);
+}
+
+// test / debugging hook: 0 = auto (MFMA prefill), 1 = force the token-by-token walk through the decode kernels
+extern "C" int fq3_set_prefill_mode(fq3_ctx* c, int mode) {
+    if (!c) return fail(FQ3_EINVAL, "null ctx");
+    c->prefill_mode = mode;
+    return FQ3_OK;
+}
 
 // -------------------------------------------------------------------------------------------------
 // Sampler dispatch: single-wave kernels when top_p >= 1 (default), workgroup kernel otherwise

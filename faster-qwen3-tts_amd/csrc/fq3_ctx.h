@@ -1,0 +1,49 @@
+// Internal: context layout shared by the decode TU (fq3_api.hip) and the prefill TU (fq3_prefill.hip).
+#pragma once
+#include "../../include/fq3hip.h"
+#include "decode_kernels.cuh"
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+struct StackBufs {
+    std::vector<void*> k, v;          // per layer [n_kv][max_seq][128]
+    int max_seq = 0, workers = 1;
+};
+
+struct fq3_ctx {
+    fq3_config cfg{};
+    int esz = 2;
+    std::vector<fq3_layer_weights> tl, pl;
+    fq3_weight_table wt{};
+    std::vector<const void*> pemb, lmh;
+    const void** d_pemb = nullptr;    // device array of the 15 predictor embedding tables
+    bool bound = false;
+    StackBufs tk, pk;
+    // scratch (device)
+    void *h = nullptr, *xin = nullptr, *qkv = nullptr, *act = nullptr, *logits = nullptr, *past_hidden = nullptr;
+    void *pred_in = nullptr, *pred_x = nullptr, *pred_next = nullptr, *plogits = nullptr, *tmp_hidden = nullptr;
+    float* part = nullptr;
+    float* rope_now = nullptr;
+    unsigned char* seen_api = nullptr;
+    fq3::DecodeState* st = nullptr;
+    unsigned char* seen = nullptr;
+    int* codes = nullptr;
+    int64_t* ids64 = nullptr;
+    int n_pad = 0, rope_delta = 0;
+    int prefill_mode = 0;         // 0 auto (MFMA), 1 token walk
+    bool talker_wave = true;      // talker sampler variant baked into the captured graph
+    fq3_sampling pred_sampling{0.9f, 50, 1.0f, 1, 1.0f};
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    std::vector<void*> allocs;
+    // MFMA prefill workspace (lazily allocated, sized for max_seq_len rows)
+    void *pf_x = nullptr, *pf_xn = nullptr, *pf_qkv = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_act = nullptr;
+};
+
+
+int fq3_fail_(int code, const std::string& m);                 // sets the thread-local error string
+int fq3_prefill_mfma_(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits, void* out_hidden, hipStream_t s);
+int fq3_codec_head_launch_(fq3_ctx* c, const void* hidden, void* out_logits, hipStream_t s);
+int fq3_dmalloc_(fq3_ctx* c, void** p, size_t bytes);

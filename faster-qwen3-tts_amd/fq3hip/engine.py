@@ -185,6 +185,10 @@ class Fq3Engine:
                                      hid.data_ptr(), self._stream()))
         return logits, hid
 
+    def set_prefill_mode(self, mode: int):
+        """0 = MFMA prefill (default), 1 = token-by-token walk through the decode kernels (test hook)."""
+        L.check(self.lib.fq3_set_prefill_mode(self.ctx, int(mode)))
+
     def codec_head(self, hidden: torch.Tensor) -> torch.Tensor:
         self._chk(hidden, self.cfg.talker.hidden_size, "codec_head hidden")
         out = self.new(self.cfg.talker.vocab_size)

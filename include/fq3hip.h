@@ -123,6 +123,9 @@ int fq3_talker_step(fq3_ctx* ctx, const void* embeds, int position, void* out_hi
 int fq3_prefill(fq3_ctx* ctx, const void* embeds, int L, int n_pad, void* out_logits, void* out_hidden,
                 void* stream);
 
+/* Test hook: 0 = matrix-core prefill (default), 1 = walk the prompt token by token through the decode kernels. */
+int fq3_set_prefill_mode(fq3_ctx* ctx, int mode);
+
 /* talker.codec_head (generate.py:182): logits T[V] = codec_head(hidden T[H]) (hidden is post-norm). */
 int fq3_codec_head(fq3_ctx* ctx, const void* hidden, void* out_logits, void* stream);
 

@@ -28,8 +28,9 @@ def _tol(dtype, scale):
     return 2e-4 * max(1.0, scale) if dtype == torch.float32 else 0.025 * max(1.0, scale)
 
 
+@pytest.mark.parametrize("prefill_mode", [0, 1])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_prefill_and_steps_match_oracle(dtype):
+def test_prefill_and_steps_match_oracle(dtype, prefill_mode):
     from oracle import qwen3tts_oracle as O
     cfg = tiny_test_config()
     W = synth_weights(cfg, 0, dtype)
@@ -38,6 +39,7 @@ def test_prefill_and_steps_match_oracle(dtype):
     orc = O.OracleTTS(cfg, W, max_seq_len=96)
     o_logits, o_hidden, _, L = orc.prefill(tie, tam)
     eng = _engine(cfg, W, dtype)
+    eng.set_prefill_mode(prefill_mode)      # 0: MFMA GEMM prefill, 1: token walk through the decode kernels
     logits, hidden = eng.prefill(tie[0].cuda().contiguous())
     torch.cuda.synchronize()
     sc = float(o_hidden.float().abs().max())
@@ -58,8 +60,9 @@ def test_prefill_and_steps_match_oracle(dtype):
     assert (v.float().cpu() - ov.float()).abs().max() <= _tol(dtype, float(ov.float().abs().max()))
 
 
+@pytest.mark.parametrize("prefill_mode", [0, 1])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_left_padded_prompt(dtype):
+def test_left_padded_prompt(dtype, prefill_mode):
     from oracle import qwen3tts_oracle as O
     cfg = tiny_test_config()
     W = synth_weights(cfg, 0, dtype)
@@ -69,6 +72,7 @@ def test_left_padded_prompt(dtype):
     orc = O.OracleTTS(cfg, W, max_seq_len=96)
     o_logits, o_hidden, _, L = orc.prefill(tie, tam)
     eng = _engine(cfg, W, dtype)
+    eng.set_prefill_mode(prefill_mode)
     logits, hidden = eng.prefill(tie[0].cuda().contiguous(), n_pad=5)
     assert (hidden.float().cpu() - o_hidden.float().view(-1)).abs().max() <= _tol(dtype, float(o_hidden.float().abs().max()))
     x = torch.randn(1, 1, cfg.talker.hidden_size).to(dtype)
