@@ -78,8 +78,7 @@ def one_utterance(model, prompt, seed):
     ttfa, chunks, frames = None, [], 0
     for audio, sr, timing in model._run_streaming(m, talker, config, tie, tam, tth, tpe, ref_codes, kw, CHUNK):
         if ttfa is None:
-            torch.cuda.synchronize()
-            ttfa = time.perf_counter() - t0
+            ttfa = time.perf_counter() - t0       # `audio` is a host array: the first chunk is complete here
         chunks.append(audio)
         frames = timing["total_steps_so_far"]
     torch.cuda.synchronize()

@@ -17,7 +17,7 @@
 
 namespace fq3 {
 
-enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_COMBINE = 2 };
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_COMBINE = 2, PRO_ATTN = 3 };
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2 };
 
 constexpr int kHeadDim = 128;        // Qwen3-TTS talker / predictor head_dim
@@ -40,7 +40,132 @@ struct GemvArgs {
     void* xn_out;                                  // optional: block 0 stores the prologue result as T[K]
     int up_off;                                    // SWIGLU: first "up" row
     const float* part; int n_part; int rep;        // PRO_COMBINE: attention partial slots
+    // PRO_ATTN (short-context attention computed redundantly in every workgroup: code predictor, <= 17 keys)
+    const void* qkv; const void* q_norm_w; const void* k_norm_w;
+    const float* cos_row; const float* sin_row;
+    void* kcache; void* vcache; int max_seq; int pos; int n_kv; float scale;
 };
+
+// Attention over a SHORT context for all heads inside one workgroup, result (T-rounded, fp32 image) into
+// xs[q_dim].  Wave w owns kv heads w, w+4, ...: no cross-wave merge.  Used as the o_proj prologue of the
+// code predictor (context <= 2 + 15 tokens, predictor_graph.py:46), which removes one launch per layer.
+template <typename T, int REP>
+__device__ __forceinline__ void attn_small_prologue(const GemvArgs& a, float* xs, float* scratch) {
+    constexpr int HD = kHeadDim;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int sub = lane >> 4, c = lane & 15;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    const int q_dim = a.n_kv * REP * HD, kv_dim = a.n_kv * HD;
+    float* qs = scratch + wave * (REP + 2) * HD;          // [REP][HD] q, then k, then v (wave-private)
+    float* knew = qs + REP * HD;
+    float* vnew = knew + HD;
+    const float cs = a.cos_row[lane], sn = a.sin_row[lane];
+    const T* qw = reinterpret_cast<const T*>(a.q_norm_w);
+    const T* kw = reinterpret_cast<const T*>(a.k_norm_w);
+    const float qw0 = DT<T>::ld(qw + lane), qw1 = DT<T>::ld(qw + lane + 64);
+    const float kw0 = DT<T>::ld(kw + lane), kw1 = DT<T>::ld(kw + lane + 64);
+    const int pos = a.pos;
+    const int iters = (a.n_kv + 3) / 4;
+    for (int it = 0; it < iters; ++it) {
+        const int g = it * 4 + wave;
+        const bool active = g < a.n_kv;
+        const int gg = active ? g : 0;
+        T* kc = reinterpret_cast<T*>(a.kcache) + (size_t)gg * a.max_seq * HD;
+        T* vc = reinterpret_cast<T*>(a.vcache) + (size_t)gg * a.max_seq * HD;
+        Raw8<T> kr[4], vr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int key = i * 4 + sub;
+            key = key < a.max_seq ? key : a.max_seq - 1;
+            ldraw<false>(kr[i], kc + (size_t)key * HD + c * 8);
+            ldraw<false>(vr[i], vc + (size_t)key * HD + c * 8);
+        }
+        // q heads, new k (norm + RoPE), new v
+#pragma unroll
+        for (int vec = 0; vec < REP + 2; ++vec) {
+            const T* src = vec < REP ? qkv + (size_t)(gg * REP + vec) * HD
+                         : (vec == REP ? qkv + q_dim + (size_t)gg * HD : qkv + q_dim + kv_dim + (size_t)gg * HD);
+            float x0 = DT<T>::ld(src + lane), x1 = DT<T>::ld(src + lane + 64);
+            if (vec <= REP) {
+                const float w0 = vec < REP ? qw0 : kw0, w1 = vec < REP ? qw1 : kw1;
+                const float ss = wave_sum(fmaf(x0, x0, x1 * x1));
+                const float rs = 1.0f / sqrtf(ss / (float)HD + a.eps);
+                const float n0 = DT<T>::rnd(w0 * DT<T>::rnd(x0 * rs));
+                const float n1 = DT<T>::rnd(w1 * DT<T>::rnd(x1 * rs));
+                x0 = DT<T>::rnd(DT<T>::rnd(n0 * cs) + DT<T>::rnd(-n1 * sn));
+                x1 = DT<T>::rnd(DT<T>::rnd(n1 * cs) + DT<T>::rnd(n0 * sn));
+            }
+            float* dst = vec < REP ? qs + vec * HD : (vec == REP ? knew : vnew);
+            dst[lane] = x0; dst[lane + 64] = x1;
+            if (vec >= REP && active && blockIdx.x == 0) {        // one workgroup appends K/V to the cache
+                T* cp = (vec == REP ? kc : vc) + (size_t)pos * HD;
+                DT<T>::st(cp + lane, x0); DT<T>::st(cp + lane + 64, x1);
+            }
+        }
+        __syncthreads();
+        float qr[REP][8], m[REP], l[REP], o[REP][8];
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            m[h] = -1e30f; l[h] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { qr[h][i] = qs[h * HD + c * 8 + i]; o[h][i] = 0.f; }
+        }
+        auto step = [&](const float (&kf)[8], const float (&vf)[8], bool valid) {
+#pragma unroll
+            for (int h = 0; h < REP; ++h) {
+                float sc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sc = fmaf(qr[h][i], kf[i], sc);
+                sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64);
+                sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
+                sc = valid ? sc * a.scale : -INFINITY;
+                const float mn = fmaxf(m[h], sc);
+                const float al = __expf(m[h] - mn), p = __expf(sc - mn);
+                l[h] = fmaf(l[h], al, p);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[h][i] = fmaf(o[h][i], al, valid ? p * vf[i] : 0.f);
+                m[h] = mn;
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float kf[8], vf[8];
+            unpack(kr[i], kf); unpack(vr[i], vf);
+            step(kf, vf, i * 4 + sub < pos);
+        }
+        {
+            float kf[8], vf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { kf[i] = knew[c * 8 + i]; vf[i] = vnew[c * 8 + i]; }
+            step(kf, vf, sub == 0);
+        }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+#pragma unroll
+            for (int h = 0; h < REP; ++h) {
+                const float mo = __shfl_xor(m[h], off, 64), lo = __shfl_xor(l[h], off, 64);
+                const float M = fmaxf(m[h], mo);
+                const float wa = __expf(m[h] - M), wb = __expf(mo - M);
+                l[h] = l[h] * wa + lo * wb;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float oo = __shfl_xor(o[h][i], off, 64);
+                    o[h][i] = o[h][i] * wa + oo * wb;
+                }
+                m[h] = M;
+            }
+        }
+        if (active && sub == 0) {
+#pragma unroll
+            for (int h = 0; h < REP; ++h) {
+                const float inv = 1.0f / l[h];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xs[(size_t)(g * REP + h) * HD + c * 8 + i] = DT<T>::rnd(o[h][i] * inv);
+            }
+        }
+        __syncthreads();
+    }
+}
 
 template <int NCH> struct RowsInFlight { static constexpr int v = NCH >= 12 ? 1 : (NCH >= 6 ? 2 : 4); };
 
@@ -48,7 +173,7 @@ template <typename T, int NCH, int PRO, int EPI, bool NT>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;     // physical rows per logical row
     constexpr int RB = (RowsInFlight<NCH>::v / NR) > 0 ? (RowsInFlight<NCH>::v / NR) : 1;
-    extern __shared__ __attribute__((aligned(16))) float xs[];      // PRO_COMBINE only: K floats
+    extern __shared__ __attribute__((aligned(16))) float xs[];      // PRO_COMBINE / PRO_ATTN only: K floats (+ scratch)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int K = a.K;
     const T* W = reinterpret_cast<const T*>(a.W);
@@ -79,7 +204,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         biasv[r] = (a.bias && rv) ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + row) : 0.f;
     }
     float xr[NCH][8];
-    if (PRO == PRO_COMBINE) {
+    if (PRO == PRO_ATTN) {
+        float* scratch = xs + K;
+        if (a.rep == 1) attn_small_prologue<T, 1>(a, xs, scratch);
+        else if (a.rep == 2) attn_small_prologue<T, 2>(a, xs, scratch);
+        else attn_small_prologue<T, 4>(a, xs, scratch);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int off = j * 512 + lane * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xr[j][i] = off < K ? xs[off + i] : 0.f;
+        }
+    } else if (PRO == PRO_COMBINE) {
         // thread t merges the attention partials of elements [8t, 8t+8) (one head); result via LDS
         for (int c0 = tid; c0 * 8 < K; c0 += 256) {
             const int e0 = c0 * 8;

@@ -5,6 +5,7 @@
 #include "sampler_wave.cuh"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -88,6 +89,8 @@ extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
     if ((r = dmalloc(c, (void**)&c->ids64, (size_t)64 * sizeof(int64_t)))) return r;
     if ((r = dmalloc(c, (void**)&c->d_pemb, (size_t)64 * sizeof(void*)))) return r;
     HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    if (const char* e = getenv("FQ3_NT")) c->opt_nt = atoi(e);
+    if (const char* e = getenv("FQ3_FUSED_ATTN")) c->opt_fused_attn = atoi(e);
     *out = c;
     return FQ3_OK;
 }
@@ -146,7 +149,8 @@ static void launch_gemv_n(GemvArgs a, hipStream_t s) {
     if (R > RB) R = RB;
     a.R = R;
     const int grid = (a.N + 4 * R - 1) / (4 * R);
-    const size_t shm = PRO == PRO_COMBINE ? (size_t)a.K * sizeof(float) : 0;
+    const size_t shm = PRO == PRO_COMBINE ? (size_t)a.K * sizeof(float)
+                     : (PRO == PRO_ATTN ? (size_t)(a.K + 4 * (a.rep + 2) * kHeadDim) * sizeof(float) : 0);
     hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT>), dim3(grid), dim3(256), shm, s, a);
 }
 template <typename T, int PRO, int EPI, bool NT>
@@ -185,7 +189,9 @@ static int run_stack(fq3_ctx* c, bool talker, const StepSrc& src, hipStream_t s)
     StackBufs& kv = talker ? c->tk : c->pk;
     const int rep = d.n_heads / d.n_kv_heads;
     const int q_dim = d.n_heads * kHeadDim, kv_dim = d.n_kv_heads * kHeadDim;
-    const bool nt = talker;     // talker weights stream once per frame; predictor weights are re-read 16x
+    // talker weights stream once per frame (non-temporal); predictor weights are re-read 16x per frame and
+    // should stay in the 256 MB Infinity Cache (default policy).  FQ3_NT overrides: 0 none, 1 talker, 2 all.
+    const bool nt = c->opt_nt == 2 || (c->opt_nt == 1 && talker);
     // RoPE row: immediate position -> table row chosen on the host; device position -> the row the
     // frame's embed_sum kernel staged in rope_now
     const float *cos_row, *sin_row;
@@ -206,22 +212,30 @@ static int run_stack(fq3_ctx* c, bool talker, const StepSrc& src, hipStream_t s)
         g.W = w.qkv; g.N = q_dim + 2 * kv_dim; g.K = d.hidden; g.x = xin;
         g.norm_w = w.input_norm; g.y = c->qkv;
         if (int r = launch_gemv<PRO_NORM, EPI_STORE>(c, g, nt, s)) return r;
-        // 2. attention
-        AttnArgs a{};
-        a.qkv = c->qkv; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm; a.eps = d.rms_eps;
-        a.cos_row = cos_row; a.sin_row = sin_row;
-        a.kcache = kv.k[i]; a.vcache = kv.v[i]; a.max_seq = kv.max_seq;
-        a.pos_ptr = src.pos_ptr; a.pos_imm = src.pos_imm;
-        a.n_pad = talker ? c->n_pad : 0;
-        a.n_kv = d.n_kv_heads; a.part = c->part;
-        a.scale = 1.0f / sqrtf((float)kHeadDim);
-        if (c->cfg.dtype == FQ3_BF16) launch_attn_t<bf16_t>(a, rep, kv.workers, s);
-        else launch_attn_t<float>(a, rep, kv.workers, s);
-        // 3. combine + o_proj + residual
+        // 2+3. attention, then o_proj + residual
         GemvArgs o{};
-        o.W = w.o; o.N = d.hidden; o.K = q_dim; o.y = c->h; o.res = xin;
-        o.part = c->part; o.n_part = kv.workers; o.rep = rep;
-        if (int r = launch_gemv<PRO_COMBINE, EPI_RESIDUAL>(c, o, nt, s)) return r;
+        o.W = w.o; o.N = d.hidden; o.K = q_dim; o.y = c->h; o.res = xin; o.rep = rep;
+        const bool fused_attn = c->opt_fused_attn && !talker && !src.pos_ptr && src.pos_imm <= 16;
+        if (fused_attn) {
+            // short context (code predictor): attention recomputed inside every o_proj workgroup -> 4 launches/layer
+            o.qkv = c->qkv; o.q_norm_w = w.q_norm; o.k_norm_w = w.k_norm; o.eps = d.rms_eps;
+            o.cos_row = cos_row; o.sin_row = sin_row; o.kcache = kv.k[i]; o.vcache = kv.v[i]; o.max_seq = kv.max_seq;
+            o.pos = src.pos_imm; o.n_kv = d.n_kv_heads; o.scale = 1.0f / sqrtf((float)kHeadDim);
+            if (int r = launch_gemv<PRO_ATTN, EPI_RESIDUAL>(c, o, nt, s)) return r;
+        } else {
+            AttnArgs a{};
+            a.qkv = c->qkv; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm; a.eps = d.rms_eps;
+            a.cos_row = cos_row; a.sin_row = sin_row;
+            a.kcache = kv.k[i]; a.vcache = kv.v[i]; a.max_seq = kv.max_seq;
+            a.pos_ptr = src.pos_ptr; a.pos_imm = src.pos_imm;
+            a.n_pad = talker ? c->n_pad : 0;
+            a.n_kv = d.n_kv_heads; a.part = c->part;
+            a.scale = 1.0f / sqrtf((float)kHeadDim);
+            if (c->cfg.dtype == FQ3_BF16) launch_attn_t<bf16_t>(a, rep, kv.workers, s);
+            else launch_attn_t<float>(a, rep, kv.workers, s);
+            o.part = c->part; o.n_part = kv.workers;
+            if (int r = launch_gemv<PRO_COMBINE, EPI_RESIDUAL>(c, o, nt, s)) return r;
+        }
         // 4. norm + gate/up + SwiGLU
         GemvArgs m{};
         m.eps = d.rms_eps; m.W = w.gate_up; m.N = d.inter; m.K = d.hidden; m.x = c->h;

@@ -31,6 +31,8 @@ struct fq3_ctx {
     int* codes = nullptr;
     int64_t* ids64 = nullptr;
     int n_pad = 0, rope_delta = 0;
+    int opt_nt = 1;               // weight-load cache policy (see run_stack)
+    int opt_fused_attn = 0;       // predictor attention inside the o_proj launch (measured: no gain on MI355X, kept for A/B)
     int prefill_mode = 0;         // 0 auto (MFMA), 1 token walk
     bool talker_wave = true;      // talker sampler variant baked into the captured graph
     fq3_sampling pred_sampling{0.9f, 50, 1.0f, 1, 1.0f};

@@ -70,13 +70,11 @@ __device__ int sample_wave_core(Raw8<T> (&xraw)[NC], int V, const SampleCfg& c, 
         constexpr int kLowBit = sizeof(T) == 2 ? 16 : 0;       // bf16 values live in the top 16 bits
         for (int bit = 31; bit >= kLowBit; --bit) {
             const uint32_t cand = prefix | (1u << bit);
-            int cnt = 0;
+            int cnt = 0;                 // wave-uniform: ballots + scalar popcounts, no cross-lane shuffles
 #pragma unroll
             for (int j = 0; j < NC; ++j)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) cnt += key[j][i] >= cand ? 1 : 0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+                for (int i = 0; i < 8; ++i) cnt += __popcll(__ballot(key[j][i] >= cand));
             if (cnt >= kk) prefix = cand;
         }
 #pragma unroll

@@ -405,15 +405,50 @@ class FasterQwen3TTS:
         stream = fn(talker=talker, talker_input_embeds=tie, attention_mask=tam, trailing_text_hiddens=tth,
                     tts_pad_embed=tpe, config=config, predictor_graph=self.predictor_graph,
                     talker_graph=self.talker_graph, chunk_size=chunk_size, **gen_kwargs)
+        dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
+        use_side = torch.cuda.is_available() and hasattr(tok, "decode_tensor")
+        if use_side and getattr(self, "_voc_stream", None) is None:
+            self._voc_stream = torch.cuda.Stream(device=dev)
         for chunk, timing in stream:
+            ev = timing.pop("codes_ready_event", None)
+            if use_side:
+                chunk.record_stream(self._voc_stream)
             all_codes.append(chunk)
             n_new = chunk.shape[0]
-            flat = torch.cat(all_codes, dim=0)
+
+            def vocode(codes_in):
+                # the codec runs on its own stream so that it overlaps the next chunk's decode kernels
+                if not use_side:
+                    lst, rate = tok.decode({"audio_codes": codes_in.unsqueeze(0)})
+                    return _to_numpy(lst[0]), rate
+                side = self._voc_stream
+                if ev is not None:
+                    side.wait_event(ev)
+                else:
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    lst, rate = tok.decode({"audio_codes": codes_in.unsqueeze(0)})
+                    out = _to_numpy(lst[0])          # .cpu() synchronises the side stream only
+                return out, rate
+
+            if use_side:
+                with torch.cuda.stream(self._voc_stream):
+                    if ev is not None:
+                        self._voc_stream.wait_event(ev)
+                    flat = torch.cat(all_codes, dim=0)
+            else:
+                flat = torch.cat(all_codes, dim=0)
             n_total = flat.shape[0]
             if spf is None:
-                inp = torch.cat([ref_codes.to(flat.device), flat], dim=0) if ref_codes is not None else flat
-                audio_list, sr = tok.decode({"audio_codes": inp.unsqueeze(0)})
-                audio = _to_numpy(audio_list[0])
+                if ref_codes is not None:
+                    if use_side:
+                        with torch.cuda.stream(self._voc_stream):
+                            inp = torch.cat([ref_codes.to(flat.device), flat], dim=0)
+                    else:
+                        inp = torch.cat([ref_codes.to(flat.device), flat], dim=0)
+                else:
+                    inp = flat
+                audio, sr = vocode(inp)
                 if ref_codes is not None:
                     audio = audio[int(ref_codes.shape[0] / max(inp.shape[0], 1) * len(audio)):]
                 new_audio = audio[prev_len:]
@@ -424,8 +459,7 @@ class FasterQwen3TTS:
                 start = max(0, n_total - n_new - context_frames)
                 window = flat[start:]
                 n_ctx = window.shape[0] - n_new
-                audio_list, sr = tok.decode({"audio_codes": window.unsqueeze(0)})
-                audio = _to_numpy(audio_list[0])
+                audio, sr = vocode(window)
                 new_audio = audio[int(round(n_ctx * spf)):] if n_ctx > 0 else audio
             yield new_audio, sr, timing
 

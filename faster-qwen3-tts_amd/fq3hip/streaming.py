@@ -30,17 +30,21 @@ def fast_generate_streaming(talker, talker_input_embeds: torch.Tensor, attention
     t_prefill = time.time() - t_start
     issued, emitted, chunk_count, done = 0, 0, 0, False
     chunk_start = time.time()
-    while not done and issued < max_frames:
-        issued = run_frames(eng, tn, pn, issued, min(chunk_size, max_frames - issued))
-        n, done = eng.decode_poll()
+    issued = run_frames(eng, tn, pn, issued, min(chunk_size, max_frames))
+    while True:
+        n, done = eng.decode_poll()              # host sync: chunk k is complete
         new = n - emitted
         if new <= 0:
             break
         chunk = eng.decode_codes(emitted, new)
-        torch.cuda.synchronize(eng.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(eng.device))
         emitted = n
-        # streaming.py:157-188: full chunks carry is_final=False; only a trailing partial chunk is final
-        is_final = new < chunk_size
+        is_final = new < chunk_size              # streaming.py:157-188: only a trailing partial chunk is final
+        more = (not done) and (not is_final) and issued < max_frames
+        if more:
+            # look-ahead: chunk k+1 decodes while the consumer vocodes chunk k on its own stream
+            issued = run_frames(eng, tn, pn, issued, min(chunk_size, max_frames - issued))
         yield chunk, {
             "chunk_index": chunk_count,
             "chunk_steps": new,
@@ -48,10 +52,11 @@ def fast_generate_streaming(talker, talker_input_embeds: torch.Tensor, attention
             "decode_ms": (time.time() - chunk_start) * 1000,
             "total_steps_so_far": emitted,
             "is_final": is_final,
+            "codes_ready_event": ready,          # extra key: lets a consumer on another stream wait for `chunk` only
         }
         chunk_count += 1
         chunk_start = time.time()
-        if is_final:
+        if not more:
             break
 
 

@@ -85,7 +85,9 @@ def test_streaming_equals_non_streaming(model_and_weights):
     metas = [(t["chunk_index"], t["chunk_steps"], t["total_steps_so_far"], t["is_final"]) for _, t in chunks]
     assert metas == [(0, 8, 8, False), (1, 8, 16, False), (2, 5, 21, True)]
     assert chunks[0][1]["prefill_ms"] > 0 and chunks[1][1]["prefill_ms"] == 0
-    assert set(chunks[0][1]) == {"chunk_index", "chunk_steps", "prefill_ms", "decode_ms", "total_steps_so_far", "is_final"}
+    # the reference's keys, plus one extra (an event that lets another stream wait for just this chunk)
+    assert set(chunks[0][1]) - {"codes_ready_event"} == {"chunk_index", "chunk_steps", "prefill_ms", "decode_ms",
+                                                          "total_steps_so_far", "is_final"}
     # parity_mode (no hipGraph) gives the same ids
     codes2, _ = fast_generate(talker, tie, tam, tth, tpe, config, m.predictor_graph, m.talker_graph, max_new_tokens=21,
                               parity_mode=True, **GREEDY)
