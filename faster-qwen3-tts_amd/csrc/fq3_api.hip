@@ -387,13 +387,8 @@ __global__ void build_seen_kernel(const int64_t* history, int n, unsigned char* 
 }
 template <typename F>
 static void dispatch_nc(int V, F&& f) {
-    const int nc = (V + 511) / 512;
-    if (nc <= 1) f(std::integral_constant<int, 1>{});
-    else if (nc <= 2) f(std::integral_constant<int, 2>{});
-    else if (nc <= 3) f(std::integral_constant<int, 3>{});
-    else if (nc <= 4) f(std::integral_constant<int, 4>{});
-    else if (nc <= 6) f(std::integral_constant<int, 6>{});
-    else f(std::integral_constant<int, 8>{});
+    if (V <= 2048) f(std::integral_constant<int, 1>{});
+    else f(std::integral_constant<int, 2>{});
 }
 
 template <typename T>
@@ -402,7 +397,7 @@ static void launch_sample_pred(const DecodeState* st, const T* lg, int V, int cb
                                hipStream_t s) {
     if (wave) dispatch_nc(V, [&](auto nc) {
         constexpr int NC = decltype(nc)::value;
-        hipLaunchKernelGGL((sample_pred_wave_kernel<T, NC>), dim3(1), dim3(64), 0, s, st, lg, V, cb, cfg, nz, codes, G,
+        hipLaunchKernelGGL((sample_pred_wave_kernel<T, NC>), dim3(1), dim3(256), 0, s, st, lg, V, cb, cfg, nz, codes, G,
                            out64, next_emb, next_in, H);
     });
     else hipLaunchKernelGGL((sample_pred_kernel<T>), dim3(1), dim3(256), 0, s, st, lg, V, cb, cfg, nz, codes, G, out64,
@@ -412,7 +407,7 @@ template <typename T>
 static void launch_sample_talker(DecodeState* st, const T* lg, int V, const unsigned char* seen, bool wave, hipStream_t s) {
     if (wave) dispatch_nc(V, [&](auto nc) {
         constexpr int NC = decltype(nc)::value;
-        hipLaunchKernelGGL((sample_talker_wave_kernel<T, NC>), dim3(1), dim3(64), 0, s, st, lg, V, seen);
+        hipLaunchKernelGGL((sample_talker_wave_kernel<T, NC>), dim3(1), dim3(256), 0, s, st, lg, V, seen);
     });
     else hipLaunchKernelGGL((sample_talker_kernel<T>), dim3(1), dim3(256), 0, s, st, lg, V, seen);
 }
@@ -427,7 +422,7 @@ static void launch_sample_api(fq3_ctx* c, const T* lg, int V, const SampleCfg& c
         }
         dispatch_nc(V, [&](auto nc) {
             constexpr int NC = decltype(nc)::value;
-            hipLaunchKernelGGL((sample_api_wave_kernel<T, NC>), dim3(1), dim3(64), 0, s, lg, V, cfg, seen, noise, out);
+            hipLaunchKernelGGL((sample_api_wave_kernel<T, NC>), dim3(1), dim3(256), 0, s, lg, V, cfg, seen, noise, out);
         });
     } else {
         hipLaunchKernelGGL((sample_api_kernel<T>), dim3(1), dim3(256), 0, s, lg, V, cfg, history, n_hist, noise, out);
