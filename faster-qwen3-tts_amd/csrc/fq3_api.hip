@@ -152,6 +152,8 @@ static void launch_gemv_n(GemvArgs a, hipStream_t s) {
     const size_t shm = PRO == PRO_COMBINE ? (size_t)a.K * sizeof(float)
                      : (PRO == PRO_ATTN ? (size_t)(a.K + 4 * (a.rep + 2) * kHeadDim) * sizeof(float) : 0);
     hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT>), dim3(grid), dim3(256), shm, s, a);
+    static const bool dup = getenv("FQ3_EXPERIMENT_DUP") != nullptr;     // timing experiment only (results are wrong)
+    if (dup) hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT>), dim3(grid), dim3(256), shm, s, a);
 }
 template <typename T, int PRO, int EPI, bool NT>
 static int launch_gemv_t(const GemvArgs& a, hipStream_t s) {
