@@ -280,3 +280,79 @@ def test_fused_predictor_attention_variant(monkeypatch):
     ids, lg = eng.predictor_loop(x.view(-1).cuda(), want_logits=True)
     assert torch.equal(ids.cpu(), o_ids)
     assert (lg.float().cpu() - o_logits.float()).abs().max() <= 5e-4
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_eos_stop_and_position_limit(graph):
+    from oracle import qwen3tts_oracle as O
+    cfg = tiny_test_config()
+    dtype = torch.float32
+    W = synth_weights(cfg, 0, dtype)
+    # (1) position limit: generate.py:174-177 stops silently at max_seq_len - 1 after recording the frame
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, 30, 4, 0, dtype=dtype)
+    orc = O.OracleTTS(cfg, W, max_seq_len=40)
+    orc.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    sp = O.SamplingParams(max_new_tokens=50, **{**O.GREEDY, "min_new_tokens": 50})
+    ref = orc.generate(tie, tam, tth, tpe, sp)
+    eng = _engine(cfg, W, dtype, max_seq=40)
+    eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    codes = _run_loop(eng, cfg, dtype, tie, tam, tth, tpe, max_new=50, min_new=50, rp=1.0, graph=graph)
+    assert ref.shape[0] == 10 and torch.equal(codes, ref)          # 30 + 9 = 39 = max_seq_len - 1
+    n, done = eng.decode_poll()
+    assert done and n == 10
+    # (2) EOS: zero every non-EOS row of codec_head -> all real logits are 0, EOS row kept -> as soon as
+    # suppression ends the arg-max is EOS (or id 0 when the EOS logit is negative): compare with the oracle
+    W2 = dict(W)
+    hw = torch.zeros_like(W["talker.codec_head.weight"])
+    hw[cfg.codec_eos_token_id] = W["talker.codec_head.weight"][cfg.codec_eos_token_id].abs() * 4
+    W2["talker.codec_head.weight"] = hw
+    W2["talker.model.norm.weight"] = W["talker.model.norm.weight"].abs()
+    orc2 = O.OracleTTS(cfg, W2, max_seq_len=96)
+    orc2.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    sp2 = O.SamplingParams(max_new_tokens=12, **{**O.GREEDY, "min_new_tokens": 3})
+    tie2, tam2, tth2, tpe2, _ = synth_prompt(cfg, 16, 4, 0, dtype=dtype)
+    ref2 = orc2.generate(tie2, tam2, tth2, tpe2, sp2)
+    eng2 = _engine(cfg, W2, dtype)
+    eng2.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    codes2 = _run_loop(eng2, cfg, dtype, tie2, tam2, tth2, tpe2, max_new=12, min_new=3, rp=1.0, graph=graph)
+    assert ref2 is not None and ref2.shape[0] < 12          # EOS ended the run before the budget
+    assert torch.equal(codes2, ref2)
+    assert (codes2[:, 0] != cfg.codec_eos_token_id).all()   # EOS is never emitted (tests/test_e2e_parity.py:70-74)
+
+
+def test_long_run_wraps_noise_ring_and_is_seed_deterministic():
+    """> 64 frames crosses the Exp(1) noise-ring refill (fq3hip/generate.py NOISE_RING); same seed -> same ids."""
+    from fq3hip.model import FasterQwen3TTS
+    from fq3hip.generate import fast_generate
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, torch.bfloat16)
+    m = FasterQwen3TTS.from_weights(cfg, W, device="cuda", dtype=torch.bfloat16, max_seq_len=160, codec_max_frames=16, max_frames=96)
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, 12, 4, 0, dtype=torch.bfloat16)
+    inner = m.model.model
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(77)
+        codes, timing = fast_generate(inner.talker, tie.cuda(), tam.cuda(), tth.cuda(), tpe.cuda(), inner.config.talker_config,
+                                      m.predictor_graph, m.talker_graph, max_new_tokens=80, min_new_tokens=80)
+        outs.append(codes.cpu())
+    assert outs[0].shape == (80, 16) and torch.equal(outs[0], outs[1])
+    assert int(outs[0][:, 0].max()) < cfg.talker.vocab_size - 1024 and int(outs[0][:, 1:].max()) < cfg.predictor.vocab_size
+    assert len(set(outs[0][:, 0].tolist())) > 4            # it is actually sampling
+
+
+def test_projection_model_1p7b_shape_family():
+    """Predictor narrower than the talker (1.7B family): small_to_mtp_projection path (predictor_graph.py:118,145)."""
+    from oracle import qwen3tts_oracle as O
+    cfg = tiny_test_config(hidden=512, pred_hidden=256, heads=4, kv_heads=2)
+    assert cfg.predictor_has_projection
+    dtype = torch.float32
+    W = synth_weights(cfg, 0, dtype)
+    assert "talker.code_predictor.small_to_mtp_projection.weight" in W
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, 14, 4, 0, dtype=dtype)
+    orc = O.OracleTTS(cfg, W, max_seq_len=96)
+    orc.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    ref = orc.generate(tie, tam, tth, tpe, O.SamplingParams(max_new_tokens=10, **O.GREEDY))
+    eng = _engine(cfg, W, dtype)
+    eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    codes = _run_loop(eng, cfg, dtype, tie, tam, tth, tpe, max_new=10, min_new=0, rp=1.0, graph=True)
+    assert torch.equal(codes, ref)
