@@ -63,17 +63,64 @@ def build_model(device):
     W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor", "codec"))
     model = FasterQwen3TTS.from_weights(cfg, W, device=device, dtype=torch.bfloat16, max_seq_len=2048,
                                         codec_max_frames=REF_FRAMES + FRAMES + 16, max_frames=FRAMES + 8)
+    model._bench_weights = W
     return cfg, model
 
 
-def one_utterance(model, prompt, seed):
+def concurrent_throughput(cfg, model, prompt, device, streams=4, utterances=2):
+    """Extra (not the headline): S utterances in flight on ONE GPU, each with its own decode context, codec
+    workspace, hipGraph and HIP stream, all borrowing the single weight replica.  Batch-1 decode leaves
+    >90 % of the chip idle (latency-bound launches), so independent utterances overlap almost freely."""
+    import threading
+    from fq3hip.model import FasterQwen3TTS
+    models = [model] + [FasterQwen3TTS.from_weights(cfg, model._bench_weights, device=device, dtype=torch.bfloat16,
+                                                    max_seq_len=2048, codec_max_frames=REF_FRAMES + FRAMES + 16,
+                                                    max_frames=FRAMES + 8, share=model) for _ in range(streams - 1)]
+    bar = threading.Barrier(streams)
+    res = [None] * streams
+
+    errors = []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(torch.device(device))
+            st = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(st):
+                one_utterance(models[i], prompt, 5000 + i, sync=st.synchronize)     # per-context warm-up + graph capture
+                bar.wait(timeout=60)
+                t0 = time.perf_counter()
+                frames, ttfas = 0, []
+                for u in range(utterances):
+                    ttfa, wall, n, _ = one_utterance(models[i], prompt, 6000 + 10 * i + u, sync=st.synchronize)
+                    frames += n; ttfas.append(ttfa)
+                res[i] = (t0, time.perf_counter(), frames, ttfas)
+        except BaseException as e:      # never leave the other workers parked on the barrier
+            errors.append(repr(e))
+            bar.abort()
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(streams)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=180)
+    if errors or any(r is None for r in res):
+        return {"streams": streams, "error": "; ".join(errors) or "worker timed out"}
+    t0 = min(r[0] for r in res); t1 = max(r[1] for r in res)
+    frames = sum(r[2] for r in res)
+    ttfas = [x for r in res for x in r[3]]
+    return {"streams": streams, "utterances": streams * utterances, "value": round(frames * FRAME_S / (t1 - t0), 3),
+            "unit": "x real-time (aggregate audio s / wall s, one GPU)", "ttfa_ms_p50": round(1000 * float(np.median(ttfas)), 2)}
+
+
+def one_utterance(model, prompt, seed, sync=None):
     """Streaming voice-clone of one synthetic utterance.  Returns (ttfa_s, wall_s, n_frames, pcm)."""
+    sync = sync or torch.cuda.synchronize
     tie, tam, tth, tpe, ref_codes = prompt
     m = model.model.model
     talker, config = m.talker, m.config.talker_config
     torch.manual_seed(seed)
     kw = model._gen_kwargs(FRAMES, FRAMES, 0.9, 50, 1.0, True, 1.05)
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     ttfa, chunks, frames = None, [], 0
     for audio, sr, timing in model._run_streaming(m, talker, config, tie, tam, tth, tpe, ref_codes, kw, CHUNK):
@@ -81,7 +128,7 @@ def one_utterance(model, prompt, seed):
             ttfa = time.perf_counter() - t0       # `audio` is a host array: the first chunk is complete here
         chunks.append(audio)
         frames = timing["total_steps_so_far"]
-    torch.cuda.synchronize()
+    sync()
     wall = time.perf_counter() - t0
     return ttfa, wall, frames, np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
 
@@ -154,6 +201,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--concurrent", type=int, default=0, help="extra: utterances in flight per GPU for a throughput figure (0 = skip)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -190,6 +238,13 @@ def main():
         ttfas.append(ttfa); rtfs.append(n * FRAME_S / wall); frames_total += n
     barrier()
     elapsed = time.perf_counter() - t0
+
+    conc = None
+    if args.concurrent > 1 and rank == 0:
+        try:
+            conc = concurrent_throughput(cfg, model, prompt, device, streams=args.concurrent)
+        except Exception as e:      # an extra; never lose the headline line to it
+            conc = {"error": repr(e)}
 
     # max over ranks of the wall time, sum of frames, gather of TTFAs and (result gather) PCM lengths
     if world > 1:
@@ -234,6 +289,8 @@ def main():
                          "traffic": 3.54e9, "traffic_source": "profiles/r01_pmc_fetch_size.txt",
                          "launch_ms": round(frame_ms, 4)},
         }
+        if conc is not None:
+            out["concurrent_utterances_one_gpu"] = conc
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg)

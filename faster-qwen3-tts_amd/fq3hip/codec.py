@@ -66,7 +66,7 @@ class HipSpeechTokenizer:
     """``speech_tokenizer`` replacement whose ``decode`` runs on the HIP codec kernels."""
 
     def __init__(self, cfg: CodecConfig, weights: Weights, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
-                 max_frames: int = 1024):
+                 max_frames: int = 1024, share: "HipSpeechTokenizer" = None):
         self.lib = L.load()
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         self.sample_rate = int(cfg.sample_rate)
@@ -88,16 +88,16 @@ class HipSpeechTokenizer:
         self.h = L.vp()
         with torch.cuda.device(self.device):
             L.check(self.lib.fq3_codec_create(C.byref(cc), C.byref(self.h)))
-        self._keep: List[torch.Tensor] = []
-        packed = pack_codec_weights(weights, cfg)
-        for name, t in packed.items():
-            t = t.to(device=self.device, dtype=dtype).contiguous()
-            self._keep.append(t)
-            L.check(self.lib.fq3_codec_bind(self.h, name.encode(), t.data_ptr(), t.numel()))
-        cs, sn = rope_tables(cfg.head_dim, cfg.rope_theta, self.max_frames, dtype)
-        for name, t in (("rope.cos", cs), ("rope.sin", sn)):
-            t = t.to(self.device).contiguous()
-            self._keep.append(t)
+        self._bound: Dict[str, torch.Tensor] = {}
+        if share is not None and share.dtype == dtype and share.device == self.device and share.max_frames == self.max_frames:
+            self._bound = dict(share._bound)            # borrow the packed tensors of another decoder instance
+        else:
+            for name, t in pack_codec_weights(weights, cfg).items():
+                self._bound[name] = t.to(device=self.device, dtype=dtype).contiguous()
+            cs, sn = rope_tables(cfg.head_dim, cfg.rope_theta, self.max_frames, dtype)
+            self._bound["rope.cos"] = cs.to(self.device).contiguous()
+            self._bound["rope.sin"] = sn.to(self.device).contiguous()
+        for name, t in self._bound.items():
             L.check(self.lib.fq3_codec_bind(self.h, name.encode(), t.data_ptr(), t.numel()))
         L.check(self.lib.fq3_codec_finalize(self.h, None))
 

@@ -33,7 +33,9 @@ class Fq3Engine:
     """One decode context (talker + predictor static state) on one GPU.  Not re-entrant."""
 
     def __init__(self, cfg: TTSConfig, weights: Weights, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
-                 max_seq_len: int = 2048, max_frames: int = 4096):
+                 max_seq_len: int = 2048, max_frames: int = 4096, share: Optional["Fq3Engine"] = None):
+        """``share``: another engine on the same device/dtype whose packed weight tensors this context borrows
+        (one weight replica per GPU, one context -- KV cache, loop state, graph -- per concurrent utterance)."""
         if dtype not in (torch.bfloat16, torch.float32):
             raise ValueError("fq3hip supports torch.bfloat16 and torch.float32")
         self.lib = L.load()
@@ -53,11 +55,21 @@ class Fq3Engine:
         c.num_code_groups = cfg.num_code_groups
         c.max_seq_len = self.max_seq_len
         c.codec_eos_token_id = cfg.codec_eos_token_id
-        c.has_projection = 1 if "talker.code_predictor.small_to_mtp_projection.weight" in weights else 0
+        c.has_projection = 1 if ("talker.code_predictor.small_to_mtp_projection.weight" in weights or
+                                 (share is not None and share._table.proj_w)) else 0
         c.max_frames = self.max_frames
         with torch.cuda.device(self.device):
             L.check(self.lib.fq3_ctx_create(C.byref(c), C.byref(self.ctx)))
-            self._bind(weights)
+            if share is not None:
+                if share.dtype != dtype or share.device != self.device or share.max_seq_len < self.max_seq_len:
+                    raise ValueError("shared engine must match dtype/device and cover max_seq_len (RoPE tables)")
+                self._share = share                       # keeps the borrowed tensors alive
+                self._table = share._table
+                self.codec_embedding, self.codec_head_w = share.codec_embedding, share.codec_head_w
+                self.predictor_embeddings = share.predictor_embeddings
+                L.check(self.lib.fq3_bind_weights(self.ctx, C.byref(self._table)))
+            else:
+                self._bind(weights)
         self.weights = weights
         self._pred_sampling = dict(do_sample=True, top_k=50, top_p=1.0, temperature=0.9)
 

@@ -93,7 +93,7 @@ def fast_generate(talker, talker_input_embeds: torch.Tensor, attention_mask: tor
         talker, talker_input_embeds, attention_mask, trailing_text_hiddens, tts_pad_embed, config, predictor_graph,
         talker_graph, max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty,
         use_graph=not parity_mode)
-    torch.cuda.synchronize(eng.device)
+    torch.cuda.current_stream(eng.device).synchronize()
     t_prefill = time.time() - t_start
     t_decode_start = time.time()
     issued, n, done = 0, 0, False
@@ -101,7 +101,7 @@ def fast_generate(talker, talker_input_embeds: torch.Tensor, attention_mask: tor
         issued = run_frames(eng, tn, pn, issued, min(poll_every, max_frames - issued))
         n, done = eng.decode_poll()
     codes = eng.decode_codes(0, n) if n > 0 else None
-    torch.cuda.synchronize(eng.device)
+    torch.cuda.current_stream(eng.device).synchronize()
     t_decode = time.time() - t_decode_start
     timing = {
         "prefill_ms": t_prefill * 1000,

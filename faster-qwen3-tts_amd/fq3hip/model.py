@@ -120,15 +120,19 @@ class FasterQwen3TTS:
 
     @classmethod
     def from_weights(cls, cfg, weights, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
-                     max_seq_len: int = 2048, tokenizer=None, codec_max_frames: int = 1024, max_frames: int = 2048):
-        """Build from an in-memory weight table (real or seeded synthetic, ``fq3hip.weights``)."""
+                     max_seq_len: int = 2048, tokenizer=None, codec_max_frames: int = 1024, max_frames: int = 2048,
+                     share: Optional["FasterQwen3TTS"] = None):
+        """Build from an in-memory weight table (real or seeded synthetic, ``fq3hip.weights``).
+        ``share``: an existing model on the same GPU whose weight replica this instance borrows -- one
+        instance (decode context + codec workspace) per concurrently running utterance."""
         if not str(device).startswith("cuda") or not torch.cuda.is_available():
             raise ValueError("CUDA graphs require CUDA device")
         from .native_model import NativeQwen3TTS
         from .predictor_graph import PredictorGraph
         from .talker_graph import TalkerGraph
         base = NativeQwen3TTS(cfg, weights, device=device, dtype=dtype, max_seq_len=max_seq_len, tokenizer=tokenizer,
-                              codec_max_frames=codec_max_frames, max_frames=max_frames)
+                              codec_max_frames=codec_max_frames, max_frames=max_frames,
+                              share=share.model if share is not None else None)
         pg = PredictorGraph(base.engine, do_sample=True, top_k=50, temperature=0.9)      # model.py:209-218
         tg = TalkerGraph(base.engine)
         return cls(base_model=base, predictor_graph=pg, talker_graph=tg, device=device, dtype=dtype,

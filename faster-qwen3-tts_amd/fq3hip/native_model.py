@@ -145,16 +145,19 @@ class NativeQwen3TTS:
     """``base_model`` in the reference's terms: text helpers + ``.model``."""
 
     def __init__(self, cfg: TTSConfig, weights: Weights, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
-                 max_seq_len: int = 2048, tokenizer=None, codec_max_frames: int = 1024, max_frames: int = 2048):
+                 max_seq_len: int = 2048, tokenizer=None, codec_max_frames: int = 1024, max_frames: int = 2048,
+                 share: Optional["NativeQwen3TTS"] = None):
         self.cfg = cfg
         self.device = torch.device(device)
         self.dtype = dtype
-        self.engine = Fq3Engine(cfg, weights, device=device, dtype=dtype, max_seq_len=max_seq_len, max_frames=max_frames)
+        self.engine = Fq3Engine(cfg, weights, device=device, dtype=dtype, max_seq_len=max_seq_len, max_frames=max_frames,
+                                share=share.engine if share is not None else None)
         text = {k: v for k, v in weights.items() if k.startswith(("talker.model.text_embedding", "talker.text_projection"))}
         talker = NativeTalker(cfg, self.engine, text if text else None)
         tok = None
         if any(k.startswith("decoder.") for k in weights):
-            tok = HipSpeechTokenizer(cfg.codec, weights, device=device, dtype=dtype, max_frames=codec_max_frames)
+            tok = HipSpeechTokenizer(cfg.codec, weights, device=device, dtype=dtype, max_frames=codec_max_frames,
+                                     share=share.model.speech_tokenizer if share is not None else None)
         self.model = NativeInner(cfg, talker, tok)
         self.tokenizer = tokenizer or ByteTokenizer(cfg.text_vocab_size)
 

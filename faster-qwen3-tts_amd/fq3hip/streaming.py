@@ -26,7 +26,7 @@ def fast_generate_streaming(talker, talker_input_embeds: torch.Tensor, attention
         talker, talker_input_embeds, attention_mask, trailing_text_hiddens, tts_pad_embed, config, predictor_graph,
         talker_graph, max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty,
         use_graph=use_graph)
-    torch.cuda.synchronize(eng.device)
+    torch.cuda.current_stream(eng.device).synchronize()
     t_prefill = time.time() - t_start
     issued, emitted, chunk_count, done = 0, 0, 0, False
     chunk_start = time.time()
