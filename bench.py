@@ -206,14 +206,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (there is no CPU path for the product)")
+    # FQ3_BENCH_BACKEND=gloo + FQ3_BENCH_ONE_DEVICE=1: smoke-test the N>1 code path on a 1-GPU box
+    backend = os.environ.get("FQ3_BENCH_BACKEND", "nccl")
+    if os.environ.get("FQ3_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (there is no CPU path for the product)")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
+    coll_dev = device if backend == "nccl" else "cpu"
 
     from fq3hip.weights import synth_prompt
     cfg, model = build_model(device)
@@ -249,15 +257,15 @@ def main():
     # max over ranks of the wall time, sum of frames, gather of TTFAs and (result gather) PCM lengths
     if world > 1:
         from fq3hip.sharding import gather_arrays
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
-        ft = torch.tensor([frames_total], device=device, dtype=torch.float64)
+        ft = torch.tensor([frames_total], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(ft)
         frames_total = int(ft)
-        all_ttfa = gather_arrays(np.asarray(ttfas, dtype=np.float32), device)
+        all_ttfa = gather_arrays(np.asarray(ttfas, dtype=np.float32), coll_dev)
         ttfas = [float(x) for a in all_ttfa for x in a]
-        gathered = gather_arrays(pcm.astype(np.float32), device)       # the result gather of the north star
+        gathered = gather_arrays(pcm.astype(np.float32), coll_dev)     # the result gather of the north star
         n_gathered = sum(len(a) for a in gathered)
     else:
         n_gathered = len(pcm)

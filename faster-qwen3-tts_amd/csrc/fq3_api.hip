@@ -584,7 +584,8 @@ extern "C" int fq3_graph_capture(fq3_ctx* c, void* stream) {
     if (c->exec) return FQ3_OK;
     (void)stream;
     hipStream_t cs = c->cap_stream;
-    HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    // relaxed mode: other host threads (other utterances' contexts, the allocator) may issue HIP calls meanwhile
+    HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
     int r = enqueue_frame(c, cs);
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(cs, &g);

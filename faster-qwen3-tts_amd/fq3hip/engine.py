@@ -6,6 +6,7 @@ arithmetic step of the decode path runs in ``libfq3hip.so``.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, Optional
 
 import torch
@@ -14,6 +15,7 @@ from . import _lib as L
 from .config import TTSConfig, StackConfig
 
 Weights = Dict[str, torch.Tensor]
+_CAPTURE_LOCK = threading.Lock()
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -271,7 +273,8 @@ class Fq3Engine:
         L.check(self.lib.fq3_decode_begin(self.ctx, C.byref(p), self._stream()))
 
     def graph_capture(self):
-        L.check(self.lib.fq3_graph_capture(self.ctx, self._stream()))
+        with _CAPTURE_LOCK:          # one capture at a time per process (several contexts may share a GPU)
+            L.check(self.lib.fq3_graph_capture(self.ctx, self._stream()))
 
     def graph_reset(self):
         L.check(self.lib.fq3_graph_reset(self.ctx))
