@@ -356,3 +356,60 @@ def test_projection_model_1p7b_shape_family():
     eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
     codes = _run_loop(eng, cfg, dtype, tie, tam, tth, tpe, max_new=10, min_new=0, rp=1.0, graph=True)
     assert torch.equal(codes, ref)
+
+
+def _real_shape_cfg(size):
+    """Real per-layer shapes (so the NCH=2/4/6/12 GEMV instantiations and the 3072/2048-wide samplers that the
+    benchmark runs are the ones checked), but only 2 + 1 layers so the CPU oracle stays fast."""
+    from fq3hip.config import qwen3_tts_0p6b, qwen3_tts_1p7b
+    cfg = qwen3_tts_0p6b() if size == "0.6b" else qwen3_tts_1p7b()
+    cfg.talker.num_hidden_layers = 2
+    cfg.predictor.num_hidden_layers = 1
+    return cfg
+
+
+@pytest.mark.parametrize("size", ["0.6b", "1.7b"])
+def test_real_layer_shapes_fp32_exact(size):
+    from oracle import qwen3tts_oracle as O
+    cfg = _real_shape_cfg(size)
+    dtype = torch.float32
+    W = synth_weights(cfg, 0, dtype, parts=("talker", "predictor"))
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, 70, 8, 0, dtype=dtype)
+    orc = O.OracleTTS(cfg, W, max_seq_len=128)
+    orc.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    kw = dict(max_new_tokens=5, **{**O.GREEDY, "min_new_tokens": 5})
+    ref = orc.generate(tie, tam, tth, tpe, O.SamplingParams(**kw), record_margins=True)
+    assert min(orc.margins + orc.pred_margins) > 1e-4         # no exact near-tie in this vector
+    eng = _engine(cfg, W, dtype, max_seq=128)
+    eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    for mode in (0, 1):
+        eng.set_prefill_mode(mode)
+        codes = _run_loop(eng, cfg, dtype, tie, tam, tth, tpe, max_new=5, min_new=5, rp=1.0, graph=True)
+        assert torch.equal(codes, ref), (size, mode)
+    # hidden state of one more step, elementwise
+    x = torch.randn(1, 1, cfg.talker.hidden_size, generator=torch.Generator().manual_seed(2))
+    oh = orc.talker_step(x, 70 + 5)
+    gh = eng.talker_step(x.view(-1).cuda(), 70 + 5)
+    assert (gh.float().cpu() - oh.float().view(-1)).abs().max() <= 2e-4 * max(1.0, float(oh.abs().max()))
+
+
+def test_real_layer_shapes_bf16_close():
+    from oracle import qwen3tts_oracle as O
+    cfg = _real_shape_cfg("0.6b")
+    dtype = torch.bfloat16
+    W = synth_weights(cfg, 0, dtype, parts=("talker", "predictor"))
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, 70, 8, 0, dtype=dtype)
+    tie = tie * 30
+    orc = O.OracleTTS(cfg, W, max_seq_len=128)
+    o_logits, o_hidden, _, L = orc.prefill(tie, tam)
+    eng = _engine(cfg, W, dtype, max_seq=128)
+    logits, hidden = eng.prefill(tie[0].cuda().contiguous())
+    sc = float(o_hidden.float().abs().max())
+    assert (hidden.float().cpu() - o_hidden.float().view(-1)).abs().max() <= 0.025 * max(1.0, sc)
+    assert (logits.float().cpu() - o_logits.float().view(-1)).abs().max() <= 0.025 * max(1.0, float(o_logits.float().abs().max()))
+    x = torch.randn(1, 2, cfg.talker.hidden_size, generator=torch.Generator().manual_seed(3)).to(dtype)
+    orc.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    _, ol = orc.predictor_loop(x, return_logits=True)
+    _, gl = eng.predictor_loop(x.view(-1).cuda(), want_logits=True)
+    assert (gl[0].float().cpu() - ol[0].float()).abs().max() <= 0.025 * max(1.0, float(ol[0].float().abs().max()))
