@@ -282,6 +282,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random weights at 0.6B shapes, synthetic 200-token ICL prompt)",
             "config": {"workload": "configs[1]: Qwen3-TTS-12Hz-0.6B-Base voice-clone streaming chunk_size=8, hipGraph decode",
                        "prompt_tokens": PROMPT_LEN, "ref_frames": REF_FRAMES, "frames_per_utterance": FRAMES,
+                       "timed_region": "prefill + decode + streaming vocoder; prompt embeddings are the (HBM-resident) input, "
+                                       "text tokenisation / prompt assembly is host glue outside the hot path",
                        "utterances_per_gpu": args.steps, "sampling": "T=0.9 top_k=50 top_p=1.0 rep=1.05 (predictor T=0.9 top_k=50)",
                        "parallelism": f"utterance-sharded x{world} (replicas, result gather only)"},
             "ttfa_ms_p50": round(1000 * float(np.median(ttfas)), 2), "ttfa_ms_mean": round(1000 * float(np.mean(ttfas)), 2),

@@ -198,3 +198,25 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no CPU / PyTorch fallback"):
         _lib.load()
+
+
+def test_drop_in_import_name():
+    """`from faster_qwen3_tts import FasterQwen3TTS` and the reference's submodule names resolve to fq3hip."""
+    import importlib
+    pkg = importlib.import_module("faster_qwen3_tts")
+    from faster_qwen3_tts import FasterQwen3TTS as A
+    assert A is FasterQwen3TTS
+    for m in ("model", "generate", "streaming", "sampling", "talker_graph", "predictor_graph"):
+        mod = importlib.import_module(f"faster_qwen3_tts.{m}")
+        assert mod.__name__ == f"fq3hip.{m}"
+    from faster_qwen3_tts.generate import fast_generate
+    from faster_qwen3_tts.streaming import fast_generate_streaming, parity_generate_streaming
+    from faster_qwen3_tts.sampling import sample_logits, apply_repetition_penalty
+    import inspect
+    # argument order of the decode loops = reference generate.py:16-37 / streaming.py:19-36
+    assert list(inspect.signature(fast_generate).parameters)[:8] == [
+        "talker", "talker_input_embeds", "attention_mask", "trailing_text_hiddens", "tts_pad_embed", "config",
+        "predictor_graph", "talker_graph"]
+    assert list(inspect.signature(fast_generate_streaming).parameters)[:8] == list(inspect.signature(fast_generate).parameters)[:8]
+    assert inspect.signature(fast_generate_streaming).parameters["chunk_size"].default == 12
+    assert [p for p in inspect.signature(sample_logits).parameters][:1] == ["logits"]

@@ -22,7 +22,7 @@ def main():
     torch.cuda.synchronize()
     for rep in range(2):
         t0 = time.time(); logits, hidden = eng.prefill(x); torch.cuda.synchronize()
-        print(f"prefill(200, token-by-token) {1e3*(time.time()-t0):.1f} ms")
+        print(f"prefill(200 tokens, MFMA) {1e3*(time.time()-t0):.1f} ms")
     V = cfg.talker.vocab_size
     kw = dict(temperature=0.9, top_k=50, top_p=1.0, do_sample=True)
     nf = 64
