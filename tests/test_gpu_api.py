@@ -139,3 +139,71 @@ def test_sampling_module_on_gpu():
     l2 = torch.zeros(1, 1, 10, device="cuda"); l2[..., 7] = 1.0; l2[..., 8] = -1.0
     out = apply_repetition_penalty(l2.clone(), torch.tensor([7, 8, 8], device="cuda"), 1.1)
     assert out[0, 0, 7].item() == pytest.approx(1 / 1.1, rel=1e-6) and out[0, 0, 8].item() == pytest.approx(-1.1, rel=1e-6)
+
+
+def test_prefill_kv_import_from_hf_style_cache(model_and_weights):
+    """TalkerGraph.prefill_kv with an HF-style cache (layer -> (k, v) [1, kv_heads, L, d]), talker_graph.py:153-170."""
+    from fq3hip.engine import Fq3Engine
+    from fq3hip.talker_graph import TalkerGraph
+    cfg, W, m = model_and_weights
+    eng = m.talker_graph.engine
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn(37, cfg.talker.hidden_size, generator=g) * 0.5).cuda()
+    eng.prefill(x.contiguous())
+    cache = []
+    for li in range(cfg.talker.num_hidden_layers):
+        k, v = eng.kv_export(li, 37)
+        cache.append((k.unsqueeze(0).clone(), v.unsqueeze(0).clone()))
+    step_in = torch.randn(cfg.talker.hidden_size, generator=g).cuda()
+    want = eng.talker_step(step_in, 37).clone()
+    eng2 = Fq3Engine(cfg, W, device="cuda", dtype=torch.float32, max_seq_len=64, max_frames=8)
+    tg2 = TalkerGraph(eng2)
+    assert tg2.prefill_kv(cache) == 37
+    tg2.set_generation_state(torch.ones(1, 37, dtype=torch.long), None)
+    got = tg2.run(step_in.view(1, 1, -1), 37)
+    assert torch.equal(got.view(-1), want)
+    tiny = Fq3Engine(cfg, W, device="cuda", dtype=torch.float32, max_seq_len=32, max_frames=8)
+    with pytest.raises(RuntimeError, match="Input is too long"):
+        TalkerGraph(tiny).prefill_kv(cache)
+
+
+@pytest.mark.parametrize("kind", ["custom_voice", "voice_design"])
+def test_custom_voice_and_voice_design_paths(kind):
+    """generate_custom_voice / generate_voice_design (model.py:1139-1505): same decode core, different prompt."""
+    import copy
+    from fq3hip.model import FasterQwen3TTS
+    from fq3hip.generate import fast_generate
+    cfg = copy.deepcopy(tiny_test_config())
+    cfg.tts_model_type = kind
+    cfg.tts_model_size = "1b7"
+    cfg.spk_id = {"bob": 7}
+    cfg.spk_is_dialect = {"bob": False}
+    W = synth_weights(cfg, 0, torch.float32, parts=("talker", "predictor", "codec", "text"))
+    m = FasterQwen3TTS.from_weights(cfg, W, device="cuda", dtype=torch.float32, max_seq_len=160, codec_max_frames=64, max_frames=32)
+    m.predictor_graph.do_sample = False
+    m.predictor_graph.top_k = 0
+    text = "Say this in a designed voice."
+    if kind == "custom_voice":
+        prep = m._custom_prepare(text, "bob", "English", "speak slowly", None)
+        with pytest.raises(ValueError):
+            m.generate_custom_voice(text, "alice", "English")
+        with pytest.raises(ValueError):
+            m.generate_custom_voice(text, "bob", "Klingon")
+    else:
+        prep = m._design_prepare(text, "a calm low voice", "English", None)
+    _, talker, config, tie, tam, tth, tpe = prep
+    assert tth.shape[1] == 1            # non_streaming_mode defaults to True here: the whole text is prefilled
+    codes, _ = fast_generate(talker, tie, tam, tth, tpe, config, m.predictor_graph, m.talker_graph, max_new_tokens=10, **GREEDY)
+    from oracle import qwen3tts_oracle as O
+    orc = O.OracleTTS(cfg, W, max_seq_len=160)
+    orc.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    ref = orc.generate(tie.cpu(), tam.cpu(), tth.cpu(), tpe.cpu(), O.SamplingParams(max_new_tokens=10, **GREEDY))
+    assert torch.equal(codes.cpu(), ref)
+    if kind == "custom_voice":
+        audio, sr = m.generate_custom_voice(text, "bob", "English", instruct="speak slowly", max_new_tokens=10, **GREEDY)
+        chunks = list(m.generate_custom_voice_streaming(text, "bob", "English", max_new_tokens=10, chunk_size=4, **GREEDY))
+    else:
+        audio, sr = m.generate_voice_design(text, "a calm low voice", "English", max_new_tokens=10, **GREEDY)
+        chunks = list(m.generate_voice_design_streaming(text, "a calm low voice", "English", max_new_tokens=10, chunk_size=4, **GREEDY))
+    assert sr == 24000 and len(audio[0]) == m.speech_tokenizer.num_samples(codes.shape[0])
+    assert sum(c[2]["chunk_steps"] for c in chunks) == codes.shape[0]
