@@ -40,6 +40,8 @@ struct GemvArgs {
     void* xn_out;                                  // optional: block 0 stores the prologue result as T[K]
     int up_off;                                    // SWIGLU: first "up" row
     const float* part; int n_part; int rep;        // PRO_COMBINE: attention partial slots
+    // second token of an M = 2 launch
+    const void* x2; void* y2; const void* res2; size_t part_stride2;
     // PRO_ATTN (short-context attention computed redundantly in every workgroup: code predictor, <= 17 keys)
     const void* qkv; const void* q_norm_w; const void* k_norm_w;
     const float* cos_row; const float* sin_row;
@@ -169,11 +171,14 @@ __device__ __forceinline__ void attn_small_prologue(const GemvArgs& a, float* xs
 
 template <int NCH> struct RowsInFlight { static constexpr int v = NCH >= 12 ? 1 : (NCH >= 6 ? 2 : 4); };
 
-template <typename T, int NCH, int PRO, int EPI, bool NT>
+// M = number of tokens that share one pass over the weights (2 only for the code predictor's two-token
+// prefill, predictor_graph.py:121-128: weights are read once, both tokens' dot products are formed).
+template <typename T, int NCH, int PRO, int EPI, bool NT, int M = 1>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
+    static_assert(M == 1 || PRO != PRO_ATTN, "the fused short-context attention prologue is single-token");
     constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;     // physical rows per logical row
     constexpr int RB = (RowsInFlight<NCH>::v / NR) > 0 ? (RowsInFlight<NCH>::v / NR) : 1;
-    extern __shared__ __attribute__((aligned(16))) float xs[];      // PRO_COMBINE / PRO_ATTN only: K floats (+ scratch)
+    extern __shared__ __attribute__((aligned(16))) float xs[];      // PRO_COMBINE / PRO_ATTN only: M*K floats (+ scratch)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int K = a.K;
     const T* W = reinterpret_cast<const T*>(a.W);
@@ -195,15 +200,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
                 else zero(raw[h][r][j]);
             }
         }
-    float resv[RB], biasv[RB];
+    float resv[M][RB], biasv[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const int row = row0 + r;
         const bool rv = (r < a.R) && (row < a.N);
-        resv[r] = (EPI == EPI_RESIDUAL && rv) ? DT<T>::ld(reinterpret_cast<const T*>(a.res) + row) : 0.f;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const T* rp = reinterpret_cast<const T*>(m == 0 ? a.res : a.res2);
+            resv[m][r] = (EPI == EPI_RESIDUAL && rv) ? DT<T>::ld(rp + row) : 0.f;
+        }
         biasv[r] = (a.bias && rv) ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + row) : 0.f;
     }
-    float xr[NCH][8];
+    float xr[M][NCH][8];
     if (PRO == PRO_ATTN) {
         float* scratch = xs + K;
         if (a.rep == 1) attn_small_prologue<T, 1>(a, xs, scratch);
@@ -213,77 +222,89 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         for (int j = 0; j < NCH; ++j) {
             const int off = j * 512 + lane * 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xr[j][i] = off < K ? xs[off + i] : 0.f;
+            for (int i = 0; i < 8; ++i) xr[0][j][i] = off < K ? xs[off + i] : 0.f;
         }
     } else if (PRO == PRO_COMBINE) {
         // thread t merges the attention partials of elements [8t, 8t+8) (one head); result via LDS
-        for (int c0 = tid; c0 * 8 < K; c0 += 256) {
-            const int e0 = c0 * 8;
-            const int head = e0 / kHeadDim, d0 = e0 - head * kHeadDim;
-            const int g = head / a.rep, hh = head - g * a.rep;
-            const float* p0 = a.part + ((size_t)(g * kMaxWorkers) * a.rep + hh) * kPartStride;
-            const size_t sstride = (size_t)a.rep * kPartStride;
-            f32x4 oa[kMaxWorkers], ob[kMaxWorkers];
-            float pm[kMaxWorkers], pl[kMaxWorkers];
 #pragma unroll
-            for (int s = 0; s < kMaxWorkers; ++s) {
-                if (s < a.n_part) {
-                    const float* ps = p0 + s * sstride;
-                    oa[s] = *reinterpret_cast<const f32x4*>(ps + d0);
-                    ob[s] = *reinterpret_cast<const f32x4*>(ps + d0 + 4);
-                    pm[s] = ps[kHeadDim]; pl[s] = ps[kHeadDim + 1];
-                } else { oa[s] = f32x4{0.f, 0.f, 0.f, 0.f}; ob[s] = oa[s]; pm[s] = -1e30f; pl[s] = 0.f; }
+        for (int m = 0; m < M; ++m) {
+            const float* part = a.part + (size_t)m * a.part_stride2;
+            for (int c0 = tid; c0 * 8 < K; c0 += 256) {
+                const int e0 = c0 * 8;
+                const int head = e0 / kHeadDim, d0 = e0 - head * kHeadDim;
+                const int g = head / a.rep, hh = head - g * a.rep;
+                const float* p0 = part + ((size_t)(g * kMaxWorkers) * a.rep + hh) * kPartStride;
+                const size_t sstride = (size_t)a.rep * kPartStride;
+                f32x4 oa[kMaxWorkers], ob[kMaxWorkers];
+                float pm[kMaxWorkers], pl[kMaxWorkers];
+#pragma unroll
+                for (int s = 0; s < kMaxWorkers; ++s) {
+                    if (s < a.n_part) {
+                        const float* ps = p0 + s * sstride;
+                        oa[s] = *reinterpret_cast<const f32x4*>(ps + d0);
+                        ob[s] = *reinterpret_cast<const f32x4*>(ps + d0 + 4);
+                        pm[s] = ps[kHeadDim]; pl[s] = ps[kHeadDim + 1];
+                    } else { oa[s] = f32x4{0.f, 0.f, 0.f, 0.f}; ob[s] = oa[s]; pm[s] = -1e30f; pl[s] = 0.f; }
+                }
+                float Mx = pm[0];
+#pragma unroll
+                for (int s = 1; s < kMaxWorkers; ++s) Mx = fmaxf(Mx, pm[s]);
+                f32x4 na = f32x4{0.f, 0.f, 0.f, 0.f}, nb = na;
+                float den = 0.f;
+#pragma unroll
+                for (int s = 0; s < kMaxWorkers; ++s) {
+                    const float w = __expf(pm[s] - Mx);
+                    na += oa[s] * w; nb += ob[s] * w; den = fmaf(w, pl[s], den);
+                }
+                const float inv = 1.0f / den;
+                float* d = xs + (size_t)m * K + e0;
+                d[0] = DT<T>::rnd(na.x * inv); d[1] = DT<T>::rnd(na.y * inv); d[2] = DT<T>::rnd(na.z * inv); d[3] = DT<T>::rnd(na.w * inv);
+                d[4] = DT<T>::rnd(nb.x * inv); d[5] = DT<T>::rnd(nb.y * inv); d[6] = DT<T>::rnd(nb.z * inv); d[7] = DT<T>::rnd(nb.w * inv);
             }
-            float M = pm[0];
-#pragma unroll
-            for (int s = 1; s < kMaxWorkers; ++s) M = fmaxf(M, pm[s]);
-            f32x4 na = f32x4{0.f, 0.f, 0.f, 0.f}, nb = na;
-            float den = 0.f;
-#pragma unroll
-            for (int s = 0; s < kMaxWorkers; ++s) {
-                const float w = __expf(pm[s] - M);
-                na += oa[s] * w; nb += ob[s] * w; den = fmaf(w, pl[s], den);
-            }
-            const float inv = 1.0f / den;
-            float* d = xs + e0;
-            d[0] = DT<T>::rnd(na.x * inv); d[1] = DT<T>::rnd(na.y * inv); d[2] = DT<T>::rnd(na.z * inv); d[3] = DT<T>::rnd(na.w * inv);
-            d[4] = DT<T>::rnd(nb.x * inv); d[5] = DT<T>::rnd(nb.y * inv); d[6] = DT<T>::rnd(nb.z * inv); d[7] = DT<T>::rnd(nb.w * inv);
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int off = j * 512 + lane * 8;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) xr[j][i] = off < K ? xs[off + i] : 0.f;
-        }
-    } else {
-        // every wave reads the whole input vector itself (L2-resident, 2-12 KB): no LDS, no barrier
-        const T* x = reinterpret_cast<const T*>(a.x);
-        Raw8<T> xraw[NCH], nraw[NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int off = j * 512 + lane * 8;
-            if (off < K) {
-                ldraw<false>(xraw[j], x + off);
-                if (PRO == PRO_NORM) ldraw<false>(nraw[j], reinterpret_cast<const T*>(a.norm_w) + off);
-            } else { zero(xraw[j]); if (PRO == PRO_NORM) zero(nraw[j]); }
-        }
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) unpack(xraw[j], xr[j]);
-        if (PRO == PRO_NORM) {
-            float ss = 0.f;
-#pragma unroll
-            for (int j = 0; j < NCH; ++j)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
-            ss = wave_sum(ss);
-            const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+        for (int m = 0; m < M; ++m)
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
-                float nw[8];
-                unpack(nraw[j], nw);
+                const int off = j * 512 + lane * 8;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) xr[j][i] = DT<T>::rnd(nw[i] * DT<T>::rnd(xr[j][i] * rs));
+                for (int i = 0; i < 8; ++i) xr[m][j][i] = off < K ? xs[(size_t)m * K + off + i] : 0.f;
+            }
+    } else {
+        // every wave reads the whole input vector itself (L2-resident, 2-12 KB): no LDS, no barrier
+        Raw8<T> xraw[M][NCH], nraw[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int off = j * 512 + lane * 8;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const T* x = reinterpret_cast<const T*>(m == 0 ? a.x : a.x2);
+                if (off < K) ldraw<false>(xraw[m][j], x + off); else zero(xraw[m][j]);
+            }
+            if (PRO == PRO_NORM) {
+                if (off < K) ldraw<false>(nraw[j], reinterpret_cast<const T*>(a.norm_w) + off); else zero(nraw[j]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) unpack(xraw[m][j], xr[m][j]);
+            if (PRO == PRO_NORM) {
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ss = fmaf(xr[m][j][i], xr[m][j][i], ss);
+                ss = wave_sum(ss);
+                const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    float nw[8];
+                    unpack(nraw[j], nw);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xr[m][j][i] = DT<T>::rnd(nw[i] * DT<T>::rnd(xr[m][j][i] * rs));
+                }
             }
         }
     }
@@ -294,7 +315,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
             const int off = j * 512 + lane * 8;
             if (off < K)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) DT<T>::st(o + off + i, xr[j][i]);
+                for (int i = 0; i < 8; ++i) DT<T>::st(o + off + i, xr[0][j][i]);
         }
     }
 
@@ -303,25 +324,28 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     for (int r = 0; r < RB; ++r) {
         const int row = row0 + r;
         if (r >= a.R || row >= a.N) break;            // wave-uniform
-        float acc[NR];
 #pragma unroll
-        for (int h = 0; h < NR; ++h) {
-            float s = 0.f;
+        for (int m = 0; m < M; ++m) {
+            float acc[NR];
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) s = dot8<T>(raw[h][r][j], xr[j], s);
-            acc[h] = wave_sum(s);
-        }
-        if (lane == 0) {
-            T* y = reinterpret_cast<T*>(a.y);
-            if (EPI == EPI_SWIGLU) {
-                const float g = DT<T>::rnd(acc[0]);
-                const float u = DT<T>::rnd(acc[NR - 1]);
-                const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
-                DT<T>::st(y + row, sg * u);
-            } else {
-                float v = DT<T>::rnd(acc[0] + biasv[r]);
-                if (EPI == EPI_RESIDUAL) v = v + resv[r];
-                DT<T>::st(y + row, v);
+            for (int h = 0; h < NR; ++h) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) s = dot8<T>(raw[h][r][j], xr[m][j], s);
+                acc[h] = wave_sum(s);
+            }
+            if (lane == 0) {
+                T* y = reinterpret_cast<T*>(m == 0 ? a.y : a.y2);
+                if (EPI == EPI_SWIGLU) {
+                    const float g = DT<T>::rnd(acc[0]);
+                    const float u = DT<T>::rnd(acc[NR - 1]);
+                    const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
+                    DT<T>::st(y + row, sg * u);
+                } else {
+                    float v = DT<T>::rnd(acc[0] + biasv[r]);
+                    if (EPI == EPI_RESIDUAL) v = v + resv[m][r];
+                    DT<T>::st(y + row, v);
+                }
             }
         }
     }

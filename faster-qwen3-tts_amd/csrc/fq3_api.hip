@@ -69,6 +69,10 @@ extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
     const int frames = cfg->max_frames > 0 ? cfg->max_frames : 4096;
     c->cfg.max_frames = frames;
     if ((r = dmalloc(c, &c->h, (size_t)Hm * c->esz))) return r;
+    if ((r = dmalloc(c, &c->h2, (size_t)Hm * c->esz))) return r;
+    if ((r = dmalloc(c, &c->qkv2, (size_t)qkvm * c->esz))) return r;
+    if ((r = dmalloc(c, &c->act2, (size_t)Im * c->esz))) return r;
+    if ((r = dmalloc(c, &c->pred_x2, (size_t)p.hidden * c->esz))) return r;
     if ((r = dmalloc(c, &c->xin, (size_t)Hm * c->esz))) return r;
     if ((r = dmalloc(c, &c->tmp_hidden, (size_t)Hm * c->esz))) return r;
     if ((r = dmalloc(c, &c->qkv, (size_t)qkvm * c->esz))) return r;
@@ -80,7 +84,8 @@ extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
     if ((r = dmalloc(c, &c->pred_x, (size_t)p.hidden * c->esz))) return r;
     if ((r = dmalloc(c, &c->plogits, (size_t)(G - 1) * p.vocab * c->esz))) return r;
     const int maxkv = std::max(t.n_kv_heads, p.n_kv_heads);
-    if ((r = dmalloc(c, (void**)&c->part, (size_t)maxkv * kMaxWorkers * 4 * kPartStride * sizeof(float)))) return r;
+    c->part_stride = (size_t)maxkv * kMaxWorkers * 4 * kPartStride;
+    if ((r = dmalloc(c, (void**)&c->part, 2 * c->part_stride * sizeof(float)))) return r;
     if ((r = dmalloc(c, (void**)&c->rope_now, 2 * 64 * sizeof(float)))) return r;
     if ((r = dmalloc(c, (void**)&c->seen_api, kMaxVocab))) return r;
     if ((r = dmalloc(c, (void**)&c->st, sizeof(DecodeState)))) return r;
@@ -91,6 +96,7 @@ extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     if (const char* e = getenv("FQ3_NT")) c->opt_nt = atoi(e);
     if (const char* e = getenv("FQ3_FUSED_ATTN")) c->opt_fused_attn = atoi(e);
+    if (const char* e = getenv("FQ3_M2")) c->opt_m2 = atoi(e);
     *out = c;
     return FQ3_OK;
 }
@@ -140,7 +146,7 @@ extern "C" int fq3_bind_weights(fq3_ctx* c, const fq3_weight_table* w) {
 // -------------------------------------------------------------------------------------------------
 // GEMV dispatch
 // -------------------------------------------------------------------------------------------------
-template <typename T, int NCH, int PRO, int EPI, bool NT>
+template <typename T, int NCH, int PRO, int EPI, bool NT, int M = 1>
 static void launch_gemv_n(GemvArgs a, hipStream_t s) {
     constexpr int NR = EPI == EPI_SWIGLU ? 2 : 1;
     constexpr int RB = (RowsInFlight<NCH>::v / NR) > 0 ? (RowsInFlight<NCH>::v / NR) : 1;
@@ -149,11 +155,27 @@ static void launch_gemv_n(GemvArgs a, hipStream_t s) {
     if (R > RB) R = RB;
     a.R = R;
     const int grid = (a.N + 4 * R - 1) / (4 * R);
-    const size_t shm = PRO == PRO_COMBINE ? (size_t)a.K * sizeof(float)
+    const size_t shm = PRO == PRO_COMBINE ? (size_t)M * a.K * sizeof(float)
                      : (PRO == PRO_ATTN ? (size_t)(a.K + 4 * (a.rep + 2) * kHeadDim) * sizeof(float) : 0);
-    hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT>), dim3(grid), dim3(256), shm, s, a);
+    hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT, M>), dim3(grid), dim3(256), shm, s, a);
     static const bool dup = getenv("FQ3_EXPERIMENT_DUP") != nullptr;     // timing experiment only (results are wrong)
-    if (dup) hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT>), dim3(grid), dim3(256), shm, s, a);
+    if (dup) hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT, M>), dim3(grid), dim3(256), shm, s, a);
+}
+// two-token launches: code predictor only (default cache policy), hidden sizes up to 2048 / intermediate up to 6144
+template <typename T, int PRO, int EPI>
+static int launch_gemv2_t(const GemvArgs& a, hipStream_t s) {
+    const int need = (a.K + 511) / 512;
+    if (need <= 1) launch_gemv_n<T, 1, PRO, EPI, false, 2>(a, s);
+    else if (need <= 2) launch_gemv_n<T, 2, PRO, EPI, false, 2>(a, s);
+    else if (need <= 4) launch_gemv_n<T, 4, PRO, EPI, false, 2>(a, s);
+    else if (need <= 6) launch_gemv_n<T, 6, PRO, EPI, false, 2>(a, s);
+    else if (need <= 12) launch_gemv_n<T, 12, PRO, EPI, false, 2>(a, s);
+    else return fail(FQ3_EUNSUPPORTED, "GEMV inner dimension above 6144");
+    return 0;
+}
+template <int PRO, int EPI>
+static int launch_gemv2(const fq3_ctx* c, const GemvArgs& a, hipStream_t s) {
+    return c->cfg.dtype == FQ3_BF16 ? launch_gemv2_t<bf16_t, PRO, EPI>(a, s) : launch_gemv2_t<float, PRO, EPI>(a, s);
 }
 template <typename T, int PRO, int EPI, bool NT>
 static int launch_gemv_t(const GemvArgs& a, hipStream_t s) {
@@ -247,6 +269,48 @@ static int run_stack(fq3_ctx* c, bool talker, const StepSrc& src, hipStream_t s)
         GemvArgs dn{};
         dn.W = w.down; dn.N = d.hidden; dn.K = d.inter; dn.x = c->act; dn.y = c->h; dn.res = c->h;
         if (int r = launch_gemv<PRO_PLAIN, EPI_RESIDUAL>(c, dn, nt, s)) return r;
+    }
+    return 0;
+}
+
+// The code predictor's two-token prefill (predictor_graph.py:121-128) as ONE pass over the weights: every GEMV
+// is launched with M = 2 (weights read once), attention runs once per token (token B attends to A and B).
+// Token A = x_a at cache slot 0, token B = x_b at slot 1; results: c->h (token A), c->h2 (token B).
+static int run_predictor_pair(fq3_ctx* c, const void* x_a, const void* x_b, hipStream_t s) {
+    const fq3_stack_dims& d = c->cfg.predictor;
+    StackBufs& kv = c->pk;
+    const int rep = d.n_heads / d.n_kv_heads;
+    const int q_dim = d.n_heads * kHeadDim, kv_dim = d.n_kv_heads * kHeadDim;
+    for (int i = 0; i < d.n_layers; ++i) {
+        const fq3_layer_weights& w = c->pl[i];
+        const void* xa = i == 0 ? x_a : c->h;
+        const void* xb = i == 0 ? x_b : c->h2;
+        GemvArgs g{};
+        g.eps = d.rms_eps; g.W = w.qkv; g.N = q_dim + 2 * kv_dim; g.K = d.hidden; g.x = xa; g.x2 = xb;
+        g.norm_w = w.input_norm; g.y = c->qkv; g.y2 = c->qkv2;
+        if (int r = launch_gemv2<PRO_NORM, EPI_STORE>(c, g, s)) return r;
+        for (int m = 0; m < 2; ++m) {
+            AttnArgs a{};
+            a.qkv = m == 0 ? c->qkv : c->qkv2; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm; a.eps = d.rms_eps;
+            a.cos_row = c->wt.pred_cos + (size_t)m * 64; a.sin_row = c->wt.pred_sin + (size_t)m * 64;
+            a.kcache = kv.k[i]; a.vcache = kv.v[i]; a.max_seq = kv.max_seq;
+            a.pos_ptr = nullptr; a.pos_imm = m; a.n_pad = 0; a.n_kv = d.n_kv_heads;
+            a.part = c->part + (size_t)m * c->part_stride; a.scale = 1.0f / sqrtf((float)kHeadDim);
+            if (c->cfg.dtype == FQ3_BF16) launch_attn_t<bf16_t>(a, rep, kv.workers, s);
+            else launch_attn_t<float>(a, rep, kv.workers, s);
+        }
+        GemvArgs o{};
+        o.W = w.o; o.N = d.hidden; o.K = q_dim; o.y = c->h; o.y2 = c->h2; o.res = xa; o.res2 = xb; o.rep = rep;
+        o.part = c->part; o.part_stride2 = c->part_stride; o.n_part = kv.workers;
+        if (int r = launch_gemv2<PRO_COMBINE, EPI_RESIDUAL>(c, o, s)) return r;
+        GemvArgs m{};
+        m.eps = d.rms_eps; m.W = w.gate_up; m.N = d.inter; m.K = d.hidden; m.x = c->h; m.x2 = c->h2;
+        m.norm_w = w.post_norm; m.y = c->act; m.y2 = c->act2; m.up_off = d.inter;
+        if (int r = launch_gemv2<PRO_NORM, EPI_SWIGLU>(c, m, s)) return r;
+        GemvArgs dn{};
+        dn.W = w.down; dn.N = d.hidden; dn.K = d.inter; dn.x = c->act; dn.x2 = c->act2; dn.y = c->h; dn.y2 = c->h2;
+        dn.res = c->h; dn.res2 = c->h2;
+        if (int r = launch_gemv2<PRO_PLAIN, EPI_RESIDUAL>(c, dn, s)) return r;
     }
     return 0;
 }
@@ -480,6 +544,21 @@ static int predictor_passes_t(fq3_ctx* c, const DecodeState* st_dev, const void*
     SampleCfg scfg = to_cfg(c->pred_sampling);
     // pass schedule: token A (past_hidden, pos 0), token B (embed(tok0), pos 1), then 14 single-token passes
     for (int pass = 0; pass < G; ++pass) {              // G = 16 token passes
+        const void* hsrc = c->h;                        // where this pass leaves its last hidden state
+        if (pass == 0 && c->opt_m2) {
+            // two-token prefill in one pass over the weights
+            const T* xa = (const T*)pred_input;
+            const T* xb = (const T*)pred_input + Ht;
+            if (c->cfg.has_projection) {
+                GemvArgs g{};
+                g.W = c->wt.proj_w; g.bias = c->wt.proj_b; g.N = p.hidden; g.K = Ht; g.x = xa; g.x2 = xb; g.y = c->pred_x; g.y2 = c->pred_x2;
+                if (int r = launch_gemv2<PRO_PLAIN, EPI_STORE>(c, g, s)) return r;
+                xa = (const T*)c->pred_x; xb = (const T*)c->pred_x2;
+            }
+            if (int r = run_predictor_pair(c, xa, xb, s)) return r;
+            pass = 1;                                   // token B (slot 1) produced codebook 0 below
+            hsrc = c->h2;
+        } else {
         const T* x_talker = pass < 2 ? (const T*)pred_input + (size_t)pass * Ht : (const T*)c->pred_next;
         const void* x0 = x_talker;
         if (c->cfg.has_projection) {                    // small_to_mtp_projection (predictor_graph.py:118,145)
@@ -490,11 +569,12 @@ static int predictor_passes_t(fq3_ctx* c, const DecodeState* st_dev, const void*
         }
         StepSrc src{x0, nullptr, pass};
         if (int r = run_stack(c, false, src, s)) return r;
+        }
         if (pass == 0) continue;                        // first prefill token: only its K/V are needed
         const int cb = pass - 1;                        // codebook produced by this pass
         T* lg = out_logits ? (T*)out_logits + (size_t)cb * Vp : (T*)c->plogits + (size_t)cb * Vp;
         GemvArgs hgm{};
-        hgm.eps = p.rms_eps; hgm.W = c->lmh[cb]; hgm.N = Vp; hgm.K = p.hidden; hgm.x = c->h;
+        hgm.eps = p.rms_eps; hgm.W = c->lmh[cb]; hgm.N = Vp; hgm.K = p.hidden; hgm.x = hsrc;
         hgm.norm_w = c->wt.predictor_final_norm; hgm.y = lg;
         if (int r = launch_gemv<PRO_NORM, EPI_STORE>(c, hgm, false, s)) return r;
         const T* nz = noise_imm ? (const T*)noise_imm + (size_t)cb * Vp : nullptr;

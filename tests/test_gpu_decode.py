@@ -413,3 +413,26 @@ def test_real_layer_shapes_bf16_close():
     _, ol = orc.predictor_loop(x, return_logits=True)
     _, gl = eng.predictor_loop(x.view(-1).cuda(), want_logits=True)
     assert (gl[0].float().cpu() - ol[0].float()).abs().max() <= 0.025 * max(1.0, float(ol[0].float().abs().max()))
+
+
+@pytest.mark.parametrize("m2", ["0", "1"])
+def test_predictor_two_token_prefill_modes(monkeypatch, m2):
+    """FQ3_M2=1: the predictor's two-token prefill is one M=2 pass over the weights; FQ3_M2=0 (default): two
+    single-token passes.  Both must reproduce the oracle (fp32 exact ids, logits to 5e-4), also for a model with
+    the small_to_mtp projection."""
+    from oracle import qwen3tts_oracle as O
+    monkeypatch.setenv("FQ3_M2", m2)
+    for cfg in (tiny_test_config(), tiny_test_config(hidden=512, pred_hidden=256)):
+        dtype = torch.float32
+        W = synth_weights(cfg, 0, dtype)
+        orc = O.OracleTTS(cfg, W, max_seq_len=96)
+        orc.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+        eng = _engine(cfg, W, dtype)
+        eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+        g = torch.Generator().manual_seed(23)
+        for _ in range(2):
+            x = torch.randn(1, 2, cfg.talker.hidden_size, generator=g)
+            o_ids, o_logits = orc.predictor_loop(x, return_logits=True)
+            ids, lg = eng.predictor_loop(x.view(-1).cuda(), want_logits=True)
+            assert torch.equal(ids.cpu(), o_ids)
+            assert (lg.float().cpu() - o_logits.float()).abs().max() <= 5e-4
