@@ -205,7 +205,7 @@ static void launch_attn_t(const AttnArgs& a, int rep, int workers, hipStream_t s
 
 // One token through every layer of a stack (no final norm).  Layer 0 reads its input (and its
 // residual) from x0 [+ (*x0_idx) * hidden]; later layers work in place on c->h.
-struct StepSrc { const void* x0; const int* pos_ptr; int pos_imm; };
+struct StepSrc { const void* x0; const int* pos_ptr; int pos_imm; bool kv_only_tail = false; };
 
 static int run_stack(fq3_ctx* c, bool talker, const StepSrc& src, hipStream_t s) {
     const fq3_stack_dims& d = talker ? c->cfg.talker : c->cfg.predictor;
@@ -236,6 +236,9 @@ static int run_stack(fq3_ctx* c, bool talker, const StepSrc& src, hipStream_t s)
         g.W = w.qkv; g.N = q_dim + 2 * kv_dim; g.K = d.hidden; g.x = xin;
         g.norm_w = w.input_norm; g.y = c->qkv;
         if (int r = launch_gemv<PRO_NORM, EPI_STORE>(c, g, nt, s)) return r;
+        // the first predictor prefill token only feeds K/V to later passes: its last layer needs nothing after the
+        // cache append (which the attention launch performs)
+        const bool tail_skip = src.kv_only_tail && i == d.n_layers - 1;
         // 2+3. attention, then o_proj + residual
         GemvArgs o{};
         o.W = w.o; o.N = d.hidden; o.K = q_dim; o.y = c->h; o.res = xin; o.rep = rep;
@@ -257,6 +260,7 @@ static int run_stack(fq3_ctx* c, bool talker, const StepSrc& src, hipStream_t s)
             a.scale = 1.0f / sqrtf((float)kHeadDim);
             if (c->cfg.dtype == FQ3_BF16) launch_attn_t<bf16_t>(a, rep, kv.workers, s);
             else launch_attn_t<float>(a, rep, kv.workers, s);
+            if (tail_skip) break;
             o.part = c->part; o.n_part = kv.workers;
             if (int r = launch_gemv<PRO_COMBINE, EPI_RESIDUAL>(c, o, nt, s)) return r;
         }
@@ -568,6 +572,7 @@ static int predictor_passes_t(fq3_ctx* c, const DecodeState* st_dev, const void*
             x0 = c->pred_x;
         }
         StepSrc src{x0, nullptr, pass};
+        src.kv_only_tail = pass == 0 && c->opt_fused_attn == 0;
         if (int r = run_stack(c, false, src, s)) return r;
         }
         if (pass == 0) continue;                        // first prefill token: only its K/V are needed
