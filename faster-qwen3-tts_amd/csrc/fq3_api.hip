@@ -153,6 +153,10 @@ static void launch_gemv_n(GemvArgs a, hipStream_t s) {
     int R = (a.N + 1023) / 1024;            // aim at >= 256 workgroups of 4 waves
     if (R < 1) R = 1;
     if (R > RB) R = RB;
+    // rows per wave are capped at 2 (512-768 workgroups for the big GEMVs): measured 2.97 vs 3.07 ms/frame against
+    // the 256-workgroup shape (4 rows per wave); FQ3_RMAX overrides
+    static const int rmax = getenv("FQ3_RMAX") ? atoi(getenv("FQ3_RMAX")) : 2;
+    if (rmax > 0 && R > rmax) R = rmax;
     a.R = R;
     const int grid = (a.N + 4 * R - 1) / (4 * R);
     const size_t shm = PRO == PRO_COMBINE ? (size_t)M * a.K * sizeof(float)
