@@ -234,12 +234,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # decode runs on a high-priority stream, the codec side stream keeps the default (lower) priority, so the
-    # latency-critical frame graph is dispatched ahead of the vocoder's bulk GEMMs when both have work queued
-    lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
-    main_stream = torch.cuda.Stream(device=device, priority=hi) if os.environ.get("FQ3_BENCH_PRIO", "1") == "1" else torch.cuda.current_stream()
-    torch.cuda.synchronize()
-    torch.cuda.set_stream(main_stream)
+    # (a high-priority decode stream was tried: no single-stream gain, and it quarters the throughput of the
+    #  concurrent-utterance mode -- profiles/r01_concurrent_streams.txt -- so everything stays on default-priority streams)
     for i in range(args.warmup):
         one_utterance(model, prompt, 1000 + i)
     frame_ms, p_mid = measure_frame_graph(model, prompt)
