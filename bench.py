@@ -98,11 +98,12 @@ def concurrent_throughput(cfg, model, prompt, device, streams=4, utterances=2):
             errors.append(repr(e))
             bar.abort()
 
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(streams)]
+    th = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(streams)]
     for t in th:
         t.start()
+    deadline = time.time() + 150
     for t in th:
-        t.join(timeout=180)
+        t.join(timeout=max(1.0, deadline - time.time()))
     if errors or any(r is None for r in res):
         return {"streams": streams, "error": "; ".join(errors) or "worker timed out"}
     t0 = min(r[0] for r in res); t1 = max(r[1] for r in res)
@@ -201,7 +202,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--concurrent", type=int, default=0, help="extra: utterances in flight per GPU for a throughput figure (0 = skip)")
+    ap.add_argument("--concurrent", type=int, default=4,
+                    help="extra figure (N=1 only, after the timed region): utterances in flight on one GPU (0 = skip)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -250,7 +252,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     conc = None
-    if args.concurrent > 1 and rank == 0:
+    if args.concurrent > 1 and world == 1:
         try:
             conc = concurrent_throughput(cfg, model, prompt, device, streams=args.concurrent)
         except Exception as e:      # an extra; never lose the headline line to it
