@@ -33,14 +33,15 @@ int fq3_dmalloc_(fq3_ctx* c, void** p, size_t bytes) { return dmalloc(c, p, byte
 static bool dims_ok(const fq3_stack_dims& d) {
     return d.head_dim == kHeadDim && d.hidden % 8 == 0 && d.inter % 8 == 0 && d.n_heads % d.n_kv_heads == 0 &&
            (d.n_heads / d.n_kv_heads == 1 || d.n_heads / d.n_kv_heads == 2 || d.n_heads / d.n_kv_heads == 4) &&
-           d.vocab <= kMaxVocab && d.hidden <= 8192 && d.inter <= 8192 * 3;
+           d.vocab <= kMaxVocab && d.vocab % 8 == 0 && d.hidden <= 8192 && d.inter <= 8192 * 3 && d.n_layers >= 1;
 }
 
 extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
     if (!cfg || !out) return fail(FQ3_EINVAL, "null argument");
     if (cfg->dtype != FQ3_BF16 && cfg->dtype != FQ3_F32) return fail(FQ3_EINVAL, "dtype must be FQ3_BF16 or FQ3_F32");
     if (!dims_ok(cfg->talker) || !dims_ok(cfg->predictor))
-        return fail(FQ3_EUNSUPPORTED, "unsupported dims (need head_dim 128, GQA ratio 1/2/4, vocab <= 4096)");
+        return fail(FQ3_EUNSUPPORTED, "unsupported dims (need head_dim 128, GQA ratio 1/2/4, vocab <= 4096 and a multiple of 8, "
+                                      "hidden / intermediate multiples of 8)");
     if (cfg->num_code_groups < 2 || cfg->num_code_groups > 64) return fail(FQ3_EINVAL, "num_code_groups");
     if (cfg->max_seq_len < 8) return fail(FQ3_EINVAL, "max_seq_len");
     fq3_ctx* c = new fq3_ctx();
@@ -517,7 +518,7 @@ extern "C" int fq3_sample(fq3_ctx* c, const void* logits, int V, const fq3_sampl
                           int n_hist, int sup_lo, int sup_hi, int keep_id, int suppress_eos, const void* noise,
                           int64_t* out_token, void* stream) {
     if (!c || !logits || !sp || !out_token) return fail(FQ3_EINVAL, "null argument");
-    if (V <= 0 || V > kMaxVocab) return fail(FQ3_EUNSUPPORTED, "vocab above 4096");
+    if (V <= 0 || V > kMaxVocab || V % 8) return fail(FQ3_EUNSUPPORTED, "vocab must be a multiple of 8 and at most 4096");
     if (sp->do_sample && !noise) return fail(FQ3_EINVAL, "do_sample needs a noise vector");
     if (sp->do_sample && !(sp->temperature > 0.f)) return fail(FQ3_EINVAL, "temperature must be > 0");
     SampleCfg cfg = to_cfg(*sp);
@@ -619,6 +620,8 @@ extern "C" int fq3_decode_begin(fq3_ctx* c, const fq3_decode_params* p, void* st
     if (p->talker.do_sample && !(p->talker.temperature > 0.f)) return fail(FQ3_EINVAL, "temperature must be > 0");
     if (p->max_new_tokens > c->cfg.max_frames) return fail(FQ3_EINVAL, "max_new_tokens exceeds the context's max_frames");
     if (p->prefill_len <= 0 || p->prefill_len > c->cfg.max_seq_len) return fail(FQ3_EINVAL, "prefill_len");
+    if (p->first_token < 0 || p->first_token >= c->cfg.talker.vocab) return fail(FQ3_EINVAL, "first_token outside the codec vocabulary");
+    if (p->gen_step < 0 || p->min_new_tokens < 0 || p->max_new_tokens < 0) return fail(FQ3_EINVAL, "negative counters");
     const bool wave = p->talker.top_p >= 1.0f;
     if (wave != c->talker_wave) { fq3_graph_reset(c); c->talker_wave = wave; }
     hipStream_t s = (hipStream_t)stream;

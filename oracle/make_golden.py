@@ -69,7 +69,7 @@ def golden_sampler(samp):
         dict(temperature=0.9, top_k=50, top_p=0.9, do_sample=True),
         dict(temperature=1.0, top_k=0, top_p=1.0, do_sample=True),
     ]
-    V_list = [3072, 2048, 1100, 1280]
+    V_list = [3072, 2048, 1104, 1280]
     n = 0
     n_same = 0
     for dt in (torch.float32, torch.bfloat16):
