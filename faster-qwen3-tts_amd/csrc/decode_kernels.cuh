@@ -23,7 +23,7 @@ enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2 };
 constexpr int kHeadDim = 128;        // Qwen3-TTS talker / predictor head_dim
 constexpr int kKeysPerTile = 64;     // keys one attention workgroup handles per loop trip
 constexpr int kMaxWorkers = 8;       // attention workgroups (partial slots) per kv head
-constexpr int kPartStride = kHeadDim + 2;
+constexpr int kPartStride = kHeadDim + 4;     // 128 values + {m, l} + pad: keeps every slot 16-byte aligned
 
 // Latency notes (measured on MI355X, profiles/r01_decode_trace_v0.txt): a dependent global round
 // trip between two kernels costs ~0.5-1 us, so every kernel below issues ALL of its global loads
@@ -528,6 +528,119 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
         float* p = a.part + (((size_t)g * kMaxWorkers + s) * REP + h) * kPartStride;
         p[d] = num;
         if (d == 0) { p[HD] = M; p[HD + 1] = den; }
+    }
+}
+
+// ================================================================================================
+// Code-predictor attention (context <= 17 keys, GQA ratio 2): ONE wave per kv group, everything in
+// registers -- vectors are loaded in the 16-lanes-per-vector layout, head RMSNorm / RoPE / scores use
+// 16-lane shuffles, the 16 cached keys are covered by 4 key groups x 4 sub-groups, no LDS, no barrier,
+// 8 workgroups in total.  Writes partial slot 0 in the format the o_proj combine prologue reads.
+// ================================================================================================
+template <typename T>
+__global__ __launch_bounds__(64) void attn_pred_kernel(AttnArgs a) {
+    constexpr int HD = kHeadDim, REP = 2;
+    const int g = blockIdx.x, lane = threadIdx.x & 63;
+    const int sub = lane >> 4, c = lane & 15;
+    const int pos = a.pos_imm;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    const int q_dim = a.n_kv * REP * HD, kv_dim = a.n_kv * HD;
+    T* kc = reinterpret_cast<T*>(a.kcache) + (size_t)g * a.max_seq * HD;
+    T* vc = reinterpret_cast<T*>(a.vcache) + (size_t)g * a.max_seq * HD;
+    Raw8<T> kr[4], vr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int key = i * 4 + sub;
+        key = key < a.max_seq ? key : a.max_seq - 1;
+        ldraw<false>(kr[i], kc + (size_t)key * HD + c * 8);
+        ldraw<false>(vr[i], vc + (size_t)key * HD + c * 8);
+    }
+    Raw8<T> qraw[REP], knraw, vnraw, qwraw, kwraw;
+#pragma unroll
+    for (int h = 0; h < REP; ++h) ldraw<false>(qraw[h], qkv + (size_t)(g * REP + h) * HD + c * 8);
+    ldraw<false>(knraw, qkv + q_dim + (size_t)g * HD + c * 8);
+    ldraw<false>(vnraw, qkv + q_dim + kv_dim + (size_t)g * HD + c * 8);
+    ldraw<false>(qwraw, reinterpret_cast<const T*>(a.q_norm_w) + c * 8);
+    ldraw<false>(kwraw, reinterpret_cast<const T*>(a.k_norm_w) + c * 8);
+    float cs[8], sn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { cs[i] = a.cos_row[(c * 8 + i) & 63]; sn[i] = a.sin_row[(c * 8 + i) & 63]; }
+    // head RMSNorm + RoPE; the rotate_half partner of dim d (d +- 64) lives in lane c ^ 8 of the same 16-lane group
+    auto norm_rope = [&](const Raw8<T>& raw, const Raw8<T>& wraw, float (&out)[8]) {
+        float x[8], w[8];
+        unpack(raw, x); unpack(wraw, w);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss = fmaf(x[i], x[i], ss);
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+        const float rs = 1.0f / sqrtf(ss / (float)HD + a.eps);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = DT<T>::rnd(w[i] * DT<T>::rnd(x[i] * rs));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float partner = __shfl_xor(x[i], 8, 64);
+            const float rot = c < 8 ? -partner : partner;
+            out[i] = DT<T>::rnd(DT<T>::rnd(x[i] * cs[i]) + DT<T>::rnd(rot * sn[i]));
+        }
+    };
+    float qr[REP][8], knew[8], vnew[8];
+#pragma unroll
+    for (int h = 0; h < REP; ++h) norm_rope(qraw[h], qwraw, qr[h]);
+    norm_rope(knraw, kwraw, knew);
+    unpack(vnraw, vnew);
+    if (sub == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { DT<T>::st(kc + (size_t)pos * HD + c * 8 + i, knew[i]); DT<T>::st(vc + (size_t)pos * HD + c * 8 + i, vnew[i]); }
+    }
+    float m[REP], l[REP], o[REP][8];
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+        m[h] = -1e30f; l[h] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[h][i] = 0.f;
+    }
+    auto step = [&](const float (&kf)[8], const float (&vf)[8], bool valid) {
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            float sc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sc = fmaf(qr[h][i], kf[i], sc);
+            sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
+            sc = valid ? sc * a.scale : -INFINITY;
+            const float mn = fmaxf(m[h], sc), al = __expf(m[h] - mn), p = __expf(sc - mn);
+            l[h] = fmaf(l[h], al, p);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[h][i] = fmaf(o[h][i], al, valid ? p * vf[i] : 0.f);
+            m[h] = mn;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float kf[8], vf[8];
+        unpack(kr[i], kf); unpack(vr[i], vf);
+        step(kf, vf, i * 4 + sub < pos);
+    }
+    step(knew, vnew, sub == 0);
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            const float mo = __shfl_xor(m[h], off, 64), lo = __shfl_xor(l[h], off, 64);
+            const float M = fmaxf(m[h], mo), wa = __expf(m[h] - M), wb = __expf(mo - M);
+            l[h] = l[h] * wa + lo * wb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float oo = __shfl_xor(o[h][i], off, 64); o[h][i] = o[h][i] * wa + oo * wb; }
+            m[h] = M;
+        }
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            float* p = a.part + (((size_t)g * kMaxWorkers + 0) * REP + h) * kPartStride;
+            *reinterpret_cast<f32x4*>(p + c * 8) = f32x4{o[h][0], o[h][1], o[h][2], o[h][3]};
+            *reinterpret_cast<f32x4*>(p + c * 8 + 4) = f32x4{o[h][4], o[h][5], o[h][6], o[h][7]};
+            if (c == 0) { p[HD] = m[h]; p[HD + 1] = l[h]; }
+        }
     }
 }
 

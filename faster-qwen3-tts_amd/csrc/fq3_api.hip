@@ -98,6 +98,7 @@ extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
     if (const char* e = getenv("FQ3_NT")) c->opt_nt = atoi(e);
     if (const char* e = getenv("FQ3_FUSED_ATTN")) c->opt_fused_attn = atoi(e);
     if (const char* e = getenv("FQ3_M2")) c->opt_m2 = atoi(e);
+    if (const char* e = getenv("FQ3_PRED_ATTN")) c->opt_pred_attn = atoi(e);
     *out = c;
     return FQ3_OK;
 }
@@ -263,7 +264,12 @@ static int run_stack(fq3_ctx* c, bool talker, const StepSrc& src, hipStream_t s)
             a.n_pad = talker ? c->n_pad : 0;
             a.n_kv = d.n_kv_heads; a.part = c->part;
             a.scale = 1.0f / sqrtf((float)kHeadDim);
-            if (c->cfg.dtype == FQ3_BF16) launch_attn_t<bf16_t>(a, rep, kv.workers, s);
+            const bool pred_attn = c->opt_pred_attn && !talker && !src.pos_ptr && rep == 2 && src.pos_imm <= 16 && kv.workers == 1;
+            if (pred_attn) {
+                // short-context single-wave attention (8 workgroups, registers only)
+                if (c->cfg.dtype == FQ3_BF16) hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(d.n_kv_heads), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL((attn_pred_kernel<float>), dim3(d.n_kv_heads), dim3(64), 0, s, a);
+            } else if (c->cfg.dtype == FQ3_BF16) launch_attn_t<bf16_t>(a, rep, kv.workers, s);
             else launch_attn_t<float>(a, rep, kv.workers, s);
             if (tail_skip) break;
             o.part = c->part; o.n_part = kv.workers;

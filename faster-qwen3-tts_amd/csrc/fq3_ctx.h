@@ -37,6 +37,7 @@ struct fq3_ctx {
     int opt_fused_attn = 0;       // predictor attention inside the o_proj launch (measured: no gain on MI355X, kept for A/B)
     int opt_m2 = 0;               // code predictor: FQ3_M2=1 runs the two-token prefill as one M = 2 pass over the weights
                                   // (parity-tested; measured 3.12 vs 3.04 ms/frame, so off by default)
+    int opt_pred_attn = 1;        // code predictor: single-wave register-only attention kernel (FQ3_PRED_ATTN=0: generic kernel)
     int prefill_mode = 0;         // 0 auto (MFMA), 1 token walk
     bool talker_wave = true;      // talker sampler variant baked into the captured graph
     fq3_sampling pred_sampling{0.9f, 50, 1.0f, 1, 1.0f};

@@ -436,3 +436,26 @@ def test_predictor_two_token_prefill_modes(monkeypatch, m2):
             ids, lg = eng.predictor_loop(x.view(-1).cuda(), want_logits=True)
             assert torch.equal(ids.cpu(), o_ids)
             assert (lg.float().cpu() - o_logits.float()).abs().max() <= 5e-4
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_predictor_attention_kernel_variants(monkeypatch, mode):
+    """FQ3_PRED_ATTN=1 (default): single-wave register-only attention for the code predictor; 0: the generic
+    split-KV kernel.  Same ids / logits (fp32), for plain and projection models, bf16 close."""
+    from oracle import qwen3tts_oracle as O
+    monkeypatch.setenv("FQ3_PRED_ATTN", mode)
+    for cfg in (tiny_test_config(), tiny_test_config(hidden=512, pred_hidden=256)):
+        for dtype in (torch.float32, torch.bfloat16):
+            W = synth_weights(cfg, 0, dtype)
+            orc = O.OracleTTS(cfg, W, max_seq_len=96)
+            orc.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+            eng = _engine(cfg, W, dtype)
+            eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+            x = torch.randn(1, 2, cfg.talker.hidden_size, generator=torch.Generator().manual_seed(29)).to(dtype)
+            o_ids, o_logits = orc.predictor_loop(x, return_logits=True)
+            ids, lg = eng.predictor_loop(x.view(-1).cuda(), want_logits=True)
+            if dtype == torch.float32:
+                assert torch.equal(ids.cpu(), o_ids)
+                assert (lg.float().cpu() - o_logits.float()).abs().max() <= 5e-4
+            else:
+                assert (lg[0].float().cpu() - o_logits[0].float()).abs().max() <= 0.15
