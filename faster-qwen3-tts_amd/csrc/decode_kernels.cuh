@@ -17,7 +17,7 @@
 
 namespace fq3 {
 
-enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_COMBINE = 2, PRO_ATTN = 3 };
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_COMBINE = 2 };
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2 };
 
 constexpr int kHeadDim = 128;        // Qwen3-TTS talker / predictor head_dim
@@ -31,7 +31,7 @@ constexpr int kPartStride = kHeadDim + 4;     // 128 values + {m, l} + pad: keep
 // needs at most one workgroup barrier.
 
 struct GemvArgs {
-    const void* W; int N; int K; int R;           // N logical rows (pairs for SWIGLU); R rows per wave
+    const void* W; int N; int K;                  // N logical rows (pairs for SWIGLU)
     const void* x;                                 // input vector T[K] (PRO_PLAIN / PRO_NORM)
     const void* norm_w; float eps;
     const void* bias;
@@ -42,224 +42,131 @@ struct GemvArgs {
     const float* part; int n_part; int rep;        // PRO_COMBINE: attention partial slots
     // second token of an M = 2 launch
     const void* x2; void* y2; const void* res2; size_t part_stride2;
-    // PRO_ATTN (short-context attention computed redundantly in every workgroup: code predictor, <= 17 keys)
-    const void* qkv; const void* q_norm_w; const void* k_norm_w;
-    const float* cos_row; const float* sin_row;
-    void* kcache; void* vcache; int max_seq; int pos; int n_kv; float scale;
 };
 
-// Attention over a SHORT context for all heads inside one workgroup, result (T-rounded, fp32 image) into
-// xs[q_dim].  Wave w owns kv heads w, w+4, ...: no cross-wave merge.  Used as the o_proj prologue of the
-// code predictor (context <= 2 + 15 tokens, predictor_graph.py:46), which removes one launch per layer.
-template <typename T, int REP>
-__device__ __forceinline__ void attn_small_prologue(const GemvArgs& a, float* xs, float* scratch) {
-    constexpr int HD = kHeadDim;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int sub = lane >> 4, c = lane & 15;
-    const T* qkv = reinterpret_cast<const T*>(a.qkv);
-    const int q_dim = a.n_kv * REP * HD, kv_dim = a.n_kv * HD;
-    float* qs = scratch + wave * (REP + 2) * HD;          // [REP][HD] q, then k, then v (wave-private)
-    float* knew = qs + REP * HD;
-    float* vnew = knew + HD;
-    const float cs = a.cos_row[lane], sn = a.sin_row[lane];
-    const T* qw = reinterpret_cast<const T*>(a.q_norm_w);
-    const T* kw = reinterpret_cast<const T*>(a.k_norm_w);
-    const float qw0 = DT<T>::ld(qw + lane), qw1 = DT<T>::ld(qw + lane + 64);
-    const float kw0 = DT<T>::ld(kw + lane), kw1 = DT<T>::ld(kw + lane + 64);
-    const int pos = a.pos;
-    const int iters = (a.n_kv + 3) / 4;
-    for (int it = 0; it < iters; ++it) {
-        const int g = it * 4 + wave;
-        const bool active = g < a.n_kv;
-        const int gg = active ? g : 0;
-        T* kc = reinterpret_cast<T*>(a.kcache) + (size_t)gg * a.max_seq * HD;
-        T* vc = reinterpret_cast<T*>(a.vcache) + (size_t)gg * a.max_seq * HD;
-        Raw8<T> kr[4], vr[4];
+// one thread's share of the split-KV merge: the partial slots of 8 consecutive head dims
+struct CombineRegs {
+    f32x4 oa[kMaxWorkers], ob[kMaxWorkers];
+    float pm[kMaxWorkers], pl[kMaxWorkers];
+};
+// (all loads unconditional -- slots >= n_part re-read slot 0 and are neutralised afterwards -- because a load inside
+// a branch makes the compiler's s_waitcnt bookkeeping fall back to vmcnt(0), which would also wait for the weights)
+__device__ __forceinline__ void combine_load(CombineRegs& c, const float* part, int e0, int rep, int n_part) {
+    const int head = e0 / kHeadDim, d0 = e0 - head * kHeadDim;
+    const int g = head / rep, hh = head - g * rep;
+    const float* p0 = part + ((size_t)(g * kMaxWorkers) * rep + hh) * kPartStride;
+    const size_t sstride = (size_t)rep * kPartStride;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int key = i * 4 + sub;
-            key = key < a.max_seq ? key : a.max_seq - 1;
-            ldraw<false>(kr[i], kc + (size_t)key * HD + c * 8);
-            ldraw<false>(vr[i], vc + (size_t)key * HD + c * 8);
-        }
-        // q heads, new k (norm + RoPE), new v
-#pragma unroll
-        for (int vec = 0; vec < REP + 2; ++vec) {
-            const T* src = vec < REP ? qkv + (size_t)(gg * REP + vec) * HD
-                         : (vec == REP ? qkv + q_dim + (size_t)gg * HD : qkv + q_dim + kv_dim + (size_t)gg * HD);
-            float x0 = DT<T>::ld(src + lane), x1 = DT<T>::ld(src + lane + 64);
-            if (vec <= REP) {
-                const float w0 = vec < REP ? qw0 : kw0, w1 = vec < REP ? qw1 : kw1;
-                const float ss = wave_sum(fmaf(x0, x0, x1 * x1));
-                const float rs = 1.0f / sqrtf(ss / (float)HD + a.eps);
-                const float n0 = DT<T>::rnd(w0 * DT<T>::rnd(x0 * rs));
-                const float n1 = DT<T>::rnd(w1 * DT<T>::rnd(x1 * rs));
-                x0 = DT<T>::rnd(DT<T>::rnd(n0 * cs) + DT<T>::rnd(-n1 * sn));
-                x1 = DT<T>::rnd(DT<T>::rnd(n1 * cs) + DT<T>::rnd(n0 * sn));
-            }
-            float* dst = vec < REP ? qs + vec * HD : (vec == REP ? knew : vnew);
-            dst[lane] = x0; dst[lane + 64] = x1;
-            if (vec >= REP && active && blockIdx.x == 0) {        // one workgroup appends K/V to the cache
-                T* cp = (vec == REP ? kc : vc) + (size_t)pos * HD;
-                DT<T>::st(cp + lane, x0); DT<T>::st(cp + lane + 64, x1);
-            }
-        }
-        __syncthreads();
-        float qr[REP][8], m[REP], l[REP], o[REP][8];
-#pragma unroll
-        for (int h = 0; h < REP; ++h) {
-            m[h] = -1e30f; l[h] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { qr[h][i] = qs[h * HD + c * 8 + i]; o[h][i] = 0.f; }
-        }
-        auto step = [&](const float (&kf)[8], const float (&vf)[8], bool valid) {
-#pragma unroll
-            for (int h = 0; h < REP; ++h) {
-                float sc = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) sc = fmaf(qr[h][i], kf[i], sc);
-                sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64);
-                sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
-                sc = valid ? sc * a.scale : -INFINITY;
-                const float mn = fmaxf(m[h], sc);
-                const float al = __expf(m[h] - mn), p = __expf(sc - mn);
-                l[h] = fmaf(l[h], al, p);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o[h][i] = fmaf(o[h][i], al, valid ? p * vf[i] : 0.f);
-                m[h] = mn;
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float kf[8], vf[8];
-            unpack(kr[i], kf); unpack(vr[i], vf);
-            step(kf, vf, i * 4 + sub < pos);
-        }
-        {
-            float kf[8], vf[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { kf[i] = knew[c * 8 + i]; vf[i] = vnew[c * 8 + i]; }
-            step(kf, vf, sub == 0);
-        }
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-#pragma unroll
-            for (int h = 0; h < REP; ++h) {
-                const float mo = __shfl_xor(m[h], off, 64), lo = __shfl_xor(l[h], off, 64);
-                const float M = fmaxf(m[h], mo);
-                const float wa = __expf(m[h] - M), wb = __expf(mo - M);
-                l[h] = l[h] * wa + lo * wb;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float oo = __shfl_xor(o[h][i], off, 64);
-                    o[h][i] = o[h][i] * wa + oo * wb;
-                }
-                m[h] = M;
-            }
-        }
-        if (active && sub == 0) {
-#pragma unroll
-            for (int h = 0; h < REP; ++h) {
-                const float inv = 1.0f / l[h];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) xs[(size_t)(g * REP + h) * HD + c * 8 + i] = DT<T>::rnd(o[h][i] * inv);
-            }
-        }
-        __syncthreads();
+    for (int s = 0; s < kMaxWorkers; ++s) {
+        const float* ps = p0 + (s < n_part ? s : 0) * sstride;
+        c.oa[s] = *reinterpret_cast<const f32x4*>(ps + d0);
+        c.ob[s] = *reinterpret_cast<const f32x4*>(ps + d0 + 4);
+        c.pm[s] = ps[kHeadDim]; c.pl[s] = ps[kHeadDim + 1];
     }
 }
+template <typename T>
+__device__ __forceinline__ void combine_finish(CombineRegs& c, int n_part, float (&f)[8]) {
+#pragma unroll
+    for (int s = 1; s < kMaxWorkers; ++s)
+        if (s >= n_part) { c.pm[s] = -1e30f; c.pl[s] = 0.f; }       // weight exp(-1e30 - Mx) = 0 on finite slot-0 data
+    float Mx = c.pm[0];
+#pragma unroll
+    for (int s = 1; s < kMaxWorkers; ++s) Mx = fmaxf(Mx, c.pm[s]);
+    f32x4 na = f32x4{0.f, 0.f, 0.f, 0.f}, nb = na;
+    float den = 0.f;
+#pragma unroll
+    for (int s = 0; s < kMaxWorkers; ++s) {
+        const float w = __expf(c.pm[s] - Mx);
+        na += c.oa[s] * w; nb += c.ob[s] * w; den = fmaf(w, c.pl[s], den);
+    }
+    const float inv = 1.0f / den;
+    f[0] = na.x * inv; f[1] = na.y * inv; f[2] = na.z * inv; f[3] = na.w * inv;
+    f[4] = nb.x * inv; f[5] = nb.y * inv; f[6] = nb.z * inv; f[7] = nb.w * inv;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) DT<T>::rnd2(f[i], f[i + 1]);
+}
 
-template <int NCH> struct RowsInFlight { static constexpr int v = NCH >= 12 ? 1 : (NCH >= 6 ? 2 : 4); };
+// Rows per wave (R, compile time): 2 for the big matrices so that >= 512 workgroups are in flight per launch
+// (measured 2.97 vs 3.07 ms/frame against 4 rows per wave), 1 when N <= 1024 or a row is long.
+template <int NCH, int EPI> struct MaxRows {
+    static constexpr int NR = EPI == EPI_SWIGLU ? 2 : 1;
+    static constexpr int v = NCH >= 12 ? 1 : (NCH >= 6 ? (2 / NR) : 2);
+};
 
 // M = number of tokens that share one pass over the weights (2 only for the code predictor's two-token
 // prefill, predictor_graph.py:121-128: weights are read once, both tokens' dot products are formed).
-template <typename T, int NCH, int PRO, int EPI, bool NT, int M = 1>
+// Order of work (profiles/r01_kernel_chain.txt): the small input-side loads are issued FIRST, the weight rows
+// second, so that the prologue arithmetic (RMSNorm / split-KV merge, ~0.5-1 us of VALU time) runs while the
+// weights are still in flight; vmcnt retires in order, so the opposite order exposes it.
+template <typename T, int NCH, int PRO, int EPI, bool NT, int M = 1, int R = 1>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
-    static_assert(M == 1 || PRO != PRO_ATTN, "the fused short-context attention prologue is single-token");
     constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;     // physical rows per logical row
-    constexpr int RB = (RowsInFlight<NCH>::v / NR) > 0 ? (RowsInFlight<NCH>::v / NR) : 1;
-    extern __shared__ __attribute__((aligned(16))) float xs[];      // PRO_COMBINE / PRO_ATTN only: M*K floats (+ scratch)
+    extern __shared__ __attribute__((aligned(16))) float xs[];      // PRO_COMBINE only: M*K floats
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int K = a.K;
     const T* W = reinterpret_cast<const T*>(a.W);
-    const int row0 = (blockIdx.x * 4 + wave) * a.R;
+    const int row0 = (blockIdx.x * 4 + wave) * R;
 
-    // ---- 1. issue every global load this thread will ever need ------------------------------------
-    Raw8<T> raw[NR][RB][NCH];
+    // ---- 1. input-side loads (unconditional: out-of-range chunks re-read chunk 0 and are zeroed later) ------
+    Raw8<T> xraw[M][NCH], nraw[NCH];
+    CombineRegs cr[M];
+    if constexpr (PRO == PRO_COMBINE) {
+        const int e0 = tid * 8 < K ? tid * 8 : 0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) combine_load(cr[m], a.part + (size_t)m * a.part_stride2, e0, a.rep, a.n_part);
+    } else {
+        // every wave reads the whole input vector itself (L2-resident, 2-12 KB): no LDS, no barrier
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int off = j * 512 + lane * 8, offc = off < K ? off : 0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) ldraw<false>(xraw[m][j], reinterpret_cast<const T*>(m == 0 ? a.x : a.x2) + offc);
+            if constexpr (PRO == PRO_NORM) ldraw<false>(nraw[j], reinterpret_cast<const T*>(a.norm_w) + offc);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 2. weight rows (tail wave: clamped row, result discarded; short K: clamped chunk, x is zero there) ----
+    Raw8<T> raw[NR][R][NCH];
 #pragma unroll
     for (int h = 0; h < NR; ++h)
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int row = row0 + r;
-            const bool rv = (r < a.R) && (row < a.N);
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r < a.N ? row0 + r : a.N - 1;
             const T* wr = W + (size_t)(row + h * a.up_off) * K;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 const int off = j * 512 + lane * 8;
-                if (rv && off < K) ldraw<NT>(raw[h][r][j], wr + off);
-                else zero(raw[h][r][j]);
+                ldraw<NT>(raw[h][r][j], wr + (off < K ? off : 0));
             }
         }
-    float resv[M][RB], biasv[RB];
+    float resv[M][R], biasv[R];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        const int row = row0 + r;
-        const bool rv = (r < a.R) && (row < a.N);
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r < a.N ? row0 + r : a.N - 1;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             const T* rp = reinterpret_cast<const T*>(m == 0 ? a.res : a.res2);
-            resv[m][r] = (EPI == EPI_RESIDUAL && rv) ? DT<T>::ld(rp + row) : 0.f;
+            resv[m][r] = 0.f;
+            if constexpr (EPI == EPI_RESIDUAL) resv[m][r] = DT<T>::ld(rp + row);
         }
-        biasv[r] = (a.bias && rv) ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + row) : 0.f;
+        const T* bp = a.bias ? reinterpret_cast<const T*>(a.bias) + row : W;       // branch-free: always a valid address
+        const float bv = DT<T>::ld(bp);
+        biasv[r] = a.bias ? bv : 0.f;
     }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 3. prologue arithmetic (weights still in flight) --------------------------------------------------
     float xr[M][NCH][8];
-    if (PRO == PRO_ATTN) {
-        float* scratch = xs + K;
-        if (a.rep == 1) attn_small_prologue<T, 1>(a, xs, scratch);
-        else if (a.rep == 2) attn_small_prologue<T, 2>(a, xs, scratch);
-        else attn_small_prologue<T, 4>(a, xs, scratch);
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int off = j * 512 + lane * 8;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) xr[0][j][i] = off < K ? xs[off + i] : 0.f;
-        }
-    } else if (PRO == PRO_COMBINE) {
-        // thread t merges the attention partials of elements [8t, 8t+8) (one head); result via LDS
+    if constexpr (PRO == PRO_COMBINE) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            const float* part = a.part + (size_t)m * a.part_stride2;
-            for (int c0 = tid; c0 * 8 < K; c0 += 256) {
-                const int e0 = c0 * 8;
-                const int head = e0 / kHeadDim, d0 = e0 - head * kHeadDim;
-                const int g = head / a.rep, hh = head - g * a.rep;
-                const float* p0 = part + ((size_t)(g * kMaxWorkers) * a.rep + hh) * kPartStride;
-                const size_t sstride = (size_t)a.rep * kPartStride;
-                f32x4 oa[kMaxWorkers], ob[kMaxWorkers];
-                float pm[kMaxWorkers], pl[kMaxWorkers];
-#pragma unroll
-                for (int s = 0; s < kMaxWorkers; ++s) {
-                    if (s < a.n_part) {
-                        const float* ps = p0 + s * sstride;
-                        oa[s] = *reinterpret_cast<const f32x4*>(ps + d0);
-                        ob[s] = *reinterpret_cast<const f32x4*>(ps + d0 + 4);
-                        pm[s] = ps[kHeadDim]; pl[s] = ps[kHeadDim + 1];
-                    } else { oa[s] = f32x4{0.f, 0.f, 0.f, 0.f}; ob[s] = oa[s]; pm[s] = -1e30f; pl[s] = 0.f; }
-                }
-                float Mx = pm[0];
-#pragma unroll
-                for (int s = 1; s < kMaxWorkers; ++s) Mx = fmaxf(Mx, pm[s]);
-                f32x4 na = f32x4{0.f, 0.f, 0.f, 0.f}, nb = na;
-                float den = 0.f;
-#pragma unroll
-                for (int s = 0; s < kMaxWorkers; ++s) {
-                    const float w = __expf(pm[s] - Mx);
-                    na += oa[s] * w; nb += ob[s] * w; den = fmaf(w, pl[s], den);
-                }
-                const float inv = 1.0f / den;
-                float* d = xs + (size_t)m * K + e0;
-                d[0] = DT<T>::rnd(na.x * inv); d[1] = DT<T>::rnd(na.y * inv); d[2] = DT<T>::rnd(na.z * inv); d[3] = DT<T>::rnd(na.w * inv);
-                d[4] = DT<T>::rnd(nb.x * inv); d[5] = DT<T>::rnd(nb.y * inv); d[6] = DT<T>::rnd(nb.z * inv); d[7] = DT<T>::rnd(nb.w * inv);
+            float f[8];
+            combine_finish<T>(cr[m], a.n_part, f);
+            if (tid * 8 < K) {
+                float* d = xs + (size_t)m * K + tid * 8;
+                reinterpret_cast<f32x4*>(d)[0] = f32x4{f[0], f[1], f[2], f[3]};
+                reinterpret_cast<f32x4*>(d)[1] = f32x4{f[4], f[5], f[6], f[7]};
             }
         }
         __syncthreads();
@@ -267,30 +174,22 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         for (int m = 0; m < M; ++m)
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
-                const int off = j * 512 + lane * 8;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) xr[m][j][i] = off < K ? xs[(size_t)m * K + off + i] : 0.f;
+                const int off = j * 512 + lane * 8, offc = off < K ? off : 0;
+                const float z = off < K ? 1.f : 0.f;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(xs + (size_t)m * K + offc) * z;
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(xs + (size_t)m * K + offc + 4) * z;
+                xr[m][j][0] = lo.x; xr[m][j][1] = lo.y; xr[m][j][2] = lo.z; xr[m][j][3] = lo.w;
+                xr[m][j][4] = hi.x; xr[m][j][5] = hi.y; xr[m][j][6] = hi.z; xr[m][j][7] = hi.w;
             }
     } else {
-        // every wave reads the whole input vector itself (L2-resident, 2-12 KB): no LDS, no barrier
-        Raw8<T> xraw[M][NCH], nraw[NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int off = j * 512 + lane * 8;
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const T* x = reinterpret_cast<const T*>(m == 0 ? a.x : a.x2);
-                if (off < K) ldraw<false>(xraw[m][j], x + off); else zero(xraw[m][j]);
-            }
-            if (PRO == PRO_NORM) {
-                if (off < K) ldraw<false>(nraw[j], reinterpret_cast<const T*>(a.norm_w) + off); else zero(nraw[j]);
-            }
-        }
 #pragma unroll
         for (int m = 0; m < M; ++m) {
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) unpack(xraw[m][j], xr[m][j]);
-            if (PRO == PRO_NORM) {
+            for (int j = 0; j < NCH; ++j) {
+                if (j * 512 + lane * 8 >= K) zero(xraw[m][j]);
+                unpack(xraw[m][j], xr[m][j]);
+            }
+            if constexpr (PRO == PRO_NORM) {
                 float ss = 0.f;
 #pragma unroll
                 for (int j = 0; j < NCH; ++j)
@@ -303,50 +202,63 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
                     float nw[8];
                     unpack(nraw[j], nw);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) xr[m][j][i] = DT<T>::rnd(nw[i] * DT<T>::rnd(xr[m][j][i] * rs));
+                    for (int i = 0; i < 8; i += 2) {
+                        float u = xr[m][j][i] * rs, v = xr[m][j][i + 1] * rs;
+                        DT<T>::rnd2(u, v);
+                        u *= nw[i]; v *= nw[i + 1];
+                        DT<T>::rnd2(u, v);
+                        xr[m][j][i] = u; xr[m][j][i + 1] = v;
+                    }
                 }
             }
         }
     }
-    if (a.xn_out && blockIdx.x == 0 && wave == 0) {
-        T* o = reinterpret_cast<T*>(a.xn_out);
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int off = j * 512 + lane * 8;
-            if (off < K)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) DT<T>::st(o + off + i, xr[0][j][i]);
-        }
-    }
 
-    // ---- 2. dot products + epilogue ------------------------------------------------------------------
+    // ---- 4. dot products, all reductions together, epilogue ----------------------------------------------
+    float acc[M][R][NR];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        const int row = row0 + r;
-        if (r >= a.R || row >= a.N) break;            // wave-uniform
+    for (int m = 0; m < M; ++m)
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            float acc[NR];
+        for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int h = 0; h < NR; ++h) {
                 float s = 0.f;
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) s = dot8<T>(raw[h][r][j], xr[m][j], s);
-                acc[h] = wave_sum(s);
+                acc[m][r][h] = s;
             }
-            if (lane == 0) {
-                T* y = reinterpret_cast<T*>(m == 0 ? a.y : a.y2);
-                if (EPI == EPI_SWIGLU) {
-                    const float g = DT<T>::rnd(acc[0]);
-                    const float u = DT<T>::rnd(acc[NR - 1]);
-                    const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
-                    DT<T>::st(y + row, sg * u);
-                } else {
-                    float v = DT<T>::rnd(acc[0] + biasv[r]);
-                    if (EPI == EPI_RESIDUAL) v = v + resv[m][r];
-                    DT<T>::st(y + row, v);
-                }
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int h = 0; h < NR; ++h) acc[m][r][h] = wave_sum(acc[m][r][h]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float v;
+            if constexpr (EPI == EPI_SWIGLU) {
+                const float g = DT<T>::rnd(acc[m][r][0]);
+                const float u = DT<T>::rnd(acc[m][r][NR - 1]);
+                const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
+                v = sg * u;
+            } else {
+                v = DT<T>::rnd(acc[m][r][0] + biasv[r]);
+                if constexpr (EPI == EPI_RESIDUAL) v = v + resv[m][r];
             }
+            if (lane == 0 && row < a.N) DT<T>::st(reinterpret_cast<T*>(m == 0 ? a.y : a.y2) + row, v);
+        }
+    }
+    // optional copy of the prologue result (codec_head: the normed hidden is the next frame's past_hidden); last,
+    // so that the conditional store does not disturb the waitcnt bookkeeping of the loads above
+    if (a.xn_out && blockIdx.x == 0 && wave == 0) {
+        T* o = reinterpret_cast<T*>(a.xn_out);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int off = j * 512 + lane * 8;
+            if (off < K) DT<T>::st8(o + off, xr[0][j]);
         }
     }
 }
@@ -366,6 +278,7 @@ struct AttnArgs {
     void* kcache; void* vcache; int max_seq;
     const int* pos_ptr; int pos_imm; int n_pad;
     int n_kv; float* part; float scale;
+    int rep; void* out;                               // attn_pred_kernel: q heads per kv head, final output T[q_dim]
 };
 
 template <typename T, int REP>
@@ -400,20 +313,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     float px0[NV], px1[NV], pw0[NV], pw1[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int vec = wave + 4 * i;
-        px0[i] = px1[i] = pw0[i] = pw1[i] = 0.f;
-        if (vec < REP + 2) {
-            const T* src = vec < REP ? qkv + (size_t)(g * REP + vec) * HD
-                         : (vec == REP ? qkv + q_dim + (size_t)g * HD : qkv + q_dim + kv_dim + (size_t)g * HD);
-            px0[i] = DT<T>::ld(src + lane); px1[i] = DT<T>::ld(src + lane + 64);
-            if (vec <= REP) {
-                const T* w = reinterpret_cast<const T*>(vec < REP ? a.q_norm_w : a.k_norm_w);
-                pw0[i] = DT<T>::ld(w + lane); pw1[i] = DT<T>::ld(w + lane + 64);
-            }
-        }
+        // unconditional loads (a surplus wave re-reads the v row and drops it): a load inside a branch makes the
+        // compiler fall back to s_waitcnt vmcnt(0) right there, which also waits for the key tile above
+        const int vec = wave + 4 * i < REP + 2 ? wave + 4 * i : REP + 1;
+        const T* src = vec < REP ? qkv + (size_t)(g * REP + vec) * HD
+                     : (vec == REP ? qkv + q_dim + (size_t)g * HD : qkv + q_dim + kv_dim + (size_t)g * HD);
+        px0[i] = DT<T>::ld(src + lane); px1[i] = DT<T>::ld(src + lane + 64);
+        const T* w = reinterpret_cast<const T*>(vec < REP ? a.q_norm_w : a.k_norm_w);
+        pw0[i] = DT<T>::ld(w + lane); pw1[i] = DT<T>::ld(w + lane + 64);
     }
     const float cs = a.cos_row[lane], sn = a.sin_row[lane];
     const int pos = a.pos_ptr ? *a.pos_ptr : a.pos_imm;
+    __builtin_amdgcn_sched_barrier(0);           // keep every load above the arithmetic (one round trip, not two)
 
     const int t_pos = pos / KS;
     const bool owner = (t_pos % S) == s;
@@ -461,8 +372,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
             float sc = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) sc = fmaf(qr[h][i], kf[i], sc);
-            sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64);
-            sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
+            sc = row16_sum(sc);
             sc = valid ? sc * a.scale : -INFINITY;
             const float mn = fmaxf(m[h], sc);
             const float al = __expf(m[h] - mn);
@@ -489,22 +399,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
         for (int i = 0; i < 8; ++i) { kf[i] = knew[c * 8 + i]; vf[i] = vnew[c * 8 + i]; }
         step(kf, vf, owner && wave == 0 && sub == 0 && pos >= a.n_pad);
     }
-    // merge the four 16-lane key groups of the wave
+    // merge the four 16-lane key groups of the wave (lane-wise across rows, VALU permlane swaps)
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
+    for (int h = 0; h < REP; ++h) {
+        const float M = xrow_max(m[h]);
+        const float w = __expf(m[h] - M);
+        l[h] = xrow_sum(l[h] * w);
 #pragma unroll
-        for (int h = 0; h < REP; ++h) {
-            const float mo = __shfl_xor(m[h], off, 64), lo = __shfl_xor(l[h], off, 64);
-            const float M = fmaxf(m[h], mo);
-            const float wa = __expf(m[h] - M), wb = __expf(mo - M);
-            l[h] = l[h] * wa + lo * wb;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float oo = __shfl_xor(o[h][i], off, 64);
-                o[h][i] = o[h][i] * wa + oo * wb;
-            }
-            m[h] = M;
-        }
+        for (int i = 0; i < 8; ++i) o[h][i] = xrow_sum(o[h][i] * w);
+        m[h] = M;
     }
     if (sub == 0) {
 #pragma unroll
@@ -532,22 +435,31 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 }
 
 // ================================================================================================
-// Code-predictor attention (context <= 17 keys, GQA ratio 2): ONE wave per kv group, everything in
-// registers -- vectors are loaded in the 16-lanes-per-vector layout, head RMSNorm / RoPE / scores use
-// 16-lane shuffles, the 16 cached keys are covered by 4 key groups x 4 sub-groups, no LDS, no barrier,
-// 8 workgroups in total.  Writes partial slot 0 in the format the o_proj combine prologue reads.
+// Code-predictor attention (context <= 17 keys): ONE wave per q head, everything in registers, no LDS, no
+// barrier, no partial slots -- the wave writes the final (normalised, T-rounded) head output, so the o_proj
+// GEMV that follows needs no merge prologue.  Lane layout: 4 rows x 16 lanes; a row holds a full 128-dim
+// vector (8 dims per lane); row r scores cached keys r, 4+r, 8+r, 12+r and row 0 also the new token's own key.
+// Exact (non-online) softmax: wave-wide max, then one exp per key.  Both q heads of a GQA group recompute the
+// new key's norm + RoPE; the group's first head appends K/V to the cache.
 // ================================================================================================
 template <typename T>
 __global__ __launch_bounds__(64) void attn_pred_kernel(AttnArgs a) {
-    constexpr int HD = kHeadDim, REP = 2;
-    const int g = blockIdx.x, lane = threadIdx.x & 63;
-    const int sub = lane >> 4, c = lane & 15;
+    constexpr int HD = kHeadDim;
+    const int head = blockIdx.x, g = head / a.rep, hh = head - g * a.rep;
+    const int lane = threadIdx.x & 63, sub = lane >> 4, c = lane & 15;
     const int pos = a.pos_imm;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
-    const int q_dim = a.n_kv * REP * HD, kv_dim = a.n_kv * HD;
+    const int q_dim = a.n_kv * a.rep * HD, kv_dim = a.n_kv * HD;
     T* kc = reinterpret_cast<T*>(a.kcache) + (size_t)g * a.max_seq * HD;
     T* vc = reinterpret_cast<T*>(a.vcache) + (size_t)g * a.max_seq * HD;
-    Raw8<T> kr[4], vr[4];
+    Raw8<T> qraw, knraw, vnraw, qwraw, kwraw, kr[4], vr[4];
+    ldraw<false>(qraw, qkv + (size_t)head * HD + c * 8);
+    ldraw<false>(knraw, qkv + q_dim + (size_t)g * HD + c * 8);
+    ldraw<false>(vnraw, qkv + q_dim + kv_dim + (size_t)g * HD + c * 8);
+    ldraw<false>(qwraw, reinterpret_cast<const T*>(a.q_norm_w) + c * 8);
+    ldraw<false>(kwraw, reinterpret_cast<const T*>(a.k_norm_w) + c * 8);
+    const f32x4 cs0 = *reinterpret_cast<const f32x4*>(a.cos_row + ((c * 8) & 63)), cs1 = *reinterpret_cast<const f32x4*>(a.cos_row + ((c * 8 + 4) & 63));
+    const f32x4 sn0 = *reinterpret_cast<const f32x4*>(a.sin_row + ((c * 8) & 63)), sn1 = *reinterpret_cast<const f32x4*>(a.sin_row + ((c * 8 + 4) & 63));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int key = i * 4 + sub;
@@ -555,93 +467,81 @@ __global__ __launch_bounds__(64) void attn_pred_kernel(AttnArgs a) {
         ldraw<false>(kr[i], kc + (size_t)key * HD + c * 8);
         ldraw<false>(vr[i], vc + (size_t)key * HD + c * 8);
     }
-    Raw8<T> qraw[REP], knraw, vnraw, qwraw, kwraw;
-#pragma unroll
-    for (int h = 0; h < REP; ++h) ldraw<false>(qraw[h], qkv + (size_t)(g * REP + h) * HD + c * 8);
-    ldraw<false>(knraw, qkv + q_dim + (size_t)g * HD + c * 8);
-    ldraw<false>(vnraw, qkv + q_dim + kv_dim + (size_t)g * HD + c * 8);
-    ldraw<false>(qwraw, reinterpret_cast<const T*>(a.q_norm_w) + c * 8);
-    ldraw<false>(kwraw, reinterpret_cast<const T*>(a.k_norm_w) + c * 8);
-    float cs[8], sn[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { cs[i] = a.cos_row[(c * 8 + i) & 63]; sn[i] = a.sin_row[(c * 8 + i) & 63]; }
-    // head RMSNorm + RoPE; the rotate_half partner of dim d (d +- 64) lives in lane c ^ 8 of the same 16-lane group
+    __builtin_amdgcn_sched_barrier(0);           // keep every load above the arithmetic (one round trip, not two)
+    const float sgn = c < 8 ? -1.f : 1.f;        // rotate_half: dims < 64 take -x[d + 64], dims >= 64 take +x[d - 64]
+    const float cs[8] = {cs0.x, cs0.y, cs0.z, cs0.w, cs1.x, cs1.y, cs1.z, cs1.w};
+    const float sn[8] = {sgn * sn0.x, sgn * sn0.y, sgn * sn0.z, sgn * sn0.w, sgn * sn1.x, sgn * sn1.y, sgn * sn1.z, sgn * sn1.w};
+    // head RMSNorm + RoPE; the rotate_half partner of dim d (d +- 64) lives in lane c ^ 8 of the same row
     auto norm_rope = [&](const Raw8<T>& raw, const Raw8<T>& wraw, float (&out)[8]) {
         float x[8], w[8];
         unpack(raw, x); unpack(wraw, w);
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) ss = fmaf(x[i], x[i], ss);
-        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+        ss = row16_sum(ss);
         const float rs = 1.0f / sqrtf(ss / (float)HD + a.eps);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = DT<T>::rnd(w[i] * DT<T>::rnd(x[i] * rs));
+        for (int i = 0; i < 8; i += 2) {
+            float u = x[i] * rs, v = x[i + 1] * rs;
+            DT<T>::rnd2(u, v);
+            u *= w[i]; v *= w[i + 1];
+            DT<T>::rnd2(u, v);
+            x[i] = u; x[i + 1] = v;
+        }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float partner = __shfl_xor(x[i], 8, 64);
-            const float rot = c < 8 ? -partner : partner;
-            out[i] = DT<T>::rnd(DT<T>::rnd(x[i] * cs[i]) + DT<T>::rnd(rot * sn[i]));
+        for (int i = 0; i < 8; i += 2) {
+            float a0 = x[i] * cs[i], a1 = x[i + 1] * cs[i + 1];
+            float b0 = row16_xor8(x[i]) * sn[i], b1 = row16_xor8(x[i + 1]) * sn[i + 1];
+            DT<T>::rnd2(a0, a1); DT<T>::rnd2(b0, b1);
+            float r0 = a0 + b0, r1 = a1 + b1;
+            DT<T>::rnd2(r0, r1);
+            out[i] = r0; out[i + 1] = r1;
         }
     };
-    float qr[REP][8], knew[8], vnew[8];
-#pragma unroll
-    for (int h = 0; h < REP; ++h) norm_rope(qraw[h], qwraw, qr[h]);
+    float qr[8], knew[8], vnew[8];
+    norm_rope(qraw, qwraw, qr);
     norm_rope(knraw, kwraw, knew);
     unpack(vnraw, vnew);
-    if (sub == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { DT<T>::st(kc + (size_t)pos * HD + c * 8 + i, knew[i]); DT<T>::st(vc + (size_t)pos * HD + c * 8 + i, vnew[i]); }
+    if (hh == 0 && sub == 0) {
+        DT<T>::st8(kc + (size_t)pos * HD + c * 8, knew);
+        DT<T>::st8(vc + (size_t)pos * HD + c * 8, vnew);
     }
-    float m[REP], l[REP], o[REP][8];
-#pragma unroll
-    for (int h = 0; h < REP; ++h) {
-        m[h] = -1e30f; l[h] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[h][i] = 0.f;
-    }
-    auto step = [&](const float (&kf)[8], const float (&vf)[8], bool valid) {
-#pragma unroll
-        for (int h = 0; h < REP; ++h) {
-            float sc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sc = fmaf(qr[h][i], kf[i], sc);
-            sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
-            sc = valid ? sc * a.scale : -INFINITY;
-            const float mn = fmaxf(m[h], sc), al = __expf(m[h] - mn), p = __expf(sc - mn);
-            l[h] = fmaf(l[h], al, p);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[h][i] = fmaf(o[h][i], al, valid ? p * vf[i] : 0.f);
-            m[h] = mn;
-        }
-    };
+    float sc[5];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float kf[8], vf[8];
-        unpack(kr[i], kf); unpack(vr[i], vf);
-        step(kf, vf, i * 4 + sub < pos);
+        float kf[8], s = 0.f;
+        unpack(kr[i], kf);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) s = fmaf(qr[d], kf[d], s);
+        s = row16_sum(s);
+        sc[i] = (i * 4 + sub < pos) ? s * a.scale : -INFINITY;
     }
-    step(knew, vnew, sub == 0);
+    {
+        float s = 0.f;
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-#pragma unroll
-        for (int h = 0; h < REP; ++h) {
-            const float mo = __shfl_xor(m[h], off, 64), lo = __shfl_xor(l[h], off, 64);
-            const float M = fmaxf(m[h], mo), wa = __expf(m[h] - M), wb = __expf(mo - M);
-            l[h] = l[h] * wa + lo * wb;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { const float oo = __shfl_xor(o[h][i], off, 64); o[h][i] = o[h][i] * wa + oo * wb; }
-            m[h] = M;
-        }
+        for (int d = 0; d < 8; ++d) s = fmaf(qr[d], knew[d], s);
+        s = row16_sum(s);
+        sc[4] = sub == 0 ? s * a.scale : -INFINITY;
     }
-    if (sub == 0) {
+    const float mx = wave_max(fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), sc[4]));
+    float p[5], lsum = 0.f, o[8];
 #pragma unroll
-        for (int h = 0; h < REP; ++h) {
-            float* p = a.part + (((size_t)g * kMaxWorkers + 0) * REP + h) * kPartStride;
-            *reinterpret_cast<f32x4*>(p + c * 8) = f32x4{o[h][0], o[h][1], o[h][2], o[h][3]};
-            *reinterpret_cast<f32x4*>(p + c * 8 + 4) = f32x4{o[h][4], o[h][5], o[h][6], o[h][7]};
-            if (c == 0) { p[HD] = m[h]; p[HD + 1] = l[h]; }
-        }
+    for (int i = 0; i < 5; ++i) { p[i] = __expf(sc[i] - mx); lsum += p[i]; }
+    lsum = wave_sum(lsum) * (1.0f / 16.0f);          // every lane of a row carries the row's sum
+#pragma unroll
+    for (int d = 0; d < 8; ++d) o[d] = p[4] * vnew[d];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float vf[8];
+        if (!(i * 4 + sub < pos)) zero(vr[i]);      // never-written cache slots may hold NaN bit patterns: 0 * NaN
+        unpack(vr[i], vf);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o[d] = fmaf(p[i], vf[d], o[d]);
     }
+    const float inv = 1.0f / lsum;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) o[d] = xrow_sum(o[d]) * inv;
+    if (sub == 0) DT<T>::st8(reinterpret_cast<T*>(a.out) + (size_t)head * HD + c * 8, o);
 }
 
 // ================================================================================================

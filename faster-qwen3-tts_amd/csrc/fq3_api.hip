@@ -72,6 +72,7 @@ extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
     if ((r = dmalloc(c, &c->h, (size_t)Hm * c->esz))) return r;
     if ((r = dmalloc(c, &c->h2, (size_t)Hm * c->esz))) return r;
     if ((r = dmalloc(c, &c->qkv2, (size_t)qkvm * c->esz))) return r;
+    if ((r = dmalloc(c, &c->attn_out, (size_t)qkvm * c->esz))) return r;
     if ((r = dmalloc(c, &c->act2, (size_t)Im * c->esz))) return r;
     if ((r = dmalloc(c, &c->pred_x2, (size_t)p.hidden * c->esz))) return r;
     if ((r = dmalloc(c, &c->xin, (size_t)Hm * c->esz))) return r;
@@ -96,7 +97,6 @@ extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
     if ((r = dmalloc(c, (void**)&c->d_pemb, (size_t)64 * sizeof(void*)))) return r;
     HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     if (const char* e = getenv("FQ3_NT")) c->opt_nt = atoi(e);
-    if (const char* e = getenv("FQ3_FUSED_ATTN")) c->opt_fused_attn = atoi(e);
     if (const char* e = getenv("FQ3_M2")) c->opt_m2 = atoi(e);
     if (const char* e = getenv("FQ3_PRED_ATTN")) c->opt_pred_attn = atoi(e);
     *out = c;
@@ -149,23 +149,22 @@ extern "C" int fq3_bind_weights(fq3_ctx* c, const fq3_weight_table* w) {
 // GEMV dispatch
 // -------------------------------------------------------------------------------------------------
 template <typename T, int NCH, int PRO, int EPI, bool NT, int M = 1>
-static void launch_gemv_n(GemvArgs a, hipStream_t s) {
-    constexpr int NR = EPI == EPI_SWIGLU ? 2 : 1;
-    constexpr int RB = (RowsInFlight<NCH>::v / NR) > 0 ? (RowsInFlight<NCH>::v / NR) : 1;
-    int R = (a.N + 1023) / 1024;            // aim at >= 256 workgroups of 4 waves
-    if (R < 1) R = 1;
-    if (R > RB) R = RB;
-    // rows per wave are capped at 2 (512-768 workgroups for the big GEMVs): measured 2.97 vs 3.07 ms/frame against
-    // the 256-workgroup shape (4 rows per wave); FQ3_RMAX overrides
+static void launch_gemv_n(const GemvArgs& a, hipStream_t s) {
+    // rows per wave: 2 for the big matrices (512-768 workgroups), 1 when N <= 1024 or a row is long; FQ3_RMAX=1 forces 1
     static const int rmax = getenv("FQ3_RMAX") ? atoi(getenv("FQ3_RMAX")) : 2;
+    int R = (a.N + 1023) / 1024;
+    if (R > MaxRows<NCH, EPI>::v) R = MaxRows<NCH, EPI>::v;
     if (rmax > 0 && R > rmax) R = rmax;
-    a.R = R;
+    if (R < 1) R = 1;
     const int grid = (a.N + 4 * R - 1) / (4 * R);
-    const size_t shm = PRO == PRO_COMBINE ? (size_t)M * a.K * sizeof(float)
-                     : (PRO == PRO_ATTN ? (size_t)(a.K + 4 * (a.rep + 2) * kHeadDim) * sizeof(float) : 0);
-    hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT, M>), dim3(grid), dim3(256), shm, s, a);
+    const size_t shm = PRO == PRO_COMBINE ? (size_t)M * a.K * sizeof(float) : 0;
     static const bool dup = getenv("FQ3_EXPERIMENT_DUP") != nullptr;     // timing experiment only (results are wrong)
-    if (dup) hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT, M>), dim3(grid), dim3(256), shm, s, a);
+    for (int rep = 0; rep < (dup ? 2 : 1); ++rep) {
+        if constexpr (MaxRows<NCH, EPI>::v >= 2) {
+            if (R == 2) { hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT, M, 2>), dim3(grid), dim3(256), shm, s, a); continue; }
+        }
+        hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT, M, 1>), dim3(grid), dim3(256), shm, s, a);
+    }
 }
 // two-token launches: code predictor only (default cache policy), hidden sizes up to 2048 / intermediate up to 6144
 template <typename T, int PRO, int EPI>
@@ -248,28 +247,25 @@ static int run_stack(fq3_ctx* c, bool talker, const StepSrc& src, hipStream_t s)
         // 2+3. attention, then o_proj + residual
         GemvArgs o{};
         o.W = w.o; o.N = d.hidden; o.K = q_dim; o.y = c->h; o.res = xin; o.rep = rep;
-        const bool fused_attn = c->opt_fused_attn && !talker && !src.pos_ptr && src.pos_imm <= 16;
-        if (fused_attn) {
-            // short context (code predictor): attention recomputed inside every o_proj workgroup -> 4 launches/layer
-            o.qkv = c->qkv; o.q_norm_w = w.q_norm; o.k_norm_w = w.k_norm; o.eps = d.rms_eps;
-            o.cos_row = cos_row; o.sin_row = sin_row; o.kcache = kv.k[i]; o.vcache = kv.v[i]; o.max_seq = kv.max_seq;
-            o.pos = src.pos_imm; o.n_kv = d.n_kv_heads; o.scale = 1.0f / sqrtf((float)kHeadDim);
-            if (int r = launch_gemv<PRO_ATTN, EPI_RESIDUAL>(c, o, nt, s)) return r;
+        AttnArgs a{};
+        a.qkv = c->qkv; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm; a.eps = d.rms_eps;
+        a.cos_row = cos_row; a.sin_row = sin_row;
+        a.kcache = kv.k[i]; a.vcache = kv.v[i]; a.max_seq = kv.max_seq;
+        a.pos_ptr = src.pos_ptr; a.pos_imm = src.pos_imm;
+        a.n_pad = talker ? c->n_pad : 0;
+        a.n_kv = d.n_kv_heads; a.part = c->part;
+        a.scale = 1.0f / sqrtf((float)kHeadDim);
+        a.rep = rep; a.out = c->attn_out;
+        const bool pred_attn = c->opt_pred_attn && !talker && !src.pos_ptr && src.pos_imm <= 16;
+        if (pred_attn) {
+            // short context: one wave per q head, final head output written directly -> plain o_proj, no merge
+            if (c->cfg.dtype == FQ3_BF16) hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(d.n_heads), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((attn_pred_kernel<float>), dim3(d.n_heads), dim3(64), 0, s, a);
+            if (tail_skip) break;
+            o.x = c->attn_out;
+            if (int r = launch_gemv<PRO_PLAIN, EPI_RESIDUAL>(c, o, nt, s)) return r;
         } else {
-            AttnArgs a{};
-            a.qkv = c->qkv; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm; a.eps = d.rms_eps;
-            a.cos_row = cos_row; a.sin_row = sin_row;
-            a.kcache = kv.k[i]; a.vcache = kv.v[i]; a.max_seq = kv.max_seq;
-            a.pos_ptr = src.pos_ptr; a.pos_imm = src.pos_imm;
-            a.n_pad = talker ? c->n_pad : 0;
-            a.n_kv = d.n_kv_heads; a.part = c->part;
-            a.scale = 1.0f / sqrtf((float)kHeadDim);
-            const bool pred_attn = c->opt_pred_attn && !talker && !src.pos_ptr && rep == 2 && src.pos_imm <= 16 && kv.workers == 1;
-            if (pred_attn) {
-                // short-context single-wave attention (8 workgroups, registers only)
-                if (c->cfg.dtype == FQ3_BF16) hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(d.n_kv_heads), dim3(64), 0, s, a);
-                else hipLaunchKernelGGL((attn_pred_kernel<float>), dim3(d.n_kv_heads), dim3(64), 0, s, a);
-            } else if (c->cfg.dtype == FQ3_BF16) launch_attn_t<bf16_t>(a, rep, kv.workers, s);
+            if (c->cfg.dtype == FQ3_BF16) launch_attn_t<bf16_t>(a, rep, kv.workers, s);
             else launch_attn_t<float>(a, rep, kv.workers, s);
             if (tail_skip) break;
             o.part = c->part; o.n_part = kv.workers;
@@ -583,7 +579,7 @@ static int predictor_passes_t(fq3_ctx* c, const DecodeState* st_dev, const void*
             x0 = c->pred_x;
         }
         StepSrc src{x0, nullptr, pass};
-        src.kv_only_tail = pass == 0 && c->opt_fused_attn == 0;
+        src.kv_only_tail = pass == 0;
         if (int r = run_stack(c, false, src, s)) return r;
         }
         if (pass == 0) continue;                        // first prefill token: only its K/V are needed

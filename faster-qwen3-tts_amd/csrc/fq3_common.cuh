@@ -8,11 +8,14 @@ namespace fq3 {
 typedef uint16_t bf16_t;   // raw bfloat16 bits
 
 __device__ __forceinline__ float bf16_to_f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even, same as torch's float->bfloat16 cast (NaN not special-cased: inputs are finite or +-inf)
-__device__ __forceinline__ bf16_t f_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even, same as torch's float->bfloat16 cast: gfx950 has the conversion in hardware
+// (v_cvt_pk_bf16_f32), one instruction instead of the 5-op integer emulation
+__device__ __forceinline__ bf16_t f_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+typedef float fq3_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 fq3_bf16x2 __attribute__((ext_vector_type(2)));
+// two values per v_cvt_pk_bf16_f32: returns lo = bf16(a), hi = bf16(b)
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(fq3_f32x2{a, b}, fq3_bf16x2));
 }
 
 template <typename T> struct DT;
@@ -20,11 +23,20 @@ template <> struct DT<bf16_t> {
     static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f(*p); }
     static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f_to_bf16(v); }
     static __device__ __forceinline__ float rnd(float v) { return bf16_to_f(f_to_bf16(v)); }
+    // round two values with one conversion instruction
+    static __device__ __forceinline__ void rnd2(float& a, float& b) {
+        const uint32_t u = pack_bf16x2(a, b);
+        a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xFFFF0000u);
+    }
+    // store 8 consecutive values (16-byte aligned destination)
+    static __device__ __forceinline__ void st8(bf16_t* p, const float (&f)[8]);
 };
 template <> struct DT<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
     static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
     static __device__ __forceinline__ float rnd(float v) { return v; }
+    static __device__ __forceinline__ void rnd2(float&, float&) {}
+    static __device__ __forceinline__ void st8(float* p, const float (&f)[8]);
 };
 
 // ---- 8-element (one lane's chunk) raw loads: issue now, convert later ------------------------
@@ -33,6 +45,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> { u32x4 v; };
 template <> struct Raw8<float> { f32x4 a, b; };
+
+__device__ __forceinline__ void DT<bf16_t>::st8(bf16_t* p, const float (&f)[8]) {
+    *reinterpret_cast<u32x4*>(p) = u32x4{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+}
+__device__ __forceinline__ void DT<float>::st8(float* p, const float (&f)[8]) {
+    reinterpret_cast<f32x4*>(p)[0] = f32x4{f[0], f[1], f[2], f[3]};
+    reinterpret_cast<f32x4*>(p)[1] = f32x4{f[4], f[5], f[6], f[7]};
+}
 
 template <bool NT> __device__ __forceinline__ void ldraw(Raw8<bf16_t>& r, const bf16_t* p) {
     if (NT) r.v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
@@ -70,15 +90,55 @@ template <typename T> __device__ __forceinline__ float dot8(const Raw8<T>& r, co
 }
 
 // ---- wave / block reductions ------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// DPP (data-parallel primitive) lane exchanges run in the VALU pipe; __shfl_xor compiles to ds_bpermute_b32, an LDS
+// round trip of ~100 cycles.  A 64-lane butterfly of six dependent bpermutes costs ~0.25 us -- measurable against a
+// 3-5 us decode kernel -- so every reduction below is DPP: 4 row ops inside each 16-lane row, then row_bcast:15/31.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppRor8 = 0x128;
+// every lane gets the sum / max over its 16-lane row (same pairing as an xor-1,2,4,8 butterfly)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<kDppXor1, 0xF>(0.f, v); v += dpp_move<kDppXor2, 0xF>(0.f, v);
+    v += dpp_move<kDppHalfMirror, 0xF>(0.f, v); v += dpp_move<kDppMirror, 0xF>(0.f, v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_move<kDppXor1, 0xF>(v, v)); v = fmaxf(v, dpp_move<kDppXor2, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<kDppHalfMirror, 0xF>(v, v)); v = fmaxf(v, dpp_move<kDppMirror, 0xF>(v, v));
     return v;
+}
+// value of lane (lane ^ 8) inside the 16-lane row
+__device__ __forceinline__ float row16_xor8(float v) { return dpp_move<kDppRor8, 0xF>(v, v); }
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    v += dpp_move<kDppBcast15, 0xA>(0.f, v);        // rows 1, 3 += row 0, 2
+    v += dpp_move<kDppBcast31, 0xC>(0.f, v);        // rows 2, 3 += rows 0 + 1
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    v = fmaxf(v, dpp_move<kDppBcast15, 0xA>(v, v));
+    v = fmaxf(v, dpp_move<kDppBcast31, 0xC>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// lane-wise reductions ACROSS the four 16-lane rows (lanes c, c+16, c+32, c+48): gfx950's v_permlane32_swap /
+// v_permlane16_swap exchange half-waves / odd-even rows in the VALU pipe; swap(v, v) leaves {v[lane], v[partner]} in
+// the two results, so a commutative combine needs no knowledge of which is which.  Every lane gets the result.
+typedef unsigned fq3_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float xrow_sum(float v) {
+    fq3_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r.x) + __uint_as_float(r.y);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float xrow_max(float v) {
+    fq3_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
 }
 // block-wide sum for blockDim.x == 64*NW; red must hold NW floats; all threads get the result
 template <int NW> __device__ __forceinline__ float block_sum(float v, float* red) {

@@ -23,6 +23,7 @@ struct fq3_ctx {
     // scratch (device)
     void *h = nullptr, *xin = nullptr, *qkv = nullptr, *act = nullptr, *logits = nullptr, *past_hidden = nullptr;
     void *pred_in = nullptr, *pred_x = nullptr, *pred_next = nullptr, *plogits = nullptr, *tmp_hidden = nullptr;
+    void *attn_out = nullptr;       // final attention output T[q_dim] (code predictor's single-wave kernel)
     void *h2 = nullptr, *qkv2 = nullptr, *act2 = nullptr, *pred_x2 = nullptr;      // second token of the M = 2 predictor prefill
     size_t part_stride = 0;
     float* part = nullptr;
@@ -34,10 +35,9 @@ struct fq3_ctx {
     int64_t* ids64 = nullptr;
     int n_pad = 0, rope_delta = 0;
     int opt_nt = 1;               // weight-load cache policy (see run_stack)
-    int opt_fused_attn = 0;       // predictor attention inside the o_proj launch (measured: no gain on MI355X, kept for A/B)
     int opt_m2 = 0;               // code predictor: FQ3_M2=1 runs the two-token prefill as one M = 2 pass over the weights
                                   // (parity-tested; measured 3.12 vs 3.04 ms/frame, so off by default)
-    int opt_pred_attn = 1;        // code predictor: single-wave register-only attention kernel (FQ3_PRED_ATTN=0: generic kernel)
+    int opt_pred_attn = 1;        // code predictor: one-wave-per-head register-only attention writing the final head output (FQ3_PRED_ATTN=0: generic split-KV kernel + merge)
     int prefill_mode = 0;         // 0 auto (MFMA), 1 token walk
     bool talker_wave = true;      // talker sampler variant baked into the captured graph
     fq3_sampling pred_sampling{0.9f, 50, 1.0f, 1, 1.0f};

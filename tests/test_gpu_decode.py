@@ -263,25 +263,6 @@ def test_too_long_prompt_raises():
         eng.prefill(x)
 
 
-def test_fused_predictor_attention_variant(monkeypatch):
-    """FQ3_FUSED_ATTN=1 moves the predictor's (<= 17 key) attention into the o_proj launch; same ids/logits."""
-    from oracle import qwen3tts_oracle as O
-    monkeypatch.setenv("FQ3_FUSED_ATTN", "1")
-    cfg = tiny_test_config()
-    dtype = torch.float32
-    W = synth_weights(cfg, 0, dtype)
-    orc = O.OracleTTS(cfg, W, max_seq_len=96)
-    orc.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
-    eng = _engine(cfg, W, dtype)
-    eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
-    g = torch.Generator().manual_seed(19)
-    x = torch.randn(1, 2, cfg.talker.hidden_size, generator=g)
-    o_ids, o_logits = orc.predictor_loop(x, return_logits=True)
-    ids, lg = eng.predictor_loop(x.view(-1).cuda(), want_logits=True)
-    assert torch.equal(ids.cpu(), o_ids)
-    assert (lg.float().cpu() - o_logits.float()).abs().max() <= 5e-4
-
-
 @pytest.mark.parametrize("graph", [False, True])
 def test_eos_stop_and_position_limit(graph):
     from oracle import qwen3tts_oracle as O

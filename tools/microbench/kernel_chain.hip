@@ -1,0 +1,278 @@
+// Kernel-tuning harness (measurement tool, not product code): replays chains of the PRODUCT decode kernels
+// (csrc/decode_kernels.cuh, csrc/sampler_wave.cuh) from a hipGraph, one kernel type per chain, at the 0.6B
+// shapes, and prints wall time per launch.  Dependencies are the graph's stream-order edges; weights rotate over
+// 5 copies so that no launch finds its matrix hot in L2.  No torch, no Python: ~10 s of GPU time per run.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <functional>
+#include "../../faster-qwen3-tts_amd/csrc/decode_kernels.cuh"
+#include "../../faster-qwen3-tts_amd/csrc/sampler.cuh"
+#include "../../faster-qwen3-tts_amd/csrc/sampler_wave.cuh"
+#ifdef FQ3_HAVE_VARIANTS
+#include "variants.cuh"
+#endif
+using namespace fq3;
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
+
+static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (unsigned short)(u >> 16); }
+static void* dev_bf16(size_t n, float scale, float offset = 0.f) {
+    std::vector<unsigned short> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = f2bf(offset + scale * ((rand() & 0xffff) / 32768.f - 1.f));
+    void* d; CHK(hipMalloc(&d, n * 2)); CHK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
+    return d;
+}
+static void* dev_f32(size_t n, float scale) {
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() & 0xffff) / 32768.f - 1.f);
+    void* d; CHK(hipMalloc(&d, n * 4)); CHK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
+static hipStream_t st;
+static hipEvent_t e0, e1;
+static int g_reps = 20;
+
+static double chain(const char* name, int n, const std::function<void(int)>& launch) {
+    hipGraph_t g; hipGraphExec_t ge;
+    CHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    for (int i = 0; i < n; ++i) launch(i);
+    CHK(hipStreamEndCapture(st, &g)); CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    for (int w = 0; w < 3; ++w) CHK(hipGraphLaunch(ge, st));
+    CHK(hipStreamSynchronize(st));
+    float ms = 0;
+    CHK(hipEventRecord(e0, st));
+    for (int r = 0; r < g_reps; ++r) CHK(hipGraphLaunch(ge, st));
+    CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms, e0, e1));
+    CHK(hipGetLastError());
+    const double us = 1e3 * ms / g_reps / n;
+    printf("%-64s %7.3f us/launch   (%d launches: %.3f ms)\n", name, us, n, ms / g_reps);
+    CHK(hipGraphExecDestroy(ge)); CHK(hipGraphDestroy(g));
+    return us;
+}
+
+template <int NCH, int PRO, int EPI, bool NT>
+static void gemv(const GemvArgs& a, int R) {
+    const int grid = (a.N + 4 * R - 1) / (4 * R);
+    const size_t shm = PRO == PRO_COMBINE ? (size_t)a.K * sizeof(float) : 0;
+    if constexpr (MaxRows<NCH, EPI>::v >= 2) {
+        if (R == 2) { hipLaunchKernelGGL((gemv_kernel<bf16_t, NCH, PRO, EPI, NT, 1, 2>), dim3(grid), dim3(256), shm, st, a); return; }
+    }
+    if (R != 1) { fprintf(stderr, "R=%d not built for NCH=%d\n", R, NCH); exit(2); }
+    hipLaunchKernelGGL((gemv_kernel<bf16_t, NCH, PRO, EPI, NT, 1, 1>), dim3(grid), dim3(256), shm, st, a);
+}
+
+// ---- self-checks: cheap CPU references so that a 15-second harness run also catches logic errors ---------------
+static float bf2f(unsigned short v) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, &u, 4); return f; }
+static float rbf(float f) { return bf2f(f2bf(f)); }
+static std::vector<float> fetch_bf16(const void* d, size_t n) {
+    std::vector<unsigned short> h(n); CHK(hipMemcpy(h.data(), d, n * 2, hipMemcpyDeviceToHost));
+    std::vector<float> f(n); for (size_t i = 0; i < n; ++i) f[i] = bf2f(h[i]); return f;
+}
+static std::vector<float> fetch_f32(const void* d, size_t n) { std::vector<float> f(n); CHK(hipMemcpy(f.data(), d, n * 4, hipMemcpyDeviceToHost)); return f; }
+static int g_fail = 0;
+static void report(const char* what, double err, double tol) {
+    printf("check %-52s max err %.3e (tol %.1e) %s\n", what, err, tol, err <= tol ? "ok" : "FAIL");
+    if (!(err <= tol)) ++g_fail;
+}
+__global__ void lane_ops_kernel(float* out) {
+    const int lane = threadIdx.x;
+    const float v = (float)(lane * lane % 37) + 0.25f * lane;
+    out[lane] = wave_sum(v); out[64 + lane] = wave_max(v); out[128 + lane] = row16_sum(v); out[192 + lane] = row16_max(v);
+    out[256 + lane] = row16_xor8(v); out[320 + lane] = xrow_sum(v); out[384 + lane] = xrow_max(v); out[448 + lane] = v;
+}
+static void check_lane_ops() {
+    float* d; CHK(hipMalloc(&d, 512 * 4));
+    hipLaunchKernelGGL(lane_ops_kernel, dim3(1), dim3(64), 0, st, d); CHK(hipStreamSynchronize(st));
+    auto o = fetch_f32(d, 512); const float* v = &o[448];
+    double e = 0;
+    float tot = 0, mx = -1e30f; for (int i = 0; i < 64; ++i) { tot += v[i]; mx = fmaxf(mx, v[i]); }
+    for (int l = 0; l < 64; ++l) {
+        float rs = 0, rm = -1e30f, xs = 0, xm = -1e30f;
+        for (int i = 0; i < 16; ++i) { rs += v[(l & 48) + i]; rm = fmaxf(rm, v[(l & 48) + i]); }
+        for (int r = 0; r < 4; ++r) { xs += v[(l & 15) + 16 * r]; xm = fmaxf(xm, v[(l & 15) + 16 * r]); }
+        e = fmax(e, fabs(o[l] - tot)); e = fmax(e, fabs(o[64 + l] - mx)); e = fmax(e, fabs(o[128 + l] - rs)); e = fmax(e, fabs(o[192 + l] - rm));
+        e = fmax(e, fabs(o[256 + l] - v[l ^ 8])); e = fmax(e, fabs(o[320 + l] - xs)); e = fmax(e, fabs(o[384 + l] - xm));
+    }
+    report("DPP / permlane-swap lane reductions", e, 1e-3);
+}
+
+__global__ void empty_kernel(const float* p) { if (p == nullptr) __builtin_trap(); }
+
+int main(int argc, char** argv) {
+    const char* only = argc > 1 ? argv[1] : "";
+    g_reps = argc > 2 ? atoi(argv[2]) : 20;
+    auto want = [&](const char* tag) { return only[0] == 0 || strstr(tag, only) != nullptr || strcmp(only, "all") == 0; };
+    srand(7);
+    CHK(hipStreamCreate(&st)); CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const int H = 1024, I = 3072, QD = 2048, KVD = 1024, NQKV = QD + 2 * KVD, Vp = 2048, Vt = 3072, NKV = 8;
+    const int NL = 5;
+    void *Wqkv[NL], *Wo[NL], *Wgu[NL], *Wdn[NL], *Whead[NL], *WheadT;
+    for (int l = 0; l < NL; ++l) {
+        Wqkv[l] = dev_bf16((size_t)NQKV * H, 1.f / sqrtf((float)H));
+        Wo[l] = dev_bf16((size_t)H * QD, 1.f / sqrtf((float)QD));
+        Wgu[l] = dev_bf16((size_t)2 * I * H, 1.f / sqrtf((float)H));
+        Wdn[l] = dev_bf16((size_t)H * I, 1.f / sqrtf((float)I));
+        Whead[l] = dev_bf16((size_t)Vp * H, 1.f / sqrtf((float)H));
+    }
+    WheadT = dev_bf16((size_t)Vt * H, 1.f / sqrtf((float)H));
+    void* norm_w = dev_bf16(H, 0.05f, 1.f);
+    void* hd_w = dev_bf16(128, 0.05f, 1.f);
+    void* bufA = dev_bf16(8192, 1.f);
+    void* bufB = dev_bf16(8192, 1.f);
+    void* qkv = dev_bf16(NQKV, 1.f);
+    void* act = dev_bf16(I, 1.f);
+    void* attn_out = dev_bf16(QD, 1.f);
+    float* cosr = (float*)dev_f32(128, 1.f);
+    const int pred_seq = 17, talk_seq = 2048;
+    void* pk = dev_bf16((size_t)NKV * pred_seq * 128, 1.f);
+    void* pv = dev_bf16((size_t)NKV * pred_seq * 128, 1.f);
+    void* tk[NL]; void* tv[NL];
+    for (int l = 0; l < NL; ++l) { tk[l] = dev_bf16((size_t)NKV * talk_seq * 128, 1.f); tv[l] = dev_bf16((size_t)NKV * talk_seq * 128, 1.f); }
+    float* part = (float*)dev_f32((size_t)NKV * kMaxWorkers * 2 * kPartStride, 0.5f);
+    void* logits = dev_bf16(Vt, 3.f);
+    void* noise = dev_bf16((size_t)16 * Vt, 0.4f, 0.6f);
+    void* emb = dev_bf16((size_t)Vp * H, 1.f);
+    int* codes; CHK(hipMalloc(&codes, 16384 * 16 * 4)); CHK(hipMemset(codes, 0, 16384 * 16 * 4));
+    unsigned char* seen; CHK(hipMalloc(&seen, kMaxVocab)); CHK(hipMemset(seen, 0, kMaxVocab));
+    int64_t* out64; CHK(hipMalloc(&out64, 64 * 8));
+    int* pos_dev; CHK(hipMalloc(&pos_dev, 4)); { int p = 300; CHK(hipMemcpy(pos_dev, &p, 4, hipMemcpyHostToDevice)); }
+    // a frozen DecodeState for the talker sampler (done = 0; frame never advances in this harness is fine for timing)
+    DecodeState hs{}; hs.token = 5; hs.frame = 0; hs.pos = 300; hs.done = 0; hs.min_new = 2; hs.max_new = 4000; hs.noise_frames = 1;
+    hs.eos_id = 2150; hs.max_seq = talk_seq; hs.sup_lo = Vt - 1024; hs.sup_hi = Vt; hs.t_temperature = 0.9f; hs.t_top_k = 50; hs.t_top_p = 1.f;
+    hs.t_do_sample = 1; hs.t_rep_penalty = 1.05f; hs.p_temperature = 0.9f; hs.p_top_k = 50; hs.p_top_p = 1.f; hs.p_do_sample = 1;
+    hs.talker_noise = noise; hs.pred_noise = noise;
+    DecodeState* st_dev; CHK(hipMalloc(&st_dev, sizeof hs)); CHK(hipMemcpy(st_dev, &hs, sizeof hs, hipMemcpyHostToDevice));
+
+    const int N = 320;
+    printf("# chain of %d dependent launches per line, %d graph replays; MI355X, 0.6B predictor/talker shapes, bf16\n", N, g_reps);
+    if (want("empty")) chain("empty kernel (1 wave)", N, [&](int) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, st, cosr); });
+
+    auto qkv_args = [&](int i) { GemvArgs g{}; g.eps = 1e-6f; g.W = Wqkv[i % NL]; g.N = NQKV; g.K = H; g.x = (i & 1) ? bufB : bufA; g.norm_w = norm_w; g.y = qkv; return g; };
+    auto o_args = [&](int i, int n_part) { GemvArgs g{}; g.W = Wo[i % NL]; g.N = H; g.K = QD; g.y = (i & 1) ? bufA : bufB; g.res = (i & 1) ? bufB : bufA; g.rep = 2; g.part = part; g.n_part = n_part; return g; };
+    auto gu_args = [&](int i) { GemvArgs g{}; g.eps = 1e-6f; g.W = Wgu[i % NL]; g.N = I; g.K = H; g.x = (i & 1) ? bufB : bufA; g.norm_w = norm_w; g.y = act; g.up_off = I; return g; };
+    auto dn_args = [&](int i) { GemvArgs g{}; g.W = Wdn[i % NL]; g.N = H; g.K = I; g.x = act; g.y = (i & 1) ? bufA : bufB; g.res = (i & 1) ? bufB : bufA; return g; };
+    auto head_args = [&](int i) { GemvArgs g{}; g.eps = 1e-6f; g.W = Whead[i % NL]; g.N = Vp; g.K = H; g.x = (i & 1) ? bufB : bufA; g.norm_w = norm_w; g.y = logits; return g; };
+    auto pattn_args = [&](int pos) { AttnArgs a{}; a.qkv = qkv; a.q_norm_w = hd_w; a.k_norm_w = hd_w; a.eps = 1e-6f; a.cos_row = cosr; a.sin_row = cosr + 64;
+        a.kcache = pk; a.vcache = pv; a.max_seq = pred_seq; a.pos_ptr = nullptr; a.pos_imm = pos; a.n_pad = 0; a.n_kv = NKV; a.part = part; a.scale = 0.0883883f; a.rep = 2; a.out = attn_out; return a; };
+    auto tattn_args = [&](int i) { AttnArgs a = pattn_args(0); a.kcache = tk[i % NL]; a.vcache = tv[i % NL]; a.max_seq = talk_seq; a.pos_ptr = pos_dev; return a; };
+    SampleCfg pc{}; pc.temperature = 0.9f; pc.top_k = 50; pc.top_p = 1.f; pc.do_sample = 1; pc.rep_penalty = 1.f; pc.sup_lo = 0; pc.sup_hi = 0; pc.keep_id = -1; pc.sup_extra = -1;
+
+
+    if (want("check")) {
+        check_lane_ops();
+        // qkv: y = W . (norm_w * rnd(x * rs)) -- compare rows against a double-precision reference
+        auto Wh = fetch_bf16(Wqkv[0], (size_t)NQKV * H); auto xh = fetch_bf16(bufA, H); auto nh = fetch_bf16(norm_w, H);
+        std::vector<float> xn(H); { double ss = 0; for (int i = 0; i < H; ++i) ss += (double)xh[i] * xh[i]; const float rs = 1.f / sqrtf((float)(ss / H) + 1e-6f);
+            for (int i = 0; i < H; ++i) xn[i] = rbf(nh[i] * rbf(xh[i] * rs)); }
+        for (int R = 1; R <= 2; ++R) {
+            gemv<2, PRO_NORM, EPI_STORE, false>(qkv_args(0), R); CHK(hipStreamSynchronize(st));
+            auto y = fetch_bf16(qkv, NQKV); double e = 0;
+            for (int r = 0; r < NQKV; ++r) { double acc = 0; for (int i = 0; i < H; ++i) acc += (double)Wh[(size_t)r * H + i] * xn[i]; e = fmax(e, fabs(y[r] - acc) / (1.0 + fabs(acc))); }
+            report(R == 1 ? "gemv NORM/STORE R=1 (qkv)" : "gemv NORM/STORE R=2 (qkv)", e, 1e-2);
+        }
+        {   // gate_up + SwiGLU
+            auto Wg = fetch_bf16(Wgu[0], (size_t)2 * I * H);
+            gemv<2, PRO_NORM, EPI_SWIGLU, false>(gu_args(0), 2); CHK(hipStreamSynchronize(st));
+            auto y = fetch_bf16(act, I); double e = 0;
+            for (int r = 0; r < I; ++r) { double g = 0, u = 0; for (int i = 0; i < H; ++i) { g += (double)Wg[(size_t)r * H + i] * xn[i]; u += (double)Wg[(size_t)(r + I) * H + i] * xn[i]; }
+                const float gg = rbf((float)g), uu = rbf((float)u); const double ref = rbf(gg / (1.f + expf(-gg))) * uu; e = fmax(e, fabs(y[r] - ref) / (1.0 + fabs(ref))); }
+            report("gemv NORM/SWIGLU R=2 (gate_up)", e, 1e-2);
+        }
+        {   // down + residual (in place on bufB <- bufA residual)
+            auto Wd = fetch_bf16(Wdn[0], (size_t)H * I); auto ah = fetch_bf16(act, I); auto rh = fetch_bf16(bufA, H);
+            gemv<6, PRO_PLAIN, EPI_RESIDUAL, false>(dn_args(0), 1); CHK(hipStreamSynchronize(st));
+            auto y = fetch_bf16(bufB, H); double e = 0;
+            for (int r = 0; r < H; ++r) { double acc = 0; for (int i = 0; i < I; ++i) acc += (double)Wd[(size_t)r * I + i] * ah[i]; const double ref = rbf((float)acc) + rh[r]; e = fmax(e, fabs(y[r] - ref) / (1.0 + fabs(ref))); }
+            report("gemv PLAIN/RESIDUAL R=1 (down)", e, 1e-2);
+            CHK(hipMemcpy(bufB, bufA, 8192 * 2, hipMemcpyDeviceToDevice));
+        }
+        {   // predictor attention, pos 8, against fp32 reference with the same rounding points
+            hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(2 * NKV), dim3(64), 0, st, pattn_args(8)); CHK(hipStreamSynchronize(st));
+            auto qh = fetch_bf16(qkv, NQKV); auto wn = fetch_bf16(hd_w, 128); auto cs = fetch_f32(cosr, 128);
+            auto kh = fetch_bf16(pk, (size_t)NKV * pred_seq * 128), vh = fetch_bf16(pv, (size_t)NKV * pred_seq * 128); auto out = fetch_bf16(attn_out, QD);
+            auto norm_rope = [&](const float* x, float* o) { double ss = 0; for (int d = 0; d < 128; ++d) ss += (double)x[d] * x[d]; const float rs = 1.f / sqrtf((float)(ss / 128) + 1e-6f);
+                float n[128]; for (int d = 0; d < 128; ++d) n[d] = rbf(wn[d] * rbf(x[d] * rs));
+                for (int d = 0; d < 128; ++d) { const float rot = d < 64 ? -n[d + 64] : n[d - 64]; o[d] = rbf(rbf(n[d] * cs[d & 63]) + rbf(rot * cs[64 + (d & 63)])); } };
+            double e = 0;
+            for (int h = 0; h < 16; ++h) { const int g = h / 2; float q[128], kn[128];
+                norm_rope(&qh[(size_t)h * 128], q); norm_rope(&qh[QD + (size_t)g * 128], kn);
+                double sc[9], mx = -1e30; for (int k = 0; k < 9; ++k) { const float* kk = k < 8 ? &kh[((size_t)g * pred_seq + k) * 128] : kn; double a2 = 0; for (int d = 0; d < 128; ++d) a2 += (double)q[d] * kk[d]; sc[k] = a2 * 0.0883883; mx = fmax(mx, sc[k]); }
+                double l = 0; for (int k = 0; k < 9; ++k) { sc[k] = exp(sc[k] - mx); l += sc[k]; }
+                for (int d = 0; d < 128; ++d) { double o = 0; for (int k = 0; k < 9; ++k) o += sc[k] * (k < 8 ? vh[((size_t)g * pred_seq + k) * 128 + d] : qh[QD + KVD + (size_t)g * 128 + d]); o /= l;
+                    e = fmax(e, fabs(out[(size_t)h * 128 + d] - o) / (1.0 + fabs(o))); } }
+            report("attn_pred_kernel pos 8 (16 heads)", e, 2e-2);
+            // the group's first head must have appended K (normed + roped) and V at slot 8
+            auto k2 = fetch_bf16(pk, (size_t)NKV * pred_seq * 128); float kn[128]; norm_rope(&qh[QD], kn); double e2 = 0;
+            for (int d = 0; d < 128; ++d) e2 = fmax(e2, fabs(k2[(size_t)8 * 128 + d] - kn[d]));
+            report("attn_pred_kernel KV append (group 0)", e2, 2e-2);
+        }
+        {   // talker attention + COMBINE o_proj against PLAIN o_proj fed by the reference merge is covered by pytest; here: finite + sane
+            hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 2>), dim3(NKV, 8), dim3(256), 0, st, tattn_args(0)); 
+            gemv<4, PRO_COMBINE, EPI_RESIDUAL, false>(o_args(0, 8), 1); CHK(hipStreamSynchronize(st));
+            auto y = fetch_bf16(bufB, H); double s2 = 0; int bad = 0; for (float v : y) { if (!(fabs(v) < 1e4)) ++bad; s2 += (double)v * v; }
+            report("attn_decode + COMBINE o_proj finite", bad, 0.5);
+            CHK(hipMemcpy(bufB, bufA, 8192 * 2, hipMemcpyDeviceToDevice));
+        }
+        if (g_fail) { printf("SELF-CHECK FAILURES: %d\n", g_fail); }
+    }
+    if (want("qkv")) {
+        chain("qkv   gemv<2,NORM,STORE>      N=4096 K=1024 R=2 grid 512", N, [&](int i) { gemv<2, PRO_NORM, EPI_STORE, false>(qkv_args(i), 2); });
+        chain("qkv   gemv<2,NORM,STORE>      N=4096 K=1024 R=1 grid 1024", N, [&](int i) { gemv<2, PRO_NORM, EPI_STORE, false>(qkv_args(i), 1); });
+        chain("qkv   gemv<2,NORM,STORE> NT   N=4096 K=1024 R=2 grid 512", N, [&](int i) { gemv<2, PRO_NORM, EPI_STORE, true>(qkv_args(i), 2); });
+        chain("qkv   gemv<2,PLAIN,STORE>     N=4096 K=1024 R=2 grid 512 (no norm)", N, [&](int i) { gemv<2, PRO_PLAIN, EPI_STORE, false>(qkv_args(i), 2); });
+    }
+    if (want("pattn")) {
+        chain("pattn attn_pred_kernel        16 x 64 thr, pos 8 (final output)", N, [&](int) { hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(2 * NKV), dim3(64), 0, st, pattn_args(8)); });
+        chain("pattn attn_decode_kernel<2>    8 x 256 thr, pos 8 (1 worker)", N, [&](int) { hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 2>), dim3(NKV, 1), dim3(256), 0, st, pattn_args(8)); });
+    }
+    if (want("tattn"))
+        chain("tattn attn_decode_kernel<2>    8x8 x 256 thr, pos 300 (device pos)", N, [&](int i) { hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 2>), dim3(NKV, 8), dim3(256), 0, st, tattn_args(i)); });
+    if (want("oproj")) {
+        chain("oproj gemv<4,COMBINE,RESID>   N=1024 K=2048 R=1 grid 256, 1 part", N, [&](int i) { gemv<4, PRO_COMBINE, EPI_RESIDUAL, false>(o_args(i, 1), 1); });
+        chain("oproj gemv<4,COMBINE,RESID>   N=1024 K=2048 R=1 grid 256, 8 parts", N, [&](int i) { gemv<4, PRO_COMBINE, EPI_RESIDUAL, false>(o_args(i, 8), 1); });
+        chain("oproj gemv<4,PLAIN,RESID>     N=1024 K=2048 R=1 grid 256 (no combine)", N, [&](int i) { GemvArgs g = o_args(i, 1); g.x = attn_out; gemv<4, PRO_PLAIN, EPI_RESIDUAL, false>(g, 1); });
+    }
+    if (want("gateup")) {
+        chain("gateup gemv<2,NORM,SWIGLU>    N=3072 K=1024 R=2 grid 384", N, [&](int i) { gemv<2, PRO_NORM, EPI_SWIGLU, false>(gu_args(i), 2); });
+        chain("gateup gemv<2,NORM,SWIGLU>    N=3072 K=1024 R=1 grid 768", N, [&](int i) { gemv<2, PRO_NORM, EPI_SWIGLU, false>(gu_args(i), 1); });
+    }
+    if (want("down")) {
+        chain("down  gemv<6,PLAIN,RESID>     N=1024 K=3072 R=1 grid 256", N, [&](int i) { gemv<6, PRO_PLAIN, EPI_RESIDUAL, false>(dn_args(i), 1); });
+    }
+    if (want("head")) {
+        chain("head  gemv<2,NORM,STORE>      N=2048 K=1024 R=2 grid 256", N, [&](int i) { gemv<2, PRO_NORM, EPI_STORE, false>(head_args(i), 2); });
+        chain("head  gemv<2,NORM,STORE>      N=2048 K=1024 R=1 grid 512", N, [&](int i) { gemv<2, PRO_NORM, EPI_STORE, false>(head_args(i), 1); });
+    }
+    if (want("sample")) {
+        chain("sample sample_pred_wave_kernel<1>  V=2048 top_k=50 (immediate cfg)", N, [&](int i) {
+            hipLaunchKernelGGL((sample_pred_wave_kernel<bf16_t, 1>), dim3(1), dim3(256), 0, st, (const DecodeState*)nullptr, (const bf16_t*)logits, Vp, i % 15, pc,
+                               (const bf16_t*)noise, (int*)nullptr, 16, out64, (const bf16_t*)emb, (bf16_t*)bufA, H); });
+        chain("sample sample_pred_wave_kernel<1>  V=2048 (device state)", N, [&](int i) {
+            hipLaunchKernelGGL((sample_pred_wave_kernel<bf16_t, 1>), dim3(1), dim3(256), 0, st, (const DecodeState*)st_dev, (const bf16_t*)logits, Vp, i % 15, pc,
+                               (const bf16_t*)nullptr, codes, 16, (int64_t*)nullptr, (const bf16_t*)emb, (bf16_t*)bufA, H); });
+        chain("sample sample_talker_wave_kernel<2> V=3072 top_k=50 rep 1.05", N, [&](int) {
+            hipLaunchKernelGGL((sample_talker_wave_kernel<bf16_t, 2>), dim3(1), dim3(256), 0, st, st_dev, (const bf16_t*)logits, Vt, (const unsigned char*)seen); });
+        CHK(hipMemcpy(st_dev, &hs, sizeof hs, hipMemcpyHostToDevice));
+    }
+    if (want("layer")) {
+        chain("layer  predictor layer x64 (qkv, attn_pred, o plain, gate_up, down)", N, [&](int j) {
+            const int i = j / 5;
+            switch (j % 5) {
+                case 0: gemv<2, PRO_NORM, EPI_STORE, false>(qkv_args(i), 2); break;
+                case 1: hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(2 * NKV), dim3(64), 0, st, pattn_args(8)); break;
+                case 2: { GemvArgs g = o_args(i, 1); g.x = attn_out; gemv<4, PRO_PLAIN, EPI_RESIDUAL, false>(g, 1); } break;
+                case 3: gemv<2, PRO_NORM, EPI_SWIGLU, false>(gu_args(i + 1), 2); break;
+                default: gemv<6, PRO_PLAIN, EPI_RESIDUAL, false>(dn_args(i + 1), 1); break;
+            }
+        });
+    }
+#ifdef FQ3_HAVE_VARIANTS
+    run_variants(want, chain);
+#endif
+    return 0;
+}
