@@ -73,6 +73,7 @@ extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
     if ((r = dmalloc(c, &c->h2, (size_t)Hm * c->esz))) return r;
     if ((r = dmalloc(c, &c->qkv2, (size_t)qkvm * c->esz))) return r;
     if ((r = dmalloc(c, &c->attn_out, (size_t)qkvm * c->esz))) return r;
+    if ((r = dmalloc(c, &c->attn_out2, (size_t)qkvm * c->esz))) return r;
     if ((r = dmalloc(c, &c->act2, (size_t)Im * c->esz))) return r;
     if ((r = dmalloc(c, &c->pred_x2, (size_t)p.hidden * c->esz))) return r;
     if ((r = dmalloc(c, &c->xin, (size_t)Hm * c->esz))) return r;
@@ -307,13 +308,22 @@ static int run_predictor_pair(fq3_ctx* c, const void* x_a, const void* x_b, hipS
             a.kcache = kv.k[i]; a.vcache = kv.v[i]; a.max_seq = kv.max_seq;
             a.pos_ptr = nullptr; a.pos_imm = m; a.n_pad = 0; a.n_kv = d.n_kv_heads;
             a.part = c->part + (size_t)m * c->part_stride; a.scale = 1.0f / sqrtf((float)kHeadDim);
-            if (c->cfg.dtype == FQ3_BF16) launch_attn_t<bf16_t>(a, rep, kv.workers, s);
+            a.rep = rep; a.out = m == 0 ? c->attn_out : c->attn_out2;
+            if (c->opt_pred_attn) {
+                if (c->cfg.dtype == FQ3_BF16) hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(d.n_heads), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL((attn_pred_kernel<float>), dim3(d.n_heads), dim3(64), 0, s, a);
+            } else if (c->cfg.dtype == FQ3_BF16) launch_attn_t<bf16_t>(a, rep, kv.workers, s);
             else launch_attn_t<float>(a, rep, kv.workers, s);
         }
         GemvArgs o{};
         o.W = w.o; o.N = d.hidden; o.K = q_dim; o.y = c->h; o.y2 = c->h2; o.res = xa; o.res2 = xb; o.rep = rep;
-        o.part = c->part; o.part_stride2 = c->part_stride; o.n_part = kv.workers;
-        if (int r = launch_gemv2<PRO_COMBINE, EPI_RESIDUAL>(c, o, s)) return r;
+        if (c->opt_pred_attn) {
+            o.x = c->attn_out; o.x2 = c->attn_out2;
+            if (int r = launch_gemv2<PRO_PLAIN, EPI_RESIDUAL>(c, o, s)) return r;
+        } else {
+            o.part = c->part; o.part_stride2 = c->part_stride; o.n_part = kv.workers;
+            if (int r = launch_gemv2<PRO_COMBINE, EPI_RESIDUAL>(c, o, s)) return r;
+        }
         GemvArgs m{};
         m.eps = d.rms_eps; m.W = w.gate_up; m.N = d.inter; m.K = d.hidden; m.x = c->h; m.x2 = c->h2;
         m.norm_w = w.post_norm; m.y = c->act; m.y2 = c->act2; m.up_off = d.inter;

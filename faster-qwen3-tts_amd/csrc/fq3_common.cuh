@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace fq3 {
 
@@ -123,6 +124,19 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_move<kDppBcast15, 0xA>(v, v));
     v = fmaxf(v, dpp_move<kDppBcast31, 0xC>(v, v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+    auto mv = [](auto ctrl, auto mask, int x) {
+        return __builtin_amdgcn_update_dpp(x, x, decltype(ctrl)::value, decltype(mask)::value, 0xF, false);
+    };
+    using std::integral_constant;
+    v = min(v, mv(integral_constant<int, kDppXor1>{}, integral_constant<int, 0xF>{}, v));
+    v = min(v, mv(integral_constant<int, kDppXor2>{}, integral_constant<int, 0xF>{}, v));
+    v = min(v, mv(integral_constant<int, kDppHalfMirror>{}, integral_constant<int, 0xF>{}, v));
+    v = min(v, mv(integral_constant<int, kDppMirror>{}, integral_constant<int, 0xF>{}, v));
+    v = min(v, mv(integral_constant<int, kDppBcast15>{}, integral_constant<int, 0xA>{}, v));
+    v = min(v, mv(integral_constant<int, kDppBcast31>{}, integral_constant<int, 0xC>{}, v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 // lane-wise reductions ACROSS the four 16-lane rows (lanes c, c+16, c+32, c+48): gfx950's v_permlane32_swap /
 // v_permlane16_swap exchange half-waves / odd-even rows in the VALU pipe; swap(v, v) leaves {v[lane], v[partner]} in

@@ -23,7 +23,7 @@ struct fq3_ctx {
     // scratch (device)
     void *h = nullptr, *xin = nullptr, *qkv = nullptr, *act = nullptr, *logits = nullptr, *past_hidden = nullptr;
     void *pred_in = nullptr, *pred_x = nullptr, *pred_next = nullptr, *plogits = nullptr, *tmp_hidden = nullptr;
-    void *attn_out = nullptr;       // final attention output T[q_dim] (code predictor's single-wave kernel)
+    void *attn_out = nullptr, *attn_out2 = nullptr;   // final attention output T[q_dim] (code predictor's one-wave-per-head kernel)
     void *h2 = nullptr, *qkv2 = nullptr, *act2 = nullptr, *pred_x2 = nullptr;      // second token of the M = 2 predictor prefill
     size_t part_stride = 0;
     float* part = nullptr;
@@ -35,8 +35,8 @@ struct fq3_ctx {
     int64_t* ids64 = nullptr;
     int n_pad = 0, rope_delta = 0;
     int opt_nt = 1;               // weight-load cache policy (see run_stack)
-    int opt_m2 = 0;               // code predictor: FQ3_M2=1 runs the two-token prefill as one M = 2 pass over the weights
-                                  // (parity-tested; measured 3.12 vs 3.04 ms/frame, so off by default)
+    int opt_m2 = 1;               // code predictor: the two-token prefill is ONE M = 2 pass over the weights (FQ3_M2=0: two
+                                  // single-token passes); parity-tested both ways; 2.06 vs 2.11 ms/frame with the v4 kernels
     int opt_pred_attn = 1;        // code predictor: one-wave-per-head register-only attention writing the final head output (FQ3_PRED_ATTN=0: generic split-KV kernel + merge)
     int prefill_mode = 0;         // 0 auto (MFMA), 1 token walk
     bool talker_wave = true;      // talker sampler variant baked into the captured graph

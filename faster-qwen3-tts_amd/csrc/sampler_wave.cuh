@@ -6,13 +6,12 @@
 
 namespace fq3 {
 
+// larger value wins, ties -> lower index (amax2), as two DPP reductions: value max, then min index among its holders
 __device__ __forceinline__ ArgMax wave_argmax(ArgMax a) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ArgMax b; b.v = __shfl_xor(a.v, o, 64); b.i = __shfl_xor(a.i, o, 64);
-        a = amax2(a, b);
-    }
-    return a;
+    ArgMax r;
+    r.v = wave_max(a.v);
+    r.i = wave_min_i32(a.v == r.v ? a.i : 0x7fffffff);
+    return r;
 }
 
 // Scratch for the 4-wave sampler: tiny, so the kernels stay at high occupancy-irrelevant size.
@@ -88,7 +87,9 @@ __device__ int sample_wave_core(Raw8<T> (&xraw)[NC], int V, const SampleCfg& c, 
     if (c.top_k > 0) {
         // k-th largest key by MSB-first bitwise search: count(key >= candidate) = ballot popcounts per wave,
         // the four wave counts meet in double-buffered LDS slots (one barrier per bit).  An LDS histogram
-        // serialises badly here (the top byte of the keys is nearly constant -> 64-way atomic conflicts).
+        // serialises badly here (the top byte of the keys is nearly constant -> 64-way atomic conflicts), and a
+        // 4-bits-per-round variant (15 candidate digits, 120 ballots per round, 4 barriers) measured 15.2 us against
+        // 6.9 us for this loop: a ballot + popcount costs more than the barrier it saves.
         const int kk = min(c.top_k, V);
         uint32_t key[NC][8];
 #pragma unroll
