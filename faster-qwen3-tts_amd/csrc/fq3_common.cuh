@@ -138,6 +138,15 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     v = min(v, mv(integral_constant<int, kDppBcast31>{}, integral_constant<int, 0xC>{}, v));
     return __builtin_amdgcn_readlane(v, 63);
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_move_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += dpp_move_i<kDppXor1, 0xF>(0, v); v += dpp_move_i<kDppXor2, 0xF>(0, v);
+    v += dpp_move_i<kDppHalfMirror, 0xF>(0, v); v += dpp_move_i<kDppMirror, 0xF>(0, v);
+    v += dpp_move_i<kDppBcast15, 0xA>(0, v);
+    v += dpp_move_i<kDppBcast31, 0xC>(0, v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
 // lane-wise reductions ACROSS the four 16-lane rows (lanes c, c+16, c+32, c+48): gfx950's v_permlane32_swap /
 // v_permlane16_swap exchange half-waves / odd-even rows in the VALU pipe; swap(v, v) leaves {v[lane], v[partner]} in
 // the two results, so a commutative combine needs no knowledge of which is which.  Every lane gets the result.

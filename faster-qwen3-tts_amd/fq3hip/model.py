@@ -9,6 +9,8 @@ decode loop state lives on the GPU.
 """
 from __future__ import annotations
 
+import os
+
 import logging
 from pathlib import Path
 from typing import Any, Dict, Generator, List, Optional, Tuple, Union
@@ -412,7 +414,9 @@ class FasterQwen3TTS:
         dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
         use_side = torch.cuda.is_available() and hasattr(tok, "decode_tensor")
         if use_side and getattr(self, "_voc_stream", None) is None:
-            self._voc_stream = torch.cuda.Stream(device=dev)
+            # FQ3_VOC_PRIORITY (development knob): HIP stream priority of the vocoder stream (larger = lower)
+            prio = os.environ.get("FQ3_VOC_PRIORITY")
+            self._voc_stream = torch.cuda.Stream(device=dev) if prio is None else torch.cuda.Stream(device=dev, priority=int(prio))
         for chunk, timing in stream:
             ev = timing.pop("codes_ready_event", None)
             if use_side:
