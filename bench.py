@@ -295,12 +295,12 @@ def main():
             "decode_ms_per_frame": round(frame_ms, 4), "gathered_samples": int(n_gathered),
             "reference_published": {"rtx4090_rtf": 4.78, "rtx4090_ttfa_ms": 156, "h100_rtf": 3.884, "h100_ttfa_ms": 228,
                                     "source": "reference README.md:227,229 (CUDA graphs, other hardware)"},
-            "roofline": {"bound": "hbm", "kernel": "decode-frame hipGraph (574 launches: predictor 16 passes + talker 28 layers + heads + samplers)",
+            "roofline": {"bound": "hbm", "kernel": "decode-frame hipGraph (554 launches: predictor M=2 prefill pass + 14 token passes, talker 28 layers, heads, samplers)",
                          "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                          "algorithmic_bytes_per_launch": int(bytes_frame), "kv_len": p_mid,
                          # measured once per round with a separate `rocprofv3 --pmc FETCH_SIZE` pass (x2 gfx950 correction):
-                         # the 16 predictor token passes re-read their 157 MB through the fabric every pass
-                         "traffic": 3.54e9, "traffic_source": "profiles/r01_pmc_fetch_size.txt",
+                         # the 15 predictor weight passes re-read their 157 MB through the fabric every pass
+                         "traffic": 3.37e9, "traffic_source": "profiles/r01_pmc_fetch_size.txt",
                          "launch_ms": round(frame_ms, 4)},
         }
         if conc is not None:

@@ -1,17 +1,18 @@
 // Decode-step kernels for the Qwen3-TTS talker / code predictor (gfx950, wave64).
 //
-// Design: batch-1 decode is a chain of M=1 GEMVs; every kernel boundary costs
-// ~1.2-1.5 us on MI355X and a grid barrier costs more, so a layer is FIVE weight-streaming launches
-// with everything else fused into their prologues/epilogues:
-//   1. RMSNorm  -> [q|k|v] GEMV                                  (gemv<PRO_NORM, EPI_STORE>)
-//   2. q/k head-RMSNorm + RoPE + KV append + split-KV attention   (attn_decode)
-//   3. split combine -> o_proj GEMV -> + residual                 (gemv<PRO_COMBINE, EPI_RESIDUAL>)
-//   4. RMSNorm -> [gate|up] GEMV -> SiLU(gate)*up                 (gemv<PRO_NORM, EPI_SWIGLU>)
-//   5. down GEMV -> + residual                                    (gemv<PRO_PLAIN, EPI_RESIDUAL>)
-// Weights go HBM -> VGPR with 16-byte loads, all of a wave's rows in flight before the first use;
-// x is staged once per block in LDS (fp32) and then held in registers; reductions are wave
-// butterflies.  Rounding points follow the module-by-module Torch execution the reference replays
-// (bf16 after every Linear / norm / RoPE / residual add; fp32 inside dot products and softmax).
+// Design: batch-1 decode is a chain of M=1 GEMVs; an empty hipGraph node costs 1.56 us on
+// MI355X, a lean GEMV ~2.2-3.3 us, a device-wide barrier inside a persistent kernel 6.6-16 us, so a layer is FIVE
+// weight-streaming launches with everything else fused into their prologues/epilogues:
+//   1. RMSNorm  -> [q|k|v] GEMV                                   (gemv<PRO_NORM, EPI_STORE>)
+//   2. q/k head-RMSNorm + RoPE + KV append + attention             (attn_pred: final output | attn_decode: split-KV)
+//   3. [split merge ->] o_proj GEMV -> + residual                  (gemv<PRO_PLAIN | PRO_COMBINE, EPI_RESIDUAL>)
+//   4. RMSNorm -> [gate|up] GEMV -> SiLU(gate)*up                  (gemv<PRO_NORM, EPI_SWIGLU>)
+//   5. down GEMV -> + residual                                     (gemv<PRO_PLAIN, EPI_RESIDUAL>)
+// Per-kernel rules (each one measured with tools/microbench/kernel_chain.hip): input-side loads are issued before
+// the weight rows so the prologue arithmetic runs while the weights are in flight; every load is unconditional
+// (clamped address) so that s_waitcnt stays exact; lane reductions are DPP / permlane swaps, never ds_bpermute;
+// bf16 rounding is v_cvt_pk_bf16_f32.  Rounding points follow the module-by-module Torch execution the reference
+// replays (bf16 after every Linear / norm / RoPE / residual add; fp32 inside dot products and softmax).
 #pragma once
 #include "fq3_common.cuh"
 

@@ -12,9 +12,6 @@
 #include "../../faster-qwen3-tts_amd/csrc/decode_kernels.cuh"
 #include "../../faster-qwen3-tts_amd/csrc/sampler.cuh"
 #include "../../faster-qwen3-tts_amd/csrc/sampler_wave.cuh"
-#ifdef FQ3_HAVE_VARIANTS
-#include "variants.cuh"
-#endif
 using namespace fq3;
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
@@ -271,8 +268,5 @@ int main(int argc, char** argv) {
             }
         });
     }
-#ifdef FQ3_HAVE_VARIANTS
-    run_variants(want, chain);
-#endif
-    return 0;
+    return g_fail ? 1 : 0;
 }
