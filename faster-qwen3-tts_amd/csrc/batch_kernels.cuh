@@ -1,0 +1,248 @@
+// Batched decode (the reference fixes batch = 1, talker_graph.py:46 /
+// predictor_graph.py:70): B utterances ("lanes") advance in lock-step through ONE launch chain and ONE pass over
+// the weights per frame.  Every lane keeps its own single-stream context (KV caches, DecodeState, history, codes,
+// noise rings -- prefill and fq3_decode_begin are the single-stream entry points); only the per-frame chain is
+// replaced.  The lane-local kernels below are thin wrappers that point the single-stream bodies at lane `l`;
+// gemv_batch_kernel is the M = B GEMV: tokens prepared (RMSNorm / split-KV merge, T-rounded) cooperatively into
+// LDS, weight rows in registers, every wave walks the B tokens.  Same arithmetic, order and rounding as gemv_kernel,
+// so a lane's ids are bit-identical to the same utterance decoded alone (tests/test_gpu_batch.py).
+#pragma once
+#include "decode_kernels.cuh"
+#include "sampler.cuh"
+#include "sampler_wave.cuh"
+
+namespace fq3 {
+
+constexpr int kMaxLanes = 8;
+
+struct LaneTab {
+    DecodeState* st[kMaxLanes];
+    int* codes[kMaxLanes];
+    unsigned char* seen[kMaxLanes];
+    void* past_hidden[kMaxLanes];
+};
+struct LaneKV { void* k[kMaxLanes]; void* v[kMaxLanes]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void frame_begin_batch_kernel(LaneTab t, const T* codec_emb, T* pred_in, int H, int G) {
+    const int l = blockIdx.x;
+    frame_begin_body<T>(t.st[l], codec_emb, reinterpret_cast<const T*>(t.past_hidden[l]), pred_in + (size_t)l * 2 * H,
+                        t.codes[l], t.seen[l], H, G);
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void embed_sum_batch_kernel(LaneTab t, EmbTables tabs, T* x, int H, const float* cos_tab,
+                                                              const float* sin_tab, int rope_len, float* rope_now) {
+    const int l = blockIdx.x;
+    embed_sum_body<T, G>(t.st[l], tabs, t.codes[l], x + (size_t)l * H, H, cos_tab, sin_tab, rope_len, t.st[l]->rope_delta,
+                         rope_now + (size_t)l * kHeadDim);
+}
+
+// code-predictor attention: grid (n_heads, B)
+template <typename T>
+__global__ __launch_bounds__(64) void attn_pred_batch_kernel(AttnArgs a, LaneKV kv, int qkv_stride, int out_stride) {
+    const int l = blockIdx.y;
+    a.qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)l * qkv_stride;
+    a.out = reinterpret_cast<T*>(a.out) + (size_t)l * out_stride;
+    a.kcache = kv.k[l]; a.vcache = kv.v[l];
+    attn_pred_body<T>(a);
+}
+
+// talker attention: grid (n_kv, workers, B); position, pad count and RoPE row are the lane's own
+template <typename T, int REP>
+__global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, LaneKV kv, LaneTab t, int qkv_stride,
+                                                                const float* rope_now, size_t part_stride) {
+    const int l = blockIdx.z;
+    a.qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)l * qkv_stride;
+    a.kcache = kv.k[l]; a.vcache = kv.v[l];
+    a.pos_ptr = &t.st[l]->pos;
+    a.n_pad = t.st[l]->n_pad;
+    a.cos_row = rope_now + (size_t)l * kHeadDim; a.sin_row = a.cos_row + 64;
+    a.part = a.part + (size_t)l * part_stride;
+    attn_decode_body<T, REP>(a);
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void sample_pred_batch_kernel(LaneTab t, const T* logits, size_t logit_stride, int V, int cb,
+                                                               int G, const T* next_emb, T* next_in, int H) {
+    const int l = blockIdx.x;
+    SampleCfg c{};                       // policy comes from the lane's DecodeState
+    c.rep_penalty = 1.0f; c.sup_lo = 0; c.sup_hi = 0; c.keep_id = -1; c.sup_extra = -1;
+    sample_pred_wave_body<T, NC>(t.st[l], logits + (size_t)l * logit_stride, V, cb, c, (const T*)nullptr, t.codes[l], G,
+                                 (int64_t*)nullptr, next_emb, next_in + (size_t)l * H, H);
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void sample_talker_batch_kernel(LaneTab t, const T* logits, int V) {
+    const int l = blockIdx.x;
+    sample_talker_wave_body<T, NC>(t.st[l], logits + (size_t)l * V, V, t.seen[l]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct BatchGemvArgs {
+    const void* W; int N; int K; int B;
+    const void* x; int x_stride;                   // T[B][x_stride]          (PRO_PLAIN / PRO_NORM)
+    const void* norm_w; float eps;
+    const void* bias;
+    void* y; int y_stride;                         // T[B][y_stride]
+    const void* res; int res_stride;               // T[B][res_stride]        (EPI_RESIDUAL), may alias y
+    int up_off;
+    const float* part; size_t part_stride; int n_part; int rep;       // PRO_COMBINE: lane l's slots at part + l * part_stride
+    void* xn_out[kMaxLanes];                       // optional per-lane copy of the prepared token (codec_head -> past_hidden)
+};
+
+// One row per wave (4 rows per workgroup); B <= kMaxLanes is a launch argument, the loops are unrolled to kMaxLanes
+// and guarded (uniform branches), so one instantiation serves every batch size.
+template <typename T, int NCH, int PRO, int EPI>
+__global__ __launch_bounds__(256) void gemv_batch_kernel(BatchGemvArgs a) {
+    constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int TPW = kMaxLanes / 4;                          // tokens prepared per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* xs = reinterpret_cast<T*>(smem_raw);                     // [B][K], normalised / merged + rounded
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int K = a.K, B = a.B;
+    const T* W = reinterpret_cast<const T*>(a.W);
+    const int row = blockIdx.x * 4 + wave;
+    const int rowc = row < a.N ? row : a.N - 1;
+
+    // ---- 1. token loads: wave w prepares tokens w and w + 4 (clamped, unconditional) ----
+    Raw8<T> xraw[TPW][NCH], nraw[NCH];
+    if constexpr (PRO != PRO_COMBINE) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int off = j * 512 + lane * 8, offc = off < K ? off : 0;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int m = wave + 4 * t < B ? wave + 4 * t : B - 1;
+                ldraw<false>(xraw[t][j], reinterpret_cast<const T*>(a.x) + (size_t)m * a.x_stride + offc);
+            }
+            if constexpr (PRO == PRO_NORM) ldraw<false>(nraw[j], reinterpret_cast<const T*>(a.norm_w) + offc);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 2. this wave's weight row(s) ----
+    Raw8<T> raw[NR][NCH];
+#pragma unroll
+    for (int h = 0; h < NR; ++h) {
+        const T* wr = W + (size_t)(rowc + h * a.up_off) * K;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int off = j * 512 + lane * 8;
+            ldraw<false>(raw[h][j], wr + (off < K ? off : 0));
+        }
+    }
+    float resv[kMaxLanes];
+#pragma unroll
+    for (int m = 0; m < kMaxLanes; ++m) {
+        resv[m] = 0.f;
+        if constexpr (EPI == EPI_RESIDUAL) {
+            const int mc = m < B ? m : B - 1;
+            resv[m] = DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)mc * a.res_stride + rowc);
+        }
+    }
+    const T* bp = a.bias ? reinterpret_cast<const T*>(a.bias) + rowc : W;
+    const float bv = DT<T>::ld(bp);
+    const float biasv = a.bias ? bv : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 3. prepare the tokens while the weights fly; stage them in LDS ----
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int m = wave + 4 * t;
+        const int mc = m < B ? m : B - 1;
+        float xr[NCH][8];
+        if constexpr (PRO == PRO_COMBINE) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int off = j * 512 + lane * 8;
+                CombineRegs cr;
+                combine_load(cr, a.part + (size_t)mc * a.part_stride, off < K ? off : 0, a.rep, a.n_part);
+                combine_finish<T>(cr, a.n_part, xr[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                if (j * 512 + lane * 8 >= K) zero(xraw[t][j]);
+                unpack(xraw[t][j], xr[j]);
+            }
+            if constexpr (PRO == PRO_NORM) {
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
+                ss = wave_sum(ss);
+                const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    float nw[8];
+                    unpack(nraw[j], nw);
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) {
+                        float u = xr[j][i] * rs, v = xr[j][i + 1] * rs;
+                        DT<T>::rnd2(u, v);
+                        u *= nw[i]; v *= nw[i + 1];
+                        DT<T>::rnd2(u, v);
+                        xr[j][i] = u; xr[j][i + 1] = v;
+                    }
+                }
+            }
+        }
+        if (m < B) {
+            T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[m]) : nullptr;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int off = j * 512 + lane * 8;
+                if (off < K) {
+                    DT<T>::st8(xs + (size_t)m * K + off, xr[j]);
+                    if (xo) DT<T>::st8(xo + off, xr[j]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 4. walk the B tokens: same chunk order and fma chain as gemv_kernel's dot8 ----
+    float acc[kMaxLanes][NR];
+#pragma unroll
+    for (int m = 0; m < kMaxLanes; ++m) {
+#pragma unroll
+        for (int h = 0; h < NR; ++h) acc[m][h] = 0.f;
+        if (m < B) {
+            float xr[NCH][8];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int off = j * 512 + lane * 8;
+                Raw8<T> q;
+                ldraw<false>(q, xs + (size_t)m * K + (off < K ? off : 0));
+                if (off >= K) zero(q);
+                unpack(q, xr[j]);
+            }
+#pragma unroll
+            for (int h = 0; h < NR; ++h) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) s = dot8<T>(raw[h][j], xr[j], s);
+                acc[m][h] = s;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < kMaxLanes; ++m)
+#pragma unroll
+        for (int h = 0; h < NR; ++h) acc[m][h] = wave_sum(acc[m][h]);
+#pragma unroll
+    for (int m = 0; m < kMaxLanes; ++m) {
+        float v;
+        if constexpr (EPI == EPI_SWIGLU) {
+            const float g = DT<T>::rnd(acc[m][0]);
+            const float u = DT<T>::rnd(acc[m][NR - 1]);
+            const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
+            v = sg * u;
+        } else {
+            v = DT<T>::rnd(acc[m][0] + biasv);
+            if constexpr (EPI == EPI_RESIDUAL) v = v + resv[m];
+        }
+        if (lane == 0 && row < a.N && m < B) DT<T>::st(reinterpret_cast<T*>(a.y) + (size_t)m * a.y_stride + row, v);
+    }
+}
+
+}  // namespace fq3

@@ -283,7 +283,7 @@ struct AttnArgs {
 };
 
 template <typename T, int REP>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_decode_body(const AttnArgs& a) {
     constexpr int HD = kHeadDim, KS = kKeysPerTile, NG = KS / 16;
     const int g = blockIdx.x, s = blockIdx.y, S = gridDim.y;
     __shared__ float qs[REP][HD];
@@ -435,6 +435,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     }
 }
 
+template <typename T, int REP>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) { attn_decode_body<T, REP>(a); }
+
 // ================================================================================================
 // Code-predictor attention (context <= 17 keys): ONE wave per q head, everything in registers, no LDS, no
 // barrier, no partial slots -- the wave writes the final (normalised, T-rounded) head output, so the o_proj
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 // new key's norm + RoPE; the group's first head appends K/V to the cache.
 // ================================================================================================
 template <typename T>
-__global__ __launch_bounds__(64) void attn_pred_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_pred_body(const AttnArgs& a) {
     constexpr int HD = kHeadDim;
     const int head = blockIdx.x, g = head / a.rep, hh = head - g * a.rep;
     const int lane = threadIdx.x & 63, sub = lane >> 4, c = lane & 15;
@@ -545,6 +548,9 @@ __global__ __launch_bounds__(64) void attn_pred_kernel(AttnArgs a) {
     if (sub == 0) DT<T>::st8(reinterpret_cast<T*>(a.out) + (size_t)head * HD + c * 8, o);
 }
 
+template <typename T>
+__global__ __launch_bounds__(64) void attn_pred_kernel(AttnArgs a) { attn_pred_body<T>(a); }
+
 // ================================================================================================
 // Small glue kernels
 // ================================================================================================
@@ -586,13 +592,14 @@ struct DecodeState {
     float p_temperature; int p_top_k; float p_top_p; int p_do_sample;
     const void* trailing_text; const void* tts_pad; const void* talker_noise; const void* pred_noise;
     const void* past_hidden_init;
+    int n_pad, rope_delta;        // copies of the context's generation state for the batched frame (fq3_batch.hip)
 };
 
 // frame prologue: EOS / limit test, record first-codebook id, history bitmap, predictor input
 // [past_hidden ; embed(token)]  (generate.py:150-159)
 template <typename T>
-__global__ __launch_bounds__(256) void frame_begin_kernel(DecodeState* st, const T* codec_emb, const T* past_hidden,
-                                                          T* pred_in, int* codes, unsigned char* seen, int H, int G) {
+__device__ __forceinline__ void frame_begin_body(DecodeState* st, const T* codec_emb, const T* past_hidden,
+                                                 T* pred_in, int* codes, unsigned char* seen, int H, int G) {
     if (st->done) return;
     const int tok = st->token;
     if (tok == st->eos_id || st->frame >= st->max_new) {
@@ -606,15 +613,20 @@ __global__ __launch_bounds__(256) void frame_begin_kernel(DecodeState* st, const
         pred_in[H + e] = codec_emb[(size_t)tok * H + e];
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void frame_begin_kernel(DecodeState* st, const T* codec_emb, const T* past_hidden,
+                                                          T* pred_in, int* codes, unsigned char* seen, int H, int G) {
+    frame_begin_body<T>(st, codec_emb, past_hidden, pred_in, codes, seen, H, G);
+}
 
 // 16-way embedding sum + text/pad embed -> talker input (generate.py:162-171); position limit test
 // (generate.py:174-177) happens here, after the frame's codes have been recorded.
 struct EmbTables { const void* t[32]; };      // [0] = talker codec embedding, [1..G-1] = predictor tables
 
 template <typename T, int G>
-__global__ __launch_bounds__(256) void embed_sum_kernel(DecodeState* st, EmbTables tabs, const int* codes, T* x, int H,
-                                                        const float* cos_tab, const float* sin_tab, int rope_len,
-                                                        int rope_delta, float* rope_now) {
+__device__ __forceinline__ void embed_sum_body(DecodeState* st, const EmbTables& tabs, const int* codes, T* x, int H,
+                                               const float* cos_tab, const float* sin_tab, int rope_len,
+                                               int rope_delta, float* rope_now) {
     // one round trip for the state + this frame's 16 ids, one for the 16 embedding rows
     const int done = st->done, frame = st->frame, pos = st->pos, gen_step = st->gen_step;
     const int trailing_len = st->trailing_len, max_seq = st->max_seq;
@@ -655,6 +667,12 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(DecodeState* st, EmbTabl
 #pragma unroll
         for (int i = 0; i < 8; ++i) DT<T>::st(x + e0 + i, DT<T>::rnd(sum[i]) + f[i]);
     }
+}
+template <typename T, int G>
+__global__ __launch_bounds__(256) void embed_sum_kernel(DecodeState* st, EmbTables tabs, const int* codes, T* x, int H,
+                                                        const float* cos_tab, const float* sin_tab, int rope_len,
+                                                        int rope_delta, float* rope_now) {
+    embed_sum_body<T, G>(st, tabs, codes, x, H, cos_tab, sin_tab, rope_len, rope_delta, rope_now);
 }
 
 }  // namespace fq3

@@ -642,6 +642,7 @@ extern "C" int fq3_decode_begin(fq3_ctx* c, const fq3_decode_params* p, void* st
     h.min_new = p->min_new_tokens; h.max_new = p->max_new_tokens; h.trailing_len = p->trailing_len;
     h.noise_frames = p->noise_frames > 0 ? p->noise_frames : 1;
     h.eos_id = c->cfg.codec_eos_token_id; h.max_seq = c->cfg.max_seq_len;
+    h.n_pad = c->n_pad; h.rope_delta = c->rope_delta;
     h.sup_lo = c->cfg.talker.vocab - 1024 > 0 ? c->cfg.talker.vocab - 1024 : 0; h.sup_hi = c->cfg.talker.vocab;
     h.t_temperature = p->talker.temperature; h.t_top_k = p->talker.top_k; h.t_top_p = p->talker.top_p;
     h.t_do_sample = p->talker.do_sample; h.t_rep_penalty = p->talker.repetition_penalty;

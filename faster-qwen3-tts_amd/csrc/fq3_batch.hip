@@ -1,0 +1,292 @@
+// libfq3hip.so: batched decode -- B single-stream contexts ("lanes") advanced in lock-step by one launch chain.
+// See batch_kernels.cuh for the design; the C ABI is declared in include/fq3hip.h (fq3_batch_*).
+#include "fq3_ctx.h"
+#include "batch_kernels.cuh"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+using namespace fq3;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fq3_fail_(FQ3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct fq3_batch {
+    std::vector<fq3_ctx*> lanes;
+    int B = 0;
+    // activations, one row per lane
+    void *h = nullptr, *xin = nullptr, *qkv = nullptr, *act = nullptr, *attn_out = nullptr, *logits = nullptr;
+    void *pred_in = nullptr, *pred_x = nullptr, *pred_next = nullptr, *plogits = nullptr;
+    float *part = nullptr, *rope_now = nullptr;
+    size_t part_stride = 0;
+    int Hm = 0, Im = 0, qkvm = 0;
+    LaneTab tab{};
+    std::vector<LaneKV> tkv, pkv;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    std::vector<void*> allocs;
+};
+
+static int bmalloc(fq3_batch* b, void** p, size_t bytes) {
+    HIPCHK(hipMalloc(p, bytes));
+    HIPCHK(hipMemset(*p, 0, bytes));
+    b->allocs.push_back(*p);
+    return 0;
+}
+
+extern "C" int fq3_batch_graph_reset(fq3_batch* b) {
+    if (!b) return fq3_fail_(FQ3_EINVAL, "null batch");
+    if (b->exec) { (void)hipGraphExecDestroy(b->exec); b->exec = nullptr; }
+    if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
+    return FQ3_OK;
+}
+
+extern "C" int fq3_batch_destroy(fq3_batch* b) {
+    if (!b) return FQ3_OK;
+    (void)hipDeviceSynchronize();
+    fq3_batch_graph_reset(b);
+    if (b->cap_stream) (void)hipStreamDestroy(b->cap_stream);
+    for (void* p : b->allocs) (void)hipFree(p);
+    delete b;
+    return FQ3_OK;
+}
+
+extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out) {
+    if (!lanes || !out) return fq3_fail_(FQ3_EINVAL, "null argument");
+    if (n_lanes < 1 || n_lanes > kMaxLanes) return fq3_fail_(FQ3_EINVAL, "n_lanes must be 1..8");
+    for (int i = 0; i < n_lanes; ++i) {
+        if (!lanes[i] || !lanes[i]->bound) return fq3_fail_(FQ3_ESTATE, "every lane needs a context with bound weights");
+        for (int j = 0; j < i; ++j) if (lanes[i] == lanes[j]) return fq3_fail_(FQ3_EINVAL, "a context can fill only one lane");
+    }
+    const fq3_ctx* c0 = lanes[0];
+    for (int i = 1; i < n_lanes; ++i) {
+        const fq3_ctx* c = lanes[i];
+        const bool same_cfg = c->cfg.dtype == c0->cfg.dtype && c->cfg.num_code_groups == c0->cfg.num_code_groups &&
+            c->cfg.has_projection == c0->cfg.has_projection && c->cfg.codec_eos_token_id == c0->cfg.codec_eos_token_id &&
+            c->cfg.talker.hidden == c0->cfg.talker.hidden && c->cfg.talker.inter == c0->cfg.talker.inter &&
+            c->cfg.talker.n_layers == c0->cfg.talker.n_layers && c->cfg.talker.n_heads == c0->cfg.talker.n_heads &&
+            c->cfg.talker.n_kv_heads == c0->cfg.talker.n_kv_heads && c->cfg.talker.vocab == c0->cfg.talker.vocab &&
+            c->cfg.predictor.hidden == c0->cfg.predictor.hidden && c->cfg.predictor.inter == c0->cfg.predictor.inter &&
+            c->cfg.predictor.n_layers == c0->cfg.predictor.n_layers && c->cfg.predictor.vocab == c0->cfg.predictor.vocab &&
+            c->tk.max_seq == c0->tk.max_seq && c->tk.workers == c0->tk.workers;
+        // one weight replica: every lane must have been bound to the same table
+        const bool same_w = c->wt.codec_head == c0->wt.codec_head && c->wt.codec_embedding == c0->wt.codec_embedding &&
+            c->tl[0].qkv == c0->tl[0].qkv && c->pl[0].qkv == c0->pl[0].qkv && c->wt.talker_cos == c0->wt.talker_cos;
+        if (!same_cfg || !same_w) return fq3_fail_(FQ3_EINVAL, "lanes must share one config, one max_seq_len and one weight replica");
+    }
+    if (c0->cfg.num_code_groups != 16) return fq3_fail_(FQ3_EUNSUPPORTED, "the fused loop is built for 16 code groups");
+    fq3_batch* b = new fq3_batch();
+    b->lanes.assign(lanes, lanes + n_lanes);
+    b->B = n_lanes;
+    const fq3_stack_dims &t = c0->cfg.talker, &p = c0->cfg.predictor;
+    const int esz = c0->esz, G = c0->cfg.num_code_groups, B = n_lanes;
+    b->Hm = std::max(t.hidden, p.hidden); b->Im = std::max(t.inter, p.inter);
+    b->qkvm = std::max(t.n_heads + 2 * t.n_kv_heads, p.n_heads + 2 * p.n_kv_heads) * kHeadDim;
+    const int Vm = std::max(t.vocab, p.vocab);
+    int r;
+    auto A = [&](void** ptr, size_t n) { return bmalloc(b, ptr, n); };
+    if ((r = A(&b->h, (size_t)B * b->Hm * esz)) || (r = A(&b->xin, (size_t)B * b->Hm * esz)) ||
+        (r = A(&b->qkv, (size_t)B * b->qkvm * esz)) || (r = A(&b->act, (size_t)B * b->Im * esz)) ||
+        (r = A(&b->attn_out, (size_t)B * b->qkvm * esz)) || (r = A(&b->logits, (size_t)B * Vm * esz)) ||
+        (r = A(&b->pred_in, (size_t)B * 2 * t.hidden * esz)) || (r = A(&b->pred_x, (size_t)B * p.hidden * esz)) ||
+        (r = A(&b->pred_next, (size_t)B * t.hidden * esz)) || (r = A(&b->plogits, (size_t)B * (G - 1) * p.vocab * esz))) {
+        fq3_batch_destroy(b); return r;
+    }
+    b->part_stride = (size_t)std::max(t.n_kv_heads, p.n_kv_heads) * kMaxWorkers * 4 * kPartStride;
+    if ((r = A((void**)&b->part, (size_t)B * b->part_stride * sizeof(float))) ||
+        (r = A((void**)&b->rope_now, (size_t)B * kHeadDim * sizeof(float)))) { fq3_batch_destroy(b); return r; }
+    for (int l = 0; l < B; ++l) {
+        fq3_ctx* c = lanes[l];
+        b->tab.st[l] = c->st; b->tab.codes[l] = c->codes; b->tab.seen[l] = c->seen; b->tab.past_hidden[l] = c->past_hidden;
+    }
+    b->tkv.resize(t.n_layers); b->pkv.resize(p.n_layers);
+    for (int i = 0; i < t.n_layers; ++i) for (int l = 0; l < B; ++l) { b->tkv[i].k[l] = lanes[l]->tk.k[i]; b->tkv[i].v[l] = lanes[l]->tk.v[i]; }
+    for (int i = 0; i < p.n_layers; ++i) for (int l = 0; l < B; ++l) { b->pkv[i].k[l] = lanes[l]->pk.k[i]; b->pkv[i].v[l] = lanes[l]->pk.v[i]; }
+    if (hipStreamCreateWithFlags(&b->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+        fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "hipStreamCreateWithFlags");
+    }
+    *out = b;
+    return FQ3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int PRO, int EPI>
+static int launch_gemv_batch_t(const BatchGemvArgs& a, int esz, hipStream_t s) {
+    const int need = (a.K + 511) / 512;
+    const int grid = (a.N + 3) / 4;
+    const size_t shm = (size_t)a.B * a.K * esz;
+    auto go = [&](auto nch) -> int {
+        constexpr int NCH = decltype(nch)::value;
+        auto kern = gemv_batch_kernel<T, NCH, PRO, EPI>;
+        if (shm > 48 * 1024) {
+            if (shm > 150 * 1024) return fq3_fail_(FQ3_EUNSUPPORTED, "batch x inner dimension does not fit the 160 KB LDS");
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, a);
+        return 0;
+    };
+    if (need <= 1) return go(std::integral_constant<int, 1>{});
+    if (need <= 2) return go(std::integral_constant<int, 2>{});
+    if (need <= 4) return go(std::integral_constant<int, 4>{});
+    if constexpr (PRO != PRO_COMBINE) {          // the split-KV merge prologue is built for q_dim <= 2048 (16 heads)
+        if (need <= 6) return go(std::integral_constant<int, 6>{});
+        if (need <= 12) return go(std::integral_constant<int, 12>{});
+    }
+    return fq3_fail_(FQ3_EUNSUPPORTED, "GEMV inner dimension above 6144 (2048 for the attention merge)");
+}
+template <int PRO, int EPI>
+static int launch_gemv_batch(const fq3_ctx* c, const BatchGemvArgs& a, hipStream_t s) {
+    return c->cfg.dtype == FQ3_BF16 ? launch_gemv_batch_t<bf16_t, PRO, EPI>(a, 2, s) : launch_gemv_batch_t<float, PRO, EPI>(a, 4, s);
+}
+
+struct BatchSrc { const void* x0; int x0_stride; int pos_imm; bool talker; bool kv_only_tail; };
+
+template <typename T>
+static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
+    fq3_ctx* c = b->lanes[0];
+    const bool talker = src.talker;
+    const fq3_stack_dims& d = talker ? c->cfg.talker : c->cfg.predictor;
+    const std::vector<fq3_layer_weights>& L = talker ? c->tl : c->pl;
+    const int rep = d.n_heads / d.n_kv_heads, B = b->B;
+    const int q_dim = d.n_heads * kHeadDim, kv_dim = d.n_kv_heads * kHeadDim;
+    for (int i = 0; i < d.n_layers; ++i) {
+        const fq3_layer_weights& w = L[i];
+        const void* xin = i == 0 ? src.x0 : b->h;
+        const int xin_stride = i == 0 ? src.x0_stride : b->Hm;
+        BatchGemvArgs g{};
+        g.B = B; g.eps = d.rms_eps; g.W = w.qkv; g.N = q_dim + 2 * kv_dim; g.K = d.hidden; g.x = xin; g.x_stride = xin_stride;
+        g.norm_w = w.input_norm; g.y = b->qkv; g.y_stride = b->qkvm;
+        if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, g, s)) return r;
+        const bool tail_skip = src.kv_only_tail && i == d.n_layers - 1;
+        AttnArgs a{};
+        a.qkv = b->qkv; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm; a.eps = d.rms_eps;
+        a.n_kv = d.n_kv_heads; a.scale = 1.0f / sqrtf((float)kHeadDim); a.rep = rep;
+        BatchGemvArgs o{};
+        o.B = B; o.W = w.o; o.N = d.hidden; o.K = q_dim; o.y = b->h; o.y_stride = b->Hm; o.res = xin; o.res_stride = xin_stride; o.rep = rep;
+        if (talker) {
+            a.max_seq = c->tk.max_seq; a.part = b->part;
+            const dim3 grid(d.n_kv_heads, c->tk.workers, B);
+            if (rep == 1) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 1>), grid, dim3(256), 0, s, a, b->tkv[i], b->tab, b->qkvm, b->rope_now, b->part_stride);
+            else if (rep == 2) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 2>), grid, dim3(256), 0, s, a, b->tkv[i], b->tab, b->qkvm, b->rope_now, b->part_stride);
+            else hipLaunchKernelGGL((attn_decode_batch_kernel<T, 4>), grid, dim3(256), 0, s, a, b->tkv[i], b->tab, b->qkvm, b->rope_now, b->part_stride);
+            o.part = b->part; o.part_stride = b->part_stride; o.n_part = c->tk.workers;
+            if (int r = launch_gemv_batch<PRO_COMBINE, EPI_RESIDUAL>(c, o, s)) return r;
+        } else {
+            int rp = src.pos_imm; const int rl = c->wt.pred_rope_len;
+            rp = rp < 0 ? 0 : (rp >= rl ? rl - 1 : rp);
+            a.cos_row = c->wt.pred_cos + (size_t)rp * 64; a.sin_row = c->wt.pred_sin + (size_t)rp * 64;
+            a.max_seq = c->pk.max_seq; a.pos_ptr = nullptr; a.pos_imm = src.pos_imm; a.n_pad = 0; a.out = b->attn_out;
+            hipLaunchKernelGGL((attn_pred_batch_kernel<T>), dim3(d.n_heads, B), dim3(64), 0, s, a, b->pkv[i], b->qkvm, b->qkvm);
+            if (tail_skip) break;
+            o.x = b->attn_out; o.x_stride = b->qkvm;
+            if (int r = launch_gemv_batch<PRO_PLAIN, EPI_RESIDUAL>(c, o, s)) return r;
+        }
+        BatchGemvArgs m{};
+        m.B = B; m.eps = d.rms_eps; m.W = w.gate_up; m.N = d.inter; m.K = d.hidden; m.x = b->h; m.x_stride = b->Hm;
+        m.norm_w = w.post_norm; m.y = b->act; m.y_stride = b->Im; m.up_off = d.inter;
+        if (int r = launch_gemv_batch<PRO_NORM, EPI_SWIGLU>(c, m, s)) return r;
+        BatchGemvArgs dn{};
+        dn.B = B; dn.W = w.down; dn.N = d.hidden; dn.K = d.inter; dn.x = b->act; dn.x_stride = b->Im; dn.y = b->h; dn.y_stride = b->Hm;
+        dn.res = b->h; dn.res_stride = b->Hm;
+        if (int r = launch_gemv_batch<PRO_PLAIN, EPI_RESIDUAL>(c, dn, s)) return r;
+    }
+    return 0;
+}
+
+template <typename T>
+static int enqueue_batch_frame_t(fq3_batch* b, hipStream_t s) {
+    fq3_ctx* c = b->lanes[0];
+    const fq3_stack_dims &t = c->cfg.talker, &p = c->cfg.predictor;
+    const int G = c->cfg.num_code_groups, H = t.hidden, Vp = p.vocab, B = b->B;
+    hipLaunchKernelGGL((frame_begin_batch_kernel<T>), dim3(B), dim3(256), 0, s, b->tab, (const T*)c->wt.codec_embedding,
+                       (T*)b->pred_in, H, G);
+    // predictor: token A (past_hidden, slot 0), token B (embed(tok0), slot 1), then 14 single-token passes
+    for (int pass = 0; pass < G; ++pass) {
+        const void* x_talker = pass < 2 ? (const void*)((const T*)b->pred_in + (size_t)pass * H) : (const void*)b->pred_next;
+        const int x_stride = pass < 2 ? 2 * H : H;
+        const void* x0 = x_talker; int x0_stride = x_stride;
+        if (c->cfg.has_projection) {                      // small_to_mtp_projection (predictor_graph.py:118,145)
+            BatchGemvArgs g{};
+            g.B = B; g.W = c->wt.proj_w; g.bias = c->wt.proj_b; g.N = p.hidden; g.K = H; g.x = x_talker; g.x_stride = x_stride;
+            g.y = b->pred_x; g.y_stride = p.hidden;
+            if (int r = launch_gemv_batch<PRO_PLAIN, EPI_STORE>(c, g, s)) return r;
+            x0 = b->pred_x; x0_stride = p.hidden;
+        }
+        BatchSrc src{x0, x0_stride, pass, false, pass == 0};
+        if (int r = run_stack_batch<T>(b, src, s)) return r;
+        if (pass == 0) continue;
+        const int cb = pass - 1;
+        T* lg = (T*)b->plogits + (size_t)cb * Vp;
+        const size_t lstride = (size_t)(G - 1) * Vp;
+        BatchGemvArgs hg{};
+        hg.B = B; hg.eps = p.rms_eps; hg.W = c->lmh[cb]; hg.N = Vp; hg.K = p.hidden; hg.x = b->h; hg.x_stride = b->Hm;
+        hg.norm_w = c->wt.predictor_final_norm; hg.y = lg; hg.y_stride = (int)lstride;
+        if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, hg, s)) return r;
+        const T* next_emb = cb + 1 < G - 1 ? (const T*)c->pemb[cb] : nullptr;
+        if (Vp <= 2048) hipLaunchKernelGGL((sample_pred_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, b->tab, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);
+        else hipLaunchKernelGGL((sample_pred_batch_kernel<T, 2>), dim3(B), dim3(256), 0, s, b->tab, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);
+    }
+    EmbTables tabs{};
+    tabs.t[0] = c->wt.codec_embedding;
+    for (int i = 1; i < G; ++i) tabs.t[i] = c->pemb[i - 1];
+    hipLaunchKernelGGL((embed_sum_batch_kernel<T, 16>), dim3(B), dim3(256), 0, s, b->tab, tabs, (T*)b->xin, H, c->wt.talker_cos,
+                       c->wt.talker_sin, c->wt.talker_rope_len, b->rope_now);
+    BatchSrc src{b->xin, H, 0, true, false};
+    if (int r = run_stack_batch<T>(b, src, s)) return r;
+    BatchGemvArgs g{};
+    g.B = B; g.eps = t.rms_eps; g.W = c->wt.codec_head; g.N = t.vocab; g.K = H; g.x = b->h; g.x_stride = b->Hm;
+    g.norm_w = c->wt.talker_final_norm; g.y = b->logits; g.y_stride = t.vocab;
+    for (int l = 0; l < B; ++l) g.xn_out[l] = b->tab.past_hidden[l];
+    if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, g, s)) return r;
+    if (t.vocab <= 2048) hipLaunchKernelGGL((sample_talker_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, b->tab, (const T*)b->logits, t.vocab);
+    else hipLaunchKernelGGL((sample_talker_batch_kernel<T, 2>), dim3(B), dim3(256), 0, s, b->tab, (const T*)b->logits, t.vocab);
+    return 0;
+}
+
+static int check_lanes(fq3_batch* b) {
+    for (fq3_ctx* c : b->lanes) {
+        if (!c->talker_wave || c->pred_sampling.top_p < 1.0f)
+            return fq3_fail_(FQ3_EUNSUPPORTED, "batched decode supports top_p >= 1.0 only (register-resident sampler)");
+        if (c->tk.max_seq > 0 && (c->cfg.talker.n_heads * kHeadDim > 2048))
+            return fq3_fail_(FQ3_EUNSUPPORTED, "q_dim above 2048");
+    }
+    return 0;
+}
+static int enqueue_batch_frame(fq3_batch* b, hipStream_t s) {
+    return b->lanes[0]->cfg.dtype == FQ3_BF16 ? enqueue_batch_frame_t<bf16_t>(b, s) : enqueue_batch_frame_t<float>(b, s);
+}
+
+extern "C" int fq3_batch_graph_capture(fq3_batch* b, void* stream) {
+    if (!b) return fq3_fail_(FQ3_EINVAL, "null batch");
+    if (b->exec) return FQ3_OK;
+    (void)stream;
+    if (int r = check_lanes(b)) return r;
+    hipStream_t cs = b->cap_stream;
+    HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+    int r = enqueue_batch_frame(b, cs);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(cs, &g);
+    if (r) { if (g) (void)hipGraphDestroy(g); return r; }
+    if (e != hipSuccess) return fq3_fail_(FQ3_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    b->graph = g;
+    HIPCHK(hipGraphInstantiate(&b->exec, b->graph, nullptr, nullptr, 0));
+    return FQ3_OK;
+}
+
+extern "C" int fq3_batch_frames(fq3_batch* b, int n_frames, void* stream) {
+    if (!b) return fq3_fail_(FQ3_EINVAL, "null batch");
+    if (int r = check_lanes(b)) return r;
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < n_frames; ++i) {
+        if (b->exec) { HIPCHK(hipGraphLaunch(b->exec, s)); }
+        else if (int r = enqueue_batch_frame(b, s)) return r;
+    }
+    HIPCHK(hipGetLastError());
+    return FQ3_OK;
+}
+
+extern "C" int fq3_batch_size(const fq3_batch* b) { return b ? b->B : 0; }

@@ -168,9 +168,9 @@ __global__ __launch_bounds__(256) void sample_api_wave_kernel(const T* logits, i
 }
 
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void sample_pred_wave_kernel(const DecodeState* st, const T* logits, int V, int cb,
-                                                              SampleCfg c_imm, const T* noise_imm, int* codes, int G,
-                                                              int64_t* out64, const T* next_emb, T* next_in, int H) {
+__device__ __forceinline__ void sample_pred_wave_body(const DecodeState* st, const T* logits, int V, int cb,
+                                                      const SampleCfg& c_imm, const T* noise_imm, int* codes, int G,
+                                                      int64_t* out64, const T* next_emb, T* next_in, int H) {
     __shared__ BlkSmem sm;
     Raw8<T> xraw[NC];
     issue_logits<T, NC>(xraw, logits, V);
@@ -202,8 +202,14 @@ __global__ __launch_bounds__(256) void sample_pred_wave_kernel(const DecodeState
 }
 
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void sample_talker_wave_kernel(DecodeState* st, const T* logits, int V,
-                                                                const unsigned char* seen) {
+__global__ __launch_bounds__(256) void sample_pred_wave_kernel(const DecodeState* st, const T* logits, int V, int cb,
+                                                              SampleCfg c_imm, const T* noise_imm, int* codes, int G,
+                                                              int64_t* out64, const T* next_emb, T* next_in, int H) {
+    sample_pred_wave_body<T, NC>(st, logits, V, cb, c_imm, noise_imm, codes, G, out64, next_emb, next_in, H);
+}
+
+template <typename T, int NC>
+__device__ __forceinline__ void sample_talker_wave_body(DecodeState* st, const T* logits, int V, const unsigned char* seen) {
     __shared__ BlkSmem sm;
     Raw8<T> xraw[NC];
     issue_logits<T, NC>(xraw, logits, V);
@@ -218,6 +224,11 @@ __global__ __launch_bounds__(256) void sample_talker_wave_kernel(DecodeState* st
         ? reinterpret_cast<const T*>(st->talker_noise) + (size_t)(frame % st->noise_frames) * V : nullptr;
     const int tok = sample_wave_core<T, NC>(xraw, V, c, seen, noise, sm);
     if (threadIdx.x == 0) { st->token = tok; st->frame = frame + 1; st->pos += 1; st->gen_step += 1; }
+}
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void sample_talker_wave_kernel(DecodeState* st, const T* logits, int V,
+                                                                const unsigned char* seen) {
+    sample_talker_wave_body<T, NC>(st, logits, V, seen);
 }
 
 }  // namespace fq3

@@ -89,6 +89,12 @@ SIGNATURES = {
     "fq3_decode_codes": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "fq3_graph_capture": (C.c_int, [vp, vp]),
     "fq3_graph_reset": (C.c_int, [vp]),
+    "fq3_batch_create": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp)]),
+    "fq3_batch_destroy": (C.c_int, [vp]),
+    "fq3_batch_size": (C.c_int, [vp]),
+    "fq3_batch_frames": (C.c_int, [vp, C.c_int, vp]),
+    "fq3_batch_graph_capture": (C.c_int, [vp, vp]),
+    "fq3_batch_graph_reset": (C.c_int, [vp]),
     "fq3_codec_create": (C.c_int, [C.POINTER(CodecConfig), C.POINTER(vp)]),
     "fq3_codec_destroy": (C.c_int, [vp]),
     "fq3_codec_bind": (C.c_int, [vp, C.c_char_p, vp, C.c_int64]),

@@ -303,3 +303,53 @@ class Fq3Engine:
             self.close()
         except Exception:
             pass
+
+
+class Fq3Batch:
+    """B decode contexts ("lanes") advanced in lock-step by ONE launch chain and ONE pass over the weights per frame
+    (``fq3_batch_*``; no reference equivalent -- the reference fixes batch = 1, talker_graph.py:46).
+
+    Every lane is an ordinary :class:`Fq3Engine` sharing the first lane's weights (``share=``): prefill, generation
+    state and ``decode_begin`` happen per lane, ``frames(n)`` advances all lanes, ``decode_poll`` / ``decode_codes`` are
+    read per lane.  A finished (or never begun) lane idles on device and can be re-armed with ``decode_begin`` at any
+    frame boundary.  A lane's ids are bit-identical to the same utterance decoded alone with the same noise."""
+
+    def __init__(self, lanes):
+        lanes = list(lanes)
+        if not 1 <= len(lanes) <= 8:
+            raise ValueError("a batch holds 1..8 lanes")
+        self.lanes = lanes
+        self.lib = lanes[0].lib
+        self.device = lanes[0].device
+        arr = (L.vp * len(lanes))(*[e.ctx.value for e in lanes])
+        self.handle = L.vp()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.fq3_batch_create(arr, len(lanes), C.byref(self.handle)))
+
+    def __len__(self):
+        return len(self.lanes)
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def frames(self, n: int):
+        L.check(self.lib.fq3_batch_frames(self.handle, int(n), self._stream()))
+
+    def graph_capture(self):
+        with _CAPTURE_LOCK:
+            L.check(self.lib.fq3_batch_graph_capture(self.handle, self._stream()))
+
+    def graph_reset(self):
+        L.check(self.lib.fq3_batch_graph_reset(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self.lib.fq3_batch_destroy(self.handle)
+            self.handle = L.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+

@@ -182,6 +182,23 @@ int fq3_decode_codes(fq3_ctx* ctx, int from, int count, int64_t* out_codes_dev, 
 int fq3_graph_capture(fq3_ctx* ctx, void* stream);
 int fq3_graph_reset(fq3_ctx* ctx);
 
+/* ---- batched decode: B utterances in lock-step over one weight stream ------------------------------
+ * No reference equivalent (the reference fixes batch = 1: talker_graph.py:46, predictor_graph.py:70; SURVEY.md
+ * section 8f rank 3).  A batch borrows n_lanes (1..8) ordinary contexts that share ONE weight table, ONE config and
+ * ONE max_seq_len.  Each lane is prepared with the single-stream entry points (fq3_prefill, fq3_set_generation_state,
+ * fq3_decode_begin) and read back with fq3_decode_poll / fq3_decode_codes on ITS context; fq3_batch_frames replaces
+ * fq3_decode_frames for all lanes at once.  Lanes that are done (EOS, limits, or never begun) idle on device and can be
+ * re-armed with fq3_decode_begin between calls (continuous batching).  Sampling with top_p >= 1.0 only.  A lane's ids
+ * are bit-identical to the same utterance decoded alone with the same noise. */
+typedef struct fq3_batch fq3_batch;
+int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out);
+int fq3_batch_destroy(fq3_batch* b);
+int fq3_batch_size(const fq3_batch* b);
+/* Enqueue n_frames lock-step iterations (hipGraph replays once fq3_batch_graph_capture() has run). */
+int fq3_batch_frames(fq3_batch* b, int n_frames, void* stream);
+int fq3_batch_graph_capture(fq3_batch* b, void* stream);
+int fq3_batch_graph_reset(fq3_batch* b);
+
 /* ---- 12 Hz codec decoder (speech_tokenizer.decode, model.py:924) ---------------------------- */
 typedef struct fq3_codec fq3_codec;
 typedef struct fq3_codec_config {

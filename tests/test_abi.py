@@ -53,6 +53,15 @@ def test_null_arguments_are_errors_not_crashes(lib):
     assert lib.fq3_codec_create(None, None) == -1
     lib.fq3_codec_num_samples.restype = ctypes.c_int64
     assert lib.fq3_codec_num_samples(None, 10) == -1
+    # batched decode: lane validation precedes every device call
+    h = ctypes.c_void_p()
+    lanes = (ctypes.c_void_p * 2)(None, None)
+    lib.fq3_batch_create.restype = ctypes.c_int
+    assert lib.fq3_batch_create(None, 2, ctypes.byref(h)) == -1
+    assert lib.fq3_batch_create(lanes, 9, ctypes.byref(h)) == -1
+    assert lib.fq3_batch_create(lanes, 2, ctypes.byref(h)) == -3          # FQ3_ESTATE: lanes without bound weights
+    assert lib.fq3_batch_frames(None, 1, None) == -1 and lib.fq3_batch_graph_capture(None, None) == -1
+    assert lib.fq3_batch_size(None) == 0 and lib.fq3_batch_destroy(None) == 0
 
 
 def test_struct_layout_matches_header_sizes():

@@ -1,0 +1,135 @@
+"""GPU: batched decode (fq3_batch_*): B lanes in lock-step over one weight stream must produce, for every lane, exactly
+the ids the same utterance produces when decoded alone (same prompt, same policy, same Exp(1) noise) -- fp32 and bf16,
+direct launches and hipGraph replay, sampled and greedy, lanes of different prompt length / pad / budget, a lane that
+finishes early, a lane that is re-armed at a frame boundary (continuous batching), a lane that is never begun."""
+import os
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fq3hip.config import tiny_test_config
+from fq3hip.weights import synth_weights, synth_prompt
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _engines(cfg, W, dtype, n, max_seq=96, max_frames=64):
+    from fq3hip.engine import Fq3Engine
+    first = Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=max_seq, max_frames=max_frames)
+    return [first] + [Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=max_seq, max_frames=max_frames, share=first)
+                      for _ in range(n - 1)]
+
+
+def _utterance(cfg, dtype, seed, plen, n_pad, max_new, min_new, sample):
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, plen, 4, 0, dtype=dtype, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    V, Vp, G = cfg.talker.vocab_size, cfg.predictor.vocab_size, cfg.num_code_groups
+    nf = 16
+    return dict(tie=(tie * 30).to(dtype), n_pad=n_pad, tth=tth, tpe=tpe, max_new=max_new, min_new=min_new, sample=sample,
+                first_noise=torch.empty(V).exponential_(1, generator=g).to(dtype).cuda(),
+                tn=torch.empty(nf, V).exponential_(1, generator=g).to(dtype).cuda(),
+                pn=torch.empty(nf, G - 1, Vp).exponential_(1, generator=g).to(dtype).cuda(), nf=nf)
+
+
+def _arm(eng, cfg, u):
+    """prefill + first token + decode_begin on one lane (single-stream entry points)."""
+    kw = (dict(temperature=0.9, top_k=20, top_p=1.0, do_sample=True) if u["sample"]
+          else dict(temperature=1.0, top_k=0, top_p=1.0, do_sample=False))
+    eng.set_predictor_sampling(do_sample=u["sample"], top_k=20 if u["sample"] else 0, top_p=1.0,
+                               temperature=0.9 if u["sample"] else 1.0)
+    x = u["tie"][0].cuda().contiguous()
+    eng.set_generation_state(u["n_pad"], -u["n_pad"])
+    logits, hidden = eng.prefill(x, n_pad=u["n_pad"])
+    V = cfg.talker.vocab_size
+    tok = eng.sample(logits, sup_lo=max(0, V - 1024), sup_hi=V, keep_id=cfg.codec_eos_token_id, suppress_eos=u["min_new"] > 0,
+                     noise=u["first_noise"] if u["sample"] else None, **kw)
+    eng.decode_begin(first_token=int(tok), prefill_len=x.shape[0], gen_step=0, past_hidden=hidden,
+                     trailing_text=u["tth"][0].cuda().contiguous(), tts_pad_embed=u["tpe"].view(-1).cuda().contiguous(),
+                     repetition_penalty=1.05 if u["sample"] else 1.0, min_new_tokens=u["min_new"], max_new_tokens=u["max_new"],
+                     talker_noise=u["tn"] if u["sample"] else None, pred_noise=u["pn"] if u["sample"] else None,
+                     noise_frames=u["nf"] if u["sample"] else 0, **kw)
+
+
+def _alone(eng, cfg, u, frames):
+    _arm(eng, cfg, u)
+    eng.graph_reset()
+    eng.decode_frames(frames)
+    n, done = eng.decode_poll()
+    return eng.decode_codes(0, n).cpu(), done
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_lanes_equal_single_stream(dtype, graph):
+    from fq3hip.engine import Fq3Batch
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, dtype)
+    utts = [_utterance(cfg, dtype, 11, 20, 0, 14, 14, True), _utterance(cfg, dtype, 12, 33, 4, 9, 9, True),
+            _utterance(cfg, dtype, 13, 70, 0, 14, 2, False)]         # lane 1 stops at its budget; lane 2 has > 64 keys
+    solo = _engines(cfg, W, dtype, 1)[0]
+    ref = [_alone(solo, cfg, u, 16) for u in utts]
+    lanes = _engines(cfg, W, dtype, 4)                                # 4th lane is never begun
+    batch = Fq3Batch(lanes)
+    for e, u in zip(lanes, utts):
+        _arm(e, cfg, u)
+    if graph:
+        batch.graph_capture()
+    batch.frames(16)
+    for i, (e, (codes, done)) in enumerate(zip(lanes, ref)):
+        n, d = e.decode_poll()
+        assert n == codes.shape[0] and d == done, f"lane {i}: {n} frames (done={d}) vs {codes.shape[0]} alone (done={done})"
+        assert torch.equal(e.decode_codes(0, n).cpu(), codes), f"lane {i} ids differ from the single-stream run"
+    n, d = lanes[3].decode_poll()
+    assert n == 0 and d
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_continuous_batching_rearm_a_lane(dtype):
+    """Lane 0 finishes early, is re-armed with a new utterance while lane 1 keeps going; both match single-stream runs."""
+    from fq3hip.engine import Fq3Batch
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, dtype)
+    u_short, u_long, u_new = (_utterance(cfg, dtype, 21, 18, 0, 5, 5, True), _utterance(cfg, dtype, 22, 26, 0, 20, 20, True),
+                              _utterance(cfg, dtype, 23, 22, 3, 10, 10, True))
+    solo = _engines(cfg, W, dtype, 1)[0]
+    ref_short, ref_long, ref_new = (_alone(solo, cfg, u_short, 8)[0], _alone(solo, cfg, u_long, 24)[0], _alone(solo, cfg, u_new, 16)[0])
+    lanes = _engines(cfg, W, dtype, 2)
+    batch = Fq3Batch(lanes)
+    _arm(lanes[0], cfg, u_short); _arm(lanes[1], cfg, u_long)
+    batch.graph_capture()
+    batch.frames(8)
+    n0, d0 = lanes[0].decode_poll()
+    assert d0 and torch.equal(lanes[0].decode_codes(0, n0).cpu(), ref_short)
+    _arm(lanes[0], cfg, u_new)                                        # same graph, new utterance in lane 0
+    batch.frames(16)
+    n0, _ = lanes[0].decode_poll(); n1, _ = lanes[1].decode_poll()
+    assert torch.equal(lanes[0].decode_codes(0, n0).cpu(), ref_new)
+    assert torch.equal(lanes[1].decode_codes(0, n1).cpu(), ref_long)
+
+
+def test_batch_validation_and_throughput_note():
+    from fq3hip.engine import Fq3Batch, Fq3Engine
+    from fq3hip._lib import Fq3Error
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, torch.bfloat16)
+    a = _engines(cfg, W, torch.bfloat16, 2)
+    other = Fq3Engine(cfg, W, device="cuda", dtype=torch.bfloat16, max_seq_len=96, max_frames=64)      # its own weight replica
+    with pytest.raises(Fq3Error):
+        Fq3Batch([a[0], other])
+    with pytest.raises(Fq3Error):
+        Fq3Batch([a[0], a[0]])
+    with pytest.raises(ValueError):
+        Fq3Batch([])
+    # timing note (not an assertion): lock-step frames for 1 vs 2 lanes on the tiny model, written for the record
+    b = Fq3Batch(a)
+    for e, seed in zip(a, (31, 32)):
+        _arm(e, cfg, _utterance(cfg, torch.bfloat16, seed, 20, 0, 60, 60, True))
+    b.graph_capture(); b.frames(4); torch.cuda.synchronize()
+    t0 = time.perf_counter(); b.frames(40); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "batch_tiny_timing.txt"), "w") as f:
+        f.write(f"tiny model, 2 lanes, hipGraph: {1e3 * dt / 40:.3f} ms per lock-step frame\n")
