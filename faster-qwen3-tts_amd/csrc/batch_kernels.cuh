@@ -245,4 +245,169 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(BatchGemvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same M = B GEMV on the matrix cores (bf16 only; FQ3_BATCH_MFMA=1).  One workgroup = one tile of 16 weight rows
+// (x NR for SwiGLU); the 4 waves split K; v_mfma_f32_16x16x32_bf16 with A = weights (lane: row = lane & 15, k group =
+// lane >> 4: a 16-byte global load per lane IS the operand layout, no LDS hop), B = the prepared tokens from LDS
+// (lane: token = lane & 15, same k group), C[row = (lane >> 4) * 4 + reg][token]; layouts as in conv_gemm_kernel.
+// The fp32 accumulation order differs from the VALU kernels (<= ~1e-4 relative), so lanes are no longer bit-identical
+// to single-stream decoding: parity for this path is against the oracle with the bf16 tolerances.
+// Measured in the harness (profiles/r01_batch_gemv_prototype.txt): B=8 4.46 us per launch vs 7.30 us for the VALU kernel.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int KSTEPS, int PRO, int EPI>           // K = KSTEPS * 128
+__global__ __launch_bounds__(256) void gemv_batch_mfma_kernel(BatchGemvArgs a) {
+    typedef bf16_t T;
+    constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int K = KSTEPS * 128, KP = K + 8;                 // padded LDS row: 16 tokens x same k would share a bank
+    constexpr int NCH = (K + 511) / 512;
+    constexpr int TPW = kMaxLanes / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* xs = reinterpret_cast<T*>(smem_raw);                     // [B][KP]
+    float* red = reinterpret_cast<float*>(smem_raw + (((size_t)kMaxLanes * KP * sizeof(T) + 15) & ~(size_t)15));   // [4][NR][64][4]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int fr = lane & 15, fq = lane >> 4, B = a.B;
+    const T* W = reinterpret_cast<const T*>(a.W);
+    const int row0 = blockIdx.x * 16;
+
+    // ---- 1. token loads ----
+    Raw8<T> xraw[TPW][NCH], nraw[NCH];
+    if constexpr (PRO != PRO_COMBINE) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int off = j * 512 + lane * 8, offc = off < K ? off : 0;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int m = wave + 4 * t < B ? wave + 4 * t : B - 1;
+                ldraw<false>(xraw[t][j], reinterpret_cast<const T*>(a.x) + (size_t)m * a.x_stride + offc);
+            }
+            if constexpr (PRO == PRO_NORM) ldraw<false>(nraw[j], reinterpret_cast<const T*>(a.norm_w) + offc);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 2. this wave's K quarter of the 16 (x NR) weight rows, in A-operand layout ----
+    Raw8<T> wreg[NR][KSTEPS];
+    const int rowc = row0 + fr < a.N ? row0 + fr : a.N - 1;
+#pragma unroll
+    for (int h = 0; h < NR; ++h)
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+            ldraw<false>(wreg[h][s], W + (size_t)(rowc + h * a.up_off) * K + wave * (K / 4) + s * 32 + fq * 8);
+    // epilogue operands of wave 0: token = fr, rows row0 + fq * 4 + i
+    float resv[4], biasv[4];
+    {
+        const int tok = fr < B ? fr : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = row0 + fq * 4 + i < a.N ? row0 + fq * 4 + i : a.N - 1;
+            resv[i] = 0.f;
+            if constexpr (EPI == EPI_RESIDUAL) resv[i] = DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)tok * a.res_stride + r);
+            const T* bp = a.bias ? reinterpret_cast<const T*>(a.bias) + r : W;
+            const float bv = DT<T>::ld(bp);
+            biasv[i] = a.bias ? bv : 0.f;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 3. prepare tokens while the weights fly ----
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int m = wave + 4 * t;
+        const int mc = m < B ? m : B - 1;
+        float xr[NCH][8];
+        if constexpr (PRO == PRO_COMBINE) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int off = j * 512 + lane * 8;
+                CombineRegs cr;
+                combine_load(cr, a.part + (size_t)mc * a.part_stride, off < K ? off : 0, a.rep, a.n_part);
+                combine_finish<T>(cr, a.n_part, xr[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                if (j * 512 + lane * 8 >= K) zero(xraw[t][j]);
+                unpack(xraw[t][j], xr[j]);
+            }
+            if constexpr (PRO == PRO_NORM) {
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
+                ss = wave_sum(ss);
+                const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    float nw[8];
+                    unpack(nraw[j], nw);
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) {
+                        float u = xr[j][i] * rs, v = xr[j][i + 1] * rs;
+                        DT<T>::rnd2(u, v);
+                        u *= nw[i]; v *= nw[i + 1];
+                        DT<T>::rnd2(u, v);
+                        xr[j][i] = u; xr[j][i + 1] = v;
+                    }
+                }
+            }
+        }
+        if (m < B) {
+            T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[m]) : nullptr;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int off = j * 512 + lane * 8;
+                if (off < K) {
+                    DT<T>::st8(xs + (size_t)m * KP + off, xr[j]);
+                    if (xo) DT<T>::st8(xo + off, xr[j]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 4. MFMA over this wave's K quarter ----
+    f32x4 acc[NR];
+#pragma unroll
+    for (int h = 0; h < NR; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tokc = fr < B ? fr : 0;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        u32x4 bq = *reinterpret_cast<const u32x4*>(xs + (size_t)tokc * KP + wave * (K / 4) + s * 32 + fq * 8);
+        if (fr >= B) bq = u32x4{0u, 0u, 0u, 0u};
+        const mfma_bf16x8 bfrag = __builtin_bit_cast(mfma_bf16x8, bq);
+#pragma unroll
+        for (int h = 0; h < NR; ++h)
+            acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wreg[h][s].v), bfrag, acc[h], 0, 0, 0);
+    }
+    // ---- 5. sum the four K quarters (fixed order), epilogue on wave 0 ----
+#pragma unroll
+    for (int h = 0; h < NR; ++h) *reinterpret_cast<f32x4*>(red + ((size_t)(wave * NR + h) * 64 + lane) * 4) = acc[h];
+    __syncthreads();
+    if (wave != 0) return;
+    float tot[NR][4];
+#pragma unroll
+    for (int h = 0; h < NR; ++h) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(red + ((size_t)(0 * NR + h) * 64 + lane) * 4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + ((size_t)(w * NR + h) * 64 + lane) * 4);
+        tot[h][0] = t.x; tot[h][1] = t.y; tot[h][2] = t.z; tot[h][3] = t.w;
+    }
+    if (fr >= B) return;
+    T* yp = reinterpret_cast<T*>(a.y) + (size_t)fr * a.y_stride + row0 + fq * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v;
+        if constexpr (EPI == EPI_SWIGLU) {
+            const float g = DT<T>::rnd(tot[0][i]);
+            const float u = DT<T>::rnd(tot[NR - 1][i]);
+            const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
+            v = sg * u;
+        } else {
+            v = DT<T>::rnd(tot[0][i] + biasv[i]);
+            if constexpr (EPI == EPI_RESIDUAL) v = v + resv[i];
+        }
+        if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
+    }
+}
+
 }  // namespace fq3

@@ -29,6 +29,7 @@ struct fq3_batch {
     hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr;
     std::vector<void*> allocs;
+    int use_mfma = 0;             // FQ3_BATCH_MFMA=1: bf16 GEMVs on the matrix cores (not bit-identical to single-stream)
 };
 
 static int bmalloc(fq3_batch* b, void** p, size_t bytes) {
@@ -109,6 +110,7 @@ extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** 
     if (hipStreamCreateWithFlags(&b->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "hipStreamCreateWithFlags");
     }
+    if (const char* e = getenv("FQ3_BATCH_MFMA")) b->use_mfma = atoi(e);
     *out = b;
     return FQ3_OK;
 }
@@ -138,8 +140,41 @@ static int launch_gemv_batch_t(const BatchGemvArgs& a, int esz, hipStream_t s) {
     }
     return fq3_fail_(FQ3_EUNSUPPORTED, "GEMV inner dimension above 6144 (2048 for the attention merge)");
 }
+// matrix-core variant: bf16, K a multiple of 128 with a built step count; returns -1000 when the shape is not covered
+template <int PRO, int EPI>
+static int launch_gemv_batch_mfma(const BatchGemvArgs& a, hipStream_t s) {
+    if (a.K % 128) return -1000;
+    const int ksteps = a.K / 128;
+    const int grid = (a.N + 15) / 16;
+    constexpr int NR = EPI == EPI_SWIGLU ? 2 : 1;
+    const size_t shm = (((size_t)kMaxLanes * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NR * 256 * sizeof(float);
+    auto go = [&](auto ks) -> int {
+        constexpr int KS = decltype(ks)::value;
+        auto kern = gemv_batch_mfma_kernel<KS, PRO, EPI>;
+        if (shm > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, a);
+        return 0;
+    };
+    if constexpr (PRO == PRO_COMBINE) {
+        switch (ksteps) { case 4: return go(std::integral_constant<int, 4>{}); case 16: return go(std::integral_constant<int, 16>{}); default: return -1000; }
+    } else {
+        switch (ksteps) {
+            case 2: return go(std::integral_constant<int, 2>{});
+            case 4: return go(std::integral_constant<int, 4>{});
+            case 8: return go(std::integral_constant<int, 8>{});
+            case 16: return go(std::integral_constant<int, 16>{});
+            case 24: return go(std::integral_constant<int, 24>{});
+            default: return -1000;
+        }
+    }
+}
+static thread_local int g_batch_mfma = 0;        // set per enqueue from fq3_batch::use_mfma
 template <int PRO, int EPI>
 static int launch_gemv_batch(const fq3_ctx* c, const BatchGemvArgs& a, hipStream_t s) {
+    if (g_batch_mfma && c->cfg.dtype == FQ3_BF16) {
+        const int r = launch_gemv_batch_mfma<PRO, EPI>(a, s);
+        if (r != -1000) return r;
+    }
     return c->cfg.dtype == FQ3_BF16 ? launch_gemv_batch_t<bf16_t, PRO, EPI>(a, 2, s) : launch_gemv_batch_t<float, PRO, EPI>(a, 4, s);
 }
 
@@ -257,6 +292,7 @@ static int check_lanes(fq3_batch* b) {
     return 0;
 }
 static int enqueue_batch_frame(fq3_batch* b, hipStream_t s) {
+    g_batch_mfma = b->use_mfma;
     return b->lanes[0]->cfg.dtype == FQ3_BF16 ? enqueue_batch_frame_t<bf16_t>(b, s) : enqueue_batch_frame_t<float>(b, s);
 }
 

@@ -12,7 +12,7 @@
 #include "../../faster-qwen3-tts_amd/csrc/decode_kernels.cuh"
 #include "../../faster-qwen3-tts_amd/csrc/sampler.cuh"
 #include "../../faster-qwen3-tts_amd/csrc/sampler_wave.cuh"
-#include "batch_gemv.cuh"
+#include "../../faster-qwen3-tts_amd/csrc/batch_kernels.cuh"
 using namespace fq3;
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
@@ -270,80 +270,87 @@ int main(int argc, char** argv) {
         });
     }
 
-    // ---- batched-decode prototype (tools/microbench/batch_gemv.cuh): B tokens share one pass over the weights ----
+    // ---- batched decode (csrc/batch_kernels.cuh): B tokens share one pass over the weights ----
     if (want("batch")) {
-        constexpr int BM = 8;
-        void* xb = dev_bf16((size_t)16 * 8192, 1.f);          // [B][8192] activations in
-        void* yb = dev_bf16((size_t)16 * 8192, 1.f);          // [B][8192] activations out
-        void* y1 = dev_bf16((size_t)BM * 8192, 1.f);          // reference: B single-token launches
-        auto run_b = [&](auto tagB, int kind, int i) {
-            constexpr int B = decltype(tagB)::value;
-            BatchGemvArgs g{}; g.eps = 1e-6f; g.norm_w = norm_w; g.x = xb; g.x_stride = 8192; g.y = yb; g.y_stride = 8192; g.res = xb; g.res_stride = 8192;
-            if (kind == 0) { g.W = Wqkv[i % NL]; g.N = NQKV; g.K = H;
-                hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 2, PRO_NORM, EPI_STORE, false, B, 2>), dim3(NQKV / 8), dim3(256), (size_t)B * H * 2, st, g); }
-            else if (kind == 1) { g.W = Wo[i % NL]; g.N = H; g.K = QD;
-                hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 4, PRO_PLAIN, EPI_RESIDUAL, false, B, 1>), dim3(H / 4), dim3(256), (size_t)B * QD * 2, st, g); }
-            else if (kind == 2) { g.W = Wgu[i % NL]; g.N = I; g.K = H; g.up_off = I;
-                hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 2, PRO_NORM, EPI_SWIGLU, false, B, 2>), dim3(I / 8), dim3(256), (size_t)B * H * 2, st, g); }
-            else { g.W = Wdn[i % NL]; g.N = H; g.K = I;
-                hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 6, PRO_PLAIN, EPI_RESIDUAL, false, B, 1>), dim3(H / 4), dim3(256), (size_t)B * I * 2, st, g); }
+        void* xb = dev_bf16((size_t)8 * 8192, 1.f);           // [B][8192] activations in
+        void* yb = dev_bf16((size_t)8 * 8192, 1.f);           // batch kernel out
+        void* y1 = dev_bf16((size_t)8 * 8192, 1.f);           // reference: B single-token launches of the product kernels
+        void* ym = dev_bf16((size_t)8 * 8192, 1.f);           // MFMA kernel out
+        void* bias = dev_bf16(8192, 0.3f);
+        void* xn8 = dev_bf16((size_t)8 * 8192, 0.f);
+        float* part8 = (float*)dev_f32((size_t)8 * NKV * kMaxWorkers * 4 * kPartStride, 0.5f);
+        {   // make the softmax denominators of the synthetic partial slots positive (l in [0.5, 1.5))
+            const size_t n = (size_t)8 * NKV * kMaxWorkers * 4 * kPartStride;
+            std::vector<float> hp(n); CHK(hipMemcpy(hp.data(), part8, n * 4, hipMemcpyDeviceToHost));
+            for (size_t s0 = 0; s0 + kPartStride <= n; s0 += kPartStride) hp[s0 + kHeadDim + 1] = 1.0f + hp[s0 + kHeadDim + 1];
+            CHK(hipMemcpy(part8, hp.data(), n * 4, hipMemcpyHostToDevice));
+        }
+        const size_t pstride = (size_t)NKV * kMaxWorkers * 4 * kPartStride;
+        auto bargs = [&](int kind, int i, int B, void* y) {
+            BatchGemvArgs g{}; g.B = B; g.eps = 1e-6f; g.norm_w = norm_w; g.x = xb; g.x_stride = 8192; g.y = y; g.y_stride = 8192; g.res = xb; g.res_stride = 8192;
+            if (kind == 0) { g.W = Wqkv[i % NL]; g.N = NQKV; g.K = H; }
+            else if (kind == 1) { g.W = Wo[i % NL]; g.N = H; g.K = QD; }
+            else if (kind == 2) { g.W = Wgu[i % NL]; g.N = I; g.K = H; g.up_off = I; }
+            else if (kind == 3) { g.W = Wdn[i % NL]; g.N = H; g.K = I; }
+            else if (kind == 4) { g.W = Wo[i % NL]; g.N = H; g.K = QD; g.part = part8; g.part_stride = pstride; g.n_part = 8; g.rep = 2; }     // talker o_proj: split-KV merge
+            else { g.W = Whead[i % NL]; g.N = Vp; g.K = H; g.bias = bias; for (int m = 0; m < B; ++m) g.xn_out[m] = (bf16_t*)xn8 + (size_t)m * 8192; } // head + bias + xn_out
+            return g;
         };
-        auto run_1 = [&](int kind, int i, int m) {                // product kernels, token m of the same buffers
+        auto run_v = [&](int kind, int i, int B, void* y) {      // VALU batch kernel (bit-identical to single-token launches)
+            BatchGemvArgs g = bargs(kind, i, B, y);
+            const int grid = (g.N + 3) / 4; const size_t shm = (size_t)B * g.K * 2;
+            if (kind == 0) hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 2, PRO_NORM, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
+            else if (kind == 1) hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 4, PRO_PLAIN, EPI_RESIDUAL>), dim3(grid), dim3(256), shm, st, g);
+            else if (kind == 2) hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 2, PRO_NORM, EPI_SWIGLU>), dim3(grid), dim3(256), shm, st, g);
+            else if (kind == 3) hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 6, PRO_PLAIN, EPI_RESIDUAL>), dim3(grid), dim3(256), shm, st, g);
+            else if (kind == 4) hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 4, PRO_COMBINE, EPI_RESIDUAL>), dim3(grid), dim3(256), shm, st, g);
+            else hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 2, PRO_NORM, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
+        };
+        auto run_m = [&](int kind, int i, int B, void* y) {      // matrix-core batch kernel
+            BatchGemvArgs g = bargs(kind, i, B, y);
+            const int grid = (g.N + 15) / 16; const int NRr = kind == 2 ? 2 : 1;
+            const size_t shm = (((size_t)kMaxLanes * (g.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NRr * 256 * 4;
+            if (kind == 0) hipLaunchKernelGGL((gemv_batch_mfma_kernel<8, PRO_NORM, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
+            else if (kind == 1) hipLaunchKernelGGL((gemv_batch_mfma_kernel<16, PRO_PLAIN, EPI_RESIDUAL>), dim3(grid), dim3(256), shm, st, g);
+            else if (kind == 2) hipLaunchKernelGGL((gemv_batch_mfma_kernel<8, PRO_NORM, EPI_SWIGLU>), dim3(grid), dim3(256), shm, st, g);
+            else if (kind == 3) { auto kern = gemv_batch_mfma_kernel<24, PRO_PLAIN, EPI_RESIDUAL>;
+                CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, st, g); }
+            else if (kind == 4) hipLaunchKernelGGL((gemv_batch_mfma_kernel<16, PRO_COMBINE, EPI_RESIDUAL>), dim3(grid), dim3(256), shm, st, g);
+            else hipLaunchKernelGGL((gemv_batch_mfma_kernel<8, PRO_NORM, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
+        };
+        auto run_1 = [&](int kind, int i, int m) {                // product single-token kernels, token m of the same buffers
             GemvArgs g{}; g.eps = 1e-6f; g.norm_w = norm_w;
             g.x = (const bf16_t*)xb + (size_t)m * 8192; g.y = (bf16_t*)y1 + (size_t)m * 8192; g.res = (const bf16_t*)xb + (size_t)m * 8192;
             if (kind == 0) { g.W = Wqkv[i % NL]; g.N = NQKV; g.K = H; gemv<2, PRO_NORM, EPI_STORE, false>(g, 2); }
             else if (kind == 1) { g.W = Wo[i % NL]; g.N = H; g.K = QD; gemv<4, PRO_PLAIN, EPI_RESIDUAL, false>(g, 1); }
             else if (kind == 2) { g.W = Wgu[i % NL]; g.N = I; g.K = H; g.up_off = I; gemv<2, PRO_NORM, EPI_SWIGLU, false>(g, 2); }
-            else { g.W = Wdn[i % NL]; g.N = H; g.K = I; gemv<6, PRO_PLAIN, EPI_RESIDUAL, false>(g, 1); }
+            else if (kind == 3) { g.W = Wdn[i % NL]; g.N = H; g.K = I; gemv<6, PRO_PLAIN, EPI_RESIDUAL, false>(g, 1); }
+            else if (kind == 4) { g.W = Wo[i % NL]; g.N = H; g.K = QD; g.part = part8 + (size_t)m * pstride; g.n_part = 8; g.rep = 2; gemv<4, PRO_COMBINE, EPI_RESIDUAL, false>(g, 1); }
+            else { g.W = Whead[i % NL]; g.N = Vp; g.K = H; g.bias = bias; gemv<2, PRO_NORM, EPI_STORE, false>(g, 2); }
         };
-        const char* kn[4] = {"qkv NORM/STORE", "o PLAIN/RESID", "gate_up NORM/SWIGLU", "down PLAIN/RESID"};
-        const int outn[4] = {NQKV, H, I, H};
-        for (int kind = 0; kind < 4; ++kind) {
-            run_b(std::integral_constant<int, 8>{}, kind, 0);
-            for (int m = 0; m < 8; ++m) run_1(kind, 0, m);
+        const char* kn[6] = {"qkv NORM/STORE", "o PLAIN/RESID", "gate_up NORM/SWIGLU", "down PLAIN/RESID", "o COMBINE(8 parts)/RESID", "head NORM/STORE+bias+xn_out"};
+        const int outn[6] = {NQKV, H, I, H, H, Vp};
+        for (int B : {8, 3}) for (int kind = 0; kind < 6; ++kind) {
+            CHK(hipMemset(yb, 0, (size_t)8 * 8192 * 2)); CHK(hipMemset(ym, 0, (size_t)8 * 8192 * 2)); CHK(hipMemset(y1, 0, (size_t)8 * 8192 * 2));
+            run_v(kind, 0, B, yb); run_m(kind, 0, B, ym);
+            for (int m = 0; m < B; ++m) run_1(kind, 0, m);
             CHK(hipStreamSynchronize(st));
-            auto a8 = fetch_bf16(yb, (size_t)8 * 8192), a1 = fetch_bf16(y1, (size_t)8 * 8192);
-            int bad = 0; for (int m = 0; m < 8; ++m) for (int r = 0; r < outn[kind]; ++r) bad += a8[(size_t)m * 8192 + r] != a1[(size_t)m * 8192 + r];
-            char nm[96]; snprintf(nm, sizeof nm, "batch B=8 %s == 8 single-token launches", kn[kind]);
-            report(nm, bad, 0.5);
+            auto av = fetch_bf16(yb, (size_t)8 * 8192), am = fetch_bf16(ym, (size_t)8 * 8192), a1 = fetch_bf16(y1, (size_t)8 * 8192);
+            int bad = 0; double e = 0;
+            for (int m = 0; m < 8; ++m) for (int r = 0; r < outn[kind]; ++r) {
+                const size_t ix = (size_t)m * 8192 + r;
+                bad += av[ix] != a1[ix];                          // rows of lanes >= B must stay untouched (0) in all three
+                e = fmax(e, fabs(am[ix] - a1[ix]) / (1.0 + fabs(a1[ix])));
+            }
+            char nm[112]; snprintf(nm, sizeof nm, "batch VALU B=%d %s == single-token", B, kn[kind]); report(nm, bad, 0.5);
+            snprintf(nm, sizeof nm, "batch MFMA B=%d %s ~ single-token", B, kn[kind]); report(nm, e, 1e-2);
         }
-        auto layer_b = [&](auto tagB, const char* name) {
-            chain(name, N, [&](int j) { run_b(tagB, j % 4, j / 4); });
-        };
-        chain("batch  B=1 (product kernels): qkv, o, gate_up, down x80", N, [&](int j) { run_1(j % 4, j / 4, 0); });
-        layer_b(std::integral_constant<int, 2>{}, "batch  B=2 prototype: qkv, o, gate_up, down x80");
-        layer_b(std::integral_constant<int, 4>{}, "batch  B=4 prototype: qkv, o, gate_up, down x80");
-        layer_b(std::integral_constant<int, 8>{}, "batch  B=8 prototype: qkv, o, gate_up, down x80");
-
-        // ---- MFMA variant: compare against the VALU prototype (tolerance: fp32 summation order differs) and time it ----
-        auto run_m = [&](auto tagB, int kind, int i) {
-            constexpr int B = decltype(tagB)::value;
-            BatchGemvArgs g{}; g.eps = 1e-6f; g.norm_w = norm_w; g.x = xb; g.x_stride = 8192; g.y = yb; g.y_stride = 8192; g.res = xb; g.res_stride = 8192;
-            auto shm = [&](int K, int NR) { return (size_t)B * (K + 8) * 2 + (size_t)4 * NR * 256 * 4; };
-            if (kind == 0) { g.W = Wqkv[i % NL]; g.N = NQKV; g.K = H;
-                hipLaunchKernelGGL((gemv_batch_mfma_kernel<8, PRO_NORM, EPI_STORE, false, B>), dim3(NQKV / 16), dim3(256), shm(H, 1), st, g); }
-            else if (kind == 1) { g.W = Wo[i % NL]; g.N = H; g.K = QD;
-                hipLaunchKernelGGL((gemv_batch_mfma_kernel<16, PRO_PLAIN, EPI_RESIDUAL, false, B>), dim3(H / 16), dim3(256), shm(QD, 1), st, g); }
-            else if (kind == 2) { g.W = Wgu[i % NL]; g.N = I; g.K = H; g.up_off = I;
-                hipLaunchKernelGGL((gemv_batch_mfma_kernel<8, PRO_NORM, EPI_SWIGLU, false, B>), dim3(I / 16), dim3(256), shm(H, 2), st, g); }
-            else { g.W = Wdn[i % NL]; g.N = H; g.K = I;
-                hipLaunchKernelGGL((gemv_batch_mfma_kernel<24, PRO_PLAIN, EPI_RESIDUAL, false, B>), dim3(H / 16), dim3(256), shm(I, 1), st, g); }
-        };
-        for (int kind = 0; kind < 4; ++kind) {
-            for (int m = 0; m < 8; ++m) run_1(kind, 0, m);
-            run_m(std::integral_constant<int, 8>{}, kind, 0);
-            CHK(hipStreamSynchronize(st));
-            auto a8 = fetch_bf16(yb, (size_t)8 * 8192), a1 = fetch_bf16(y1, (size_t)8 * 8192);
-            double e = 0; for (int m = 0; m < 8; ++m) for (int r = 0; r < outn[kind]; ++r) e = fmax(e, fabs(a8[(size_t)m * 8192 + r] - a1[(size_t)m * 8192 + r]) / (1.0 + fabs(a1[(size_t)m * 8192 + r])));
-            char nm[96]; snprintf(nm, sizeof nm, "MFMA batch B=8 %s vs single-token launches", kn[kind]);
-            report(nm, e, 1e-2);
-        }
-        chain("batch  B=8  MFMA prototype: qkv, o, gate_up, down x80", N, [&](int j) { run_m(std::integral_constant<int, 8>{}, j % 4, j / 4); });
-        chain("batch  B=16 MFMA prototype: qkv, o, gate_up, down x80", N, [&](int j) { run_m(std::integral_constant<int, 16>{}, j % 4, j / 4); });
-        chain("batch  B=8  MFMA: qkv only", N, [&](int j) { run_m(std::integral_constant<int, 8>{}, 0, j); });
-        chain("batch  B=8  MFMA: o only (64 workgroups)", N, [&](int j) { run_m(std::integral_constant<int, 8>{}, 1, j); });
-        chain("batch  B=8  MFMA: gate_up only", N, [&](int j) { run_m(std::integral_constant<int, 8>{}, 2, j); });
-        chain("batch  B=8  MFMA: down only (64 workgroups)", N, [&](int j) { run_m(std::integral_constant<int, 8>{}, 3, j); });
+        chain("batch  B=1 (single-token product kernels): qkv, o, gate_up, down x80", N, [&](int j) { run_1(j % 4, j / 4, 0); });
+        chain("batch  B=8 VALU kernel: qkv, o, gate_up, down x80", N, [&](int j) { run_v(j % 4, j / 4, 8, yb); });
+        chain("batch  B=8 MFMA kernel: qkv, o, gate_up, down x80", N, [&](int j) { run_m(j % 4, j / 4, 8, ym); });
+        chain("batch  B=8 MFMA kernel: talker o_proj with 8-part merge", N, [&](int j) { run_m(4, j, 8, ym); });
+        chain("batch  B=8 VALU kernel: talker o_proj with 8-part merge", N, [&](int j) { run_v(4, j, 8, yb); });
     }
     return g_fail ? 1 : 0;
 }
