@@ -499,6 +499,72 @@ class FasterQwen3TTS:
                               self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample,
                                                repetition_penalty))
 
+    # ---- batched generation (extension: the reference has no multi-utterance entry point) ---------------------------------
+    def _batch_decoder(self, lanes: int):
+        """Lazily builds ``lanes`` decode contexts over this model's single weight replica and the scheduler on top."""
+        from .batching import BatchDecoder
+        from .engine import Fq3Engine
+        lanes = max(1, min(int(lanes), 8))
+        cached = getattr(self, "_batch_cache", None)
+        if cached is not None and cached[0] == lanes:
+            return cached[1]
+        first = self.talker_graph.engine
+        engines = [first] + [Fq3Engine(first.cfg, first.weights, device=str(first.device), dtype=first.dtype,
+                                       max_seq_len=first.max_seq_len, max_frames=first.max_frames, share=first)
+                             for _ in range(lanes - 1)]
+        pg = self.predictor_graph
+        dec = BatchDecoder(engines, predictor_policy=dict(do_sample=pg.do_sample, top_k=pg.top_k, top_p=pg.top_p,
+                                                          temperature=pg.temperature))
+        self._batch_cache = (lanes, dec)
+        return dec
+
+    @torch.inference_mode()
+    def generate_voice_clone_batch(self, texts: List[str], language: Union[str, List[str]] = "English",
+                                   ref_audio: Optional[Union[str, Path]] = None, ref_text: str = "",
+                                   max_new_tokens: int = 2048, min_new_tokens: int = 2, temperature: float = 0.9,
+                                   top_k: int = 50, top_p: float = 1.0, do_sample: bool = True,
+                                   repetition_penalty: float = 1.05, xvec_only: bool = False,
+                                   non_streaming_mode: Optional[bool] = None, append_silence: bool = True,
+                                   instruct: Optional[str] = None,
+                                   voice_clone_prompt: Optional[Union[Dict[str, Any], List[Any]]] = None,
+                                   lanes: int = 8) -> List[Tuple[list, int]]:
+        """Voice cloning of several texts with one voice: up to ``lanes`` (<= 8) utterances decode in lock-step over
+        one pass of the weights per frame (``fq3_batch_*``), finished lanes are refilled from the queue.  Returns one
+        ``([np.float32 waveform], sample_rate)`` per text, in input order; each utterance follows exactly the
+        single-utterance semantics of :meth:`generate_voice_clone` (``top_p`` must be 1.0 on this path)."""
+        from .batching import BatchRequest
+        nsm = self._resolve_non_streaming_mode(non_streaming_mode, default=False)
+        langs = language if isinstance(language, (list, tuple)) else [language] * len(texts)
+        if len(langs) != len(texts):
+            raise ValueError("language must be one string or one per text")
+        gen_kwargs = self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty)
+        reqs, ref_codes_of = [], {}
+        for i, (text, lang) in enumerate(zip(texts, langs)):
+            m, talker, config, tie, tam, tth, tpe, rc = self._prepare_generation(
+                text=text, language=lang, ref_audio=ref_audio, ref_text=ref_text, xvec_only=xvec_only,
+                non_streaming_mode=nsm, append_silence=append_silence, voice_clone_prompt=voice_clone_prompt,
+                instruct=instruct)
+            reqs.append(BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(gen_kwargs)))
+            ref_codes_of[i] = rc
+        m = self.model.model
+        out: List[Optional[Tuple[list, int]]] = [None] * len(texts)
+        for rid, codec_ids, _timing in self._batch_decoder(lanes).run(reqs):
+            if codec_ids is None:
+                out[rid] = ([np.zeros(1, dtype=np.float32)], self.sample_rate)
+                continue
+            rc = ref_codes_of[rid]
+            codes = torch.cat([rc.to(codec_ids.device), codec_ids], dim=0) if rc is not None else codec_ids
+            audio_list, sr = m.speech_tokenizer.decode({"audio_codes": codes.unsqueeze(0)})
+            ref_len = rc.shape[0] if rc is not None else 0
+            wavs = []
+            for a in audio_list:
+                a = _to_numpy(a)
+                if ref_len > 0:
+                    a = a[int(ref_len / max(codes.shape[0], 1) * len(a)):]
+                wavs.append(a)
+            out[rid] = (wavs, sr)
+        return out
+
     @torch.inference_mode()
     def generate_voice_clone_streaming(self, text: str, language: str, ref_audio: Optional[Union[str, Path]] = None,
                                        ref_text: str = "", max_new_tokens: int = 2048, min_new_tokens: int = 2,

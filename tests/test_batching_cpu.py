@@ -1,0 +1,104 @@
+"""CPU: the continuous-batching scheduler (fq3hip/batching.py) against scripted fake lanes -- admission at frame
+boundaries, lock-step issue that never crosses a lane's noise-ring boundary, per-lane budgets, early EOS, lane re-use,
+result routing by request id, top-p rejection."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+import fq3hip.batching as Bt
+
+
+class FakeLaneEngine:
+    def __init__(self, log, idx):
+        self.log, self.idx = log, idx
+        self.dtype, self.device = torch.float32, torch.device("cpu")
+        self.max_seq_len = 4096
+        self.cfg = SimpleNamespace(num_code_groups=16, talker=SimpleNamespace(hidden_size=8, num_hidden_layers=1),
+                                   predictor=SimpleNamespace(hidden_size=8, num_hidden_layers=1, vocab_size=32))
+        self.frames, self.eos_after, self.budget, self.rid = 0, 10 ** 9, 0, None
+
+    def set_predictor_sampling(self, **kw):
+        pass
+
+    def decode_poll(self):
+        n = min(self.frames, self.eos_after, self.budget)
+        return n, n >= self.eos_after
+
+    def decode_codes(self, start, count):
+        return torch.full((count, 16), float(self.rid)).long()
+
+
+class FakeBatch:
+    def __init__(self, engines):
+        self.engines, self.calls, self.captured = engines, [], 0
+
+    def graph_capture(self):
+        self.captured += 1
+
+    def frames(self, n):
+        self.calls.append(n)
+        for e in self.engines:
+            e.frames += n
+
+
+@pytest.fixture
+def sched(monkeypatch):
+    log = []
+    engines = [FakeLaneEngine(log, i) for i in range(3)]
+    refills = []
+
+    def fake_arm(talker, tie, tam, tth, tpe, config, pg, tg, max_new, min_new, temperature, top_k, top_p, do_sample, rp, use_graph):
+        eng = tg.engine
+        eng.frames, eng.budget, eng.eos_after, eng.rid = 0, int(max_new), config.eos_after, config.rid
+        log.append(("arm", eng.idx, config.rid))
+        assert use_graph is False
+        return eng, torch.zeros(1), torch.zeros(1), int(max_new)
+
+    monkeypatch.setattr(Bt, "_prefill_and_arm", fake_arm)
+    monkeypatch.setattr(Bt, "_refill", lambda eng, tn, pn: refills.append((eng.idx, eng.frames)))
+    monkeypatch.setattr(Bt, "TalkerGraph", lambda e: SimpleNamespace(engine=e))
+    monkeypatch.setattr(Bt, "PredictorGraph", lambda e, **kw: SimpleNamespace(engine=e, top_p=kw.get("top_p", 1.0), **{k: v for k, v in kw.items() if k != "top_p"}))
+    dec = Bt.BatchDecoder(engines, poll_every=8, batch_factory=FakeBatch)
+    return dec, engines, log, refills
+
+
+def _req(rid, max_new, eos_after=10 ** 9, **kw):
+    cfg = SimpleNamespace(rid=rid, eos_after=eos_after)
+    return Bt.BatchRequest(rid, None, torch.zeros(1, 4, 8), torch.ones(1, 4), torch.zeros(1, 2, 8), torch.zeros(1, 1, 8), cfg,
+                           dict(max_new_tokens=max_new, **kw))
+
+
+def test_more_requests_than_lanes_and_lane_reuse(sched):
+    dec, engines, log, refills = sched
+    reqs = [_req(0, 20), _req(1, 40, eos_after=13), _req(2, 24), _req(3, 8), _req(4, 16)]
+    out = {rid: (codes, t) for rid, codes, t in dec.run(reqs)}
+    assert set(out) == {0, 1, 2, 3, 4}
+    assert [out[r][0].shape[0] for r in range(5)] == [20, 13, 24, 8, 16]           # budget / EOS per utterance
+    assert all(int(out[r][0][0, 0]) == r for r in range(5))                        # routed by request id
+    assert out[1][1]["steps"] == 13 and set(out[0][1]) == {"prefill_ms", "decode_s", "steps", "ms_per_step", "steps_per_s"}
+    arms = [e for e in log if e[0] == "arm"]
+    assert [a[2] for a in arms[:3]] == [0, 1, 2] and len(arms) == 5                # three lanes filled first, two re-used
+    assert dec.batch.captured == 1                                                 # one graph for the whole run
+    assert all(1 <= n <= 8 for n in dec.batch.calls)
+
+
+def test_lock_step_never_crosses_a_noise_ring_boundary(sched):
+    dec, engines, log, refills = sched
+    list(dec.run([_req(0, 150), _req(1, 70)]))
+    # every lane refills its own rings exactly at its frames 0, 64, 128, ...
+    assert sorted(r for r in refills if r[0] == 0) == [(0, 0), (0, 64), (0, 128)]
+    assert sorted(r for r in refills if r[0] == 1) == [(1, 0), (1, 64)]
+    # second wave: a lane armed later has a different phase -> the step is cut at whichever boundary comes first
+    dec2_calls = len(dec.batch.calls)
+    list(dec.run([_req(5, 100)]))
+    assert sum(dec.batch.calls[dec2_calls:]) == 100
+
+
+def test_zero_budget_and_top_p_rejection(sched):
+    dec, engines, log, refills = sched
+    out = list(dec.run([_req(0, 0), _req(1, 5)]))
+    assert out[0][0] == 0 and out[0][1] is None and out[0][2]["steps"] == 0
+    assert out[1][0] == 1 and out[1][1].shape[0] == 5
+    with pytest.raises(NotImplementedError):
+        list(dec.run([_req(2, 5, top_p=0.9)]))
