@@ -113,6 +113,33 @@ def concurrent_throughput(cfg, model, prompt, device, streams=4, utterances=2):
             "unit": "x real-time (aggregate audio s / wall s, one GPU)", "ttfa_ms_p50": round(1000 * float(np.median(ttfas)), 2)}
 
 
+def batched_throughput(model, prompt, lanes=8, utterances=16):
+    """Opt-in extra (--batch B, N=1 only): `utterances` synthetic utterances through `lanes` lock-step lanes
+    (fq3_batch_*, continuous batching), vocoded as they finish.  Aggregate audio seconds / wall seconds."""
+    from fq3hip.batching import BatchRequest
+    tie, tam, tth, tpe, ref_codes = prompt
+    m = model.model.model
+    talker, config = m.talker, m.config.talker_config
+    kw = model._gen_kwargs(FRAMES, FRAMES, 0.9, 50, 1.0, True, 1.05)
+    dec = model._batch_decoder(lanes)
+    reqs = [BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(kw)) for i in range(utterances)]
+    list(dec.run(reqs[:lanes]))                                  # warm-up: contexts, graph capture
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames = 0
+    for rid, codes, timing in dec.run(reqs):
+        if codes is None:
+            continue
+        full = torch.cat([ref_codes.to(codes.device), codes], dim=0) if ref_codes is not None else codes
+        audio_list, _sr = m.speech_tokenizer.decode({"audio_codes": full.unsqueeze(0)})
+        _ = audio_list[0].cpu() if hasattr(audio_list[0], "cpu") else audio_list[0]
+        frames += codes.shape[0]
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return {"lanes": lanes, "utterances": utterances, "value": round(frames * FRAME_S / wall, 3),
+            "unit": "x real-time (aggregate audio s / wall s, one GPU, non-streaming vocoder per finished utterance)"}
+
+
 def one_utterance(model, prompt, seed, sync=None):
     """Streaming voice-clone of one synthetic utterance.  Returns (ttfa_s, wall_s, n_frames, pcm)."""
     sync = sync or torch.cuda.synchronize
@@ -202,6 +229,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="opt-in extra (N=1 only): lock-step lanes for the batched-decode throughput figure (0 = skip)")
     ap.add_argument("--concurrent", type=int, default=4,
                     help="extra figure (N=1 only, after the timed region): utterances in flight on one GPU (0 = skip)")
     args = ap.parse_args()
@@ -258,6 +287,13 @@ def main():
         except Exception as e:      # an extra; never lose the headline line to it
             conc = {"error": repr(e)}
 
+    batched = None
+    if args.batch > 1 and world == 1:
+        try:
+            batched = batched_throughput(model, prompt, lanes=min(args.batch, 8), utterances=2 * min(args.batch, 8))
+        except Exception as e:      # an extra; never lose the headline line to it
+            batched = {"error": repr(e)}
+
     # max over ranks of the wall time, sum of frames, gather of TTFAs and (result gather) PCM lengths
     if world > 1:
         from fq3hip.sharding import gather_arrays
@@ -305,6 +341,8 @@ def main():
         }
         if conc is not None:
             out["concurrent_utterances_one_gpu"] = conc
+        if batched is not None:
+            out["batched_decode_one_gpu"] = batched
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg)
