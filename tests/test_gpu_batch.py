@@ -160,8 +160,10 @@ def test_generate_voice_clone_batch_equals_single_calls():
                     reason="matrix-core batch GEMV: checked at kernel level by tools/microbench/kernel_chain (24 checks), "
                            "first end-to-end run pending (set FQ3_RUN_UNVALIDATED=1)")
 def test_mfma_batch_path_close_to_single_stream(monkeypatch):
-    """FQ3_BATCH_MFMA=1 (bf16): fp32 summation order differs, so ids must agree with the single-stream run until the first
-    decision whose top-2 margin is inside bf16 noise; here: at least the first 4 frames of every lane and > 80 % overall."""
+    """FQ3_BATCH_MFMA=1 (bf16): the fp32 summation order differs from the VALU kernels, so ids agree with the single-stream
+    run only until the first decision whose top-2 margin is inside bf16 noise (after which a greedy run diverges for good);
+    a coarse bound for the first run: every lane > 50 % identical ids, > 80 % on average.  To be tightened with
+    margin attribution (as in test_gpu_decode.py) once it has run."""
     from fq3hip.engine import Fq3Batch
     monkeypatch.setenv("FQ3_BATCH_MFMA", "1")
     cfg = tiny_test_config()
