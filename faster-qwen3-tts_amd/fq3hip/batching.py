@@ -94,15 +94,29 @@ class BatchDecoder:
         return rid, codes, timing
 
     @torch.inference_mode()
-    def run(self, requests: Iterable[BatchRequest]) -> Iterator[Tuple[Any, Optional[torch.Tensor], Dict[str, float]]]:
-        """Yields ``(rid, codes LongTensor[T, 16] or None, timing)`` as utterances finish (not in request order)."""
+    def run(self, requests: Iterable[BatchRequest], on_error: str = "raise"
+            ) -> Iterator[Tuple[Any, Optional[torch.Tensor], Dict[str, Any]]]:
+        """Yields ``(rid, codes LongTensor[T, 16] or None, timing)`` as utterances finish (not in request order).
+        ``on_error="yield"``: a request that cannot be armed (prompt longer than ``max_seq_len``, nucleus sampling, ...)
+        is reported as ``(rid, None, {"error": repr(exc), "steps": 0})`` and the other lanes keep going; the default
+        re-raises, like the single-utterance entry points."""
+        if on_error not in ("raise", "yield"):
+            raise ValueError("on_error must be 'raise' or 'yield'")
         pending = deque(requests)
         free = deque(self.lanes)
         active: List[_Lane] = []
         while pending or active:
             while pending and free:                                   # admit at a frame boundary
                 ln = free.popleft()
-                self._arm(ln, pending.popleft())
+                req = pending.popleft()
+                try:
+                    self._arm(ln, req)
+                except Exception as exc:
+                    free.appendleft(ln)
+                    if on_error == "raise":
+                        raise
+                    yield req.rid, None, {"error": repr(exc), "steps": 0}
+                    continue
                 if ln.max_frames <= 0:
                     yield self._finish(ln, 0)
                     free.append(ln)

@@ -102,3 +102,12 @@ def test_zero_budget_and_top_p_rejection(sched):
     assert out[1][0] == 1 and out[1][1].shape[0] == 5
     with pytest.raises(NotImplementedError):
         list(dec.run([_req(2, 5, top_p=0.9)]))
+
+
+def test_bad_request_can_be_reported_without_stopping_the_others(sched):
+    dec, engines, log, refills = sched
+    out = {rid: (c, t) for rid, c, t in dec.run([_req(0, 12), _req(1, 5, top_p=0.5), _req(2, 9)], on_error="yield")}
+    assert out[0][0].shape[0] == 12 and out[2][0].shape[0] == 9
+    assert out[1][0] is None and "NotImplementedError" in out[1][1]["error"] and out[1][1]["steps"] == 0
+    with pytest.raises(ValueError):
+        list(dec.run([], on_error="ignore"))
