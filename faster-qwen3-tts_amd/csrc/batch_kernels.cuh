@@ -73,9 +73,9 @@ __global__ __launch_bounds__(256) void sample_pred_batch_kernel(LaneTab t, const
 }
 
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void sample_talker_batch_kernel(LaneTab t, const T* logits, int V) {
+__global__ __launch_bounds__(256) void sample_talker_batch_kernel(LaneTab t, const T* logits, int V, int G) {
     const int l = blockIdx.x;
-    sample_talker_wave_body<T, NC>(t.st[l], logits + (size_t)l * V, V, t.seen[l]);
+    sample_talker_wave_body<T, NC>(t.st[l], logits + (size_t)l * V, V, t.seen[l], G);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

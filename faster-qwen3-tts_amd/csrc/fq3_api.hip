@@ -36,6 +36,7 @@ static bool dims_ok(const fq3_stack_dims& d) {
            d.vocab <= kMaxVocab && d.vocab % 8 == 0 && d.hidden <= 8192 && d.inter <= 8192 * 3 && d.n_layers >= 1;
 }
 
+static int ctx_build(fq3_ctx* c, const fq3_config* cfg);
 extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
     if (!cfg || !out) return fail(FQ3_EINVAL, "null argument");
     if (cfg->dtype != FQ3_BF16 && cfg->dtype != FQ3_F32) return fail(FQ3_EINVAL, "dtype must be FQ3_BF16 or FQ3_F32");
@@ -45,6 +46,12 @@ extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
     if (cfg->num_code_groups < 2 || cfg->num_code_groups > 64) return fail(FQ3_EINVAL, "num_code_groups");
     if (cfg->max_seq_len < 8) return fail(FQ3_EINVAL, "max_seq_len");
     fq3_ctx* c = new fq3_ctx();
+    if (int r = ctx_build(c, cfg)) { const std::string m = g_err; fq3_ctx_destroy(c); g_err = m; return r; }   // no half-built context leaks
+    *out = c;
+    return FQ3_OK;
+}
+
+static int ctx_build(fq3_ctx* c, const fq3_config* cfg) {
     c->cfg = *cfg;
     c->esz = cfg->dtype == FQ3_BF16 ? 2 : 4;
     const fq3_stack_dims &t = cfg->talker, &p = cfg->predictor;
@@ -97,10 +104,20 @@ extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
     if ((r = dmalloc(c, (void**)&c->ids64, (size_t)64 * sizeof(int64_t)))) return r;
     if ((r = dmalloc(c, (void**)&c->d_pemb, (size_t)64 * sizeof(void*)))) return r;
     HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
-    if (const char* e = getenv("FQ3_NT")) c->opt_nt = atoi(e);
-    if (const char* e = getenv("FQ3_M2")) c->opt_m2 = atoi(e);
-    if (const char* e = getenv("FQ3_PRED_ATTN")) c->opt_pred_attn = atoi(e);
-    *out = c;
+    return FQ3_OK;
+}
+
+// Kernel-variant switches (parity tests exercise every variant; the defaults are the measured-fastest ones).
+extern "C" int fq3_set_option(fq3_ctx* c, const char* key, int value) {
+    if (!c || !key) return fail(FQ3_EINVAL, "null argument");
+    const std::string k(key);
+    if (k == "weight_nt") c->opt_nt = value;                   // 0 none, 1 talker (default), 2 all: non-temporal weight loads
+    else if (k == "pred_m2") c->opt_m2 = value;                // predictor two-token prefill as one M = 2 pass (default 1)
+    else if (k == "pred_attn") c->opt_pred_attn = value;       // one-wave predictor attention (default 1)
+    else if (k == "rows_per_wave_max") c->opt_rmax = value;    // GEMV rows per wave cap (default 2)
+    else if (k == "prefill_mode") c->prefill_mode = value;     // 0 matrix-core prefill, 1 token walk
+    else return fail(FQ3_EINVAL, "unknown option: " + k);
+    fq3_graph_reset(c);
     return FQ3_OK;
 }
 
@@ -149,23 +166,21 @@ extern "C" int fq3_bind_weights(fq3_ctx* c, const fq3_weight_table* w) {
 // -------------------------------------------------------------------------------------------------
 // GEMV dispatch
 // -------------------------------------------------------------------------------------------------
+static thread_local int g_rmax = 2;      // set from the context before a launch sequence (fq3_set_option "rows_per_wave_max")
 template <typename T, int NCH, int PRO, int EPI, bool NT, int M = 1>
 static void launch_gemv_n(const GemvArgs& a, hipStream_t s) {
-    // rows per wave: 2 for the big matrices (512-768 workgroups), 1 when N <= 1024 or a row is long; FQ3_RMAX=1 forces 1
-    static const int rmax = getenv("FQ3_RMAX") ? atoi(getenv("FQ3_RMAX")) : 2;
+    // rows per wave: 2 for the big matrices (512-768 workgroups), 1 when N <= 1024 or a row is long
+    const int rmax = g_rmax;
     int R = (a.N + 1023) / 1024;
     if (R > MaxRows<NCH, EPI>::v) R = MaxRows<NCH, EPI>::v;
     if (rmax > 0 && R > rmax) R = rmax;
     if (R < 1) R = 1;
     const int grid = (a.N + 4 * R - 1) / (4 * R);
     const size_t shm = PRO == PRO_COMBINE ? (size_t)M * a.K * sizeof(float) : 0;
-    static const bool dup = getenv("FQ3_EXPERIMENT_DUP") != nullptr;     // timing experiment only (results are wrong)
-    for (int rep = 0; rep < (dup ? 2 : 1); ++rep) {
-        if constexpr (MaxRows<NCH, EPI>::v >= 2) {
-            if (R == 2) { hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT, M, 2>), dim3(grid), dim3(256), shm, s, a); continue; }
-        }
-        hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT, M, 1>), dim3(grid), dim3(256), shm, s, a);
+    if constexpr (MaxRows<NCH, EPI>::v >= 2) {
+        if (R == 2) { hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT, M, 2>), dim3(grid), dim3(256), shm, s, a); return; }
     }
+    hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT, M, 1>), dim3(grid), dim3(256), shm, s, a);
 }
 // two-token launches: code predictor only (default cache policy), hidden sizes up to 2048 / intermediate up to 6144
 template <typename T, int PRO, int EPI>
@@ -181,6 +196,7 @@ static int launch_gemv2_t(const GemvArgs& a, hipStream_t s) {
 }
 template <int PRO, int EPI>
 static int launch_gemv2(const fq3_ctx* c, const GemvArgs& a, hipStream_t s) {
+    g_rmax = c->opt_rmax;
     return c->cfg.dtype == FQ3_BF16 ? launch_gemv2_t<bf16_t, PRO, EPI>(a, s) : launch_gemv2_t<float, PRO, EPI>(a, s);
 }
 template <typename T, int PRO, int EPI, bool NT>
@@ -196,6 +212,7 @@ static int launch_gemv_t(const GemvArgs& a, hipStream_t s) {
 }
 template <int PRO, int EPI>
 static int launch_gemv(const fq3_ctx* c, const GemvArgs& a, bool nt, hipStream_t s) {
+    g_rmax = c->opt_rmax;
     if (c->cfg.dtype == FQ3_BF16)
         return nt ? launch_gemv_t<bf16_t, PRO, EPI, true>(a, s) : launch_gemv_t<bf16_t, PRO, EPI, false>(a, s);
     return nt ? launch_gemv_t<float, PRO, EPI, true>(a, s) : launch_gemv_t<float, PRO, EPI, false>(a, s);
@@ -220,7 +237,7 @@ static int run_stack(fq3_ctx* c, bool talker, const StepSrc& src, hipStream_t s)
     const int rep = d.n_heads / d.n_kv_heads;
     const int q_dim = d.n_heads * kHeadDim, kv_dim = d.n_kv_heads * kHeadDim;
     // talker weights stream once per frame (non-temporal); predictor weights are re-read 16x per frame and
-    // should stay in the 256 MB Infinity Cache (default policy).  FQ3_NT overrides: 0 none, 1 talker, 2 all.
+    // should stay in the 256 MB Infinity Cache (default policy).  fq3_set_option("weight_nt"): 0 none, 1 talker, 2 all.
     const bool nt = c->opt_nt == 2 || (c->opt_nt == 1 && talker);
     // RoPE row: immediate position -> table row chosen on the host; device position -> the row the
     // frame's embed_sum kernel staged in rope_now
@@ -414,8 +431,8 @@ extern "C" int fq3_codec_head(fq3_ctx* c, const void* hidden, void* out_logits, 
     return FQ3_OK;
 }
 
-// Round-1 prefill: the prompt is walked token by token through the decode-step kernels (exactly the
-// arithmetic the decode parity tests pin).  The MFMA GEMM prefill replaces this in csrc/prefill.hip.
+// Prefill: matrix-core GEMMs over all prompt rows (csrc/fq3_prefill.hip) by default; prefill_mode 1 walks the prompt
+// token by token through the decode-step kernels (the arithmetic the decode parity tests pin; kept as a cross-check).
 extern "C" int fq3_prefill(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits, void* out_hidden,
                            void* stream) {
     NEED_BOUND(c);
@@ -458,11 +475,7 @@ int fq3_codec_head_launch_(fq3_ctx* c, const void* hidden, void* out_logits, hip
 }
 
 // test / debugging hook: 0 = auto (MFMA prefill), 1 = force the token-by-token walk through the decode kernels
-extern "C" int fq3_set_prefill_mode(fq3_ctx* c, int mode) {
-    if (!c) return fail(FQ3_EINVAL, "null ctx");
-    c->prefill_mode = mode;
-    return FQ3_OK;
-}
+extern "C" int fq3_set_prefill_mode(fq3_ctx* c, int mode) { return fq3_set_option(c, "prefill_mode", mode); }
 
 // -------------------------------------------------------------------------------------------------
 // Sampler dispatch: single-wave kernels when top_p >= 1 (default), workgroup kernel otherwise
@@ -491,12 +504,12 @@ static void launch_sample_pred(const DecodeState* st, const T* lg, int V, int cb
                             next_emb, next_in, H);
 }
 template <typename T>
-static void launch_sample_talker(DecodeState* st, const T* lg, int V, const unsigned char* seen, bool wave, hipStream_t s) {
+static void launch_sample_talker(DecodeState* st, const T* lg, int V, const unsigned char* seen, int G, bool wave, hipStream_t s) {
     if (wave) dispatch_nc(V, [&](auto nc) {
         constexpr int NC = decltype(nc)::value;
-        hipLaunchKernelGGL((sample_talker_wave_kernel<T, NC>), dim3(1), dim3(256), 0, s, st, lg, V, seen);
+        hipLaunchKernelGGL((sample_talker_wave_kernel<T, NC>), dim3(1), dim3(256), 0, s, st, lg, V, seen, G);
     });
-    else hipLaunchKernelGGL((sample_talker_kernel<T>), dim3(1), dim3(256), 0, s, st, lg, V, seen);
+    else hipLaunchKernelGGL((sample_talker_kernel<T>), dim3(1), dim3(256), 0, s, st, lg, V, seen, G);
 }
 template <typename T>
 static void launch_sample_api(fq3_ctx* c, const T* lg, int V, const SampleCfg& cfg, const int64_t* history, int n_hist,
@@ -623,6 +636,16 @@ extern "C" int fq3_predictor_loop(fq3_ctx* c, const void* pred_input, const void
 // -------------------------------------------------------------------------------------------------
 // Fused on-device decode loop
 // -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_arm_kernel(DecodeState* st, DecodeState init, unsigned char* seen, int seen_bytes,
+                                                         uint32_t* past_hidden, const uint32_t* ph_src, int ph_words) {
+    for (int i = threadIdx.x; i < seen_bytes / 4; i += 256) reinterpret_cast<uint32_t*>(seen)[i] = 0u;
+    for (int i = threadIdx.x; i < ph_words; i += 256) past_hidden[i] = ph_src[i];
+    if (threadIdx.x == 0) *st = init;
+}
+__global__ void decode_set_forced_kernel(DecodeState* st, const int* forced, int* decisions) {
+    st->forced = forced; st->decisions = decisions;
+}
+
 extern "C" int fq3_decode_begin(fq3_ctx* c, const fq3_decode_params* p, void* stream) {
     NEED_BOUND(c);
     if (!p || !p->past_hidden || !p->tts_pad_embed) return fail(FQ3_EINVAL, "null argument");
@@ -649,10 +672,18 @@ extern "C" int fq3_decode_begin(fq3_ctx* c, const fq3_decode_params* p, void* st
     h.p_temperature = c->pred_sampling.temperature; h.p_top_k = c->pred_sampling.top_k; h.p_top_p = c->pred_sampling.top_p;
     h.p_do_sample = c->pred_sampling.do_sample;
     h.trailing_text = p->trailing_text; h.tts_pad = p->tts_pad_embed; h.talker_noise = p->talker_noise; h.pred_noise = p->pred_noise;
-    HIPCHK(hipMemcpyAsync(c->st, &h, sizeof h, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(c->seen, 0, kMaxVocab, s));
-    HIPCHK(hipMemcpyAsync(c->past_hidden, p->past_hidden, (size_t)c->cfg.talker.hidden * c->esz, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));     // `h` lives on this stack frame
+    // one launch arms everything; the state travels BY VALUE in the kernel arguments, so nothing on this stack frame
+    // is read after the call returns and the host does not wait for the stream
+    hipLaunchKernelGGL(decode_arm_kernel, dim3(1), dim3(256), 0, s, c->st, h, c->seen, (int)kMaxVocab,
+                       (uint32_t*)c->past_hidden, (const uint32_t*)p->past_hidden, (int)((size_t)c->cfg.talker.hidden * c->esz / 4));
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
+extern "C" int fq3_decode_set_forced(fq3_ctx* c, const int32_t* forced_codes, int32_t* decisions, void* stream) {
+    NEED_BOUND(c);
+    hipLaunchKernelGGL(decode_set_forced_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, c->st, forced_codes, decisions);
+    LAUNCH_CHECK();
     return FQ3_OK;
 }
 
@@ -677,7 +708,7 @@ static int enqueue_frame_t(fq3_ctx* c, hipStream_t s) {
     g.eps = t.rms_eps; g.W = c->wt.codec_head; g.N = t.vocab; g.K = H; g.x = c->h;
     g.norm_w = c->wt.talker_final_norm; g.y = c->logits; g.xn_out = c->past_hidden;
     if (int r = launch_gemv<PRO_NORM, EPI_STORE>(c, g, true, s)) return r;
-    launch_sample_talker<T>(st, (const T*)c->logits, t.vocab, c->seen, c->talker_wave, s);
+    launch_sample_talker<T>(st, (const T*)c->logits, t.vocab, c->seen, G, c->talker_wave, s);
     return 0;
 }
 static int enqueue_frame(fq3_ctx* c, hipStream_t s) {

@@ -29,7 +29,7 @@ struct fq3_batch {
     hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr;
     std::vector<void*> allocs;
-    int use_mfma = 0;             // FQ3_BATCH_MFMA=1: bf16 GEMVs on the matrix cores (not bit-identical to single-stream)
+    int use_mfma = 0;             // fq3_batch_set_option("mfma", 1): bf16 GEMVs on the matrix cores (not bit-identical to single-stream)
 };
 
 static int bmalloc(fq3_batch* b, void** p, size_t bytes) {
@@ -110,9 +110,15 @@ extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** 
     if (hipStreamCreateWithFlags(&b->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "hipStreamCreateWithFlags");
     }
-    if (const char* e = getenv("FQ3_BATCH_MFMA")) b->use_mfma = atoi(e);
     *out = b;
     return FQ3_OK;
+}
+
+extern "C" int fq3_batch_set_option(fq3_batch* b, const char* key, int value) {
+    if (!b || !key) return fq3_fail_(FQ3_EINVAL, "null argument");
+    if (std::string(key) == "mfma") b->use_mfma = value;      // bf16 GEMVs on the matrix cores (fp32 summation order differs from the single-stream kernels)
+    else return fq3_fail_(FQ3_EINVAL, std::string("unknown batch option: ") + key);
+    return fq3_batch_graph_reset(b);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -277,8 +283,8 @@ static int enqueue_batch_frame_t(fq3_batch* b, hipStream_t s) {
     g.norm_w = c->wt.talker_final_norm; g.y = b->logits; g.y_stride = t.vocab;
     for (int l = 0; l < B; ++l) g.xn_out[l] = b->tab.past_hidden[l];
     if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, g, s)) return r;
-    if (t.vocab <= 2048) hipLaunchKernelGGL((sample_talker_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, b->tab, (const T*)b->logits, t.vocab);
-    else hipLaunchKernelGGL((sample_talker_batch_kernel<T, 2>), dim3(B), dim3(256), 0, s, b->tab, (const T*)b->logits, t.vocab);
+    if (t.vocab <= 2048) hipLaunchKernelGGL((sample_talker_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, b->tab, (const T*)b->logits, t.vocab, G);
+    else hipLaunchKernelGGL((sample_talker_batch_kernel<T, 2>), dim3(B), dim3(256), 0, s, b->tab, (const T*)b->logits, t.vocab, G);
     return 0;
 }
 

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void sample_api_kernel(const T* logits, int V,
     __shared__ unsigned char seen_l[kMaxVocab];
     for (int i = threadIdx.x; i < V; i += 256) { sm.vals[i] = DT<T>::ld(logits + i); seen_l[i] = 0; }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_hist; i += 256) seen_l[(int)history[i]] = 1;
+    for (int i = threadIdx.x; i < n_hist; i += 256) { const int id = (int)history[i]; if (id >= 0 && id < V) seen_l[id] = 1; }
     __syncthreads();
     const int tok = sample_core<T>(sm, V, c, n_hist > 0 ? seen_l : nullptr, noise);
     if (threadIdx.x == 0) out[0] = tok;
@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256) void sample_pred_kernel(const DecodeState* st,
     }
     for (int i = threadIdx.x; i < V; i += 256) sm.vals[i] = DT<T>::ld(logits + i);
     __syncthreads();
-    const int tok = sample_core<T>(sm, V, c, nullptr, noise);
+    int tok = sample_core<T>(sm, V, c, nullptr, noise);
+    if (st) tok = forced_or(st, frame * G + 1 + cb, tok);
     if (threadIdx.x == 0) {
         if (codes) codes[(size_t)frame * G + 1 + cb] = tok;
         if (out64) out64[cb] = tok;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void sample_pred_kernel(const DecodeState* st,
 // ---- talker sampler at the end of a frame (generate.py:184-199) -----------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void sample_talker_kernel(DecodeState* st, const T* logits, int V,
-                                                            const unsigned char* seen) {
+                                                            const unsigned char* seen, int G) {
     if (st->done) return;
     __shared__ SampleSmem sm;
     SampleCfg c;
@@ -229,8 +230,9 @@ __global__ __launch_bounds__(256) void sample_talker_kernel(DecodeState* st, con
         ? reinterpret_cast<const T*>(st->talker_noise) + (size_t)(frame % st->noise_frames) * V : nullptr;
     for (int i = threadIdx.x; i < V; i += 256) sm.vals[i] = DT<T>::ld(logits + i);
     __syncthreads();
-    const int tok = sample_core<T>(sm, V, c, seen, noise);
+    int tok = sample_core<T>(sm, V, c, seen, noise);
     __syncthreads();
+    tok = forced_or(st, (frame + 1) * G, tok);
     if (threadIdx.x == 0) {
         st->token = tok; st->frame = frame + 1; st->pos += 1; st->gen_step += 1;
     }

@@ -184,7 +184,8 @@ __device__ __forceinline__ void sample_pred_wave_body(const DecodeState* st, con
         if (st->pred_noise)
             noise = reinterpret_cast<const T*>(st->pred_noise) + ((size_t)(frame % st->noise_frames) * (G - 1) + cb) * V;
     }
-    const int tok = sample_wave_core<T, NC>(xraw, V, c, nullptr, noise, sm);
+    int tok = sample_wave_core<T, NC>(xraw, V, c, nullptr, noise, sm);
+    if (st) tok = forced_or(st, frame * G + 1 + cb, tok);
     if (threadIdx.x == 0) {
         if (codes) codes[(size_t)frame * G + 1 + cb] = tok;
         if (out64) out64[cb] = tok;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void sample_pred_wave_kernel(const DecodeState
 }
 
 template <typename T, int NC>
-__device__ __forceinline__ void sample_talker_wave_body(DecodeState* st, const T* logits, int V, const unsigned char* seen) {
+__device__ __forceinline__ void sample_talker_wave_body(DecodeState* st, const T* logits, int V, const unsigned char* seen, int G) {
     __shared__ BlkSmem sm;
     Raw8<T> xraw[NC];
     issue_logits<T, NC>(xraw, logits, V);
@@ -222,13 +223,14 @@ __device__ __forceinline__ void sample_talker_wave_body(DecodeState* st, const T
     c.sup_extra = (frame + 1 < st->min_new) ? st->eos_id : -1;
     const T* noise = st->talker_noise
         ? reinterpret_cast<const T*>(st->talker_noise) + (size_t)(frame % st->noise_frames) * V : nullptr;
-    const int tok = sample_wave_core<T, NC>(xraw, V, c, seen, noise, sm);
+    int tok = sample_wave_core<T, NC>(xraw, V, c, seen, noise, sm);
+    tok = forced_or(st, (frame + 1) * G, tok);
     if (threadIdx.x == 0) { st->token = tok; st->frame = frame + 1; st->pos += 1; st->gen_step += 1; }
 }
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void sample_talker_wave_kernel(DecodeState* st, const T* logits, int V,
-                                                                const unsigned char* seen) {
-    sample_talker_wave_body<T, NC>(st, logits, V, seen);
+                                                                const unsigned char* seen, int G) {
+    sample_talker_wave_body<T, NC>(st, logits, V, seen, G);
 }
 
 }  // namespace fq3

@@ -72,6 +72,7 @@ SIGNATURES = {
     "fq3_ctx_create": (C.c_int, [C.POINTER(Config), C.POINTER(vp)]),
     "fq3_ctx_destroy": (C.c_int, [vp]),
     "fq3_bind_weights": (C.c_int, [vp, C.POINTER(WeightTable)]),
+    "fq3_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "fq3_kv_import": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp]),
     "fq3_kv_export": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp]),
     "fq3_set_generation_state": (C.c_int, [vp, C.c_int, C.c_int]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "fq3_sample": (C.c_int, [vp, vp, C.c_int, C.POINTER(Sampling), vp, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_int, vp, vp, vp]),
     "fq3_decode_begin": (C.c_int, [vp, C.POINTER(DecodeParams), vp]),
+    "fq3_decode_set_forced": (C.c_int, [vp, vp, vp, vp]),
     "fq3_decode_frames": (C.c_int, [vp, C.c_int, vp]),
     "fq3_decode_poll": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]),
     "fq3_decode_codes": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
@@ -95,6 +97,7 @@ SIGNATURES = {
     "fq3_batch_frames": (C.c_int, [vp, C.c_int, vp]),
     "fq3_batch_graph_capture": (C.c_int, [vp, vp]),
     "fq3_batch_graph_reset": (C.c_int, [vp]),
+    "fq3_batch_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "fq3_codec_create": (C.c_int, [C.POINTER(CodecConfig), C.POINTER(vp)]),
     "fq3_codec_destroy": (C.c_int, [vp]),
     "fq3_codec_bind": (C.c_int, [vp, C.c_char_p, vp, C.c_int64]),
@@ -127,7 +130,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = ABI drift; let it surface
         fn.restype = res
         fn.argtypes = args
-    if lib.fq3_abi_version() != 1:
+    if lib.fq3_abi_version() != 2:
         raise ImportError("libfq3hip ABI version mismatch")
     _lib = lib
     return lib

@@ -199,6 +199,18 @@ class Fq3Engine:
                                      hid.data_ptr(), self._stream()))
         return logits, hid
 
+    def set_option(self, key: str, value: int):
+        """Kernel-variant switch (``fq3_set_option``): weight_nt, pred_m2, pred_attn, rows_per_wave_max, prefill_mode."""
+        L.check(self.lib.fq3_set_option(self.ctx, key.encode(), int(value)))
+
+    def decode_set_forced(self, forced: Optional[torch.Tensor], decisions: Optional[torch.Tensor]):
+        """Teacher-forcing test hook (``fq3_decode_set_forced``): int32 device tensors [frames + 1, 16] or None."""
+        for t in (forced, decisions):
+            if t is not None and (t.dtype != torch.int32 or not t.is_contiguous() or not t.is_cuda):
+                raise ValueError("forced / decisions must be contiguous int32 device tensors")
+        self._forced_keep = (forced, decisions)
+        L.check(self.lib.fq3_decode_set_forced(self.ctx, _ptr(forced), _ptr(decisions), self._stream()))
+
     def set_prefill_mode(self, mode: int):
         """0 = MFMA prefill (default), 1 = token-by-token walk through the decode kernels (test hook)."""
         L.check(self.lib.fq3_set_prefill_mode(self.ctx, int(mode)))
@@ -341,6 +353,10 @@ class Fq3Batch:
 
     def graph_reset(self):
         L.check(self.lib.fq3_batch_graph_reset(self.handle))
+
+    def set_option(self, key: str, value: int):
+        """``fq3_batch_set_option``: "mfma" 0|1 (matrix-core batch GEMVs, bf16)."""
+        L.check(self.lib.fq3_batch_set_option(self.handle, key.encode(), int(value)))
 
     def close(self):
         if getattr(self, "handle", None) and self.handle.value:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FQ3_ABI_VERSION 1
+#define FQ3_ABI_VERSION 2
 
 enum { FQ3_BF16 = 0, FQ3_F32 = 1 };
 enum { FQ3_OK = 0, FQ3_EINVAL = -1, FQ3_EHIP = -2, FQ3_ESTATE = -3, FQ3_ETOOLONG = -4, FQ3_EUNSUPPORTED = -5 };
@@ -97,6 +97,12 @@ int fq3_abi_version(void);
  * predictor_graph.py:34-76): allocates static KV caches, I/O buffers and scratch on the current device. */
 int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out);
 int fq3_ctx_destroy(fq3_ctx* ctx);
+
+/* Kernel-variant switches, all parity-tested both ways (no reference equivalent; the defaults are the measured-fastest):
+ *   "weight_nt" 0|1|2 (non-temporal weight loads: none | talker | all), "pred_m2" 0|1 (predictor two-token prefill as one
+ *   M = 2 pass), "pred_attn" 0|1 (one-wave predictor attention), "rows_per_wave_max" 1|2, "prefill_mode" 0|1.
+ * Resets a captured graph. */
+int fq3_set_option(fq3_ctx* ctx, const char* key, int value);
 
 /* Replaces the module references the graph objects keep (predictor_graph.py:52-58, talker_graph.py:40). */
 int fq3_bind_weights(fq3_ctx* ctx, const fq3_weight_table* table);
@@ -168,8 +174,14 @@ typedef struct fq3_decode_params {
     int32_t noise_frames;        /* rows in the noise rings; frame f reads row f % noise_frames */
 } fq3_decode_params;
 
-/* Arms the on-device loop state (token, position, history bitmap, counters). */
+/* Arms the on-device loop state (token, position, history bitmap, counters).  Asynchronous: `p` is consumed before
+ * the call returns, the buffers it points to must stay alive until the loop has finished. */
 int fq3_decode_begin(fq3_ctx* ctx, const fq3_decode_params* p, void* stream);
+/* Parity-test hook (teacher forcing; the shape of the reference's own relation tests, tests/test_e2e_parity.py:414-427,
+ * applied decision by decision): after fq3_decode_begin, every sampler of the loop records ITS OWN id in
+ * decisions[f][j] and continues with forced_codes[f][j] instead (both device int32[n_frames + 1][16]: [f][0] = the
+ * first-codebook id of frame f, [f][1 + cb] = predictor codebook cb).  NULL, NULL switches it off. */
+int fq3_decode_set_forced(fq3_ctx* ctx, const int32_t* forced_codes, int32_t* decisions, void* stream);
 /* Enqueue n_frames iterations of the loop body; each is one hipGraph replay once
  * fq3_graph_capture() has run (talker_graph.py:109-147, predictor_graph.py:169-202), otherwise the
  * same kernels are launched directly.  Frames after EOS / limits are no-ops on device. */
@@ -198,6 +210,8 @@ int fq3_batch_size(const fq3_batch* b);
 int fq3_batch_frames(fq3_batch* b, int n_frames, void* stream);
 int fq3_batch_graph_capture(fq3_batch* b, void* stream);
 int fq3_batch_graph_reset(fq3_batch* b);
+/* "mfma" 0|1: batch GEMVs on the matrix cores (bf16 contexts). */
+int fq3_batch_set_option(fq3_batch* b, const char* key, int value);
 
 /* ---- 12 Hz codec decoder (speech_tokenizer.decode, model.py:924) ---------------------------- */
 typedef struct fq3_codec fq3_codec;

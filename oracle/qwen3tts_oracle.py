@@ -250,6 +250,8 @@ class OracleTTS:
         self.pred_sampling = dict(do_sample=True, top_k=50, top_p=1.0, temperature=0.9)
         self.margins: List[float] = []        # top-2 logit gap of every first-codebook decision
         self.pred_margins: List[float] = []   # same for every predictor decision (15 per frame)
+        self.top1: List[float] = []           # winning logit of every first-codebook decision (scale for ulp attribution)
+        self.pred_top1: List[float] = []
 
     # ---- talker ----------------------------------------------------------------------
     def prefill(self, embeds: torch.Tensor, attention_mask: torch.Tensor):
@@ -298,7 +300,7 @@ class OracleTTS:
         toks, all_logits = [], []
         logits = F.linear(h[-1:], self.W[f"{pre}.lm_head.0.weight"])       # [1, Vp]
         all_logits.append(logits[0])
-        self.pred_margins.append(self._margin(logits))
+        self.pred_margins.append(self._margin(logits)); self.pred_top1.append(float(logits.float().max()))
         tok = sample_logits(logits, noise=None if noise is None else noise[0], **self.pred_sampling)
         toks.append(tok[0])
         for cb in range(1, nc):
@@ -308,7 +310,7 @@ class OracleTTS:
                               torch.tensor([1.0 + cb]))
             logits = F.linear(h[-1:], self.W[f"{pre}.lm_head.{cb}.weight"])
             all_logits.append(logits[0])
-            self.pred_margins.append(self._margin(logits))
+            self.pred_margins.append(self._margin(logits)); self.pred_top1.append(float(logits.float().max()))
             tok = sample_logits(logits, noise=None if noise is None else noise[cb], **self.pred_sampling)
             toks.append(tok[0])
         out = torch.stack(toks).to(torch.long)
@@ -335,8 +337,7 @@ class OracleTTS:
         sm = build_suppress_mask(V, eos)
         kw = dict(temperature=sp.temperature, top_k=sp.top_k, top_p=sp.top_p, do_sample=sp.do_sample)
         logits, past_hidden, gen_step, prefill_len = self.prefill(tie, tam)
-        self.margins = []
-        self.pred_margins = []
+        self.margins, self.pred_margins, self.top1, self.pred_top1 = [], [], [], []
         if record_margins:
             self._record_margin(logits, sm, [eos] if sp.min_new_tokens > 0 else None)
         token = sample_logits(logits.view(1, -1), suppress_mask=sm,
@@ -382,6 +383,7 @@ class OracleTTS:
             l[list(sup)] = float("-inf")
         top2 = torch.topk(l, 2)[0]
         self.margins.append(float(top2[0] - top2[1]))
+        self.top1.append(float(top2[0]))
 
 
 def stream_chunks(codes: Optional[torch.Tensor], chunk_size: int):

@@ -397,18 +397,18 @@ def test_real_layer_shapes_bf16_close():
 
 
 @pytest.mark.parametrize("m2", ["0", "1"])
-def test_predictor_two_token_prefill_modes(monkeypatch, m2):
-    """FQ3_M2=1: the predictor's two-token prefill is one M=2 pass over the weights; FQ3_M2=0 (default): two
+def test_predictor_two_token_prefill_modes(m2):
+    """pred_m2=1 (default): the predictor's two-token prefill is one M=2 pass over the weights; 0: two
     single-token passes.  Both must reproduce the oracle (fp32 exact ids, logits to 5e-4), also for a model with
     the small_to_mtp projection."""
     from oracle import qwen3tts_oracle as O
-    monkeypatch.setenv("FQ3_M2", m2)
     for cfg in (tiny_test_config(), tiny_test_config(hidden=512, pred_hidden=256)):
         dtype = torch.float32
         W = synth_weights(cfg, 0, dtype)
         orc = O.OracleTTS(cfg, W, max_seq_len=96)
         orc.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
         eng = _engine(cfg, W, dtype)
+        eng.set_option("pred_m2", int(m2))
         eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
         g = torch.Generator().manual_seed(23)
         for _ in range(2):
@@ -420,17 +420,17 @@ def test_predictor_two_token_prefill_modes(monkeypatch, m2):
 
 
 @pytest.mark.parametrize("mode", ["0", "1"])
-def test_predictor_attention_kernel_variants(monkeypatch, mode):
-    """FQ3_PRED_ATTN=1 (default): single-wave register-only attention for the code predictor; 0: the generic
+def test_predictor_attention_kernel_variants(mode):
+    """pred_attn=1 (default): single-wave register-only attention for the code predictor; 0: the generic
     split-KV kernel.  Same ids / logits (fp32), for plain and projection models, bf16 close."""
     from oracle import qwen3tts_oracle as O
-    monkeypatch.setenv("FQ3_PRED_ATTN", mode)
     for cfg in (tiny_test_config(), tiny_test_config(hidden=512, pred_hidden=256)):
         for dtype in (torch.float32, torch.bfloat16):
             W = synth_weights(cfg, 0, dtype)
             orc = O.OracleTTS(cfg, W, max_seq_len=96)
             orc.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
             eng = _engine(cfg, W, dtype)
+            eng.set_option("pred_attn", int(mode))
             eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
             x = torch.randn(1, 2, cfg.talker.hidden_size, generator=torch.Generator().manual_seed(29)).to(dtype)
             o_ids, o_logits = orc.predictor_loop(x, return_logits=True)

@@ -101,3 +101,16 @@ def test_streaming_vocoder_windowing_matches_full_decode_early():
     parts = list(O.streaming_vocode(tok, chunks, None, 8))
     full = tok.decode({"audio_codes": codes.unsqueeze(0)})[0][0].numpy()
     assert np.abs(np.concatenate(parts) - full).max() < 2e-4
+
+
+def test_fulldepth_golden_is_the_oracle(golden_dir):
+    """tests/golden/fulldepth.npz (the ids the GPU full-depth parity tests are scored against) is reproduced by the
+    oracle: regenerate the first frames of the 0.6B fp32 case at full depth and compare ids and margins."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(golden_dir), "..", "oracle"))
+    from oracle import make_golden_fulldepth as M
+    g = np.load(os.path.join(golden_dir, "fulldepth.npz"))
+    r, _ = M.run_case("0p6b", torch.float32, frames=3)
+    assert np.array_equal(r["codes"], g["0p6b_f32_codes"][:3])
+    assert np.allclose(r["t_margin"][:3], g["0p6b_f32_t_margin"][:3], atol=1e-4)
+    assert np.allclose(r["p_top1"], g["0p6b_f32_p_top1"][:3], atol=1e-4)

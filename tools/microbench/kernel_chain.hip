@@ -269,7 +269,7 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL((sample_pred_wave_kernel<bf16_t, 1>), dim3(1), dim3(256), 0, st, (const DecodeState*)st_dev, (const bf16_t*)logits, Vp, i % 15, pc,
                                (const bf16_t*)nullptr, codes, 16, (int64_t*)nullptr, (const bf16_t*)emb, (bf16_t*)bufA, H); });
         chain("sample sample_talker_wave_kernel<2> V=3072 top_k=50 rep 1.05", N, [&](int) {
-            hipLaunchKernelGGL((sample_talker_wave_kernel<bf16_t, 2>), dim3(1), dim3(256), 0, st, st_dev, (const bf16_t*)logits, Vt, (const unsigned char*)seen); });
+            hipLaunchKernelGGL((sample_talker_wave_kernel<bf16_t, 2>), dim3(1), dim3(256), 0, st, st_dev, (const bf16_t*)logits, Vt, (const unsigned char*)seen, 16); });
         CHK(hipMemcpy(st_dev, &hs, sizeof hs, hipMemcpyHostToDevice));
     }
     if (want("layer")) {
