@@ -558,6 +558,28 @@ extern "C" int fq3_sample(fq3_ctx* c, const void* logits, int V, const fq3_sampl
     return FQ3_OK;
 }
 
+// apply_repetition_penalty (sampling.py:10-29) as a standalone in-place operation on a logits row
+template <typename T>
+__global__ __launch_bounds__(256) void rep_penalty_kernel(T* logits, int V, const unsigned char* seen, float penalty) {
+    for (int i = threadIdx.x; i < V; i += 256) {
+        if (!seen[i]) continue;
+        const float v = DT<T>::ld(logits + i);
+        DT<T>::st(logits + i, v > 0.f ? v / penalty : v * penalty);
+    }
+}
+extern "C" int fq3_apply_repetition_penalty(fq3_ctx* c, void* logits, int V, const int64_t* history, int n_hist,
+                                            float penalty, void* stream) {
+    if (!c || !logits) return fail(FQ3_EINVAL, "null argument");
+    if (V <= 0 || V > kMaxVocab) return fail(FQ3_EUNSUPPORTED, "vocab must be at most 4096");
+    if (penalty == 1.0f || n_hist <= 0 || !history) return FQ3_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(build_seen_kernel, dim3(1), dim3(256), 0, s, history, n_hist, c->seen_api, V);
+    if (c->cfg.dtype == FQ3_BF16) hipLaunchKernelGGL((rep_penalty_kernel<bf16_t>), dim3(1), dim3(256), 0, s, (bf16_t*)logits, V, c->seen_api, penalty);
+    else hipLaunchKernelGGL((rep_penalty_kernel<float>), dim3(1), dim3(256), 0, s, (float*)logits, V, c->seen_api, penalty);
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
 extern "C" int fq3_set_predictor_sampling(fq3_ctx* c, const fq3_sampling* s) {
     if (!c || !s) return fail(FQ3_EINVAL, "null argument");
     if (s->do_sample && !(s->temperature > 0.f)) return fail(FQ3_EINVAL, "temperature must be > 0");

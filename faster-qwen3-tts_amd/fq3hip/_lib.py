@@ -84,6 +84,7 @@ SIGNATURES = {
     "fq3_predictor_loop": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "fq3_sample": (C.c_int, [vp, vp, C.c_int, C.POINTER(Sampling), vp, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_int, vp, vp, vp]),
+    "fq3_apply_repetition_penalty": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, vp]),
     "fq3_decode_begin": (C.c_int, [vp, C.POINTER(DecodeParams), vp]),
     "fq3_decode_set_forced": (C.c_int, [vp, vp, vp, vp]),
     "fq3_decode_frames": (C.c_int, [vp, C.c_int, vp]),

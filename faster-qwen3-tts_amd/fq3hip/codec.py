@@ -104,14 +104,36 @@ class HipSpeechTokenizer:
     def num_samples(self, n_frames: int) -> int:
         return int(self.lib.fq3_codec_num_samples(self.h, int(n_frames)))
 
-    def decode_tensor(self, codes: torch.Tensor) -> torch.Tensor:
-        """codes LongTensor[T, 16] -> float32 waveform tensor on the device."""
-        codes = codes.to(device=self.device, dtype=torch.long).contiguous()
+    # upstream decodes long inputs in pieces (transformers sibling ``chunked_decode``,
+    # modeling_qwen3_omni_moe.py:3686-3696: chunk_size=300, left_context_size=25)
+    CHUNK_FRAMES = 300
+    LEFT_CONTEXT = 25
+
+    def _decode_piece(self, codes: torch.Tensor) -> torch.Tensor:
         Tn = codes.shape[0]
         pcm = torch.empty(self.num_samples(Tn), dtype=torch.float32, device=self.device)
         L.check(self.lib.fq3_codec_decode(self.h, codes.data_ptr(), int(Tn), pcm.data_ptr(),
                                           torch.cuda.current_stream(self.device).cuda_stream))
         return pcm
+
+    def decode_tensor(self, codes: torch.Tensor) -> torch.Tensor:
+        """codes LongTensor[T, 16] -> float32 waveform tensor on the device.  Any T: inputs longer than the chunk size
+        are decoded piecewise with a 25-frame left context, as upstream ``chunked_decode`` does."""
+        codes = codes.to(device=self.device, dtype=torch.long).contiguous()
+        Tn = codes.shape[0]
+        ctx_max = min(self.LEFT_CONTEXT, max(0, self.max_frames - 1))
+        chunk = min(self.CHUNK_FRAMES, self.max_frames - ctx_max)
+        if Tn <= chunk:
+            return self._decode_piece(codes)
+        up = self.cfg.total_upsample
+        wavs, start = [], 0
+        while start < Tn:
+            end = min(start + chunk, Tn)
+            ctx = ctx_max if start - ctx_max > 0 else start
+            w = self._decode_piece(codes[start - ctx:end].contiguous())
+            wavs.append(w[ctx * up:])
+            start = end
+        return torch.cat(wavs)
 
     def decode(self, payload):
         codes = payload["audio_codes"]

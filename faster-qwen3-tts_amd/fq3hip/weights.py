@@ -55,8 +55,12 @@ def _stack(w: Weights, g: _Gen, prefix: str, c: StackConfig):
     w[f"{prefix}.norm.weight"] = g.gain(H)
 
 
-def _codec(w: Weights, g: _Gen, c: CodecConfig):
+def _codec(w: Weights, g: _Gen, c: CodecConfig, normalized: bool = False):
+    """``normalized``: damp the residual branches (conv2 x 0.3) so that activations stay O(1) through the 12 residual units
+    -- like a trained vocoder, and unlike the default variance-doubling trunk whose O(100) SnakeBeta phases make the
+    waveform chaotic in bf16 -- and size the output conv for a PCM std of ~0.1."""
     p = "decoder"
+    rg = 0.3 if normalized else 1.0
     nq, ns = c.num_quantizers, c.num_semantic_quantizers
     for name, n in (("rvq_first", ns), ("rvq_rest", nq - ns)):
         for j in range(n):
@@ -118,21 +122,21 @@ def _codec(w: Weights, g: _Gen, c: CodecConfig):
             w[f"{u}.conv1.conv.bias"] = g.normal(cout, std=0.02)
             w[f"{u}.act2.alpha"] = g.normal(cout, std=0.1)
             w[f"{u}.act2.beta"] = g.normal(cout, std=0.1)
-            w[f"{u}.conv2.conv.weight"] = g.normal(cout, cout, 1, std=cout ** -0.5)
-            w[f"{u}.conv2.conv.bias"] = g.normal(cout, std=0.02)
+            w[f"{u}.conv2.conv.weight"] = g.normal(cout, cout, 1, std=cout ** -0.5) * rg
+            w[f"{u}.conv2.conv.bias"] = g.normal(cout, std=0.02) * rg
     n = len(c.upsample_rates)
     cl = D // 2 ** n
     w[f"{d}.{n + 1}.alpha"] = g.normal(cl, std=0.1)
     w[f"{d}.{n + 1}.beta"] = g.normal(cl, std=0.1)
     # the synthetic trunk has O(50) activations at its end; scale the output conv so PCM stays inside
     # [-1, 1] (std ~0.15) and the final clamp does not hide kernel errors from the parity tests
-    w[f"{d}.{n + 2}.conv.weight"] = g.normal(1, cl, 7, std=(cl * 7) ** -0.5 * 0.0033)
+    w[f"{d}.{n + 2}.conv.weight"] = g.normal(1, cl, 7, std=(cl * 7) ** -0.5 * (0.06 if normalized else 0.0033))
     w[f"{d}.{n + 2}.conv.bias"] = g.normal(1, std=0.01)
 
 
 def synth_weights(cfg: TTSConfig, seed: int = 0, dtype: torch.dtype = torch.bfloat16,
                   device: str = "cpu", parts: Iterable[str] = ("talker", "predictor", "codec"),
-                  ) -> Weights:
+                  codec_normalized: bool = False) -> Weights:
     """Seeded synthetic weights.  Each part has its own generator stream so that
     ``parts`` does not change the values of the parts that are generated."""
     w: Weights = {}
@@ -162,7 +166,7 @@ def synth_weights(cfg: TTSConfig, seed: int = 0, dtype: torch.dtype = torch.bflo
         w["talker.text_projection.linear_fc2.weight"] = g.linear(t.hidden_size, th)
         w["talker.text_projection.linear_fc2.bias"] = g.normal(t.hidden_size, std=0.02)
     if "codec" in parts:
-        _codec(w, _Gen(seed * 1000 + 4), cfg.codec)
+        _codec(w, _Gen(seed * 1000 + 4), cfg.codec, normalized=codec_normalized)
     return {k: v.to(dtype=dtype).to(device) for k, v in w.items()}
 
 
@@ -215,7 +219,9 @@ def load_hf_checkpoint(path: str, dtype: torch.dtype = torch.bfloat16, device: s
                 for k, v in load_file(os.path.join(d, fn)).items():
                     if strip and k.startswith(strip):
                         k = k[len(strip):]
-                    w[k] = v.to(dtype=dtype if v.is_floating_point() else v.dtype).to(device)
+                    # the EuclideanCodebook statistics stay fp32 until the division below (upstream divides in fp32)
+                    keep32 = k.endswith("._codebook.embedding_sum") or k.endswith("._codebook.cluster_usage")
+                    w[k] = v.to(dtype=(torch.float32 if keep32 else dtype) if v.is_floating_point() else v.dtype).to(device)
 
     ingest(path)
     if os.path.isdir(tok_dir):
@@ -225,6 +231,7 @@ def load_hf_checkpoint(path: str, dtype: torch.dtype = torch.bfloat16, device: s
         base = k[: -len("embedding_sum")]
         usage = w[base + "cluster_usage"].float().clamp(min=1e-5)
         w[base + "embedding"] = (w[k].float() / usage[:, None]).to(dtype)
+        del w[k], w[base + "cluster_usage"]
     required = ["talker.model.codec_embedding.weight", "talker.codec_head.weight", "talker.model.norm.weight"]
     missing = [k for k in required if k not in w]
     if missing:

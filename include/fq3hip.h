@@ -156,6 +156,10 @@ int fq3_sample(fq3_ctx* ctx, const void* logits, int V, const fq3_sampling* s, c
                int n_hist, int sup_lo, int sup_hi, int keep_id, int suppress_eos, const void* noise,
                int64_t* out_token, void* stream);
 
+/* apply_repetition_penalty (sampling.py:10-29) alone, in place on logits T[V]: ids in history get x/p (x > 0) or x*p. */
+int fq3_apply_repetition_penalty(fq3_ctx* ctx, void* logits, int V, const int64_t* history, int n_hist, float penalty,
+                                 void* stream);
+
 /* ---- fused on-device decode loop (generate.py:149-199 / streaming.py:106-154) -------------- */
 
 typedef struct fq3_decode_params {

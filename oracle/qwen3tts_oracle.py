@@ -526,6 +526,21 @@ def codec_decode(codes: torch.Tensor, W: Weights, c) -> torch.Tensor:
     return h.clamp(min=-1, max=1).reshape(-1)
 
 
+def codec_chunked_decode(codes: torch.Tensor, W: Weights, c, chunk_size: int = 300, left_context_size: int = 25) -> torch.Tensor:
+    """modeling ``:3686-3696`` (``chunked_decode``): long inputs are decoded in ``chunk_size``-frame pieces, each with up
+    to ``left_context_size`` frames of left context whose ``context * total_upsample`` samples are dropped.  One piece
+    (T <= chunk_size) is the plain decode."""
+    T = codes.shape[0]
+    wavs, start = [], 0
+    while start < T:
+        end = min(start + chunk_size, T)
+        ctx = left_context_size if start - left_context_size > 0 else start
+        w = codec_decode(codes[start - ctx:end], W, c)
+        wavs.append(w[ctx * c.total_upsample:])
+        start = end
+    return torch.cat(wavs)
+
+
 class OracleSpeechTokenizer:
     """Duck type of upstream ``speech_tokenizer`` as the reference calls it
     (``model.py:924``; payload shape pinned by reference ``tests/test_sample_rate.py:53-75``)."""
@@ -536,7 +551,7 @@ class OracleSpeechTokenizer:
 
     def decode(self, payload):
         codes = payload["audio_codes"]
-        return [codec_decode(codes[b], self.W, self.cfg.codec) for b in range(codes.shape[0])], self.sample_rate
+        return [codec_chunked_decode(codes[b], self.W, self.cfg.codec) for b in range(codes.shape[0])], self.sample_rate
 
 
 def streaming_vocode(tok, chunks, ref_codes, chunk_size, context_frames: int = 25):

@@ -58,10 +58,91 @@ def test_codec_lengths_and_oracle_fp32(T):
         assert _rms(w2 - wav[: len(w2)]) <= 1e-4
 
 
-def test_codec_too_many_frames():
+def test_codec_single_piece_limit_is_an_abi_error():
+    """The C entry point refuses more frames than its workspace holds (the host wrapper never asks for that)."""
     from fq3hip.codec import HipSpeechTokenizer
     cfg = tiny_test_config()
     W = synth_weights(cfg, 0, torch.bfloat16, parts=("codec",))
     tok = HipSpeechTokenizer(cfg.codec, W, "cuda", torch.bfloat16, max_frames=8)
     with pytest.raises(RuntimeError):
-        tok.decode_tensor(torch.zeros(9, 16, dtype=torch.long, device="cuda"))
+        tok._decode_piece(torch.zeros(9, 16, dtype=torch.long, device="cuda"))
+
+
+def test_codec_longer_than_workspace_is_chunked_like_upstream():
+    """T > max_frames: decoded piecewise with a 25-frame left context, the upstream ``chunked_decode``
+    scheme (transformers sibling modeling_qwen3_omni_moe.py:3686-3696), equal to the oracle's restatement of it."""
+    from fq3hip.codec import HipSpeechTokenizer
+    from oracle import qwen3tts_oracle as O
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, torch.float32, parts=("codec",))
+    tok = HipSpeechTokenizer(cfg.codec, W, "cuda", torch.float32, max_frames=64)       # -> pieces of 39 + 25 context
+    g = torch.Generator().manual_seed(9)
+    codes = torch.randint(0, cfg.codec.codebook_size, (100, cfg.codec.num_quantizers), generator=g)
+    ref = O.codec_chunked_decode(codes, W, cfg.codec, chunk_size=39, left_context_size=25).numpy()
+    wavs, _ = tok.decode({"audio_codes": codes.unsqueeze(0).cuda()})
+    wav = wavs[0].cpu().numpy()
+    assert wav.shape == ref.shape
+    assert _rms(wav - ref) <= 1e-4
+
+
+# ---- the shapes bench.py runs (latent 1024, decoder_dim 1536, 8 layers, head_dim 64, window 72) -------------------
+def _real_codec(dtype, max_frames=208):
+    from fq3hip.codec import HipSpeechTokenizer
+    from fq3hip.config import qwen3_tts_0p6b
+    cfg = qwen3_tts_0p6b()
+    W = synth_weights(cfg, 0, dtype, parts=("codec",), codec_normalized=True)
+    return cfg, HipSpeechTokenizer(cfg.codec, W, "cuda", dtype, max_frames=max_frames)
+
+
+@pytest.mark.parametrize("T", [40, 100])
+def test_codec_real_shapes_fp32(T, golden_dir):
+    """fp32 context vs the fp32 oracle golden at the real shapes: RMS <= 1e-4 (north-star bound 1e-3).  T = 100 > the
+    sliding window (72), head_dim 64, decoder_dim 1536."""
+    g = np.load(os.path.join(golden_dir, "codec_real.npz"))
+    cfg, tok = _real_codec(torch.float32)
+    codes = torch.from_numpy(g[f"codes_{T}"].astype(np.int64))
+    wav = tok.decode_tensor(codes.cuda()).cpu().numpy()
+    ref = g[f"pcm_f32_{T}"]
+    assert wav.shape == ref.shape
+    err = _rms(wav - ref)
+    print(f"[parity] codec real shapes fp32 T={T}: RMS {err:.3e} (signal RMS {_rms(ref):.3f})")
+    assert err <= 1e-4, err
+
+
+@pytest.mark.parametrize("T", [40, 100])
+def test_codec_real_shapes_bf16(T, golden_dir):
+    """bf16 context at the real shapes, measured against BOTH oracles.  The north star's 1e-3 is not reachable by any
+    bf16 evaluation of this network: the oracle's own bf16 run is 8.4e-3 RMS (5 % of the signal) from its fp32 run on
+    these normalised weights (oracle/make_golden_codec_real.py).  The gate is therefore relative to that floor: the HIP
+    bf16 waveform must be no further from the fp32 truth than 1.25 x the oracle's bf16 waveform is, and closer to the
+    bf16 oracle (same rounding points) than the two oracles are to each other."""
+    g = np.load(os.path.join(golden_dir, "codec_real.npz"))
+    cfg, tok = _real_codec(torch.bfloat16)
+    codes = torch.from_numpy(g[f"codes_{T}"].astype(np.int64))
+    wav = tok.decode_tensor(codes.cuda()).cpu().numpy()
+    ref32 = g[f"pcm_f32_{T}"]
+    refb = torch.from_numpy(g[f"pcm_bf16bits_{T}"]).view(torch.bfloat16).float().numpy()
+    floor = _rms(refb - ref32)
+    d32, db = _rms(wav - ref32), _rms(wav - refb)
+    print(f"[parity] codec real shapes bf16 T={T}: HIP-vs-fp32-oracle {d32:.3e}, HIP-vs-bf16-oracle {db:.3e}, "
+          f"oracle bf16-vs-fp32 floor {floor:.3e}")
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, f"parity_codec_bf16_T{T}.txt"), "w") as f:
+        f.write(f"hip_vs_f32 {d32:.4e}\nhip_vs_bf16 {db:.4e}\noracle_floor {floor:.4e}\n")
+    assert d32 <= 1.25 * floor and db <= floor, (d32, db, floor)
+
+
+def test_codec_real_shapes_causal_prefix_property():
+    """Size-independent property at the benchmark's full length (T = 200, fp32 and bf16): the decoder is causal, so the
+    waveform of a prefix of the codes is BIT-IDENTICAL to the prefix of the waveform (what streaming relies on)."""
+    for dtype in (torch.float32, torch.bfloat16):
+        cfg, tok = _real_codec(dtype)
+        g = torch.Generator().manual_seed(77)
+        codes = torch.randint(0, cfg.codec.codebook_size, (200, cfg.codec.num_quantizers), generator=g).cuda()
+        full = tok.decode_tensor(codes)
+        for n in (73, 120):
+            part = tok.decode_tensor(codes[:n].contiguous())
+            assert torch.equal(part, full[: part.numel()]), (dtype, n)
+        assert float(full.abs().max()) <= 1.0 and float(full.std()) > 0.05
+        tok.close()
