@@ -121,15 +121,15 @@ class HipSpeechTokenizer:
         are decoded piecewise with a 25-frame left context, as upstream ``chunked_decode`` does."""
         codes = codes.to(device=self.device, dtype=torch.long).contiguous()
         Tn = codes.shape[0]
-        ctx_max = min(self.LEFT_CONTEXT, max(0, self.max_frames - 1))
-        chunk = min(self.CHUNK_FRAMES, self.max_frames - ctx_max)
-        if Tn <= chunk:
+        if Tn <= min(self.CHUNK_FRAMES, self.max_frames):
             return self._decode_piece(codes)
         up = self.cfg.total_upsample
         wavs, start = [], 0
         while start < Tn:
-            end = min(start + chunk, Tn)
-            ctx = ctx_max if start - ctx_max > 0 else start
+            ctx = self.LEFT_CONTEXT if start - self.LEFT_CONTEXT > 0 else start
+            ctx = min(ctx, self.max_frames - 1)
+            # upstream: CHUNK_FRAMES new frames per piece; a workspace smaller than 325 frames shortens the pieces
+            end = min(start + min(self.CHUNK_FRAMES, self.max_frames - ctx), Tn)
             w = self._decode_piece(codes[start - ctx:end].contiguous())
             wavs.append(w[ctx * up:])
             start = end

@@ -8,7 +8,7 @@ of the 16 x N decisions is scored under an identical history, instead of stoppin
 decision-level form of the relation the reference's own tests pin (tests/test_e2e_parity.py:414-427: fast path ids ==
 upstream ids under greedy decoding).
 
-A mismatch is *attributed to a near-tie* when the oracle's top-2 margin at that decision is below ``k_ulp`` bf16 ulps
+A mismatch is *attributed to a near-tie* when the oracle's top-2 margin at that decision is at most ``k_ulp`` bf16 ulps
 of the winning logit (ulp = 2^(floor(log2|x|) - 7)); fp32 contexts must match everywhere.
 """
 from __future__ import annotations
@@ -68,7 +68,7 @@ def score(decisions: np.ndarray, case: dict, k_ulp: float):
     m_ulp = margin / bf16_ulp(top1)
     bad = decisions != codes
     worst = float(m_ulp[bad].max()) if bad.any() else 0.0
-    unexplained = int((bad & (m_ulp >= k_ulp)).sum())
+    unexplained = int((bad & (m_ulp > k_ulp)).sum())
     return dict(total=int(codes.size), matched_decisions=int((~bad).sum()), frames=N,
                 matched_frames=int((~bad).all(axis=1).sum()), worst_mismatch_ulp=round(worst, 3),
                 smallest_margin_ulp=round(float(m_ulp.min()), 3), unexplained=unexplained, k_ulp=k_ulp)

@@ -75,7 +75,8 @@ def test_codec_longer_than_workspace_is_chunked_like_upstream():
     from oracle import qwen3tts_oracle as O
     cfg = tiny_test_config()
     W = synth_weights(cfg, 0, torch.float32, parts=("codec",))
-    tok = HipSpeechTokenizer(cfg.codec, W, "cuda", torch.float32, max_frames=64)       # -> pieces of 39 + 25 context
+    tok = HipSpeechTokenizer(cfg.codec, W, "cuda", torch.float32, max_frames=64)
+    tok.CHUNK_FRAMES = 39                                                               # pieces of 39 new + 25 context frames
     g = torch.Generator().manual_seed(9)
     codes = torch.randint(0, cfg.codec.codebook_size, (100, cfg.codec.num_quantizers), generator=g)
     ref = O.codec_chunked_decode(codes, W, cfg.codec, chunk_size=39, left_context_size=25).numpy()
