@@ -2,8 +2,19 @@
 // context dtype T, so every dense contraction (1x1 / k7 dilated / transposed convs, Linear layers) is
 // ONE implicit-GEMM kernel on the matrix cores: A rows are time rows gathered at per-tap offsets,
 // B is the pre-packed weight [N][taps*Cin].  bf16 uses v_mfma_f32_16x16x32_bf16, fp32 (parity mode)
-// uses the exact v_mfma_f32_16x16x4_f32.  Everything else (RVQ gather, norms, SnakeBeta, depthwise
-// conv, RoPE, sliding-window attention) is HBM-bound row work with 16-byte accesses.
+// uses the exact v_mfma_f32_16x16x4_f32.  Everything else (RVQ gather, norms, depthwise conv, RoPE,
+// sliding-window attention, output conv) is HBM/L2-bound row work.
+//
+// Round-2 structure (codec):
+//   * every op works on a ROW RANGE [m_lo, M): the decoder is causal with a finite receptive field after the
+//     transformer, so a streaming chunk only recomputes the rows its new samples depend on (fq3_codec.hip plans the
+//     ranges); a row's arithmetic does not depend on where the range starts, so a tail decode is bit-identical to the
+//     tail of a full decode;
+//   * SnakeBeta is an EPILOGUE of the producing GEMM (second output), computed once per element from per-channel
+//     constants prepared at bind time, instead of a separate elementwise pass in front of every conv;
+//   * SwiGLU is an epilogue of the [gate|up] GEMM (weights interleaved in 16-row groups at pack time);
+//   * the GEMM is tile-shape templated (128x128 ... 64x32) with double-buffered LDS (one barrier per K step) and the
+//     host picks the shape per layer so that skinny or narrow layers still fill the chip.
 // Rounding points follow the Torch module execution of the sibling implementation
 // (transformers modeling_qwen3_omni_moe.py:3180-3263, :3542-3696): one rounding to T per op output.
 #pragma once
@@ -17,26 +28,48 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 constexpr int kMaxTaps = 8;
 struct GemmArgs {
     const void* A; int lda; int M; int a_rows;        // rows outside [0, a_rows) read as zeros (causal left pad)
+    int m_lo;                                         // rows [m_lo, M) are computed
     int n_taps; int tap_off[kMaxTaps]; int Cin;       // K = n_taps * Cin; A row of (m, tap) = m + tap_off[tap]
     const void* W; int N;                             // packed weight [N][K]
     const void* bias; int bias_mod;                   // bias[n % bias_mod] (bias_mod = Cout for transposed convs)
     const void* scale;                                // optional per-n multiplier after the activation
     const void* res; int ldr;                         // optional residual [M][ldr]
-    void* Y; int ldy;
-    int act;                                          // 0 none, 1 exact GELU
+    void* Y; int ldy;                                 // primary output (may be null when only Y2 is wanted)
+    int act;                                          // 0 none, 1 exact GELU, 2 SwiGLU over 16-column [gate|up] groups
+    const void* sn_a; const void* sn_ib; void* Y2;    // optional second output: SnakeBeta(stored value), channel n % bias_mod
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// 64x64 output tile per workgroup (4 waves as 2x2, each wave 32x32 = 2x2 MFMA tiles), K step 32.
+// SnakeBeta on an already T-rounded value, each Torch op rounded to T (modeling :3566-3580):
+// x + (1 / (exp(beta) + 1e-9)) * sin(x * exp(alpha))^2; a = rnd(exp(alpha)), ib = rnd(1 / rnd(rnd(exp(beta)) + 1e-9))
 template <typename T>
+__device__ __forceinline__ float snake_apply(float v, float a, float ib) {
+    const float s = DT<T>::rnd(sinf(DT<T>::rnd(v * a)));
+    return v + DT<T>::rnd(ib * DT<T>::rnd(s * s));
+}
+template <typename T>
+__global__ void snake_consts_kernel(const T* alpha, const T* beta, T* a_out, T* ib_out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float a = DT<T>::rnd(expf(DT<T>::ld(alpha + c)));
+    const float b = DT<T>::rnd(expf(DT<T>::ld(beta + c)));
+    DT<T>::st(a_out + c, a);
+    DT<T>::st(ib_out + c, DT<T>::rnd(1.0f / DT<T>::rnd(b + 1e-9f)));
+}
+
+// BM x BN output tile per workgroup, 4 waves as 2 x 2, each wave (BM/2) x (BN/2) = TM x TN MFMA tiles, K step 32,
+// double-buffered LDS.  grid = (ceil(N / BN), ceil((M - m_lo) / BM)).
+template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
-    constexpr int BM = 64, BN = 64, BK = 32;
-    constexpr int LDS_LD = BK + (sizeof(T) == 2 ? 8 : 4);      // padded row (elements): breaks the 64/128-byte stride
-    __shared__ __attribute__((aligned(16))) T As[BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) T Bs[BN * LDS_LD];
+    constexpr int BK = 32;
+    constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 4);          // padded LDS row (elements): breaks the 64/128-byte stride
+    constexpr int TM = BM / 32, TN = BN / 32;
+    static_assert(TM >= 1 && TN >= 1, "tile too small");
+    __shared__ __attribute__((aligned(16))) T As[2][BM * LD];
+    __shared__ __attribute__((aligned(16))) T Bs[2][BN * LD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = a.m_lo + blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wr = wave >> 1, wc = wave & 1;
     const int K = a.n_taps * a.Cin;
     const T* A = reinterpret_cast<const T*>(a.A);
@@ -44,92 +77,157 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     constexpr int EPT = 16 / sizeof(T);                 // elements per 16-byte access
     constexpr int TPR = BK / EPT;                       // threads per tile row
     constexpr int RPP = 256 / TPR;                      // rows per pass
-    constexpr int NPASS = BM / RPP;
-    f32x4_t acc[2][2];
+    constexpr int NPA = (BM + RPP - 1) / RPP, NPB = (BN + RPP - 1) / RPP;
+    f32x4_t acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int lr = tid / TPR, lc = (tid % TPR) * EPT;
-    u32x4 areg[NPASS], breg[NPASS];
+    u32x4 areg[NPA], breg[NPB];
     auto gload = [&](int k0) {
         const int tap = k0 / a.Cin, ci = k0 - tap * a.Cin;
         const int toff = a.tap_off[tap];
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
+        for (int p = 0; p < NPA; ++p) {
             const int r = lr + p * RPP;
             const int m = m0 + r, ar = m + toff;
             areg[p] = u32x4{0u, 0u, 0u, 0u};
-            if (m < a.M && ar >= 0 && ar < a.a_rows)
+            if (r < BM && m < a.M && ar >= 0 && ar < a.a_rows)
                 areg[p] = *reinterpret_cast<const u32x4*>(A + (size_t)ar * a.lda + ci + lc);
+        }
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) {
+            const int r = lr + p * RPP;
             const int n = n0 + r;
             breg[p] = u32x4{0u, 0u, 0u, 0u};
-            if (n < a.N) breg[p] = *reinterpret_cast<const u32x4*>(W + (size_t)n * K + k0 + lc);
+            if (r < BN && n < a.N) breg[p] = *reinterpret_cast<const u32x4*>(W + (size_t)n * K + k0 + lc);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NPA; ++p) {
+            const int r = lr + p * RPP;
+            if (r < BM) *reinterpret_cast<u32x4*>(&As[buf][r * LD + lc]) = areg[p];
+        }
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) {
+            const int r = lr + p * RPP;
+            if (r < BN) *reinterpret_cast<u32x4*>(&Bs[buf][r * LD + lc]) = breg[p];
         }
     };
     gload(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            const int r = lr + p * RPP;
-            *reinterpret_cast<u32x4*>(As + r * LDS_LD + lc) = areg[p];
-            *reinterpret_cast<u32x4*>(Bs + r * LDS_LD + lc) = breg[p];
-        }
-        __syncthreads();
-        if (k0 + BK < K) gload(k0 + BK);                // next tile's loads fly under the MFMAs
-        const int fr = lane & 15, fq = lane >> 4;
+    lstore(0);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += BK, buf ^= 1) {
+        const bool more = k0 + BK < K;
+        if (more) gload(k0 + BK);                       // next tile's global loads fly under the MFMAs
+        const T* as = As[buf];
+        const T* bs = Bs[buf];
         if constexpr (sizeof(T) == 2) {
-            bf16x8_t af[2], bfr[2];
+            bf16x8_t af[TM], bfr[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8_t*>(As + (wr * 32 + i * 16 + fr) * LDS_LD + fq * 8);
-                bfr[i] = *reinterpret_cast<const bf16x8_t*>(Bs + (wc * 32 + i * 16 + fr) * LDS_LD + fq * 8);
-            }
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(as + (wr * (BM / 2) + i * 16 + fr) * LD + fq * 8);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(bs + (wc * (BN / 2) + j * 16 + fr) * LD + fq * 8);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 4) {
-                float af[2], bfr[2];
+                float af[TM], bfr[TN];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i] = reinterpret_cast<const float*>(As)[(wr * 32 + i * 16 + fr) * LDS_LD + kk + fq];
-                    bfr[i] = reinterpret_cast<const float*>(Bs)[(wc * 32 + i * 16 + fr) * LDS_LD + kk + fq];
-                }
+                for (int i = 0; i < TM; ++i) af[i] = reinterpret_cast<const float*>(as)[(wr * (BM / 2) + i * 16 + fr) * LD + kk + fq];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < TN; ++j) bfr[j] = reinterpret_cast<const float*>(bs)[(wc * (BN / 2) + j * 16 + fr) * LD + kk + fq];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
         }
+        if (more) lstore(buf ^ 1);                      // the other buffer was last read before the previous barrier
+        __syncthreads();
     }
     // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
     T* Y = reinterpret_cast<T*>(a.Y);
+    T* Y2 = reinterpret_cast<T*>(a.Y2);
+    if (a.act == 2) {
+        // SwiGLU: tile j even = gate columns, j odd = the matching up columns (16-row interleave of the packed weight)
+        if constexpr (TN >= 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wc * 32 + j * 16 + (lane & 15);
+                for (int j = 0; j < TN; j += 2) {
+                    const int np = n0 + wc * (BN / 2) + j * 16;             // physical column of the gate tile
+                    if (np >= a.N) continue;
+                    const int no = np / 2 + (lane & 15);                    // logical output column
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                        if (m >= a.M) continue;
+                        const float g = DT<T>::rnd(acc[i][j][r]), u = DT<T>::rnd(acc[i][j + 1][r]);
+                        DT<T>::st(Y + (size_t)m * a.ldy + no, DT<T>::rnd(g / (1.0f + expf(-g))) * u);
+                    }
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * (BN / 2) + j * 16 + (lane & 15);
             if (n >= a.N) continue;
-            const float b = a.bias ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + (n % a.bias_mod)) : 0.f;
+            const int ch = n % a.bias_mod;
+            const float b = a.bias ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + ch) : 0.f;
             const float sc = a.scale ? DT<T>::ld(reinterpret_cast<const T*>(a.scale) + n) : 1.f;
+            float sa = 0.f, sib = 0.f;
+            if (Y2) { sa = DT<T>::ld(reinterpret_cast<const T*>(a.sn_a) + ch); sib = DT<T>::ld(reinterpret_cast<const T*>(a.sn_ib) + ch); }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r;
+                const int m = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
                 if (m >= a.M) continue;
                 float v = DT<T>::rnd(acc[i][j][r] + b);
                 if (a.act == 1) v = DT<T>::rnd(gelu_exact(v));
                 if (a.scale) v = DT<T>::rnd(sc * v);
                 if (a.res) v = v + DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)m * a.ldr + n);
-                DT<T>::st(Y + (size_t)m * a.ldy + n, v);
+                v = DT<T>::rnd(v);
+                if (Y) DT<T>::st(Y + (size_t)m * a.ldy + n, v);
+                if (Y2) DT<T>::st(Y2 + (size_t)m * a.ldy + n, snake_apply<T>(v, sa, sib));
             }
         }
+}
+
+// ---- host-side launch: tile shape per layer ---------------------------------------------------------------------
+template <typename T, int BM, int BN>
+inline void gemm_go(const GemmArgs& a, hipStream_t s) {
+    dim3 grid((a.N + BN - 1) / BN, (a.M - a.m_lo + BM - 1) / BM);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), grid, dim3(256), 0, s, a);
+}
+template <typename T>
+inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
+    const int rows = a.M - a.m_lo;
+    if (rows <= 0) return;
+    if constexpr (sizeof(T) == 4) { gemm_go<T, 64, 64>(a, s); return; }      // fp32 = parity mode, one shape
+    else {
+        auto wgs = [&](int bm, int bn) { return (long)((rows + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+        // largest tile that still gives every CU two workgroups; narrow outputs (N = 96) avoid half-empty column tiles
+        const bool n128 = a.N % 128 == 0 || a.N >= 1024, n64 = a.N % 64 == 0 || a.N >= 512;
+        if (n128 && wgs(128, 128) >= 512) gemm_go<T, 128, 128>(a, s);
+        else if (n64 && wgs(128, 64) >= 512) gemm_go<T, 128, 64>(a, s);
+        else if (a.act != 2 && !n64 && wgs(128, 32) >= 256) gemm_go<T, 128, 32>(a, s);
+        else if (n64 && (wgs(64, 64) >= 256 || a.act == 2)) gemm_go<T, 64, 64>(a, s);
+        else if (a.act == 2) gemm_go<T, 64, 64>(a, s);
+        else gemm_go<T, 64, 32>(a, s);
+    }
 }
 
 // ---- RVQ: sequential (rounded) sum of codebook rows; one block per frame ------------------------------
@@ -150,10 +248,10 @@ __global__ void rvq_gather_kernel(RvqArgs a, const int64_t* codes, T* first, T* 
     }
 }
 
-// ---- row norms: one wave per row ------------------------------------------------------------------------
+// ---- row norms: one wave per row, rows [row_lo, rows) ---------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const T* x, const T* w, T* y, int rows, int C, float eps) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const T* x, const T* w, T* y, int row_lo, int rows, int C, float eps) {
+    const int row = row_lo + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const T* xr = x + (size_t)row * C;
     float ss = 0.f;
@@ -165,8 +263,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const T* x, const T* 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void layernorm_rows_kernel(const T* x, const T* w, const T* b, T* y, int rows, int C, float eps) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const T* x, const T* w, const T* b, T* y, int row_lo, int rows, int C, float eps) {
+    const int row = row_lo + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const T* xr = x + (size_t)row * C;
     float s = 0.f;
@@ -179,25 +277,10 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const T* x, const T
         DT<T>::st(y + (size_t)row * C + c, (DT<T>::ld(xr + c) - mean) * rstd * DT<T>::ld(w + c) + DT<T>::ld(b + c));
 }
 
-// ---- elementwise ------------------------------------------------------------------------------------------
-// SnakeBeta: x + 1/(exp(beta)+1e-9) * sin(x*exp(alpha))^2, each Torch op rounded to T (modeling :3566-3580)
+// causal depthwise conv k=7 over time, channels-last, rows [row_lo, rows)
 template <typename T>
-__global__ void snake_kernel(const T* x, const T* alpha, const T* beta, T* y, size_t n, int C) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i % C);
-    const float a = DT<T>::rnd(expf(DT<T>::ld(alpha + c)));
-    const float b = DT<T>::rnd(expf(DT<T>::ld(beta + c)));
-    const float ib = DT<T>::rnd(1.0f / DT<T>::rnd(b + 1e-9f));
-    const float v = DT<T>::ld(x + i);
-    const float s = DT<T>::rnd(sinf(DT<T>::rnd(v * a)));
-    DT<T>::st(y + i, v + DT<T>::rnd(ib * DT<T>::rnd(s * s)));
-}
-
-// causal depthwise conv k=7 over time, channels-last
-template <typename T>
-__global__ void dwconv7_kernel(const T* x, const T* w /*[C][7]*/, const T* b, T* y, int rows, int C) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void dwconv7_kernel(const T* x, const T* w /*[C][7]*/, const T* b, T* y, int row_lo, int rows, int C) {
+    const size_t i = (size_t)row_lo * C + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)rows * C) return;
     const int t = (int)(i / C), c = (int)(i % C);
     float acc = 0.f;
@@ -210,7 +293,7 @@ __global__ void dwconv7_kernel(const T* x, const T* w /*[C][7]*/, const T* b, T*
 }
 
 template <typename T>
-__global__ void silu_mul_kernel(const T* gu, T* y, int rows, int I) {     // gu [rows][2I] = gate | up
+__global__ void silu_mul_kernel(const T* gu, T* y, int rows, int I) {     // gu [rows][2I] = gate | up (not interleaved)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)rows * I) return;
     const int r = (int)(i / I), c = (int)(i % I);
@@ -233,47 +316,92 @@ __global__ void rope_rows_kernel(T* qkv, const float* cos_tab, const float* sin_
     DT<T>::st(p + j + half, DT<T>::rnd(x1 * cs) + DT<T>::rnd(x0 * sn));
 }
 
-// causal sliding-window attention, one wave per (query, head); head_dim <= 128; fp32 math, one rounding
-template <typename T>
-__global__ __launch_bounds__(256) void swa_attn_kernel(const T* qkv, T* out, int Tn, int NH, int HD, int window, float scale) {
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y, lane = threadIdx.x & 63;
-    if (q >= Tn) return;
+// Causal sliding-window attention, one wave per (query, head), head_dim in {32, 64, 128}, window <= 128; fp32 math, one
+// rounding.  Scores: one KEY per lane (the lane reads its key row with 16-byte loads, q is broadcast from LDS);
+// softmax across lanes; P.V: one (or two) head dims per lane, looping over the window with the probability broadcast by
+// v_readlane.  ~8x fewer instructions than a wave-wide reduction per key.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void swa_attn_kernel(const T* qkv, T* out, int Tn, int NH, int window, float scale) {
+    constexpr int NCH = HD / 8;
+    __shared__ float qs[4][HD];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + wave, h = blockIdx.y;
     const int QD = NH * HD;
-    const T* qp = qkv + (size_t)q * 3 * QD + (size_t)h * HD;
-    const float q0 = lane < HD ? DT<T>::ld(qp + lane) : 0.f;
-    const float q1 = lane + 64 < HD ? DT<T>::ld(qp + lane + 64) : 0.f;
-    float m = -1e30f, l = 0.f, o0 = 0.f, o1 = 0.f;
-    const int k_lo = max(0, q - window + 1);
-    for (int k = k_lo; k <= q; ++k) {
-        const T* kp = qkv + (size_t)k * 3 * QD + QD + (size_t)h * HD;
-        const T* vp = kp + QD;
-        float s = (lane < HD ? q0 * DT<T>::ld(kp + lane) : 0.f) + (lane + 64 < HD ? q1 * DT<T>::ld(kp + lane + 64) : 0.f);
-        s = wave_sum(s) * scale;
-        const float mn = fmaxf(m, s), al = __expf(m - mn), p = __expf(s - mn);
-        l = l * al + p;
-        o0 = o0 * al + (lane < HD ? p * DT<T>::ld(vp + lane) : 0.f);
-        o1 = o1 * al + (lane + 64 < HD ? p * DT<T>::ld(vp + lane + 64) : 0.f);
-        m = mn;
+    const bool live = q < Tn;
+    const int qq = live ? q : Tn - 1;
+    const T* qp = qkv + (size_t)qq * 3 * QD + (size_t)h * HD;
+    for (int d = lane; d < HD; d += 64) qs[wave][d] = DT<T>::ld(qp + d);
+    __syncthreads();
+    if (!live) return;
+    const int k_lo = max(0, q - window + 1), nk = q - k_lo + 1;       // nk in [1, window]
+    float sc[2], p[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int j = ps * 64 + lane;
+        const int kk = k_lo + (j < nk ? j : 0);
+        const T* kp = qkv + (size_t)kk * 3 * QD + QD + (size_t)h * HD;
+        Raw8<T> kr[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) ldraw<false>(kr[c], kp + c * 8);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float kf[8];
+            unpack(kr[c], kf);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s = fmaf(qs[wave][c * 8 + i], kf[i], s);
+        }
+        sc[ps] = j < nk ? s * scale : -INFINITY;
+    }
+    const float mx = wave_max(fmaxf(sc[0], sc[1]));
+    p[0] = __expf(sc[0] - mx); p[1] = __expf(sc[1] - mx);
+    const float l = wave_sum(p[0] + p[1]);
+    float o0 = 0.f, o1 = 0.f;
+    const T* vbase = qkv + (size_t)k_lo * 3 * QD + 2 * QD + (size_t)h * HD;
+#pragma unroll 8
+    for (int j = 0; j < nk; ++j) {
+        const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j < 64 ? p[0] : p[1]), j & 63));
+        const T* vp = vbase + (size_t)j * 3 * QD;
+        if (HD >= 64 || lane < HD) o0 = fmaf(pj, DT<T>::ld(vp + (lane < HD ? lane : 0)), o0);
+        if (HD > 64) o1 = fmaf(pj, DT<T>::ld(vp + lane + 64), o1);
     }
     T* op = out + (size_t)q * QD + (size_t)h * HD;
     if (lane < HD) DT<T>::st(op + lane, o0 / l);
-    if (lane + 64 < HD) DT<T>::st(op + lane + 64, o1 / l);
+    if (HD > 64) DT<T>::st(op + lane + 64, o1 / l);
 }
 
-// final causal conv k=7, C -> 1, + clamp to [-1, 1]; fp32 PCM out.  One wave per 64 output samples.
+// Output conv k=7, C -> 1, + clamp to [-1, 1]; fp32 PCM out for samples [t_lo, rows), written to pcm[t - t_lo].
+// One workgroup per 128 samples: the 134 x C input window and the 7 x C weights are staged in LDS once (rows padded to
+// an odd number of words: conflict-free), two threads per sample split the channels.
+constexpr int kFinalSpw = 128;
 template <typename T>
-__global__ __launch_bounds__(256) void final_conv_kernel(const T* x, const T* w /*[7][C]*/, const T* b, float* pcm, int rows, int C) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= rows) return;
-    float acc = 0.f;
-    for (int k = 0; k < 7; ++k) {
-        const int tt = t - 6 + k;
-        if (tt < 0) continue;
-        const T* xr = x + (size_t)tt * C;
-        for (int c = 0; c < C; ++c) acc = fmaf(DT<T>::ld(w + k * C + c), DT<T>::ld(xr + c), acc);
+__global__ __launch_bounds__(256) void final_conv_kernel(const T* x, const T* w /*[7][C]*/, const T* b, float* pcm, int t_lo, int rows, int C) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    const int pitch = C | 1;                                  // floats per staged row (odd)
+    float* xs = fsm;                                          // [kFinalSpw + 6][pitch]
+    float* ws = fsm + (kFinalSpw + 6) * pitch;                // [7][C]
+    const int t0 = t_lo + blockIdx.x * kFinalSpw;
+    for (int e = threadIdx.x; e < (kFinalSpw + 6) * C; e += 256) {
+        const int r = e / C, c = e - r * C, tt = t0 - 6 + r;
+        xs[r * pitch + c] = (tt >= 0 && tt < rows) ? DT<T>::ld(x + (size_t)tt * C + c) : 0.f;
     }
-    float v = DT<T>::rnd(acc + DT<T>::ld(b));
-    pcm[t] = fminf(1.f, fmaxf(-1.f, v));
+    for (int e = threadIdx.x; e < 7 * C; e += 256) ws[e] = DT<T>::ld(w + e);
+    __syncthreads();
+    const int s = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int c0 = half * (C / 2), c1 = half ? C : C / 2;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const float* xr = xs + (s + k) * pitch;
+        const float* wr = ws + k * C;
+        for (int c = c0; c < c1; ++c) acc = fmaf(wr[c], xr[c], acc);
+    }
+    acc += dpp_move<kDppXor1, 0xF>(0.f, acc);                 // the two halves of a sample sit in adjacent lanes
+    const int t = t0 + s;
+    if (half == 0 && t < rows) {
+        const float v = DT<T>::rnd(acc + DT<T>::ld(b));
+        pcm[t - t_lo] = fminf(1.f, fmaxf(-1.f, v));
+    }
 }
 
 }  // namespace fq3

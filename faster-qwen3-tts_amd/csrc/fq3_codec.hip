@@ -10,21 +10,30 @@
 //   depthwise    "<p>.dwconv.conv.weight" [C][7]
 //   final conv   "decoder.decoder.<n>.conv.weight" [7][C]
 //   RVQ proj     "<p>.output_proj.weight" [codebook_dim][rvq_dim]
-//   q/k/v        "<p>.self_attn.qkv.weight" [3*QD][hidden];  gate/up "<p>.mlp.gate_up.weight" [2*I][hidden]
+//   q/k/v        "<p>.self_attn.qkv.weight" [3*QD][hidden]
+//   gate/up      "<p>.mlp.gate_up.weight" [2*I][hidden], rows interleaved in groups of 16: gate[16b..16b+16), up[16b..16b+16)
 //   rope tables  "rope.cos" / "rope.sin"  fp32 [max_frames][head_dim/2]
+//
+// A decode is planned as a list of row-range ops (see Plan below): the transformer runs over all T frames (its
+// receptive field is the whole prefix), everything after it only over the rows the requested samples depend on.
 #include "../../include/fq3hip.h"
 #include "codec_kernels.cuh"
 
+#include <algorithm>
+#include <climits>
 #include <cmath>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
 
 using namespace fq3;
 
-static thread_local std::string g_cerr;
 extern "C" const char* fq3_last_error(void);
-static int cfail(int code, const std::string& m);
+// share the error string with the decode TU through a tiny setter exported from fq3_api.hip
+extern "C" void fq3_set_error_(const char* msg);
+static int cfail(int code, const std::string& m) { fq3_set_error_(m.c_str()); return code; }
+#define CHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return cfail(FQ3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct fq3_codec {
     fq3_codec_config cfg{};
@@ -33,13 +42,10 @@ struct fq3_codec {
     std::map<std::string, int64_t> wn;
     void* buf[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t buf_elems = 0;
+    void* snake_consts = nullptr;                 // per-channel SnakeBeta constants (a, ib), built at finalize
+    std::map<std::string, std::pair<const void*, const void*>> snake;     // "<prefix>" -> (a, ib)
     bool ready = false;
 };
-
-// share the error string with the decode TU through a tiny setter exported from fq3_api.hip
-extern "C" void fq3_set_error_(const char* msg);
-static int cfail(int code, const std::string& m) { fq3_set_error_(m.c_str()); return code; }
-#define CHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return cfail(FQ3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 static int64_t samples_for(const fq3_codec_config& c, int64_t T) {
     int64_t n = T;
@@ -54,7 +60,9 @@ extern "C" int fq3_codec_create(const fq3_codec_config* cfg, fq3_codec** out) {
     if (!cfg || !out) return cfail(FQ3_EINVAL, "null argument");
     if (cfg->dtype != FQ3_BF16 && cfg->dtype != FQ3_F32) return cfail(FQ3_EINVAL, "dtype");
     if (cfg->n_upsample < 0 || cfg->n_upsample > 4 || cfg->n_rates < 1 || cfg->n_rates > 8) return cfail(FQ3_EINVAL, "upsample lists");
-    if (cfg->num_quantizers > 32 || cfg->head_dim > 128 || cfg->head_dim % 2) return cfail(FQ3_EUNSUPPORTED, "codec dims");
+    if (cfg->num_quantizers > 32) return cfail(FQ3_EUNSUPPORTED, "codec dims");
+    if (cfg->head_dim != 32 && cfg->head_dim != 64 && cfg->head_dim != 128) return cfail(FQ3_EUNSUPPORTED, "codec head_dim must be 32, 64 or 128");
+    if (cfg->sliding_window < 1 || cfg->sliding_window > 128) return cfail(FQ3_EUNSUPPORTED, "codec sliding_window must be in 1..128");
     auto m32 = [](int v) { return v % 32 == 0; };
     int ch = cfg->decoder_dim;
     bool ok = m32(cfg->rvq_dim) && m32(cfg->codebook_dim) && m32(cfg->latent_dim) && m32(cfg->hidden) && m32(cfg->inter) &&
@@ -84,6 +92,7 @@ extern "C" int fq3_codec_destroy(fq3_codec* c) {
     if (!c) return FQ3_OK;
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 4; ++i) if (c->buf[i]) (void)hipFree(c->buf[i]);
+    if (c->snake_consts) (void)hipFree(c->snake_consts);
     delete c;
     return FQ3_OK;
 }
@@ -102,7 +111,21 @@ static int need(fq3_codec* c, const std::string& n, int64_t numel, const void** 
     return 0;
 }
 
-extern "C" int fq3_codec_finalize(fq3_codec* c, void* /*stream*/) {
+// every SnakeBeta of the decoder: (prefix of its alpha/beta tensors, channels)
+static std::vector<std::pair<std::string, int>> snake_sites(const fq3_codec_config& g) {
+    std::vector<std::pair<std::string, int>> v;
+    int ch = g.decoder_dim;
+    for (int i = 0; i < g.n_rates; ++i) {
+        const std::string b = "decoder.decoder." + std::to_string(i + 1) + ".block.";
+        v.push_back({b + "0.", ch});
+        ch /= 2;
+        for (int j = 2; j <= 4; ++j) { v.push_back({b + std::to_string(j) + ".act1.", ch}); v.push_back({b + std::to_string(j) + ".act2.", ch}); }
+    }
+    v.push_back({"decoder.decoder." + std::to_string(g.n_rates + 1) + ".", ch});
+    return v;
+}
+
+extern "C" int fq3_codec_finalize(fq3_codec* c, void* stream) {
     if (!c) return cfail(FQ3_EINVAL, "null codec");
     const auto& g = c->cfg;
     const int QD = g.n_heads * g.head_dim;
@@ -116,23 +139,55 @@ extern "C" int fq3_codec_finalize(fq3_codec* c, void* /*stream*/) {
     }
     if ((r = need(c, "decoder.pre_conv.conv.weight", (int64_t)g.latent_dim * 3 * g.codebook_dim, nullptr))) return r;
     if ((r = need(c, "decoder.pre_transformer.layers.0.self_attn.qkv.weight", (int64_t)3 * QD * g.hidden, nullptr))) return r;
+    if ((r = need(c, "decoder.pre_transformer.layers.0.mlp.gate_up.weight", (int64_t)2 * g.inter * g.hidden, nullptr))) return r;
+    if (g.inter % 16) return cfail(FQ3_EUNSUPPORTED, "codec intermediate size must be a multiple of 16");
     if ((r = need(c, "rope.cos", (int64_t)g.max_frames * (g.head_dim / 2), nullptr))) return r;
     if ((r = need(c, "rope.sin", (int64_t)g.max_frames * (g.head_dim / 2), nullptr))) return r;
+    // SnakeBeta constants: a = exp(alpha), ib = 1 / (exp(beta) + 1e-9), rounded like the Torch ops, once per bind
+    const auto sites = snake_sites(g);
+    size_t total = 0;
+    for (auto& s : sites) total += 2 * (size_t)s.second;
+    if (c->snake_consts) { (void)hipFree(c->snake_consts); c->snake_consts = nullptr; }
+    CHIP(hipMalloc(&c->snake_consts, total * c->esz));
+    size_t off = 0;
+    hipStream_t st = (hipStream_t)stream;
+    for (auto& s : sites) {
+        const void *al = nullptr, *be = nullptr;
+        if ((r = need(c, s.first + "alpha", s.second, &al)) || (r = need(c, s.first + "beta", s.second, &be))) return r;
+        char* base = (char*)c->snake_consts + off * c->esz;
+        void* pa = base; void* pib = base + (size_t)s.second * c->esz;
+        if (g.dtype == FQ3_BF16) hipLaunchKernelGGL((snake_consts_kernel<bf16_t>), dim3((s.second + 255) / 256), dim3(256), 0, st, (const bf16_t*)al, (const bf16_t*)be, (bf16_t*)pa, (bf16_t*)pib, s.second);
+        else hipLaunchKernelGGL((snake_consts_kernel<float>), dim3((s.second + 255) / 256), dim3(256), 0, st, (const float*)al, (const float*)be, (float*)pa, (float*)pib, s.second);
+        c->snake[s.first] = {pa, pib};
+        off += 2 * (size_t)s.second;
+    }
+    CHIP(hipStreamSynchronize(st));
     c->ready = true;
     return FQ3_OK;
 }
 
 namespace {
-struct Runner {
-    fq3_codec* c; hipStream_t s; int err = 0;
-    const void* W(const std::string& n) { const void* p = nullptr; if (!err) err = need(c, n, 0, &p); return p; }
-    template <typename T> void gemm(GemmArgs a) {
-        if (err) return;
-        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
-        hipLaunchKernelGGL((conv_gemm_kernel<T>), grid, dim3(256), 0, s, a);
-    }
+// ---- decode plan -----------------------------------------------------------------------------------------------
+// Tensors are logical values (ids); an op produces `out` (and optionally `out2`) for rows [lo, rows) and reads its inputs
+// at rows derived from lo.  need[] is propagated backwards from the requested first PCM sample.
+enum { DEP_SAME = 0, DEP_BACK = 1, DEP_DIV = 2, DEP_ALL = 3 };
+struct Dep { int t; int kind; int p; };
+struct Op {
+    int out = -1, out2 = -1;
+    std::vector<Dep> in;
+    int unit = 1;                        // rows of `out` per row of the launch (r for transposed convs)
+    std::function<void(int lo)> run;     // lo in launch rows (= out rows / unit)
 };
-template <typename T> static GemmArgs lin(const void* A, int M, int Kc, const void* W, int N, const void* bias, void* Y) {
+struct Plan {
+    std::vector<Op> ops;
+    int n_tensors = 0;
+    int tensor() { return n_tensors++; }
+    void add(Op&& o) { ops.push_back(std::move(o)); }
+};
+}  // namespace
+
+template <typename T>
+static GemmArgs lin(const void* A, int M, int Kc, const void* W, int N, const void* bias, void* Y) {
     GemmArgs a{}; a.A = A; a.lda = Kc; a.M = M; a.a_rows = M; a.n_taps = 1; a.tap_off[0] = 0; a.Cin = Kc; a.W = W; a.N = N;
     a.bias = bias; a.bias_mod = N; a.Y = Y; a.ldy = N; return a;
 }
@@ -141,107 +196,225 @@ static GemmArgs conv(const void* A, int rows, int Cin, const void* W, int Cout, 
     for (int i = 0; i < k; ++i) a.tap_off[i] = -(k - 1 - i) * dil;
     a.bias = bias; a.bias_mod = Cout; a.Y = Y; a.ldy = Cout; return a;
 }
-}  // namespace
 
 template <typename T>
-static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, float* pcm, hipStream_t s) {
+static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, int64_t first_sample, float* pcm, hipStream_t s) {
     const auto& g = c->cfg;
-    Runner R{c, s};
+    int err = 0;
+    auto W = [&](const std::string& n) -> const void* { const void* p = nullptr; if (!err) err = need(c, n, 0, &p); return p; };
+    auto SN = [&](const std::string& prefix) -> std::pair<const void*, const void*> {
+        auto it = c->snake.find(prefix);
+        if (it == c->snake.end()) { if (!err) err = cfail(FQ3_ESTATE, "snake constants missing: " + prefix); return {nullptr, nullptr}; }
+        return it->second;
+    };
     T* B0 = (T*)c->buf[0]; T* B1 = (T*)c->buf[1]; T* B2 = (T*)c->buf[2]; T* B3 = (T*)c->buf[3];
     const std::string D = "decoder.";
     auto el = [&](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
-    // ---- RVQ -------------------------------------------------------------------------------------------
+    Plan P;
+    auto gemm_op = [&](GemmArgs a, int out, int out2, std::vector<Dep> in, int unit = 1) {
+        Op o; o.out = out; o.out2 = out2; o.in = std::move(in); o.unit = unit;
+        o.run = [a, s](int lo) mutable { a.m_lo = lo; gemm_launch<T>(a, s); };
+        P.add(std::move(o));
+    };
+
+    // ---- frame-level front end: RVQ, pre_conv, transformer (all T rows: the attention stack sees the whole prefix) ----
     RvqArgs ra{}; ra.nq = g.num_quantizers; ra.n_first = g.num_semantic; ra.dim = g.rvq_dim;
     for (int j = 0; j < g.num_quantizers; ++j) {
         const bool first = j < g.num_semantic;
-        ra.books[j] = R.W(D + "quantizer." + (first ? "rvq_first" : "rvq_rest") + ".vq.layers." +
-                          std::to_string(first ? j : j - g.num_semantic) + "._codebook.embedding");
+        ra.books[j] = W(D + "quantizer." + (first ? "rvq_first" : "rvq_rest") + ".vq.layers." +
+                        std::to_string(first ? j : j - g.num_semantic) + "._codebook.embedding");
     }
-    if (R.err) return R.err;
-    T* qf = B1; T* qr = B1 + (size_t)Tn * g.rvq_dim;
-    hipLaunchKernelGGL((rvq_gather_kernel<T>), dim3(Tn), dim3(256), 0, s, ra, codes, qf, qr, Tn);
-    R.gemm<T>(lin<T>(qf, Tn, g.rvq_dim, R.W(D + "quantizer.rvq_first.output_proj.weight"), g.codebook_dim, nullptr, B0));
-    { GemmArgs a = lin<T>(qr, Tn, g.rvq_dim, R.W(D + "quantizer.rvq_rest.output_proj.weight"), g.codebook_dim, nullptr, B0);
-      a.res = B0; a.ldr = g.codebook_dim; R.gemm<T>(a); }
-    // ---- pre_conv (k=3) + transformer -------------------------------------------------------------------
-    R.gemm<T>(conv(B0, Tn, g.codebook_dim, R.W(D + "pre_conv.conv.weight"), g.latent_dim, R.W(D + "pre_conv.conv.bias"), B1, 3, 1));
-    const std::string TR = D + "pre_transformer.";
-    R.gemm<T>(lin<T>(B1, Tn, g.latent_dim, R.W(TR + "input_proj.weight"), g.hidden, R.W(TR + "input_proj.bias"), B0));   // x = B0
-    const int QD = g.n_heads * g.head_dim;
-    const float* cosT = (const float*)R.W("rope.cos"); const float* sinT = (const float*)R.W("rope.sin");
-    for (int i = 0; i < g.n_layers && !R.err; ++i) {
-        const std::string L = TR + "layers." + std::to_string(i) + ".";
-        hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Tn + 3) / 4), dim3(256), 0, s, (const T*)B0, (const T*)R.W(L + "input_layernorm.weight"), B1, Tn, g.hidden, g.rms_eps);
-        R.gemm<T>(lin<T>(B1, Tn, g.hidden, R.W(L + "self_attn.qkv.weight"), 3 * QD, nullptr, B2));
-        hipLaunchKernelGGL((rope_rows_kernel<T>), el((size_t)Tn * 2 * g.n_heads * (g.head_dim / 2)), dim3(256), 0, s, B2, cosT, sinT, Tn, QD, g.head_dim);
-        hipLaunchKernelGGL((swa_attn_kernel<T>), dim3((Tn + 3) / 4, g.n_heads), dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.head_dim, g.sliding_window, 1.0f / sqrtf((float)g.head_dim));
-        { GemmArgs a = lin<T>(B1, Tn, QD, R.W(L + "self_attn.o_proj.weight"), g.hidden, nullptr, B0);
-          a.scale = R.W(L + "self_attn_layer_scale.scale"); a.res = B0; a.ldr = g.hidden; R.gemm<T>(a); }
-        hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Tn + 3) / 4), dim3(256), 0, s, (const T*)B0, (const T*)R.W(L + "post_attention_layernorm.weight"), B1, Tn, g.hidden, g.rms_eps);
-        R.gemm<T>(lin<T>(B1, Tn, g.hidden, R.W(L + "mlp.gate_up.weight"), 2 * g.inter, nullptr, B2));
-        hipLaunchKernelGGL((silu_mul_kernel<T>), el((size_t)Tn * g.inter), dim3(256), 0, s, (const T*)B2, B1, Tn, g.inter);
-        { GemmArgs a = lin<T>(B1, Tn, g.inter, R.W(L + "mlp.down_proj.weight"), g.hidden, nullptr, B0);
-          a.scale = R.W(L + "mlp_layer_scale.scale"); a.res = B0; a.ldr = g.hidden; R.gemm<T>(a); }
+    if (err) return err;
+    const int t_front = P.tensor();            // everything up to the transformer output is one "all rows" tensor
+    {
+        Op o; o.out = t_front;
+        const void* w_first = W(D + "quantizer.rvq_first.output_proj.weight");
+        const void* w_rest = W(D + "quantizer.rvq_rest.output_proj.weight");
+        const void* w_pre = W(D + "pre_conv.conv.weight"); const void* b_pre = W(D + "pre_conv.conv.bias");
+        const std::string TR = D + "pre_transformer.";
+        const void* w_in = W(TR + "input_proj.weight"); const void* b_in = W(TR + "input_proj.bias");
+        const int QD = g.n_heads * g.head_dim;
+        const float* cosT = (const float*)W("rope.cos"); const float* sinT = (const float*)W("rope.sin");
+        struct LayerW { const void *ln1, *qkv, *o, *ls1, *ln2, *gu, *down, *ls2; };
+        std::vector<LayerW> LW(g.n_layers);
+        for (int i = 0; i < g.n_layers; ++i) {
+            const std::string L = TR + "layers." + std::to_string(i) + ".";
+            LW[i] = {W(L + "input_layernorm.weight"), W(L + "self_attn.qkv.weight"), W(L + "self_attn.o_proj.weight"),
+                     W(L + "self_attn_layer_scale.scale"), W(L + "post_attention_layernorm.weight"), W(L + "mlp.gate_up.weight"),
+                     W(L + "mlp.down_proj.weight"), W(L + "mlp_layer_scale.scale")};
+        }
+        const void* w_norm = W(TR + "norm.weight");
+        const void* w_out = W(TR + "output_proj.weight"); const void* b_out = W(TR + "output_proj.bias");
+        if (err) return err;
+        o.run = [=](int) {
+            T* qf = B1; T* qr = B1 + (size_t)Tn * g.rvq_dim;
+            hipLaunchKernelGGL((rvq_gather_kernel<T>), dim3(Tn), dim3(256), 0, s, ra, codes, qf, qr, Tn);
+            gemm_launch<T>(lin<T>(qf, Tn, g.rvq_dim, w_first, g.codebook_dim, nullptr, B0), s);
+            { GemmArgs a = lin<T>(qr, Tn, g.rvq_dim, w_rest, g.codebook_dim, nullptr, B0); a.res = B0; a.ldr = g.codebook_dim; gemm_launch<T>(a, s); }
+            gemm_launch<T>(conv(B0, Tn, g.codebook_dim, w_pre, g.latent_dim, b_pre, B1, 3, 1), s);
+            gemm_launch<T>(lin<T>(B1, Tn, g.latent_dim, w_in, g.hidden, b_in, B0), s);                     // x = B0
+            for (int i = 0; i < g.n_layers; ++i) {
+                const LayerW& w = LW[i];
+                hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Tn + 3) / 4), dim3(256), 0, s, (const T*)B0, (const T*)w.ln1, B1, 0, Tn, g.hidden, g.rms_eps);
+                gemm_launch<T>(lin<T>(B1, Tn, g.hidden, w.qkv, 3 * QD, nullptr, B2), s);
+                hipLaunchKernelGGL((rope_rows_kernel<T>), el((size_t)Tn * 2 * g.n_heads * (g.head_dim / 2)), dim3(256), 0, s, B2, cosT, sinT, Tn, QD, g.head_dim);
+                const dim3 ag((Tn + 3) / 4, g.n_heads);
+                const float sc = 1.0f / sqrtf((float)g.head_dim);
+                if (g.head_dim == 32) hipLaunchKernelGGL((swa_attn_kernel<T, 32>), ag, dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.sliding_window, sc);
+                else if (g.head_dim == 64) hipLaunchKernelGGL((swa_attn_kernel<T, 64>), ag, dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.sliding_window, sc);
+                else hipLaunchKernelGGL((swa_attn_kernel<T, 128>), ag, dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.sliding_window, sc);
+                { GemmArgs a = lin<T>(B1, Tn, QD, w.o, g.hidden, nullptr, B0); a.scale = w.ls1; a.res = B0; a.ldr = g.hidden; gemm_launch<T>(a, s); }
+                hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Tn + 3) / 4), dim3(256), 0, s, (const T*)B0, (const T*)w.ln2, B1, 0, Tn, g.hidden, g.rms_eps);
+                { GemmArgs a = lin<T>(B1, Tn, g.hidden, w.gu, 2 * g.inter, nullptr, B2); a.act = 2; a.ldy = g.inter; gemm_launch<T>(a, s); }     // SwiGLU epilogue
+                { GemmArgs a = lin<T>(B2, Tn, g.inter, w.down, g.hidden, nullptr, B0); a.scale = w.ls2; a.res = B0; a.ldr = g.hidden; gemm_launch<T>(a, s); }
+            }
+            hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Tn + 3) / 4), dim3(256), 0, s, (const T*)B0, (const T*)w_norm, B1, 0, Tn, g.hidden, g.rms_eps);
+            gemm_launch<T>(lin<T>(B1, Tn, g.hidden, w_out, g.latent_dim, b_out, B0), s);                    // h = B0 [T, latent]
+        };
+        P.add(std::move(o));
     }
-    hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Tn + 3) / 4), dim3(256), 0, s, (const T*)B0, (const T*)R.W(TR + "norm.weight"), B1, Tn, g.hidden, g.rms_eps);
-    R.gemm<T>(lin<T>(B1, Tn, g.hidden, R.W(TR + "output_proj.weight"), g.latent_dim, R.W(TR + "output_proj.bias"), B0));   // h = B0 [T, latent]
-    // ---- upsample: transposed conv (k = s) + ConvNeXt ---------------------------------------------------
+    // ---- upsample: transposed conv (k = stride) + ConvNeXt ------------------------------------------------------------
     int rows = Tn;
     const int Lc = g.latent_dim;
-    for (int i = 0; i < g.n_upsample && !R.err; ++i) {
+    int t_h = t_front;                       // lives in B0
+    for (int i = 0; i < g.n_upsample && !err; ++i) {
         const int f = g.upsampling_ratios[i];
         const std::string U = D + "upsample." + std::to_string(i) + ".";
-        { GemmArgs a = lin<T>(B0, rows, Lc, R.W(U + "0.conv.weight"), f * Lc, R.W(U + "0.conv.bias"), B1); a.bias_mod = Lc; R.gemm<T>(a); }
+        const int t_up = P.tensor(), t_dw = P.tensor(), t_ln = P.tensor(), t_pw = P.tensor(), t_o = P.tensor();
+        { GemmArgs a = lin<T>(B0, rows, Lc, W(U + "0.conv.weight"), f * Lc, W(U + "0.conv.bias"), B1); a.bias_mod = Lc;
+          gemm_op(a, t_up, -1, {{t_h, t_h == t_front ? DEP_ALL : DEP_SAME, 0}}, f); }
         rows *= f;                                                                      // B1 = [rows, Lc]
-        hipLaunchKernelGGL((dwconv7_kernel<T>), el((size_t)rows * Lc), dim3(256), 0, s, (const T*)B1, (const T*)R.W(U + "1.dwconv.conv.weight"), (const T*)R.W(U + "1.dwconv.conv.bias"), B2, rows, Lc);
-        hipLaunchKernelGGL((layernorm_rows_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)B2, (const T*)R.W(U + "1.norm.weight"), (const T*)R.W(U + "1.norm.bias"), B3, rows, Lc, 1e-6f);
-        { GemmArgs a = lin<T>(B3, rows, Lc, R.W(U + "1.pwconv1.weight"), 4 * Lc, R.W(U + "1.pwconv1.bias"), B2); a.act = 1; R.gemm<T>(a); }
-        { GemmArgs a = lin<T>(B2, rows, 4 * Lc, R.W(U + "1.pwconv2.weight"), Lc, R.W(U + "1.pwconv2.bias"), B0);
-          a.scale = R.W(U + "1.gamma"); a.res = B1; a.ldr = Lc; R.gemm<T>(a); }            // h = B0 [rows, Lc]
+        {
+            const int R = rows;
+            const T* dw = (const T*)W(U + "1.dwconv.conv.weight"); const T* db = (const T*)W(U + "1.dwconv.conv.bias");
+            Op o; o.out = t_dw; o.in = {{t_up, DEP_BACK, 6}};
+            o.run = [=](int lo) { if (lo < R) hipLaunchKernelGGL((dwconv7_kernel<T>), el((size_t)(R - lo) * Lc), dim3(256), 0, s, (const T*)B1, dw, db, B2, lo, R, Lc); };
+            P.add(std::move(o));
+            const T* nw = (const T*)W(U + "1.norm.weight"); const T* nb = (const T*)W(U + "1.norm.bias");
+            Op o2; o2.out = t_ln; o2.in = {{t_dw, DEP_SAME, 0}};
+            o2.run = [=](int lo) { if (lo < R) hipLaunchKernelGGL((layernorm_rows_kernel<T>), dim3((R - lo + 3) / 4), dim3(256), 0, s, (const T*)B2, nw, nb, B3, lo, R, Lc, 1e-6f); };
+            P.add(std::move(o2));
+        }
+        { GemmArgs a = lin<T>(B3, rows, Lc, W(U + "1.pwconv1.weight"), 4 * Lc, W(U + "1.pwconv1.bias"), B2); a.act = 1;
+          gemm_op(a, t_pw, -1, {{t_ln, DEP_SAME, 0}}); }
+        { GemmArgs a = lin<T>(B2, rows, 4 * Lc, W(U + "1.pwconv2.weight"), Lc, W(U + "1.pwconv2.bias"), B0);
+          a.scale = W(U + "1.gamma"); a.res = B1; a.ldr = Lc;
+          gemm_op(a, t_o, -1, {{t_pw, DEP_SAME, 0}, {t_up, DEP_SAME, 0}}); }             // h = B0 [rows, Lc]
+        t_h = t_o;
     }
-    // ---- decoder ----------------------------------------------------------------------------------------
+    // ---- decoder: every SnakeBeta is the epilogue of the GEMM that produces its input ---------------------------------
     const std::string DD = D + "decoder.";
     int ch = g.decoder_dim;
-    R.gemm<T>(conv(B0, rows, Lc, R.W(DD + "0.conv.weight"), ch, R.W(DD + "0.conv.bias"), B1, 7, 1));      // y = B1 [rows, ch]
-    T* y = B1; T* t0 = B0; T* t1 = B2; T* t2 = B3;
-    for (int i = 0; i < g.n_rates && !R.err; ++i) {
+    T* bufH = B1; T* bufS = B2; T* bufM = B3; T* bufN = B0;       // raw h | snaked | mid (snaked conv1 out) | next raw
+    int t_s = P.tensor();                                         // snaked input of the next GEMM
+    {   // dec.0 (k7): only its SnakeBeta image (block 1's ".0" activation) is consumed
+        auto sn = SN(DD + "1.block.0.");
+        GemmArgs a = conv(B0, rows, Lc, W(DD + "0.conv.weight"), ch, W(DD + "0.conv.bias"), nullptr, 7, 1);
+        a.sn_a = sn.first; a.sn_ib = sn.second; a.Y2 = bufS;
+        gemm_op(a, -1, t_s, {{t_h, t_h == t_front ? DEP_ALL : DEP_BACK, 6}});
+    }
+    for (int i = 0; i < g.n_rates && !err; ++i) {
         const int r = g.upsample_rates[i], co = ch / 2;
         const std::string Bk = DD + std::to_string(i + 1) + ".block.";
-        hipLaunchKernelGGL((snake_kernel<T>), el((size_t)rows * ch), dim3(256), 0, s, (const T*)y, (const T*)R.W(Bk + "0.alpha"), (const T*)R.W(Bk + "0.beta"), t0, (size_t)rows * ch, ch);
+        int t_hraw = P.tensor(), t_s2 = P.tensor();
         {   // causal transposed conv k = 2r, stride r: out[m*r + q] = in[m+1] W[:,:,q] + in[m] W[:,:,q+r]
-            GemmArgs a{}; a.A = t0; a.lda = ch; a.M = rows - 1; a.a_rows = rows; a.n_taps = 2; a.tap_off[0] = 1; a.tap_off[1] = 0; a.Cin = ch;
-            a.W = R.W(Bk + "1.conv.weight"); a.N = r * co; a.bias = R.W(Bk + "1.conv.bias"); a.bias_mod = co; a.Y = t1; a.ldy = r * co;
-            R.gemm<T>(a);
+            auto sn = SN(Bk + "2.act1.");
+            GemmArgs a{}; a.A = bufS; a.lda = ch; a.M = rows - 1; a.a_rows = rows; a.n_taps = 2; a.tap_off[0] = 1; a.tap_off[1] = 0; a.Cin = ch;
+            a.W = W(Bk + "1.conv.weight"); a.N = r * co; a.bias = W(Bk + "1.conv.bias"); a.bias_mod = co; a.Y = bufH; a.ldy = r * co;
+            a.sn_a = sn.first; a.sn_ib = sn.second; a.Y2 = bufM;
+            gemm_op(a, t_hraw, t_s2, {{t_s, DEP_SAME, 0}}, r);
         }
         rows = (rows - 1) * r; ch = co;
-        std::swap(y, t1);                                                                  // y = [rows, ch]
-        for (int j = 0; j < 3 && !R.err; ++j) {
+        std::swap(bufS, bufM);                                    // bufS = snaked new h, bufM free
+        t_s = t_s2;
+        for (int j = 0; j < 3 && !err; ++j) {
             const std::string Un = Bk + std::to_string(j + 2) + ".";
             const int dil = j == 0 ? 1 : (j == 1 ? 3 : 9);
-            hipLaunchKernelGGL((snake_kernel<T>), el((size_t)rows * ch), dim3(256), 0, s, (const T*)y, (const T*)R.W(Un + "act1.alpha"), (const T*)R.W(Un + "act1.beta"), t0, (size_t)rows * ch, ch);
-            R.gemm<T>(conv(t0, rows, ch, R.W(Un + "conv1.conv.weight"), ch, R.W(Un + "conv1.conv.bias"), t1, 7, dil));
-            hipLaunchKernelGGL((snake_kernel<T>), el((size_t)rows * ch), dim3(256), 0, s, (const T*)t1, (const T*)R.W(Un + "act2.alpha"), (const T*)R.W(Un + "act2.beta"), t0, (size_t)rows * ch, ch);
-            { GemmArgs a = conv(t0, rows, ch, R.W(Un + "conv2.conv.weight"), ch, R.W(Un + "conv2.conv.bias"), t2, 1, 1);
-              a.res = y; a.ldr = ch; R.gemm<T>(a); }
-            std::swap(y, t2);
+            const int t_mid = P.tensor();
+            {   // conv1 (k7, dilated): only snake_act2(conv1) is consumed
+                auto sn = SN(Un + "act2.");
+                GemmArgs a = conv(bufS, rows, ch, W(Un + "conv1.conv.weight"), ch, W(Un + "conv1.conv.bias"), nullptr, 7, dil);
+                a.sn_a = sn.first; a.sn_ib = sn.second; a.Y2 = bufM;
+                gemm_op(a, -1, t_mid, {{t_s, DEP_BACK, 6 * dil}});
+            }
+            // conv2 (1x1) + residual -> next raw h (unless nothing reads it) and the next activation's image of it
+            const bool last_unit = j == 2, last_block = i == g.n_rates - 1;
+            const std::string next_sn = !last_unit ? Bk + std::to_string(j + 3) + ".act1."
+                                        : (!last_block ? DD + std::to_string(i + 2) + ".block.0." : DD + std::to_string(g.n_rates + 1) + ".");
+            auto sn = SN(next_sn);
+            GemmArgs a = conv(bufM, rows, ch, W(Un + "conv2.conv.weight"), ch, W(Un + "conv2.conv.bias"), last_unit ? nullptr : (void*)bufN, 1, 1);
+            a.res = bufH; a.ldr = ch; a.sn_a = sn.first; a.sn_ib = sn.second; a.Y2 = bufS;      // bufS (conv1's input) is dead by now
+            const int t_hn = last_unit ? -1 : P.tensor(), t_sn = P.tensor();
+            gemm_op(a, t_hn, t_sn, {{t_mid, DEP_SAME, 0}, {t_hraw, DEP_SAME, 0}});
+            if (!last_unit) { std::swap(bufH, bufN); t_hraw = t_hn; }
+            t_s = t_sn;
         }
     }
-    const std::string F1 = DD + std::to_string(g.n_rates + 1) + ".", F2 = DD + std::to_string(g.n_rates + 2) + ".";
-    hipLaunchKernelGGL((snake_kernel<T>), el((size_t)rows * ch), dim3(256), 0, s, (const T*)y, (const T*)R.W(F1 + "alpha"), (const T*)R.W(F1 + "beta"), t0, (size_t)rows * ch, ch);
-    hipLaunchKernelGGL((final_conv_kernel<T>), dim3((rows + 255) / 256), dim3(256), 0, s, (const T*)t0, (const T*)R.W(F2 + "conv.weight"), (const T*)R.W(F2 + "conv.bias"), pcm, rows, ch);
-    if (R.err) return R.err;
-    if (rows != (int)samples_for(g, Tn)) return cfail(FQ3_ESTATE, "internal: sample count mismatch");
+    const int64_t n_out = samples_for(g, Tn);
+    if (rows != (int)n_out) return cfail(FQ3_ESTATE, "internal: sample count mismatch");
+    const int t_pcm = P.tensor();
+    {
+        const std::string F2 = DD + std::to_string(g.n_rates + 2) + ".";
+        const T* fw = (const T*)W(F2 + "conv.weight"); const T* fb = (const T*)W(F2 + "conv.bias");
+        const int R = rows, C = ch;
+        const T* xin = bufS;
+        Op o; o.out = t_pcm; o.in = {{t_s, DEP_BACK, 6}};
+        o.run = [=](int lo) {
+            if (lo >= R) return;
+            const size_t shm = ((size_t)(kFinalSpw + 6) * (C | 1) + 7 * (size_t)C) * sizeof(float);
+            auto kern = final_conv_kernel<T>;
+            if (shm > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            hipLaunchKernelGGL(kern, dim3((R - lo + kFinalSpw - 1) / kFinalSpw), dim3(256), shm, s, xin, fw, fb, pcm, lo, R, C);
+        };
+        P.add(std::move(o));
+    }
+    if (err) return err;
+    if (ch > 1024) return cfail(FQ3_EUNSUPPORTED, "output conv wider than 1024 channels");
+    // ---- backward pass: first row every tensor is needed from -------------------------------------------------------
+    std::vector<long> need_from(P.n_tensors, LONG_MAX);
+    need_from[t_pcm] = std::min<int64_t>(std::max<int64_t>(first_sample, 0), n_out);
+    std::vector<int> lo_of(P.ops.size(), -1);
+    for (int i = (int)P.ops.size() - 1; i >= 0; --i) {
+        const Op& o = P.ops[i];
+        long lo = LONG_MAX;
+        if (o.out >= 0) lo = std::min(lo, need_from[o.out]);
+        if (o.out2 >= 0) lo = std::min(lo, need_from[o.out2]);
+        if (lo == LONG_MAX) continue;                          // nothing downstream reads this op
+        const long lrow = std::max(0L, lo / o.unit);           // launch row (input row for transposed convs)
+        lo_of[i] = (int)lrow;
+        for (const Dep& d : o.in) {
+            long v = 0;
+            switch (d.kind) {
+                case DEP_SAME: v = lrow; break;
+                case DEP_BACK: v = lrow - d.p; break;
+                case DEP_ALL: v = 0; break;
+                default: v = lrow; break;
+            }
+            need_from[d.t] = std::min(need_from[d.t], std::max(0L, v));
+        }
+    }
+    for (size_t i = 0; i < P.ops.size(); ++i)
+        if (lo_of[i] >= 0) P.ops[i].run(lo_of[i]);
     return 0;
 }
 
-extern "C" int fq3_codec_decode(fq3_codec* c, const int64_t* codes, int T, float* pcm, void* stream) {
+static int decode_any(fq3_codec* c, const int64_t* codes, int T, int64_t first_sample, float* pcm, void* stream) {
     if (!c || !codes || !pcm) return cfail(FQ3_EINVAL, "null argument");
     if (!c->ready) return cfail(FQ3_ESTATE, "codec weights not finalized");
     if (T < 1) return cfail(FQ3_EINVAL, "need at least 1 frame");
     if (T > c->cfg.max_frames) return cfail(FQ3_ETOOLONG, "codec decode: " + std::to_string(T) + " frames exceed max_frames=" + std::to_string(c->cfg.max_frames));
+    if (first_sample < 0 || first_sample > samples_for(c->cfg, T)) return cfail(FQ3_EINVAL, "first_sample outside the waveform");
     hipStream_t s = (hipStream_t)stream;
-    int r = c->cfg.dtype == FQ3_BF16 ? decode_t<bf16_t>(c, codes, T, pcm, s) : decode_t<float>(c, codes, T, pcm, s);
+    int r = c->cfg.dtype == FQ3_BF16 ? decode_t<bf16_t>(c, codes, T, first_sample, pcm, s) : decode_t<float>(c, codes, T, first_sample, pcm, s);
     if (r) return r;
     CHIP(hipGetLastError());
     return FQ3_OK;
+}
+
+extern "C" int fq3_codec_decode(fq3_codec* c, const int64_t* codes, int T, float* pcm, void* stream) {
+    return decode_any(c, codes, T, 0, pcm, stream);
+}
+
+extern "C" int fq3_codec_decode_tail(fq3_codec* c, const int64_t* codes, int T, int64_t first_sample, float* pcm, void* stream) {
+    return decode_any(c, codes, T, first_sample, pcm, stream);
 }

@@ -115,10 +115,7 @@ GemmArgs lin(const void* A, int M, int K, const void* W, int N, void* Y) {
     GemmArgs a{}; a.A = A; a.lda = K; a.M = M; a.a_rows = M; a.n_taps = 1; a.tap_off[0] = 0; a.Cin = K; a.W = W; a.N = N;
     a.bias_mod = N; a.Y = Y; a.ldy = N; return a;
 }
-template <typename T> void gemm(const GemmArgs& a, hipStream_t s) {
-    dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
-    hipLaunchKernelGGL((conv_gemm_kernel<T>), grid, dim3(256), 0, s, a);
-}
+template <typename T> void gemm(const GemmArgs& a, hipStream_t s) { gemm_launch<T>(a, s); }
 
 template <typename T>
 int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits, void* out_hidden, hipStream_t s) {
@@ -142,7 +139,7 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
     const float scale = 1.0f / sqrtf((float)kHeadDim);
     for (int i = 0; i < d.n_layers; ++i) {
         const fq3_layer_weights& w = c->tl[i];
-        hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((L + 3) / 4), dim3(256), 0, s, (const T*)X, (const T*)w.input_norm, XN, L, H, d.rms_eps);
+        hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((L + 3) / 4), dim3(256), 0, s, (const T*)X, (const T*)w.input_norm, XN, 0, L, H, d.rms_eps);
         gemm<T>(lin<T>(XN, L, H, w.qkv, per, QKV), s);
         hipLaunchKernelGGL((qk_norm_rope_kv_kernel<T>), dim3((L * (NH + 2 * NKV) + 3) / 4), dim3(256), 0, s, QKV, (const T*)w.q_norm,
                            (const T*)w.k_norm, d.rms_eps, c->wt.talker_cos, c->wt.talker_sin, c->wt.talker_rope_len, c->rope_delta,
@@ -150,7 +147,7 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
         hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((L * NH + 3) / 4), dim3(256), 0, s, (const T*)QKV, (const T*)c->tk.k[i],
                            (const T*)c->tk.v[i], ATT, c->tk.max_seq, L, n_pad, NH, NKV, scale);
         { GemmArgs a = lin<T>(ATT, L, QD, w.o, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
-        hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((L + 3) / 4), dim3(256), 0, s, (const T*)X, (const T*)w.post_norm, XN, L, H, d.rms_eps);
+        hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((L + 3) / 4), dim3(256), 0, s, (const T*)X, (const T*)w.post_norm, XN, 0, L, H, d.rms_eps);
         gemm<T>(lin<T>(XN, L, H, w.gate_up, 2 * I, GU), s);
         hipLaunchKernelGGL((silu_mul_kernel<T>), dim3((unsigned)(((size_t)L * I + 255) / 256)), dim3(256), 0, s, (const T*)GU, ACT, L, I);
         { GemmArgs a = lin<T>(ACT, L, I, w.down, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }

@@ -105,6 +105,7 @@ SIGNATURES = {
     "fq3_codec_finalize": (C.c_int, [vp, vp]),
     "fq3_codec_num_samples": (C.c_int64, [vp, C.c_int]),
     "fq3_codec_decode": (C.c_int, [vp, vp, C.c_int, vp, vp]),
+    "fq3_codec_decode_tail": (C.c_int, [vp, vp, C.c_int, C.c_int64, vp, vp]),
 }
 
 _lib = None

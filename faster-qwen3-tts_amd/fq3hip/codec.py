@@ -44,7 +44,11 @@ def pack_codec_weights(W: Weights, c: CodecConfig) -> Weights:
         q = f"{t}.layers.{i}"
         out[f"{q}.self_attn.qkv.weight"] = torch.cat([W[f"{q}.self_attn.q_proj.weight"], W[f"{q}.self_attn.k_proj.weight"],
                                                       W[f"{q}.self_attn.v_proj.weight"]], 0).contiguous()
-        out[f"{q}.mlp.gate_up.weight"] = torch.cat([W[f"{q}.mlp.gate_proj.weight"], W[f"{q}.mlp.up_proj.weight"]], 0).contiguous()
+        # gate / up rows interleaved in groups of 16 so that one MFMA column-tile pair holds (gate, up) of the same 16
+        # logical columns and SwiGLU becomes the GEMM's epilogue
+        gp, up = W[f"{q}.mlp.gate_proj.weight"], W[f"{q}.mlp.up_proj.weight"]
+        I, H = gp.shape
+        out[f"{q}.mlp.gate_up.weight"] = torch.stack([gp.reshape(I // 16, 16, H), up.reshape(I // 16, 16, H)], 1).reshape(2 * I, H).contiguous()
     for i, f in enumerate(c.upsampling_ratios):
         u = f"{p}.upsample.{i}"
         out[f"{u}.0.conv.weight"] = convT(W[f"{u}.0.conv.weight"], f)
@@ -109,31 +113,58 @@ class HipSpeechTokenizer:
     CHUNK_FRAMES = 300
     LEFT_CONTEXT = 25
 
-    def _decode_piece(self, codes: torch.Tensor) -> torch.Tensor:
+    def _decode_piece(self, codes: torch.Tensor, first_sample: int = 0) -> torch.Tensor:
+        """One decoder pass over codes [T <= max_frames, 16]; returns samples [first_sample, num_samples(T))."""
         Tn = codes.shape[0]
-        pcm = torch.empty(self.num_samples(Tn), dtype=torch.float32, device=self.device)
-        L.check(self.lib.fq3_codec_decode(self.h, codes.data_ptr(), int(Tn), pcm.data_ptr(),
-                                          torch.cuda.current_stream(self.device).cuda_stream))
+        n = self.num_samples(Tn)
+        first_sample = max(0, min(int(first_sample), n))
+        pcm = torch.empty(n - first_sample, dtype=torch.float32, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        if first_sample == 0:
+            L.check(self.lib.fq3_codec_decode(self.h, codes.data_ptr(), int(Tn), pcm.data_ptr(), st))
+        elif first_sample < n:
+            L.check(self.lib.fq3_codec_decode_tail(self.h, codes.data_ptr(), int(Tn), first_sample, pcm.data_ptr(), st))
         return pcm
 
-    def decode_tensor(self, codes: torch.Tensor) -> torch.Tensor:
-        """codes LongTensor[T, 16] -> float32 waveform tensor on the device.  Any T: inputs longer than the chunk size
-        are decoded piecewise with a 25-frame left context, as upstream ``chunked_decode`` does."""
-        codes = codes.to(device=self.device, dtype=torch.long).contiguous()
-        Tn = codes.shape[0]
+    def _pieces(self, Tn: int):
+        """(start, end, ctx) of every decoder pass for Tn frames: one pass up to the chunk size, otherwise upstream's
+        ``chunked_decode`` schedule (CHUNK_FRAMES new frames + LEFT_CONTEXT context frames per pass)."""
         if Tn <= min(self.CHUNK_FRAMES, self.max_frames):
-            return self._decode_piece(codes)
-        up = self.cfg.total_upsample
-        wavs, start = [], 0
+            return [(0, Tn, 0)]
+        out, start = [], 0
         while start < Tn:
             ctx = self.LEFT_CONTEXT if start - self.LEFT_CONTEXT > 0 else start
             ctx = min(ctx, self.max_frames - 1)
             # upstream: CHUNK_FRAMES new frames per piece; a workspace smaller than 325 frames shortens the pieces
             end = min(start + min(self.CHUNK_FRAMES, self.max_frames - ctx), Tn)
-            w = self._decode_piece(codes[start - ctx:end].contiguous())
-            wavs.append(w[ctx * up:])
+            out.append((start, end, ctx))
             start = end
-        return torch.cat(wavs)
+        return out
+
+    def decode_tensor(self, codes: torch.Tensor, first_sample: int = 0) -> torch.Tensor:
+        """codes LongTensor[T, 16] -> float32 waveform tensor on the device.  Any T: inputs longer than the chunk size
+        are decoded piecewise with a 25-frame left context, as upstream ``chunked_decode`` does.
+
+        ``first_sample`` > 0 returns ``decode_tensor(codes)[first_sample:]`` (bit-identical) while recomputing only the
+        rows those samples depend on -- what the streaming call sites keep of each re-decode."""
+        codes = codes.to(device=self.device, dtype=torch.long).contiguous()
+        Tn = codes.shape[0]
+        up = self.cfg.total_upsample
+        wavs, pos = [], 0                      # pos = index (in the concatenated waveform) of the piece's first kept sample
+        for start, end, ctx in self._pieces(Tn):
+            n_piece = self.num_samples(end - start + ctx) - ctx * up
+            if pos + n_piece > first_sample:
+                skip = ctx * up + max(0, first_sample - pos)
+                wavs.append(self._decode_piece(codes[start - ctx:end].contiguous(), skip))
+            pos += n_piece
+        if not wavs:
+            return torch.empty(0, dtype=torch.float32, device=self.device)
+        return torch.cat(wavs) if len(wavs) != 1 else wavs[0]
+
+    def num_samples_total(self, Tn: int) -> int:
+        """Length of ``decode_tensor(codes[Tn])`` (piecewise decodes drop the context samples of every later piece)."""
+        up = self.cfg.total_upsample
+        return sum(self.num_samples(e - s + c) - c * up for s, e, c in self._pieces(Tn))
 
     def decode(self, payload):
         codes = payload["audio_codes"]

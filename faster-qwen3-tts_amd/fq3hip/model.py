@@ -412,7 +412,7 @@ class FasterQwen3TTS:
                     tts_pad_embed=tpe, config=config, predictor_graph=self.predictor_graph,
                     talker_graph=self.talker_graph, chunk_size=chunk_size, **gen_kwargs)
         dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
-        use_side = torch.cuda.is_available() and hasattr(tok, "decode_tensor")
+        use_side = torch.cuda.is_available() and hasattr(tok, "decode_tensor") and hasattr(tok, "num_samples_total")
         if use_side and getattr(self, "_voc_stream", None) is None:
             # FQ3_VOC_PRIORITY (development knob): HIP stream priority of the vocoder stream (larger = lower)
             prio = os.environ.get("FQ3_VOC_PRIORITY")
@@ -424,20 +424,25 @@ class FasterQwen3TTS:
             all_codes.append(chunk)
             n_new = chunk.shape[0]
 
-            def vocode(codes_in):
-                # the codec runs on its own stream so that it overlaps the next chunk's decode kernels
+            def vocode(codes_in, first_sample=0):
+                """waveform[first_sample:] of codes_in (host array).  The HIP tokenizer produces only that tail
+                (fq3_codec_decode_tail: bit-identical to slicing the full decode, but only the rows the tail depends on
+                are recomputed); any other tokenizer decodes everything and is sliced here."""
                 if not use_side:
                     lst, rate = tok.decode({"audio_codes": codes_in.unsqueeze(0)})
-                    return _to_numpy(lst[0]), rate
+                    return _to_numpy(lst[0])[first_sample:], rate
+                # the codec runs on its own stream so that it overlaps the next chunk's decode kernels
                 side = self._voc_stream
                 if ev is not None:
                     side.wait_event(ev)
                 else:
                     side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
-                    lst, rate = tok.decode({"audio_codes": codes_in.unsqueeze(0)})
-                    out = _to_numpy(lst[0])          # .cpu() synchronises the side stream only
-                return out, rate
+                    out = _to_numpy(tok.decode_tensor(codes_in, first_sample))      # .cpu() synchronises the side stream only
+                return out, tok.sample_rate
+
+            def n_samples(n_frames):
+                return tok.num_samples_total(n_frames) if use_side else None
 
             if use_side:
                 with torch.cuda.stream(self._voc_stream):
@@ -456,19 +461,27 @@ class FasterQwen3TTS:
                         inp = torch.cat([ref_codes.to(flat.device), flat], dim=0)
                 else:
                     inp = flat
-                audio, sr = vocode(inp)
-                if ref_codes is not None:
-                    audio = audio[int(ref_codes.shape[0] / max(inp.shape[0], 1) * len(audio)):]
-                new_audio = audio[prev_len:]
-                prev_len = len(audio)
+                ref_len = ref_codes.shape[0] if ref_codes is not None else 0
+                n_audio = n_samples(inp.shape[0])
+                if n_audio is not None:
+                    # model.py:1095-1100 without materialising what is thrown away: audio[cut:][prev_len:]
+                    cut = int(ref_len / max(inp.shape[0], 1) * n_audio) if ref_len else 0
+                    new_audio, sr = vocode(inp, cut + prev_len)
+                    gen_len = n_audio - cut
+                else:
+                    audio, sr = vocode(inp)
+                    if ref_len:
+                        audio = audio[int(ref_len / max(inp.shape[0], 1) * len(audio)):]
+                    new_audio = audio[prev_len:]
+                    gen_len = len(audio)
+                prev_len = gen_len
                 if n_total >= min_cal:
-                    spf = len(audio) / n_total
+                    spf = gen_len / n_total
             else:
                 start = max(0, n_total - n_new - context_frames)
                 window = flat[start:]
                 n_ctx = window.shape[0] - n_new
-                audio, sr = vocode(window)
-                new_audio = audio[int(round(n_ctx * spf)):] if n_ctx > 0 else audio
+                new_audio, sr = vocode(window, int(round(n_ctx * spf)) if n_ctx > 0 else 0)
             yield new_audio, sr, timing
 
     @staticmethod

@@ -238,6 +238,11 @@ int fq3_codec_finalize(fq3_codec* c, void* stream);
 int64_t fq3_codec_num_samples(const fq3_codec* c, int T);
 /* codes int64[T,16] (device) -> pcm float32[num_samples] (device), clamped to [-1,1]. */
 int fq3_codec_decode(fq3_codec* c, const int64_t* codes, int T, float* pcm, void* stream);
+/* The same decode, but only PCM samples [first_sample, num_samples(T)) are produced, into pcm[0 ..): what the streaming
+ * call sites keep of each re-decode (model.py:1095-1100 `audio[cut:][prev_len:]`, :1128-1133 `audio[ctx_samples:]`).
+ * The decoder is causal with a bounded receptive field after its transformer, so only the rows those samples depend on are
+ * recomputed; the values are bit-identical to the corresponding tail of fq3_codec_decode's output. */
+int fq3_codec_decode_tail(fq3_codec* c, const int64_t* codes, int T, int64_t first_sample, float* pcm, void* stream);
 
 #ifdef __cplusplus
 }

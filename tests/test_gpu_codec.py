@@ -147,3 +147,46 @@ def test_codec_real_shapes_causal_prefix_property():
             assert torch.equal(part, full[: part.numel()]), (dtype, n)
         assert float(full.abs().max()) <= 1.0 and float(full.std()) > 0.05
         tok.close()
+
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_codec_tail_decode_is_bit_identical_tiny(dtype):
+    """fq3_codec_decode_tail == the tail of fq3_codec_decode, bit for bit, for every kind of cut (inside the first frame,
+    mid-sequence, last sample, nothing), including the piecewise (chunked) schedule."""
+    from fq3hip.codec import HipSpeechTokenizer
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, dtype, parts=("codec",))
+    tok = HipSpeechTokenizer(cfg.codec, W, "cuda", dtype, max_frames=64)
+    g = torch.Generator().manual_seed(3)
+    for T in (3, 33, 64):
+        codes = torch.randint(0, cfg.codec.codebook_size, (T, cfg.codec.num_quantizers), generator=g).cuda()
+        full = tok.decode_tensor(codes)
+        n = full.numel()
+        assert n == tok.num_samples_total(T)
+        for first in (1, 7, n // 3, n // 2 + 11, n - 1921, n - 1, n):
+            if first < 0:
+                continue
+            tail = tok.decode_tensor(codes, first)
+            assert tail.numel() == n - first and torch.equal(tail, full[first:]), (T, first)
+    tok.CHUNK_FRAMES = 39
+    codes = torch.randint(0, cfg.codec.codebook_size, (100, cfg.codec.num_quantizers), generator=g).cuda()
+    full = tok.decode_tensor(codes)
+    assert full.numel() == tok.num_samples_total(100)
+    for first in (5, 39 * 1920 - 3, 39 * 1920 + 3, full.numel() - 4000):
+        assert torch.equal(tok.decode_tensor(codes, first), full[first:]), first
+
+
+def test_codec_tail_decode_is_bit_identical_real_shapes():
+    """The streaming cuts at the benchmark's shapes: phase 1 (170 reference + 8..32 generated frames, keep the last 8
+    frames' samples) and phase 2 (25 context + 8 new frames)."""
+    cfg, tok = _real_codec(torch.bfloat16)
+    g = torch.Generator().manual_seed(5)
+    codes = torch.randint(0, cfg.codec.codebook_size, (202, cfg.codec.num_quantizers), generator=g).cuda()
+    for T, keep_frames in ((178, 8), (202, 8), (33, 8), (33, 33)):
+        c = codes[:T].contiguous()
+        full = tok.decode_tensor(c)
+        first = max(0, full.numel() - keep_frames * 1920 - 37)
+        tail = tok.decode_tensor(c, first)
+        assert torch.equal(tail, full[first:]), (T, keep_frames)
+    tok.close()
