@@ -59,8 +59,14 @@ __global__ void snake_consts_kernel(const T* alpha, const T* beta, T* a_out, T* 
 }
 
 // BM x BN output tile per workgroup, 4 waves as 2 x 2, each wave (BM/2) x (BN/2) = TM x TN MFMA tiles, K step 32,
-// double-buffered LDS.  grid = (ceil(N / BN), ceil((M - m_lo) / BM)).
-template <typename T, int BM, int BN>
+// double-buffered LDS (one barrier per step) fed by a PF-deep REGISTER prefetch: the global loads of step s + PF are
+// issued while step s is multiplied, so PF tiles (not one) are in flight per workgroup.  The streaming chunks make most
+// of these GEMMs skinny (M = 30..400 rows against K up to 7168): few workgroups, long K loops, i.e. latency-bound --
+// with one tile in flight a step cost a full memory round trip (~0.8 us measured), PF = 8 hides it.
+// Every load is unconditional on a clamped address (out-of-range rows / the padded tail steps are zeroed when the tile
+// is staged) so that the compiler's s_waitcnt vmcnt(N) stays exact and the loads really stay in flight.
+// grid = (ceil(N / BN), ceil((M - m_lo) / BM)).
+template <typename T, int BM, int BN, int PF>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     constexpr int BK = 32;
     constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 4);          // padded LDS row (elements): breaks the 64/128-byte stride
@@ -72,6 +78,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     const int m0 = a.m_lo + blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wr = wave >> 1, wc = wave & 1;
     const int K = a.n_taps * a.Cin;
+    const int nsteps = K / BK;
     const T* A = reinterpret_cast<const T*>(a.A);
     const T* W = reinterpret_cast<const T*>(a.W);
     constexpr int EPT = 16 / sizeof(T);                 // elements per 16-byte access
@@ -85,76 +92,88 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int lr = tid / TPR, lc = (tid % TPR) * EPT;
-    u32x4 areg[NPA], breg[NPB];
-    auto gload = [&](int k0) {
-        const int tap = k0 / a.Cin, ci = k0 - tap * a.Cin;
-        const int toff = a.tap_off[tap];
+    // B rows of this thread (clamped: columns >= N are computed on a duplicate row and never stored)
+    const T* wrow[NPB];
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+        int n = n0 + lr + p * RPP;
+        n = n < a.N ? n : a.N - 1;
+        wrow[p] = W + (size_t)n * K + lc;
+    }
+    u32x4 areg[PF][NPA], breg[PF][NPB];
+    // issue cursor (step being loaded) and stage cursor (step being written to LDS): (tap, channel offset) walk K in order
+    int i_step = 0, i_tap = 0, i_ci = 0, s_step = 0, s_tap = 0, s_ci = 0;
+    auto issue = [&](int slot) {                       // loads of step i_step (clamped to the last real step) into `slot`
+        const int toff = a.tap_off[i_tap];
 #pragma unroll
         for (int p = 0; p < NPA; ++p) {
-            const int r = lr + p * RPP;
-            const int m = m0 + r, ar = m + toff;
-            areg[p] = u32x4{0u, 0u, 0u, 0u};
-            if (r < BM && m < a.M && ar >= 0 && ar < a.a_rows)
-                areg[p] = *reinterpret_cast<const u32x4*>(A + (size_t)ar * a.lda + ci + lc);
+            int ar = m0 + lr + p * RPP + toff;
+            ar = ar < 0 ? 0 : (ar >= a.a_rows ? a.a_rows - 1 : ar);
+            areg[slot][p] = *reinterpret_cast<const u32x4*>(A + (size_t)ar * a.lda + i_ci + lc);
+        }
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) breg[slot][p] = *reinterpret_cast<const u32x4*>(wrow[p] + (size_t)i_tap * a.Cin + i_ci);
+        if (i_step + 1 < nsteps) { ++i_step; i_ci += BK; if (i_ci >= a.Cin) { i_ci = 0; ++i_tap; } }
+        else i_step = nsteps;                           // further issues re-read the last tile; staged as zeros
+    };
+    auto stage = [&](int slot, int buf) {               // slot -> LDS[buf]; rows outside the problem and tail steps become zeros
+        const int toff = a.tap_off[s_tap];
+        const bool real = s_step < nsteps;
+#pragma unroll
+        for (int p = 0; p < NPA; ++p) {
+            const int r = lr + p * RPP, m = m0 + r, ar = m + toff;
+            const bool ok = real && m < a.M && ar >= 0 && ar < a.a_rows;
+            if (r < BM) *reinterpret_cast<u32x4*>(&As[buf][r * LD + lc]) = ok ? areg[slot][p] : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int p = 0; p < NPB; ++p) {
             const int r = lr + p * RPP;
-            const int n = n0 + r;
-            breg[p] = u32x4{0u, 0u, 0u, 0u};
-            if (r < BN && n < a.N) breg[p] = *reinterpret_cast<const u32x4*>(W + (size_t)n * K + k0 + lc);
+            if (r < BN) *reinterpret_cast<u32x4*>(&Bs[buf][r * LD + lc]) = breg[slot][p];
         }
+        ++s_step; s_ci += BK; if (s_ci >= a.Cin) { s_ci = 0; if (s_tap + 1 < a.n_taps) ++s_tap; }
     };
-    auto lstore = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < NPA; ++p) {
-            const int r = lr + p * RPP;
-            if (r < BM) *reinterpret_cast<u32x4*>(&As[buf][r * LD + lc]) = areg[p];
-        }
-#pragma unroll
-        for (int p = 0; p < NPB; ++p) {
-            const int r = lr + p * RPP;
-            if (r < BN) *reinterpret_cast<u32x4*>(&Bs[buf][r * LD + lc]) = breg[p];
-        }
-    };
-    gload(0);
-    lstore(0);
+    for (int d = 0; d < PF; ++d) issue(d);
+    stage(0, 0);
     __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += BK, buf ^= 1) {
-        const bool more = k0 + BK < K;
-        if (more) gload(k0 + BK);                       // next tile's global loads fly under the MFMAs
-        const T* as = As[buf];
-        const T* bs = Bs[buf];
-        if constexpr (sizeof(T) == 2) {
-            bf16x8_t af[TM], bfr[TN];
+    const int ngroups = (nsteps + PF - 1) / PF;         // the K loop runs ngroups * PF steps; the tail steps multiply zeros
+    for (int g = 0; g < ngroups; ++g) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(as + (wr * (BM / 2) + i * 16 + fr) * LD + fq * 8);
+        for (int d = 0; d < PF; ++d) {
+            const int buf = d & 1;                      // PF is even: step parity = d parity
+            issue(d);                                   // slot d was staged one step ago: free again, refill with step + PF
+            const T* as = As[buf];
+            const T* bs = Bs[buf];
+            if constexpr (sizeof(T) == 2) {
+                bf16x8_t af[TM], bfr[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(bs + (wc * (BN / 2) + j * 16 + fr) * LD + fq * 8);
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(as + (wr * (BM / 2) + i * 16 + fr) * LD + fq * 8);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 4) {
-                float af[TM], bfr[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = reinterpret_cast<const float*>(as)[(wr * (BM / 2) + i * 16 + fr) * LD + kk + fq];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bfr[j] = reinterpret_cast<const float*>(bs)[(wc * (BN / 2) + j * 16 + fr) * LD + kk + fq];
+                for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(bs + (wc * (BN / 2) + j * 16 + fr) * LD + fq * 8);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < BK; kk += 4) {
+                    float af[TM], bfr[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i] = reinterpret_cast<const float*>(as)[(wr * (BM / 2) + i * 16 + fr) * LD + kk + fq];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bfr[j] = reinterpret_cast<const float*>(bs)[(wc * (BN / 2) + j * 16 + fr) * LD + kk + fq];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
             }
+            stage((d + 1) % PF, buf ^ 1);               // next step's tile (loaded PF - 1 steps ago) -> the other buffer
+            __syncthreads();
         }
-        if (more) lstore(buf ^ 1);                      // the other buffer was last read before the previous barrier
-        __syncthreads();
     }
     // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
     T* Y = reinterpret_cast<T*>(a.Y);
@@ -209,8 +228,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 // ---- host-side launch: tile shape per layer ---------------------------------------------------------------------
 template <typename T, int BM, int BN>
 inline void gemm_go(const GemmArgs& a, hipStream_t s) {
+    constexpr int PF = (BM + BN) > 128 ? 4 : 8;         // register-prefetch depth: 4 tiles of a big shape, 8 of a small one
     dim3 grid((a.N + BN - 1) / BN, (a.M - a.m_lo + BM - 1) / BM);
-    hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, PF>), grid, dim3(256), 0, s, a);
 }
 template <typename T>
 inline void gemm_launch(const GemmArgs& a, hipStream_t s) {

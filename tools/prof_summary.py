@@ -15,23 +15,3 @@ for r, n in zip(rows, names):
 print(f"total kernel time {tot/1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
 span = cur.execute("select min(start), max(end) from rocpd_kernel_dispatch").fetchone()
 print(f"first->last dispatch span {(span[1]-span[0])/1e6:.3f} ms")
-if len(sys.argv) > 2 and sys.argv[2] == "--alternate":
-    # experiment: every GEMV was launched twice back to back; compare 1st vs 2nd launch durations
-    rows = cur.execute("""select s.kernel_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s
-                          on d.kernel_id = s.id order by d.start""").fetchall()
-    import collections
-    agg = collections.defaultdict(lambda: [[0, 0], [0, 0]])
-    prev = None
-    for name, st, en in rows:
-        if "gemv_kernel" not in name:
-            prev = None
-            continue
-        second = prev == name
-        a = agg[name][1 if second else 0]
-        a[0] += en - st; a[1] += 1
-        prev = None if second else name
-    names = subprocess.run(["c++filt"], input="\n".join(agg), capture_output=True, text=True).stdout.split("\n")
-    for (k, v), n in zip(agg.items(), names):
-        n = re.sub(r"\(.*", "", n.replace("fq3::", "").replace("unsigned short", "bf16").replace("void ", ""))
-        if v[0][1] and v[1][1]:
-            print(f"{n:50s} first {v[0][0]/v[0][1]/1e3:6.2f} us (n={v[0][1]})   second {v[1][0]/v[1][1]/1e3:6.2f} us (n={v[1][1]})")
