@@ -11,13 +11,22 @@ the API's own min_new_tokens knob) with product-default sa
 8-frame chunks through the codec decoder with the reference's phase-1/phase-2 windowing.  Inputs
 (weights, prompt embeddings) are resident in HBM before the timed region.  Utterances are sharded
 over ranks (replicated weights, no data-path collective); RCCL is used for the barrier, the max-time
-reduction and the final result gather only.  value = total audio seconds over all ranks / max wall.
+reduction and ONE final result gather.  value = total audio seconds over all ranks / max wall.
 
-The JSON line also carries:
-  roofline      decode-frame hipGraph (one replay = one 80 ms frame): algorithmic bytes of SURVEY.md
-                section 8(d) / measured replay time (HIP events on the launch stream) vs 8 TB/s
-  cpu_baseline  the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded
-                sample of the same workload (rank 0, N=1 only)
+The JSON line also carries (all measured in this run unless tagged otherwise):
+  roofline            decode-frame hipGraph (one replay = one 80 ms frame): algorithmic bytes of SURVEY.md
+                      section 8(d) / measured replay time (HIP events on the launch stream) vs 8 TB/s
+  roofline_mfma       the matrix-core kernels of the path (codec conv GEMMs, prefill GEMMs): FLOPs / event time vs the
+                      2.5 PFLOP/s dense bf16 peak
+  parity_bf16_frames  teacher-forced id agreement of this very model (bf16, full depth) with the CPU oracle's golden ids
+  batched_decode_one_gpu   8 lock-step lanes over one weight stream (fq3_batch_*), with its own HBM roofline
+  config3_sharded_batched  BASELINE configs[3] shape: 64 utterances, sharded over the ranks, 8 lanes per GPU
+  model_1p7b          BASELINE configs[2]: the 1.7B shapes, single stream (N = 1 only)
+  cpu_baseline        the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded
+                      sample of the same workload (rank 0, N=1 only)
+
+`--stub` (tests/test_bench_multirank.py): no GPU, a scripted utterance runner -- exercises exactly the N > 1 branch
+(process group, barrier, max/sum reductions, the result gather) under gloo on CPU.
 """
 from __future__ import annotations
 
@@ -40,10 +49,12 @@ PROMPT_LEN = 200
 REF_FRAMES = 170
 CHUNK = 8
 FRAME_S = 1920 / 24000.0          # 12.5 frames per second
+HBM_PEAK_GBS = 8000.0
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense (MI355X_MICROARCH.md; the 2:1-sparsity headline figure is never used)
 
 
-def algorithmic_bytes_per_frame(cfg, p: float) -> float:
-    """every bf16 weight read once per frame + the p live KV rows."""
+def algorithmic_bytes_per_frame(cfg, p: float, lanes: int = 1) -> float:
+    """every bf16 weight read once per frame + the p live KV rows (per lane)."""
     t, pc = cfg.talker, cfg.predictor
 
     def stack(c):
@@ -52,25 +63,140 @@ def algorithmic_bytes_per_frame(cfg, p: float) -> float:
     params = stack(t) + t.hidden_size * t.vocab_size + stack(pc) + (cfg.num_code_groups - 1) * pc.hidden_size * pc.vocab_size
     params += t.hidden_size * pc.hidden_size       # small_to_mtp projection (counted as in SURVEY.md)
     kv_row = t.num_hidden_layers * 2 * t.num_key_value_heads * t.head_dim * 2
-    return 2.0 * params + kv_row * p
+    return 2.0 * params + kv_row * p * lanes
 
 
-def build_model(device):
-    from fq3hip.config import qwen3_tts_0p6b
-    from fq3hip.weights import synth_weights, synth_prompt
+def codec_gemm_flops(c, T: int) -> float:
+    """FLOPs of the conv / linear contractions of one codec decode of T frames (2 * M * N * K per GEMM)."""
+    f = 0.0
+    f += 2 * T * c.rvq_dim * c.codebook_dim * 2 + 2 * T * 3 * c.codebook_dim * c.latent_dim
+    QD = c.num_attention_heads * c.head_dim
+    f += 2 * T * c.latent_dim * c.hidden_size * 2
+    f += c.num_hidden_layers * 2 * T * (c.hidden_size * 3 * QD + QD * c.hidden_size + 3 * c.hidden_size * c.intermediate_size)
+    rows = T
+    for r in c.upsampling_ratios:
+        f += 2 * rows * c.latent_dim * r * c.latent_dim
+        rows *= r
+        f += 2 * rows * c.latent_dim * 4 * c.latent_dim * 2
+    ch = c.decoder_dim
+    f += 2 * rows * 7 * c.latent_dim * ch
+    for r in c.upsample_rates:
+        f += 2 * (rows - 1) * 2 * ch * r * (ch // 2)
+        rows = (rows - 1) * r
+        ch //= 2
+        f += 3 * (2 * rows * 7 * ch * ch + 2 * rows * ch * ch)
+    return f
+
+
+def prefill_gemm_flops(cfg, L: int) -> float:
+    t = cfg.talker
+    per_layer = t.hidden_size * (t.q_dim + 2 * t.kv_dim) + t.q_dim * t.hidden_size + 3 * t.hidden_size * t.intermediate_size
+    return 2.0 * L * per_layer * t.num_hidden_layers
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU runner
+# ------------------------------------------------------------------------------------------------------------------
+def build_model(device, size="0p6b", frames=FRAMES):
+    from fq3hip.config import qwen3_tts_0p6b, qwen3_tts_1p7b
+    from fq3hip.weights import synth_weights
     from fq3hip.model import FasterQwen3TTS
-    cfg = qwen3_tts_0p6b()
-    W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor", "codec"))
+    cfg = qwen3_tts_0p6b() if size == "0p6b" else qwen3_tts_1p7b()
+    W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor", "codec"), codec_normalized=True)
     model = FasterQwen3TTS.from_weights(cfg, W, device=device, dtype=torch.bfloat16, max_seq_len=2048,
-                                        codec_max_frames=REF_FRAMES + FRAMES + 16, max_frames=FRAMES + 8)
+                                        codec_max_frames=REF_FRAMES + frames + 16, max_frames=frames + 8)
     model._bench_weights = W
     return cfg, model
 
 
+def one_utterance(model, prompt, seed, sync=None, frames=FRAMES):
+    """Streaming voice-clone of one synthetic utterance.  Returns (ttfa_s, wall_s, n_frames, pcm)."""
+    sync = sync or torch.cuda.synchronize
+    tie, tam, tth, tpe, ref_codes = prompt
+    m = model.model.model
+    talker, config = m.talker, m.config.talker_config
+    torch.manual_seed(seed)
+    kw = model._gen_kwargs(frames, frames, 0.9, 50, 1.0, True, 1.05)
+    sync()
+    t0 = time.perf_counter()
+    ttfa, chunks, n = None, [], 0
+    for audio, sr, timing in model._run_streaming(m, talker, config, tie, tam, tth, tpe, ref_codes, kw, CHUNK):
+        if ttfa is None:
+            ttfa = time.perf_counter() - t0       # `audio` is a host array: the first chunk is complete here
+        chunks.append(audio)
+        n = timing["total_steps_so_far"]
+    sync()
+    wall = time.perf_counter() - t0
+    return ttfa, wall, n, np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
+
+
+def measure_frame_graph(model, prompt, n=64, frames=FRAMES):
+    """HIP events on the launch stream around n consecutive decode-frame graph replays."""
+    from fq3hip.generate import _prefill_and_arm, run_frames
+    tie, tam, tth, tpe, _ = prompt
+    m = model.model.model
+    eng, tn, pn, _ = _prefill_and_arm(m.talker, tie, tam, tth, tpe, m.config.talker_config, model.predictor_graph,
+                                      model.talker_graph, frames, frames, 0.9, 50, 1.0, True, 1.05, use_graph=True)
+    run_frames(eng, tn, pn, 0, 64)              # frames 0..63 (ring fill + warm)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tn.exponential_(1); pn.exponential_(1)
+    e0.record()
+    eng.decode_frames(n)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    p_mid = PROMPT_LEN + 64 + n / 2
+    return ms, p_mid
+
+
+def frame_roofline(cfg, frame_ms, p_mid, lanes=1, what="decode-frame hipGraph"):
+    b = algorithmic_bytes_per_frame(cfg, p_mid, lanes)
+    ach = b / (frame_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": what, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(b), "kv_len": p_mid, "launch_ms": round(frame_ms, 4)}
+
+
+def measure_mfma(cfg, model, prompt):
+    """Event-timed matrix-core work of the path: one full-length codec decode (ref + generated frames, the non-streaming
+    call) and one 200-token prefill.  FLOPs are the GEMM FLOPs of the shapes (attention / elementwise excluded)."""
+    tok = model.model.model.speech_tokenizer
+    T = REF_FRAMES + FRAMES
+    g = torch.Generator().manual_seed(4)
+    codes = torch.randint(0, cfg.codec.codebook_size, (T, cfg.codec.num_quantizers), generator=g).to(tok.device)
+    tok.decode_tensor(codes)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        tok.decode_tensor(codes)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    fl = sum(codec_gemm_flops(cfg.codec, e - s + c) for s, e, c in tok._pieces(T))
+    out = {"codec_full_decode": {"frames": T, "ms": round(ms, 3), "gemm_tflop": round(fl / 1e12, 3),
+                                 "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "bound": "mfma"}}
+    eng = model.talker_graph.engine
+    x = prompt[0][0].contiguous()
+    eng.prefill(x)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        eng.prefill(x)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    fl = prefill_gemm_flops(cfg, x.shape[0])
+    out["prefill_200"] = {"tokens": int(x.shape[0]), "ms": round(ms, 3), "gemm_tflop": round(fl / 1e12, 3),
+                          "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "bound": "mfma"}
+    return out
+
+
 def concurrent_throughput(cfg, model, prompt, device, streams=4, utterances=2):
     """Extra (not the headline): S utterances in flight on ONE GPU, each with its own decode context, codec
-    workspace, hipGraph and HIP stream, all borrowing the single weight replica.  Batch-1 decode leaves
-    >90 % of the chip idle (latency-bound launches), so independent utterances overlap almost freely."""
+    workspace, hipGraph and HIP stream, all borrowing the single weight replica."""
     import threading
     from fq3hip.model import FasterQwen3TTS
     models = [model] + [FasterQwen3TTS.from_weights(cfg, model._bench_weights, device=device, dtype=torch.bfloat16,
@@ -78,7 +204,6 @@ def concurrent_throughput(cfg, model, prompt, device, streams=4, utterances=2):
                                                     max_frames=FRAMES + 8, share=model) for _ in range(streams - 1)]
     bar = threading.Barrier(streams)
     res = [None] * streams
-
     errors = []
 
     def worker(i):
@@ -113,83 +238,96 @@ def concurrent_throughput(cfg, model, prompt, device, streams=4, utterances=2):
             "unit": "x real-time (aggregate audio s / wall s, one GPU)", "ttfa_ms_p50": round(1000 * float(np.median(ttfas)), 2)}
 
 
-def batched_throughput(model, prompt, lanes=8, utterances=16):
-    """Opt-in extra (--batch B, N=1 only): `utterances` synthetic utterances through `lanes` lock-step lanes
-    (fq3_batch_*, continuous batching), vocoded as they finish.  Aggregate audio seconds / wall seconds."""
+def batched_run(model, prompt, n_utt, lanes=8, frames=FRAMES, seed0=2000):
+    """`n_utt` synthetic utterances (seeds seed0 + i) through `lanes` lock-step lanes (fq3_batch_*,
+    continuous batching), each vocoded (non-streaming call) as it finishes.  Returns (audio_s, wall_s, pcm lengths)."""
     from fq3hip.batching import BatchRequest
     tie, tam, tth, tpe, ref_codes = prompt
     m = model.model.model
     talker, config = m.talker, m.config.talker_config
-    kw = model._gen_kwargs(FRAMES, FRAMES, 0.9, 50, 1.0, True, 1.05)
+    kw = model._gen_kwargs(frames, frames, 0.9, 50, 1.0, True, 1.05)
     dec = model._batch_decoder(lanes)
-    reqs = [BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(kw)) for i in range(utterances)]
-    list(dec.run(reqs[:lanes]))                                  # warm-up: contexts, graph capture
+    reqs = [BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(kw)) for i in range(n_utt)]
+    torch.manual_seed(seed0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    frames = 0
+    n_frames, lens = 0, [0] * n_utt
     for rid, codes, timing in dec.run(reqs):
         if codes is None:
             continue
         full = torch.cat([ref_codes.to(codes.device), codes], dim=0) if ref_codes is not None else codes
         audio_list, _sr = m.speech_tokenizer.decode({"audio_codes": full.unsqueeze(0)})
-        _ = audio_list[0].cpu() if hasattr(audio_list[0], "cpu") else audio_list[0]
-        frames += codes.shape[0]
+        a = audio_list[0].cpu() if hasattr(audio_list[0], "cpu") else audio_list[0]
+        lens[rid] = int(len(a))
+        n_frames += codes.shape[0]
     torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    return {"lanes": lanes, "utterances": utterances, "value": round(frames * FRAME_S / wall, 3),
-            "unit": "x real-time (aggregate audio s / wall s, one GPU, non-streaming vocoder per finished utterance)"}
+    return n_frames * FRAME_S, time.perf_counter() - t0, lens
 
 
-def one_utterance(model, prompt, seed, sync=None):
-    """Streaming voice-clone of one synthetic utterance.  Returns (ttfa_s, wall_s, n_frames, pcm)."""
-    sync = sync or torch.cuda.synchronize
-    tie, tam, tth, tpe, ref_codes = prompt
-    m = model.model.model
-    talker, config = m.talker, m.config.talker_config
-    torch.manual_seed(seed)
-    kw = model._gen_kwargs(FRAMES, FRAMES, 0.9, 50, 1.0, True, 1.05)
-    sync()
-    t0 = time.perf_counter()
-    ttfa, chunks, frames = None, [], 0
-    for audio, sr, timing in model._run_streaming(m, talker, config, tie, tam, tth, tpe, ref_codes, kw, CHUNK):
-        if ttfa is None:
-            ttfa = time.perf_counter() - t0       # `audio` is a host array: the first chunk is complete here
-        chunks.append(audio)
-        frames = timing["total_steps_so_far"]
-    sync()
-    wall = time.perf_counter() - t0
-    return ttfa, wall, frames, np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
-
-
-def measure_frame_graph(model, prompt, n=64):
-    """HIP events on the launch stream around n consecutive decode-frame graph replays."""
-    from fq3hip.generate import _prefill_and_arm, run_frames
+def batched_frame_time(model, cfg, prompt, lanes=8, n=48, mfma=0):
+    """HIP events around n lock-step frame graph replays with all lanes armed (decode only)."""
+    from fq3hip.generate import _prefill_and_arm, NOISE_RING
     tie, tam, tth, tpe, _ = prompt
     m = model.model.model
-    eng, tn, pn, _ = _prefill_and_arm(m.talker, tie, tam, tth, tpe, m.config.talker_config, model.predictor_graph,
-                                      model.talker_graph, FRAMES, FRAMES, 0.9, 50, 1.0, True, 1.05, use_graph=True)
-    run_frames(eng, tn, pn, 0, 64)              # frames 0..63 (ring fill + warm)
+    dec = model._batch_decoder(lanes)
+    dec.batch.set_option("mfma", int(mfma))
+    keep = []
+    for ln in dec.lanes:
+        keep.append(_prefill_and_arm(m.talker, tie, tam, tth, tpe, m.config.talker_config, ln.predictor_graph, ln.talker_graph,
+                                     FRAMES, FRAMES, 0.9, 50, 1.0, True, 1.05, use_graph=False))
+    for _e, tn, pn, _ in keep:
+        tn.exponential_(1); pn.exponential_(1)
+    dec.batch.graph_capture()
+    dec._captured = True
+    dec.batch.frames(8)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    tn.exponential_(1); pn.exponential_(1)
     e0.record()
-    eng.decode_frames(n)
+    dec.batch.frames(n)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    p_mid = PROMPT_LEN + 64 + n / 2
-    return ms, p_mid
+    # let every lane run out so the decoder's lanes are reusable
+    dec.batch.frames(NOISE_RING - 8 - n)
+    torch.cuda.synchronize()
+    dec.batch.set_option("mfma", 0)
+    dec._captured = False
+    return ms, PROMPT_LEN + 8 + n / 2
+
+
+def parity_note(cfg, model):
+    """Teacher-forced agreement of THIS model (0.6B shapes, bf16, full depth, hipGraph replay) with the CPU oracle's
+    golden ids (tests/golden/fulldepth.npz; same seeded weights and prompt).  oracle/ is used as the checker only."""
+    from oracle import teacher_forced as TF
+    from fq3hip.weights import synth_prompt
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fulldepth.npz"))
+    frames, plen, tlen = (int(x) for x in g["meta"])
+    case = TF.load_case(g, "0p6b_bf16")
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, plen, tlen, 0, dtype=torch.bfloat16)
+    eng = model.talker_graph.engine
+    pg = model.predictor_graph
+    saved = dict(do_sample=pg.do_sample, top_k=pg.top_k, temperature=pg.temperature)
+    pg.do_sample, pg.top_k, pg.temperature = False, 0, 1.0            # greedy predictor, as the golden ids were made
+    try:
+        dec = TF.forced_decisions(eng, cfg, tie, tth, tpe, case["codes"], graph=True)
+    finally:
+        pg.do_sample, pg.top_k, pg.temperature = saved["do_sample"], saved["top_k"], saved["temperature"]
+    s = TF.score(dec, case, 4.0)
+    return {"matched_frames": s["matched_frames"], "frames": s["frames"], "matched_decisions": s["matched_decisions"],
+            "decisions": s["total"], "worst_mismatch_margin_bf16_ulp": s["worst_mismatch_ulp"], "unexplained": s["unexplained"],
+            "method": "teacher-forced vs CPU-oracle golden ids, 28+5 layers, 200-token prompt; a mismatch counts as explained "
+                      "when the oracle's own top-2 margin is <= 4 bf16 ulps (tests/test_gpu_fulldepth.py)"}
 
 
 def cpu_baseline(cfg, frames=6, budget_s=45.0):
-    """CPU oracle ("port") on the host cores: same shapes, fp32 (bf16 matmuls are not accelerated on this
-    host), same prompt; a BOUNDED sample: 200-token prefill + up to `frames` generated frames + their
-    vocoding, cut short when `budget_s` is exceeded.  RTF with the same definition as the GPU line."""
+    """CPU oracle ("port") on the host cores: same shapes, fp32 (bf16 matmuls are not accelerated on every host),
+    same prompt; a BOUNDED sample: 200-token prefill + up to `frames` generated frames + their vocoding, cut short when
+    `budget_s` is exceeded.  RTF with the same definition as the GPU line."""
     from fq3hip.weights import synth_weights, synth_prompt
     from oracle import qwen3tts_oracle as O
     cores = min(os.cpu_count() or 1, 16)        # batch-1 matvecs stop scaling (and regress) beyond ~16 threads
     torch.set_num_threads(cores)
-    W = synth_weights(cfg, 0, torch.float32, parts=("talker", "predictor", "codec"))
+    W = synth_weights(cfg, 0, torch.float32, parts=("talker", "predictor", "codec"), codec_normalized=True)
     tie, tam, tth, tpe, ref = synth_prompt(cfg, PROMPT_LEN, 32, REF_FRAMES, dtype=torch.float32)
     orc = O.OracleTTS(cfg, W, max_seq_len=512)
     t0 = time.perf_counter()
@@ -198,9 +336,7 @@ def cpu_baseline(cfg, frames=6, budget_s=45.0):
         sp = O.SamplingParams(max_new_tokens=1, min_new_tokens=1)
         codes = orc.generate(tie, tam, tth, tpe, sp)
         t1 = time.perf_counter() - t0
-        per_frame_est = None
         if t1 < budget_s / 3:
-            n_more = frames
             t2 = time.perf_counter()
             sp = O.SamplingParams(max_new_tokens=2, min_new_tokens=2)
             orc.generate(tie, tam, tth, tpe, sp)
@@ -213,7 +349,7 @@ def cpu_baseline(cfg, frames=6, budget_s=45.0):
         else:
             t_codes = t1
         tv = time.perf_counter()
-        wav = O.codec_decode(codes % cfg.codec.codebook_size, W, cfg.codec)
+        O.codec_decode(codes % cfg.codec.codebook_size, W, cfg.codec)
         t_voc = time.perf_counter() - tv
     n = codes.shape[0]
     wall = t_codes + t_voc
@@ -223,24 +359,66 @@ def cpu_baseline(cfg, frames=6, budget_s=45.0):
             "ms_per_frame": round(1000 * t_codes / n, 1)}
 
 
+def model_1p7b_block(device):
+    """BASELINE configs[2]: the 1.7B shapes (talker hidden 2048 / intermediate 6144, predictor with projection), single
+    stream: RTF / TTFA over 2 utterances + the decode-frame roofline; and 8 lock-step lanes (configs[3]'s model)."""
+    from fq3hip.weights import synth_prompt
+    cfg, model = build_model(device, "1p7b")
+    prompt = [t.to(device) if t is not None else None for t in synth_prompt(cfg, PROMPT_LEN, 32, REF_FRAMES, dtype=torch.bfloat16)]
+    one_utterance(model, prompt, 900)
+    frame_ms, p_mid = measure_frame_graph(model, prompt)
+    res = [one_utterance(model, prompt, 910 + i) for i in range(2)]
+    out = {"workload": "configs[2]: Qwen3-TTS-12Hz-1.7B-Base shapes, voice-clone streaming chunk_size=8, bf16, synthetic weights",
+           "rtf": round(float(np.mean([n * FRAME_S / w for _, w, n, _ in res])), 3),
+           "ttfa_ms_p50": round(1000 * float(np.median([t for t, _, _, _ in res])), 2),
+           "decode_ms_per_frame": round(frame_ms, 4), "roofline": frame_roofline(cfg, frame_ms, p_mid)}
+    try:
+        ms, p = batched_frame_time(model, cfg, prompt, lanes=8)
+        out["batched_b8"] = {"ms_per_lockstep_frame": round(ms, 3), "value": round(8 * 80.0 / ms, 1),
+                             "unit": "x real-time aggregate, decode only (8 lanes, one GPU)",
+                             "roofline": frame_roofline(cfg, ms, p, lanes=8, what="batched decode-frame hipGraph, 8 lanes")}
+    except Exception as e:
+        out["batched_b8"] = {"error": repr(e)}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# stub runner (CPU): same control flow through the distributed code, scripted timings
+# ------------------------------------------------------------------------------------------------------------------
+class _StubModel:
+    pass
+
+
+def _stub_utterance(seed):
+    time.sleep(0.01)
+    rng = np.random.default_rng(seed)
+    return 0.004 + 0.001 * (seed % 3), 0.01, FRAMES, rng.standard_normal(1000 + seed % 7).astype(np.float32)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=0,
-                    help="opt-in extra (N=1 only): lock-step lanes for the batched-decode throughput figure (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
+    ap.add_argument("--batch", type=int, default=8, help="lock-step lanes of the batched figures (0 = skip them)")
+    ap.add_argument("--config3-utterances", type=int, default=64, help="utterances of the sharded batched run (0 = skip)")
     ap.add_argument("--concurrent", type=int, default=4,
                     help="extra figure (N=1 only, after the timed region): utterances in flight on one GPU (0 = skip)")
+    ap.add_argument("--no-1p7b", action="store_true")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
+    stub = args.stub
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (there is no CPU path for the product)")
     # FQ3_BENCH_BACKEND=gloo + FQ3_BENCH_ONE_DEVICE=1: smoke-test the N>1 code path on a 1-GPU box
-    backend = os.environ.get("FQ3_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("FQ3_BENCH_BACKEND", "gloo" if stub else "nccl")
     if os.environ.get("FQ3_BENCH_ONE_DEVICE"):
         local_rank = 0
     if world > 1:
@@ -250,71 +428,132 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    device = "cpu" if stub else f"cuda:{local_rank}"
+    if not stub:
+        torch.cuda.set_device(local_rank)
     coll_dev = device if backend == "nccl" else "cpu"
 
-    from fq3hip.weights import synth_prompt
-    cfg, model = build_model(device)
-    prompt = [t.to(device) if t is not None else None
-              for t in synth_prompt(cfg, PROMPT_LEN, 32, REF_FRAMES, dtype=torch.bfloat16)]
-
     def barrier():
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
+
+    cfg = model = prompt = None
+    frame_ms = p_mid = None
+    if stub:
+        run_one = lambda seed: _stub_utterance(seed)
+    else:
+        from fq3hip.weights import synth_prompt
+        cfg, model = build_model(device)
+        prompt = [t.to(device) if t is not None else None
+                  for t in synth_prompt(cfg, PROMPT_LEN, 32, REF_FRAMES, dtype=torch.bfloat16)]
+        run_one = lambda seed: one_utterance(model, prompt, seed)
 
     # (a high-priority decode stream was tried: no single-stream gain, and it quarters the throughput of the
     #  concurrent-utterance mode -- profiles/r01_concurrent_streams.txt -- so everything stays on default-priority streams)
     for i in range(args.warmup):
-        one_utterance(model, prompt, 1000 + i)
-    frame_ms, p_mid = measure_frame_graph(model, prompt)
+        run_one(1000 + i)
+    if not stub:
+        frame_ms, p_mid = measure_frame_graph(model, prompt)
 
     barrier()
     t0 = time.perf_counter()
-    ttfas, rtfs, frames_total, pcm = [], [], 0, None
+    ttfas, rtfs, frames_total, pcm = [], [], 0, np.zeros(0, np.float32)
     for i in range(args.steps):
-        ttfa, wall, n, pcm = one_utterance(model, prompt, 2000 + rank * 100 + i)
+        ttfa, wall, n, pcm = run_one(2000 + rank * 100 + i)
         ttfas.append(ttfa); rtfs.append(n * FRAME_S / wall); frames_total += n
     barrier()
     elapsed = time.perf_counter() - t0
 
-    conc = None
-    if args.concurrent > 1 and world == 1:
-        try:
-            conc = concurrent_throughput(cfg, model, prompt, device, streams=args.concurrent)
-        except Exception as e:      # an extra; never lose the headline line to it
-            conc = {"error": repr(e)}
+    extras = {}
+    solo = world == 1 and not stub and not args.no_extras
 
-    batched = None
-    if args.batch > 1 and world == 1:
+    def guarded(key, fn):
         try:
-            batched = batched_throughput(model, prompt, lanes=min(args.batch, 8), utterances=2 * min(args.batch, 8))
-        except Exception as e:      # an extra; never lose the headline line to it
-            batched = {"error": repr(e)}
+            extras[key] = fn()
+        except Exception as e:          # an extra never costs the headline line
+            extras[key] = {"error": repr(e)}
 
-    # max over ranks of the wall time, sum of frames, gather of TTFAs and (result gather) PCM lengths
+    if solo and args.concurrent > 1:
+        guarded("concurrent_utterances_one_gpu", lambda: concurrent_throughput(cfg, model, prompt, device, streams=args.concurrent))
+    if solo:
+        guarded("parity_bf16_frames", lambda: parity_note(cfg, model))
+        guarded("roofline_mfma", lambda: measure_mfma(cfg, model, prompt))
+    if solo and args.batch > 1:
+        def _batched():
+            lanes = min(args.batch, 8)
+            batched_run(model, prompt, lanes, lanes)                                   # warm-up: contexts, graph capture
+            audio_s, wall, _ = batched_run(model, prompt, 2 * lanes, lanes)
+            ms, p = batched_frame_time(model, cfg, prompt, lanes)
+            out = {"lanes": lanes, "utterances": 2 * lanes, "value": round(audio_s / wall, 3),
+                   "unit": "x real-time (aggregate audio s / wall s, one GPU, prefill + lock-step decode + non-streaming vocoder per finished utterance)",
+                   "ms_per_lockstep_frame": round(ms, 3), "decode_only_value": round(lanes * 80.0 / ms, 1),
+                   "roofline": frame_roofline(cfg, ms, p, lanes=lanes, what=f"batched decode-frame hipGraph, {lanes} lanes, VALU GEMVs")}
+            try:
+                ms2, p2 = batched_frame_time(model, cfg, prompt, lanes, mfma=1)
+                out["mfma_gemv"] = {"ms_per_lockstep_frame": round(ms2, 3), "decode_only_value": round(lanes * 80.0 / ms2, 1),
+                                    "roofline": frame_roofline(cfg, ms2, p2, lanes=lanes, what=f"batched decode-frame hipGraph, {lanes} lanes, matrix-core GEMVs")}
+            except Exception as e:
+                out["mfma_gemv"] = {"error": repr(e)}
+            return out
+        guarded("batched_decode_one_gpu", _batched)
+
+    # ---- BASELINE configs[3] shape: 64 utterances sharded over the ranks, 8 lock-step lanes per GPU (all ranks take part) ----
+    c3 = None
+    if args.config3_utterances > 0 and args.batch > 1 and not args.no_extras:
+        from fq3hip.sharding import shard_indices
+        mine = shard_indices(args.config3_utterances, rank, world)
+        lanes = min(args.batch, 8)
+        err, c3_audio, c3_lens = None, 0.0, []
+        try:
+            if not stub:
+                batched_run(model, prompt, min(lanes, len(mine)), lanes)               # warm-up
+        except Exception as e:
+            err = repr(e)
+        barrier()
+        tc = time.perf_counter()
+        if err is None:
+            try:
+                if stub:
+                    time.sleep(0.005 * len(mine))
+                    c3_audio, c3_lens = len(mine) * FRAMES * FRAME_S, [1000 + i for i in mine]
+                else:
+                    c3_audio, _w, c3_lens = batched_run(model, prompt, len(mine), lanes, seed0=2000 + rank)
+            except Exception as e:
+                err = repr(e)
+        barrier()
+        c3 = {"audio_s": c3_audio, "wall": time.perf_counter() - tc, "lens": c3_lens, "lanes": lanes}
+        if err is not None:
+            c3["error"] = err
+
+    # ---- reductions: max wall, summed frames, ONE gather of the per-rank results -----------------------------------------
+    n_gathered = len(pcm)
     if world > 1:
         from fq3hip.sharding import gather_arrays
-        tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
-        ft = torch.tensor([frames_total], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(ft)
-        frames_total = int(ft)
-        all_ttfa = gather_arrays(np.asarray(ttfas, dtype=np.float32), coll_dev)
-        ttfas = [float(x) for a in all_ttfa for x in a]
-        gathered = gather_arrays(pcm.astype(np.float32), coll_dev)     # the result gather of the north star
-        n_gathered = sum(len(a) for a in gathered)
-    else:
-        n_gathered = len(pcm)
+        stats = torch.tensor([elapsed, c3["wall"] if c3 else 0.0], device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        elapsed = float(stats[0])
+        sums = torch.tensor([frames_total, c3["audio_s"] if c3 else 0.0], device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(sums)
+        frames_total = int(sums[0])
+        # result gather of the north star, one collective pair: [n_ttfa, ttfas..., n_c3, c3 lens..., pcm...] per rank
+        payload = np.concatenate([[len(ttfas)], np.asarray(ttfas, np.float32), [len(c3["lens"]) if c3 else 0],
+                                  np.asarray(c3["lens"] if c3 else [], np.float32), pcm.astype(np.float32)]).astype(np.float32)
+        parts = gather_arrays(payload, coll_dev)
+        ttfas, c3_lens_all, n_gathered = [], [], 0
+        for a in parts:
+            k = int(a[0]); ttfas += [float(x) for x in a[1:1 + k]]
+            j = int(a[1 + k]); c3_lens_all += [int(x) for x in a[2 + k:2 + k + j]]
+            n_gathered += len(a) - (2 + k + j)
+        if c3:
+            c3 = dict(c3, wall=float(stats[1]), audio_s=float(sums[1]), lens=c3_lens_all)
 
     if rank == 0:
         audio_s = frames_total * FRAME_S
         value = audio_s / elapsed
-        bytes_frame = algorithmic_bytes_per_frame(cfg, p_mid)
-        achieved = bytes_frame / (frame_ms * 1e-3) / 1e9
         out = {
             "metric": "real-time factor (audio s / wall s), Qwen3-TTS-12Hz-0.6B voice-clone streaming chunk_size=8; p50 TTFA in ttfa_ms_p50",
             "value": round(value, 3), "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -327,23 +566,39 @@ def main():
                        "utterances_per_gpu": args.steps, "sampling": "T=0.9 top_k=50 top_p=1.0 rep=1.05 (predictor T=0.9 top_k=50)",
                        "parallelism": f"utterance-sharded x{world} (replicas, result gather only)"},
             "ttfa_ms_p50": round(1000 * float(np.median(ttfas)), 2), "ttfa_ms_mean": round(1000 * float(np.mean(ttfas)), 2),
-            "rtf_single_stream_mean": round(float(np.mean(rtfs)), 3),
-            "decode_ms_per_frame": round(frame_ms, 4), "gathered_samples": int(n_gathered),
+            "rtf_single_stream_mean": round(float(np.mean(rtfs)), 3), "gathered_samples": int(n_gathered),
             "reference_published": {"rtx4090_rtf": 4.78, "rtx4090_ttfa_ms": 156, "h100_rtf": 3.884, "h100_ttfa_ms": 228,
                                     "source": "reference README.md:227,229 (CUDA graphs, other hardware)"},
-            "roofline": {"bound": "hbm", "kernel": "decode-frame hipGraph (554 launches: predictor M=2 prefill pass + 14 token passes, talker 28 layers, heads, samplers)",
-                         "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-                         "algorithmic_bytes_per_launch": int(bytes_frame), "kv_len": p_mid,
-                         # measured once per round with a separate `rocprofv3 --pmc FETCH_SIZE` pass (x2 gfx950 correction):
-                         # the 15 predictor weight passes re-read their 157 MB through the fabric every pass
-                         "traffic": 3.37e9, "traffic_source": "profiles/r01_pmc_fetch_size.txt",
-                         "launch_ms": round(frame_ms, 4)},
         }
-        if conc is not None:
-            out["concurrent_utterances_one_gpu"] = conc
-        if batched is not None:
-            out["batched_decode_one_gpu"] = batched
-        if world == 1 and not args.no_cpu_baseline:
+        if stub:
+            out["data"] = "stub (CPU control-flow test of the N > 1 branch; no kernel ran)"
+        if frame_ms is not None:
+            out["decode_ms_per_frame"] = round(frame_ms, 4)
+            rl = frame_roofline(cfg, frame_ms, p_mid, what="decode-frame hipGraph (554 launches: predictor M=2 prefill pass + 14 token "
+                                                           "passes, talker 28 layers, heads, samplers)")
+            # HBM-side traffic of one frame: separate `rocprofv3 --pmc FETCH_SIZE` pass (x2 gfx950 correction), not collected in
+            # this run: the 15 predictor weight passes re-read their 157 MB through the fabric every pass
+            rl["traffic"] = 3.37e9
+            rl["traffic_source"] = "measured_offline: profiles/r01_pmc_fetch_size.txt (FETCH_SIZE x2, 8 profiled frames)"
+            out["roofline"] = rl
+        if c3 is not None:
+            if "error" in c3:
+                out["config3_sharded_batched"] = {"error": c3["error"]}
+            else:
+                out["config3_sharded_batched"] = {
+                    "workload": f"configs[3] shape on the 0.6B shapes: {args.config3_utterances} utterances x {FRAMES} frames, round-robin over "
+                                f"{world} GPU(s), {c3['lanes']} lock-step lanes per GPU, non-streaming vocoder, result gather only",
+                    "value": round(c3["audio_s"] / c3["wall"], 3) if c3["wall"] > 0 else None,
+                    "unit": "x real-time (aggregate audio s / max wall s)", "utterances": len(c3["lens"]), "wall_s": round(c3["wall"], 3)}
+        out.update(extras)
+        if solo and not args.no_1p7b:
+            try:
+                del model
+                torch.cuda.empty_cache()
+                out["model_1p7b"] = model_1p7b_block(device)
+            except Exception as e:
+                out["model_1p7b"] = {"error": repr(e)}
+        if world == 1 and not stub and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg)
             except Exception as e:          # the baseline is a reported extra; never lose the GPU line to it

@@ -40,19 +40,20 @@ def gather_arrays(local: np.ndarray, device="cpu") -> List[np.ndarray]:
 
 def run_sharded(items: Sequence, fn: Callable, device="cpu"):
     """Run ``fn(item) -> 1-D np.ndarray`` on this rank's shard and gather every result to every rank,
-    returned in the original item order."""
+    returned in the original item order.  ONE result gather at the end (a lengths header travels in the same payload):
+    the decode itself never waits on another rank."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     mine = shard_indices(len(items), rank, world)
-    results = {i: np.asarray(fn(items[i])) for i in mine}
+    results = [np.asarray(fn(items[i]), dtype=np.float32).reshape(-1) for i in mine]
+    header = np.asarray([len(r) for r in results], dtype=np.float32)        # item lengths < 2^24: exact in fp32
+    payload = np.concatenate([header] + results) if results else header
     out: List = [None] * len(items)
-    rounds = (len(items) + world - 1) // world
-    for r in range(rounds):
-        idx = r * world + rank
-        local = results[idx] if idx < len(items) else np.zeros(0, dtype=np.float32)
-        gathered = gather_arrays(local, device)
-        for rk, g in enumerate(gathered):
-            j = r * world + rk
-            if j < len(items):
-                out[j] = g
+    for rk, flat in enumerate(gather_arrays(payload, device)):
+        idx = shard_indices(len(items), rk, world)
+        lens = [int(x) for x in flat[:len(idx)]]
+        pos = len(idx)
+        for i, n in zip(idx, lens):
+            out[i] = flat[pos:pos + n]
+            pos += n
     return out

@@ -1,0 +1,48 @@
+"""CPU, world_size 2, gloo: the REAL bench.py N > 1 branch (process-group set-up from the torchrun environment, barriers,
+MAX / SUM reductions, the single result gather, rank-0 JSON line) with a scripted utterance runner (`--stub`): what the
+driver launches at N = 2, 4, 8, minus the kernels."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, steps=2):
+    env = dict(os.environ, FQ3_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps),
+           "--warmup", "1", "--stub", "--config3-utterances", "10"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_gloo_stub():
+    d = _run(2)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["higher_is_better"] is True and d["unit"] == "x real-time"
+    # whole-job aggregate: 2 ranks x 2 utterances x 200 frames of 80 ms over the MAX wall time
+    audio_s = 2 * 2 * 200 * 0.08
+    assert abs(d["value"] * d["ms_per_step"] * d["steps"] / 1000 - audio_s) < 0.05 * audio_s
+    assert d["gathered_samples"] >= 2 * 1000          # both ranks' PCM arrived through the gather
+    c3 = d["config3_sharded_batched"]
+    assert c3["utterances"] == 10                     # 5 + 5 lengths came back through the same gather
+    assert "stub" in d["data"]
+
+
+def test_bench_single_rank_stub_has_same_shape():
+    d = _run(1, steps=1)
+    assert d["n_gpus"] == 1 and d["config3_sharded_batched"]["utterances"] == 10

@@ -156,31 +156,96 @@ def test_generate_voice_clone_batch_equals_single_calls():
         assert wa[0].shape == wb[0].shape and np.array_equal(wa[0], wb[0])
 
 
-@pytest.mark.skipif(os.environ.get("FQ3_RUN_UNVALIDATED") != "1",
-                    reason="matrix-core batch GEMV: checked at kernel level by tools/microbench/kernel_chain (24 checks), "
-                           "first end-to-end run pending (set FQ3_RUN_UNVALIDATED=1)")
-def test_mfma_batch_path_close_to_single_stream(monkeypatch):
-    """FQ3_BATCH_MFMA=1 (bf16): the fp32 summation order differs from the VALU kernels, so ids agree with the single-stream
-    run only until the first decision whose top-2 margin is inside bf16 noise (after which a greedy run diverges for good);
-    a coarse bound for the first run: every lane > 50 % identical ids, > 80 % on average.  To be tightened with
-    margin attribution (as in test_gpu_decode.py) once it has run."""
+# ---- batch lanes against the ORACLE (not against the single-stream HIP path) -----------------------------------------------
+def _oracle_greedy(cfg, W, u, frames):
+    from oracle import qwen3tts_oracle as O
+    orc = O.OracleTTS(cfg, W, max_seq_len=96)
+    orc.pred_sampling = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    tam = torch.ones(1, u["tie"].shape[1], dtype=torch.long)
+    tam[0, :u["n_pad"]] = 0
+    sp = O.SamplingParams(max_new_tokens=frames, **{**O.GREEDY, "min_new_tokens": frames})
+    codes = orc.generate(u["tie"], tam, u["tth"], u["tpe"], sp, record_margins=True)
+    return codes, orc
+
+
+def test_batch_lanes_equal_oracle_fp32():
+    """fp32: every lane of a 3-lane lock-step batch (different prompt lengths, one left-padded, one with > 64 keys)
+    reproduces the CPU oracle's greedy ids exactly -- the f3 row's parity no longer rests on the single-stream path."""
     from fq3hip.engine import Fq3Batch
-    monkeypatch.setenv("FQ3_BATCH_MFMA", "1")
     cfg = tiny_test_config()
-    dtype = torch.bfloat16
+    dtype = torch.float32
     W = synth_weights(cfg, 0, dtype)
-    utts = [_utterance(cfg, dtype, 41 + i, 20 + 7 * i, 0, 12, 12, False) for i in range(3)]
-    solo = _engines(cfg, W, dtype, 1)[0]
-    ref = [_alone(solo, cfg, u, 12)[0] for u in utts]
+    frames = 12
+    utts = [_utterance(cfg, dtype, 51, 20, 0, frames, frames, False), _utterance(cfg, dtype, 52, 33, 4, frames, frames, False),
+            _utterance(cfg, dtype, 53, 70, 0, frames, frames, False)]
+    refs = [_oracle_greedy(cfg, W, u, frames)[0] for u in utts]
     lanes = _engines(cfg, W, dtype, 3)
     batch = Fq3Batch(lanes)
     for e, u in zip(lanes, utts):
         _arm(e, cfg, u)
-    batch.frames(12)
-    agree = []
-    for e, r in zip(lanes, ref):
+    batch.graph_capture()
+    batch.frames(frames)
+    for i, (e, r) in enumerate(zip(lanes, refs)):
         n, _ = e.decode_poll()
-        c = e.decode_codes(0, n).cpu()
-        assert c.shape == r.shape
-        agree.append(float((c == r).float().mean()))
-    assert min(agree) > 0.5 and sum(agree) / len(agree) > 0.8, agree
+        assert n == frames and torch.equal(e.decode_codes(0, n).cpu(), r), f"lane {i} differs from the oracle"
+
+
+@pytest.mark.parametrize("mfma", [0, 1])
+def test_batch_lanes_vs_oracle_bf16_teacher_forced(mfma):
+    """bf16, VALU batch GEMVs (mfma=0) and matrix-core batch GEMVs (mfma=1): every lane is teacher-forced with the bf16
+    oracle's ids (fq3_decode_set_forced works per lane) and every decision scored: a mismatch must sit at an oracle
+    top-2 margin of <= 4 bf16 ulps, and >= 90 % of all decisions must be identical."""
+    import numpy as np
+    from fq3hip.engine import Fq3Batch
+    from oracle import teacher_forced as TF
+    cfg = tiny_test_config()
+    dtype = torch.bfloat16
+    W = synth_weights(cfg, 0, dtype)
+    frames, G = 12, cfg.num_code_groups
+    utts = [_utterance(cfg, dtype, 61, 20, 0, frames, frames, False), _utterance(cfg, dtype, 62, 33, 4, frames, frames, False),
+            _utterance(cfg, dtype, 63, 70, 0, frames, frames, False)]
+    cases = []
+    for u in utts:
+        codes, orc = _oracle_greedy(cfg, W, u, frames)
+        cases.append(dict(codes=codes.numpy().astype(np.int32), t_margin=np.asarray(orc.margins, np.float32),
+                          t_top1=np.asarray(orc.top1, np.float32), p_margin=np.asarray(orc.pred_margins, np.float32).reshape(frames, G - 1),
+                          p_top1=np.asarray(orc.pred_top1, np.float32).reshape(frames, G - 1)))
+    lanes = _engines(cfg, W, dtype, 3)
+    batch = Fq3Batch(lanes)
+    batch.set_option("mfma", mfma)
+    keep, tok0 = [], []
+    for e, u, c in zip(lanes, utts, cases):
+        _arm(e, cfg, u)                                                  # arms with the HIP first token ...
+        n, _ = e.decode_poll()
+        forced = torch.zeros(frames + 1, G, dtype=torch.int32)
+        forced[:frames] = torch.from_numpy(c["codes"])
+        forced[frames, 0] = int(c["codes"][-1, 0])
+        dec = torch.full((frames + 1, G), -1, dtype=torch.int32, device="cuda")
+        keep.append((forced.cuda(), dec))
+    # re-arm every lane with the ORACLE's first token (the HIP prefill decision is scored separately below)
+    for e, u, c, (f, d) in zip(lanes, utts, cases, keep):
+        x = u["tie"][0].cuda().contiguous()
+        logits, hidden = e.prefill(x, n_pad=u["n_pad"])
+        V = cfg.talker.vocab_size
+        t0 = e.sample(logits, sup_lo=max(0, V - 1024), sup_hi=V, keep_id=cfg.codec_eos_token_id, suppress_eos=True,
+                      temperature=1.0, top_k=0, top_p=1.0, do_sample=False)
+        tok0.append(int(t0))
+        e.decode_begin(first_token=int(c["codes"][0, 0]), prefill_len=x.shape[0], gen_step=0, past_hidden=hidden,
+                       trailing_text=u["tth"][0].cuda().contiguous(), tts_pad_embed=u["tpe"].view(-1).cuda().contiguous(),
+                       repetition_penalty=1.0, min_new_tokens=frames, max_new_tokens=frames, temperature=1.0, top_k=0,
+                       top_p=1.0, do_sample=False)
+        e.decode_set_forced(f, d)
+    batch.graph_capture()
+    batch.frames(frames)
+    tot = ok = 0
+    for i, (e, c, (f, d), t0) in enumerate(zip(lanes, cases, keep, tok0)):
+        n, _ = e.decode_poll()
+        assert n == frames
+        decisions = d.cpu().numpy().astype(np.int64)[:frames].copy()
+        decisions[0, 0] = t0
+        s = TF.score(decisions, c, 4.0)
+        print(f"[parity] batch lane {i} bf16 mfma={mfma}: {s}")
+        assert s["unexplained"] == 0, (i, s)
+        tot += s["total"]; ok += s["matched_decisions"]
+        e.decode_set_forced(None, None)
+    assert ok >= 0.9 * tot, (ok, tot)
