@@ -204,8 +204,10 @@ int fq3_graph_reset(fq3_ctx* ctx);
  * ONE max_seq_len.  Each lane is prepared with the single-stream entry points (fq3_prefill, fq3_set_generation_state,
  * fq3_decode_begin) and read back with fq3_decode_poll / fq3_decode_codes on ITS context; fq3_batch_frames replaces
  * fq3_decode_frames for all lanes at once.  Lanes that are done (EOS, limits, or never begun) idle on device and can be
- * re-armed with fq3_decode_begin between calls (continuous batching).  Sampling with top_p >= 1.0 only.  A lane's ids
- * are bit-identical to the same utterance decoded alone with the same noise. */
+ * re-armed with fq3_decode_begin between calls (continuous batching).  Sampling with top_p >= 1.0 only (the
+ * register-resident sampler; nucleus sampling stays on the single-stream path: fq3_batch_frames returns
+ * FQ3_EUNSUPPORTED for such a lane).  With the VALU GEMVs ("mfma" 0, the fp32 default) a lane's ids are bit-identical to
+ * the same utterance decoded alone with the same noise. */
 typedef struct fq3_batch fq3_batch;
 int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out);
 int fq3_batch_destroy(fq3_batch* b);
@@ -214,7 +216,8 @@ int fq3_batch_size(const fq3_batch* b);
 int fq3_batch_frames(fq3_batch* b, int n_frames, void* stream);
 int fq3_batch_graph_capture(fq3_batch* b, void* stream);
 int fq3_batch_graph_reset(fq3_batch* b);
-/* "mfma" 0|1: batch GEMVs on the matrix cores (bf16 contexts). */
+/* "mfma" 0|1: batch GEMVs on the matrix cores (bf16 contexts; default 1: ids checked against the oracle by teacher
+ * forcing) or on the VALU kernels (0: every lane bit-identical to the same utterance decoded alone). */
 int fq3_batch_set_option(fq3_batch* b, const char* key, int value);
 
 /* ---- 12 Hz codec decoder (speech_tokenizer.decode, model.py:924) ---------------------------- */

@@ -73,6 +73,7 @@ def test_lanes_equal_single_stream(dtype, graph):
     ref = [_alone(solo, cfg, u, 16) for u in utts]
     lanes = _engines(cfg, W, dtype, 4)                                # 4th lane is never begun
     batch = Fq3Batch(lanes)
+    batch.set_option("mfma", 0)                                       # the bit-identity property belongs to the VALU GEMVs
     for e, u in zip(lanes, utts):
         _arm(e, cfg, u)
     if graph:
@@ -98,6 +99,7 @@ def test_continuous_batching_rearm_a_lane(dtype):
     ref_short, ref_long, ref_new = (_alone(solo, cfg, u_short, 8)[0], _alone(solo, cfg, u_long, 24)[0], _alone(solo, cfg, u_new, 16)[0])
     lanes = _engines(cfg, W, dtype, 2)
     batch = Fq3Batch(lanes)
+    batch.set_option("mfma", 0)
     _arm(lanes[0], cfg, u_short); _arm(lanes[1], cfg, u_long)
     batch.graph_capture()
     batch.frames(8)
