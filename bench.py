@@ -102,25 +102,47 @@ def build_model(device, size="0p6b", frames=FRAMES):
     from fq3hip.weights import synth_weights
     from fq3hip.model import FasterQwen3TTS
     cfg = qwen3_tts_0p6b() if size == "0p6b" else qwen3_tts_1p7b()
-    W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor", "codec"), codec_normalized=True)
+    W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor", "codec", "text"), codec_normalized=True)
     model = FasterQwen3TTS.from_weights(cfg, W, device=device, dtype=torch.bfloat16, max_seq_len=2048,
                                         codec_max_frames=REF_FRAMES + frames + 16, max_frames=frames + 8)
     model._bench_weights = W
     return cfg, model
 
 
-def one_utterance(model, prompt, seed, sync=None, frames=FRAMES):
-    """Streaming voice-clone of one synthetic utterance.  Returns (ttfa_s, wall_s, n_frames, pcm)."""
+def build_request(cfg, device):
+    """The synthetic request of SURVEY.md section 8(d) expressed through the PUBLIC API, so that the timed region starts
+    where the reference's does (text in, README.md:219 / benchmarks/throughput.py:49-61): an ICL voice-clone prompt with
+    170 reference frames, a 20-token instruct turn, 90 + 112 text tokens -> 200 prompt rows (20 + 3 + 6 + 171) and 32
+    trailing-text rows.  No HF tokenizer exists offline: the byte-level stand-in of fq3hip.native_model tokenises."""
+    g = torch.Generator().manual_seed(1237)
+    ref_code = torch.cat([torch.randint(0, cfg.talker.vocab_size - 1024, (REF_FRAMES, 1), generator=g),
+                          torch.randint(0, cfg.codec.codebook_size, (REF_FRAMES, cfg.num_code_groups - 1), generator=g)], 1).to(device)
+    spk = torch.randn(cfg.talker.hidden_size, generator=g).to(device=device, dtype=torch.bfloat16)
+    words = "the quick brown fox jumps over the lazy dog and keeps running through the quiet evening fields "
+    return dict(text=(words * 2)[:112], language="English", ref_text=words[:90], instruct="speak calmly!!!",
+                voice_clone_prompt=dict(ref_code=[ref_code], ref_spk_embedding=[spk], x_vector_only_mode=[False], icl_mode=[True]))
+
+
+def prepared_prompt(model, req):
+    """(tie, tam, tth, tpe, ref_codes) of the request, for the blocks that time the decode / prefill alone."""
+    _m, _talker, _config, tie, tam, tth, tpe, rc = model._prepare_generation(
+        text=req["text"], language=req["language"], ref_text=req["ref_text"], voice_clone_prompt=req["voice_clone_prompt"],
+        instruct=req["instruct"], non_streaming_mode=False)
+    assert tie.shape[1] == PROMPT_LEN and tth.shape[1] == 32 and rc.shape[0] == REF_FRAMES, (tie.shape, tth.shape, rc.shape)
+    return [tie, tam, tth, tpe, rc]
+
+
+def one_utterance(model, req, seed, sync=None, frames=FRAMES):
+    """Streaming voice-clone of one synthetic utterance through the public entry point: tokenisation, prompt build,
+    prefill, decode, streaming vocoder.  Returns (ttfa_s, wall_s, n_frames, pcm)."""
     sync = sync or torch.cuda.synchronize
-    tie, tam, tth, tpe, ref_codes = prompt
-    m = model.model.model
-    talker, config = m.talker, m.config.talker_config
     torch.manual_seed(seed)
-    kw = model._gen_kwargs(frames, frames, 0.9, 50, 1.0, True, 1.05)
     sync()
     t0 = time.perf_counter()
     ttfa, chunks, n = None, [], 0
-    for audio, sr, timing in model._run_streaming(m, talker, config, tie, tam, tth, tpe, ref_codes, kw, CHUNK):
+    for audio, sr, timing in model.generate_voice_clone_streaming(
+            text=req["text"], language=req["language"], ref_text=req["ref_text"], voice_clone_prompt=req["voice_clone_prompt"],
+            instruct=req["instruct"], chunk_size=CHUNK, max_new_tokens=frames, min_new_tokens=frames):
         if ttfa is None:
             ttfa = time.perf_counter() - t0       # `audio` is a host array: the first chunk is complete here
         chunks.append(audio)
@@ -194,7 +216,7 @@ def measure_mfma(cfg, model, prompt):
     return out
 
 
-def concurrent_throughput(cfg, model, prompt, device, streams=4, utterances=2):
+def concurrent_throughput(cfg, model, req, device, streams=4, utterances=2):
     """Extra (not the headline): S utterances in flight on ONE GPU, each with its own decode context, codec
     workspace, hipGraph and HIP stream, all borrowing the single weight replica."""
     import threading
@@ -211,12 +233,12 @@ def concurrent_throughput(cfg, model, prompt, device, streams=4, utterances=2):
             torch.cuda.set_device(torch.device(device))
             st = torch.cuda.Stream(device=device)
             with torch.cuda.stream(st):
-                one_utterance(models[i], prompt, 5000 + i, sync=st.synchronize)     # per-context warm-up + graph capture
+                one_utterance(models[i], req, 5000 + i, sync=st.synchronize)     # per-context warm-up + graph capture
                 bar.wait(timeout=60)
                 t0 = time.perf_counter()
                 frames, ttfas = 0, []
                 for u in range(utterances):
-                    ttfa, wall, n, _ = one_utterance(models[i], prompt, 6000 + 10 * i + u, sync=st.synchronize)
+                    ttfa, wall, n, _ = one_utterance(models[i], req, 6000 + 10 * i + u, sync=st.synchronize)
                     frames += n; ttfas.append(ttfa)
                 res[i] = (t0, time.perf_counter(), frames, ttfas)
         except BaseException as e:      # never leave the other workers parked on the barrier
@@ -362,12 +384,12 @@ def cpu_baseline(cfg, frames=6, budget_s=45.0):
 def model_1p7b_block(device):
     """BASELINE configs[2]: the 1.7B shapes (talker hidden 2048 / intermediate 6144, predictor with projection), single
     stream: RTF / TTFA over 2 utterances + the decode-frame roofline; and 8 lock-step lanes (configs[3]'s model)."""
-    from fq3hip.weights import synth_prompt
     cfg, model = build_model(device, "1p7b")
-    prompt = [t.to(device) if t is not None else None for t in synth_prompt(cfg, PROMPT_LEN, 32, REF_FRAMES, dtype=torch.bfloat16)]
-    one_utterance(model, prompt, 900)
+    req = build_request(cfg, device)
+    one_utterance(model, req, 900)
+    prompt = prepared_prompt(model, req)
     frame_ms, p_mid = measure_frame_graph(model, prompt)
-    res = [one_utterance(model, prompt, 910 + i) for i in range(2)]
+    res = [one_utterance(model, req, 910 + i) for i in range(2)]
     out = {"workload": "configs[2]: Qwen3-TTS-12Hz-1.7B-Base shapes, voice-clone streaming chunk_size=8, bf16, synthetic weights",
            "rtf": round(float(np.mean([n * FRAME_S / w for _, w, n, _ in res])), 3),
            "ttfa_ms_p50": round(1000 * float(np.median([t for t, _, _, _ in res])), 2),
@@ -441,22 +463,21 @@ def main():
         if not stub:
             torch.cuda.synchronize()
 
-    cfg = model = prompt = None
+    cfg = model = prompt = req = None
     frame_ms = p_mid = None
     if stub:
         run_one = lambda seed: _stub_utterance(seed)
     else:
-        from fq3hip.weights import synth_prompt
         cfg, model = build_model(device)
-        prompt = [t.to(device) if t is not None else None
-                  for t in synth_prompt(cfg, PROMPT_LEN, 32, REF_FRAMES, dtype=torch.bfloat16)]
-        run_one = lambda seed: one_utterance(model, prompt, seed)
+        req = build_request(cfg, device)
+        run_one = lambda seed: one_utterance(model, req, seed)
 
     # (a high-priority decode stream was tried: no single-stream gain, and it quarters the throughput of the
     #  concurrent-utterance mode -- profiles/r01_concurrent_streams.txt -- so everything stays on default-priority streams)
     for i in range(args.warmup):
         run_one(1000 + i)
     if not stub:
+        prompt = prepared_prompt(model, req)
         frame_ms, p_mid = measure_frame_graph(model, prompt)
 
     barrier()
@@ -478,7 +499,7 @@ def main():
             extras[key] = {"error": repr(e)}
 
     if solo and args.concurrent > 1:
-        guarded("concurrent_utterances_one_gpu", lambda: concurrent_throughput(cfg, model, prompt, device, streams=args.concurrent))
+        guarded("concurrent_utterances_one_gpu", lambda: concurrent_throughput(cfg, model, req, device, streams=args.concurrent))
     if solo:
         guarded("parity_bf16_frames", lambda: parity_note(cfg, model))
         guarded("roofline_mfma", lambda: measure_mfma(cfg, model, prompt))
@@ -558,11 +579,12 @@ def main():
             "metric": "real-time factor (audio s / wall s), Qwen3-TTS-12Hz-0.6B voice-clone streaming chunk_size=8; p50 TTFA in ttfa_ms_p50",
             "value": round(value, 3), "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * elapsed / max(args.steps, 1), 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random weights at 0.6B shapes, synthetic 200-token ICL prompt)",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random weights at 0.6B shapes incl. text embedding / projection; 200-row ICL prompt built from text + 170 synthetic reference frames)",
             "config": {"workload": "configs[1]: Qwen3-TTS-12Hz-0.6B-Base voice-clone streaming chunk_size=8, hipGraph decode",
                        "prompt_tokens": PROMPT_LEN, "ref_frames": REF_FRAMES, "frames_per_utterance": FRAMES,
-                       "timed_region": "prefill + decode + streaming vocoder; prompt embeddings are the (HBM-resident) input, "
-                                       "text tokenisation / prompt assembly is host glue outside the hot path",
+                       "timed_region": "public generate_voice_clone_streaming(): tokenisation (byte-level stand-in tokenizer: no HF tokenizer "
+                                       "offline) + prompt build (HIP) + prefill + decode + streaming vocoder, as the reference times it "
+                                       "(README.md:219); weights, reference codes and speaker embedding are HBM-resident",
                        "utterances_per_gpu": args.steps, "sampling": "T=0.9 top_k=50 top_p=1.0 rep=1.05 (predictor T=0.9 top_k=50)",
                        "parallelism": f"utterance-sharded x{world} (replicas, result gather only)"},
             "ttfa_ms_p50": round(1000 * float(np.median(ttfas)), 2), "ttfa_ms_mean": round(1000 * float(np.mean(ttfas)), 2),

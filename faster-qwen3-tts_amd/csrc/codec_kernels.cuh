@@ -35,7 +35,7 @@ struct GemmArgs {
     const void* scale;                                // optional per-n multiplier after the activation
     const void* res; int ldr;                         // optional residual [M][ldr]
     void* Y; int ldy;                                 // primary output (may be null when only Y2 is wanted)
-    int act;                                          // 0 none, 1 exact GELU, 2 SwiGLU over 16-column [gate|up] groups
+    int act;                                          // 0 none, 1 exact GELU, 2 SwiGLU over 16-column [gate|up] groups, 3 SiLU
     const void* sn_a; const void* sn_ib; void* Y2;    // optional second output: SnakeBeta(stored value), channel n % bias_mod
 };
 
@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
                 if (m >= a.M) continue;
                 float v = DT<T>::rnd(acc[i][j][r] + b);
                 if (a.act == 1) v = DT<T>::rnd(gelu_exact(v));
+                if (a.act == 3) v = DT<T>::rnd(v / (1.0f + expf(-v)));
                 if (a.scale) v = DT<T>::rnd(sc * v);
                 if (a.res) v = v + DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)m * a.ldr + n);
                 v = DT<T>::rnd(v);

@@ -46,6 +46,11 @@ struct fq3_ctx {
     hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr;
     std::vector<void*> allocs;
+    // prompt builder (fq3_prompt.hip): text embedding table + text_projection MLP, lazily grown workspaces
+    fq3_prompt_weights pw{};
+    bool pw_bound = false;
+    void *pw_x = nullptr, *pw_h = nullptr;
+    int pw_cap = 0;
     // MFMA prefill workspace (lazily allocated, sized for max_seq_len rows)
     void *pf_x = nullptr, *pf_xn = nullptr, *pf_qkv = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_act = nullptr;
 };

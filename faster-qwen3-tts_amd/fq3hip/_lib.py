@@ -57,6 +57,11 @@ class DecodeParams(C.Structure):
                 ("noise_frames", i32)]
 
 
+class PromptWeights(C.Structure):
+    _fields_ = [("text_embedding", vp), ("fc1_w", vp), ("fc1_b", vp), ("fc2_w", vp), ("fc2_b", vp), ("text_vocab", i32),
+                ("text_hidden", i32)]
+
+
 class CodecConfig(C.Structure):
     _fields_ = [("dtype", i32), ("codebook_size", i32), ("codebook_dim", i32), ("rvq_dim", i32),
                 ("num_quantizers", i32), ("num_semantic", i32), ("latent_dim", i32), ("hidden", i32), ("inter", i32),
@@ -92,6 +97,9 @@ SIGNATURES = {
     "fq3_decode_codes": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "fq3_graph_capture": (C.c_int, [vp, vp]),
     "fq3_graph_reset": (C.c_int, [vp]),
+    "fq3_bind_prompt_weights": (C.c_int, [vp, C.POINTER(PromptWeights)]),
+    "fq3_text_project": (C.c_int, [vp, vp, C.c_int, vp, vp]),
+    "fq3_prompt_rows": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp]),
     "fq3_batch_create": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp)]),
     "fq3_batch_destroy": (C.c_int, [vp]),
     "fq3_batch_size": (C.c_int, [vp]),

@@ -221,6 +221,42 @@ class Fq3Engine:
         L.check(self.lib.fq3_codec_head(self.ctx, hidden.data_ptr(), out.data_ptr(), self._stream()))
         return out
 
+    # ---- prompt builder ----
+    def bind_prompt_weights(self, text_embedding: torch.Tensor, fc1_w: torch.Tensor, fc1_b: torch.Tensor,
+                            fc2_w: torch.Tensor, fc2_b: torch.Tensor):
+        """talker.get_text_embeddings() / talker.text_projection weights for ``text_project`` (tensors are borrowed)."""
+        ts = [t.to(device=self.device, dtype=self.dtype).contiguous() for t in (text_embedding, fc1_w, fc1_b, fc2_w, fc2_b)]
+        self._prompt_keep = ts
+        w = L.PromptWeights(*[t.data_ptr() for t in ts], int(ts[0].shape[0]), int(ts[0].shape[1]))
+        L.check(self.lib.fq3_bind_prompt_weights(self.ctx, C.byref(w)))
+
+    def text_project(self, ids: torch.Tensor) -> torch.Tensor:
+        """text_projection(text_embedding(ids)) for a flat LongTensor of token ids -> [n, H]."""
+        ids = ids.reshape(-1).to(device=self.device, dtype=torch.long).contiguous()
+        out = self.new(ids.numel(), self.cfg.talker.hidden_size)
+        L.check(self.lib.fq3_text_project(self.ctx, ids.data_ptr(), int(ids.numel()), out.data_ptr(), self._stream()))
+        return out
+
+    def prompt_rows(self, text_rows: Optional[torch.Tensor], prog: torch.Tensor, ref_codes: Optional[torch.Tensor] = None,
+                    spk_embed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Assemble prompt rows from a row program int32[n, 3] = (text_row | -1, kind, arg); see ``fq3_prompt_rows``."""
+        H = self.cfg.talker.hidden_size
+        prog = prog.to(device=self.device, dtype=torch.int32).contiguous()
+        n = prog.shape[0]
+        if text_rows is not None:
+            self._chk(text_rows, text_rows.shape[0] * H, "prompt_rows text_rows")
+        if spk_embed is not None:
+            spk_embed = spk_embed.reshape(-1).to(device=self.device, dtype=self.dtype).contiguous()
+            self._chk(spk_embed, H, "prompt_rows spk_embed")
+        if ref_codes is not None:
+            ref_codes = ref_codes.to(device=self.device, dtype=torch.long).contiguous()
+        out = self.new(n, H)
+        L.check(self.lib.fq3_prompt_rows(self.ctx, _ptr(text_rows), int(text_rows.shape[0]) if text_rows is not None else 0,
+                                         prog.data_ptr(), int(n), _ptr(ref_codes),
+                                         int(ref_codes.shape[0]) if ref_codes is not None else 0, _ptr(spk_embed),
+                                         out.data_ptr(), self._stream()))
+        return out
+
     # ---- predictor ----
     def set_predictor_sampling(self, *, do_sample: bool, top_k: int, top_p: float, temperature: float):
         s = L.Sampling(float(temperature), int(top_k), float(top_p), int(bool(do_sample)), 1.0)

@@ -257,6 +257,14 @@ class FasterQwen3TTS:
     def _build_talker_inputs_local(self, m, input_ids, ref_ids, voice_clone_prompt, languages, speakers,
                                    non_streaming_mode: bool, instruct_ids=None):
         tk, tc, mc = m.talker, m.config.talker_config, m.config
+        if len(input_ids) == 1 and getattr(tk, "hip_prompt_ready", False):
+            # native model: the whole prompt is three launches of HIP arithmetic (fq3hip/prompt.py); the tensor-op
+            # version below is kept for foreign `m` objects (an upstream qwen-tts model) and for batches
+            from .prompt import build_talker_inputs_hip
+            vcp = voice_clone_prompt
+            return build_talker_inputs_hip(m, input_ids[0], ref_ids[0] if ref_ids else None, vcp, 0, languages[0],
+                                           speakers[0] if speakers is not None else None, non_streaming_mode,
+                                           instruct_ids[0] if instruct_ids is not None else None)
         dev = tk.device
         emb_c = tk.get_input_embeddings()
         text = lambda ids: tk.text_projection(tk.get_text_embeddings()(ids))

@@ -7,8 +7,9 @@ plain weight table so that ``FasterQwen3TTS`` and the decode loops run without `
 
 * hot path (talker / predictor / sampler / codec decoder): HIP, through ``Fq3Engine`` / ``HipSpeechTokenizer``;
 * prompt building (text embedding + ``text_projection`` MLP, codec prefix embeddings, ICL reference
-  code embedding sum): host glue with a handful of torch ops on the GPU -- SURVEY.md section 8(f) row 1
-  ("next"), outside this round's kernel scope;
+  code embedding sum): HIP (``fq3_text_project`` / ``fq3_prompt_rows``, driven by ``fq3hip/prompt.py``); the
+  module-style accessors below (``get_text_embeddings``, ``text_projection``, ``generate_icl_prompt``) keep the
+  attribute surface the reference's generic code path reaches for;
 * reference-audio analysis (speaker encoder, speech-tokenizer *encoder*): not implemented; callers
   pass a precomputed ``voice_clone_prompt`` (the reference supports exactly that, model.py:320-411).
 
@@ -62,7 +63,7 @@ class _Embedding:
 
 
 class NativeTalker:
-    def __init__(self, cfg: TTSConfig, engine: Fq3Engine, text_weights: Optional[Weights]):
+    def __init__(self, cfg: TTSConfig, engine: Fq3Engine, text_weights: Optional[Weights], share: Optional["NativeTalker"] = None):
         self.cfg, self.engine = cfg, engine
         self.device = engine.device
         self.rope_deltas = None
@@ -80,8 +81,16 @@ class NativeTalker:
         self._tw = None
         if text_weights is not None:
             dt, dev = engine.dtype, engine.device
-            self._tw = {k: v.to(device=dev, dtype=dt) for k, v in text_weights.items()}
+            if share is not None and share._tw is not None and share.engine.dtype == dt and share.device == dev:
+                self._tw = share._tw                     # one device copy of the 600 MB text table per GPU
+            else:
+                self._tw = {k: v.to(device=dev, dtype=dt) for k, v in text_weights.items()}
             self._text_emb = _Embedding(self._tw["talker.model.text_embedding.weight"])
+            w = self._tw
+            engine.bind_prompt_weights(w["talker.model.text_embedding.weight"], w["talker.text_projection.linear_fc1.weight"],
+                                       w["talker.text_projection.linear_fc1.bias"], w["talker.text_projection.linear_fc2.weight"],
+                                       w["talker.text_projection.linear_fc2.bias"])
+        self.hip_prompt_ready = self._tw is not None
 
     def get_input_embeddings(self):
         return self._codec_emb
@@ -153,7 +162,7 @@ class NativeQwen3TTS:
         self.engine = Fq3Engine(cfg, weights, device=device, dtype=dtype, max_seq_len=max_seq_len, max_frames=max_frames,
                                 share=share.engine if share is not None else None)
         text = {k: v for k, v in weights.items() if k.startswith(("talker.model.text_embedding", "talker.text_projection"))}
-        talker = NativeTalker(cfg, self.engine, text if text else None)
+        talker = NativeTalker(cfg, self.engine, text if text else None, share=share.model.talker if share is not None else None)
         tok = None
         if any(k.startswith("decoder.") for k in weights):
             tok = HipSpeechTokenizer(cfg.codec, weights, device=device, dtype=dtype, max_frames=codec_max_frames,

@@ -198,6 +198,29 @@ int fq3_decode_codes(fq3_ctx* ctx, int from, int count, int64_t* out_codes_dev, 
 int fq3_graph_capture(fq3_ctx* ctx, void* stream);
 int fq3_graph_reset(fq3_ctx* ctx);
 
+/* ---- prompt builder (model.py:583-805 _build_talker_inputs_local and upstream generate_icl_prompt) -------------------
+ * Every row of the talker prompt is  text_projection(text_embedding(id))  +  a codec-stream row  (either may be absent):
+ * the text rows come from one batched MLP on the matrix cores, the codec rows are embedding gathers / the speaker
+ * embedding / the 16-way embedding sum of one reference frame, and ONE kernel assembles all rows from a small row program
+ * the host derives from the token ids (which segment goes where is control flow, not arithmetic). */
+typedef struct fq3_prompt_weights {
+    const void* text_embedding;   /* [text_vocab, text_hidden]   talker.get_text_embeddings(), model.py:605 */
+    const void* fc1_w;            /* [text_hidden, text_hidden]  talker.text_projection.linear_fc1 */
+    const void* fc1_b;            /* [text_hidden] */
+    const void* fc2_w;            /* [H, text_hidden]            talker.text_projection.linear_fc2 */
+    const void* fc2_b;            /* [H] */
+    int32_t text_vocab, text_hidden;
+} fq3_prompt_weights;
+int fq3_bind_prompt_weights(fq3_ctx* ctx, const fq3_prompt_weights* w);
+/* out T[n, H] = text_projection(text_embedding(ids int64[n]))  (fc1 -> SiLU -> fc2, one rounding per module output). */
+int fq3_text_project(fq3_ctx* ctx, const int64_t* ids, int n, void* out, void* stream);
+/* Assemble n_rows prompt rows.  prog int32[n_rows][3] = {text_row, kind, arg}: text_row indexes text_rows T[n_text, H]
+ * (-1: no text part); kind 0 no codec part, 1 codec_embedding[arg], 2 the speaker embedding spk_embed T[H],
+ * 3 the sum over the 16 codebook embeddings of reference frame arg (ref_codes int64[n_ref, 16], model.py:699-712).
+ * out[r] = text part + codec part (one rounding), or the single part that is present. */
+int fq3_prompt_rows(fq3_ctx* ctx, const void* text_rows, int n_text, const int32_t* prog, int n_rows,
+                    const int64_t* ref_codes, int n_ref, const void* spk_embed, void* out, void* stream);
+
 /* ---- batched decode: B utterances in lock-step over one weight stream ------------------------------
  * No reference equivalent (the reference fixes batch = 1: talker_graph.py:46, predictor_graph.py:70; SURVEY.md
  * section 8f rank 3).  A batch borrows n_lanes (1..8) ordinary contexts that share ONE weight table, ONE config and

@@ -583,3 +583,58 @@ def streaming_vocode(tok, chunks, ref_codes, chunk_size, context_frames: int = 2
             audio = tok.decode({"audio_codes": win.unsqueeze(0)})[0][0].flatten().float().numpy()
             new = audio[int(round(n_ctx * spf)):] if n_ctx > 0 else audio
         yield new
+
+
+# ======================================================================================
+# Prompt side: a CPU duck type of the upstream model object the reference's prompt builder reaches into
+# ======================================================================================
+class OraclePromptModel:
+    """``m`` as ``FasterQwen3TTS._build_talker_inputs_local(self, m, ...)`` uses it (reference ``model.py:583-805``):
+    ``m.talker.{device, get_input_embeddings, get_text_embeddings, text_projection}``, ``m.config`` (+ ``talker_config``),
+    ``m.generate_speaker_prompt`` and ``m.generate_icl_prompt``.  The MLP is the sibling's ResizeMLP
+    (``modeling_qwen3_omni_moe.py:2207-2215``: fc1, SiLU, fc2).  ``generate_icl_prompt`` restates upstream behaviour
+    [recalled: qwen-tts is not vendored] -- parity unpinned for that one function."""
+
+    def __init__(self, cfg, W: Weights):
+        from types import SimpleNamespace as NS
+        self.W, self._cfg = W, cfg
+        emb = lambda w: (lambda ids: F.embedding(ids, w))
+        self.talker = NS(
+            device=torch.device("cpu"),
+            get_input_embeddings=lambda: emb(W["talker.model.codec_embedding.weight"]),
+            get_text_embeddings=lambda: emb(W["talker.model.text_embedding.weight"]),
+            text_projection=lambda x: F.linear(F.silu(F.linear(x, W["talker.text_projection.linear_fc1.weight"],
+                                                                 W["talker.text_projection.linear_fc1.bias"])),
+                                               W["talker.text_projection.linear_fc2.weight"], W["talker.text_projection.linear_fc2.bias"]),
+            code_predictor=NS(get_input_embeddings=lambda: [emb(W[f"talker.code_predictor.model.codec_embedding.{j}.weight"])
+                                                            for j in range(cfg.num_code_groups - 1)]))
+        tc = NS(codec_eos_token_id=cfg.codec_eos_token_id, codec_pad_id=cfg.codec_pad_id, codec_bos_id=cfg.codec_bos_id,
+                codec_think_id=cfg.codec_think_id, codec_nothink_id=cfg.codec_nothink_id, codec_think_bos_id=cfg.codec_think_bos_id,
+                codec_think_eos_id=cfg.codec_think_eos_id, codec_language_id=dict(cfg.codec_language_id), spk_id=dict(cfg.spk_id),
+                spk_is_dialect=dict(cfg.spk_is_dialect), vocab_size=cfg.talker.vocab_size, num_code_groups=cfg.num_code_groups)
+        self.config = NS(talker_config=tc, tts_bos_token_id=cfg.tts_bos_token_id, tts_eos_token_id=cfg.tts_eos_token_id,
+                         tts_pad_token_id=cfg.tts_pad_token_id)
+
+    def generate_speaker_prompt(self, voice_clone_prompt):
+        dt = self.W["talker.codec_head.weight"].dtype
+        return [torch.as_tensor(e).to(dt) for e in voice_clone_prompt["ref_spk_embedding"]]
+
+    def generate_icl_prompt(self, text_id, ref_id, ref_code, tts_pad_embed, tts_eos_embed, non_streaming_mode):
+        t, cfg = self.talker, self._cfg
+        text_embed = t.text_projection(t.get_text_embeddings()(torch.cat([ref_id, text_id], dim=-1)))
+        text_embed = torch.cat([text_embed, tts_eos_embed], dim=1)
+        embs = [t.get_input_embeddings()(ref_code[:, :1])]
+        pe = t.code_predictor.get_input_embeddings()
+        for i in range(1, cfg.num_code_groups):
+            embs.append(pe[i - 1](ref_code[:, i:i + 1]))
+        codec_embed = torch.cat(embs, dim=1).sum(1).unsqueeze(0)
+        bos = t.get_input_embeddings()(torch.tensor([[cfg.codec_bos_id]]))
+        codec_embed = torch.cat([bos, codec_embed], dim=1)
+        tl, cl = text_embed.shape[1], codec_embed.shape[1]
+        if non_streaming_mode:
+            pad = t.get_input_embeddings()(torch.tensor([[cfg.codec_pad_id] * tl]))
+            return torch.cat([text_embed + pad, codec_embed + tts_pad_embed], dim=1), tts_pad_embed
+        if tl > cl:
+            return text_embed[:, :cl] + codec_embed, text_embed[:, cl:]
+        text_embed = torch.cat([text_embed] + [tts_pad_embed] * (cl - tl), dim=1)
+        return text_embed + codec_embed, tts_pad_embed
