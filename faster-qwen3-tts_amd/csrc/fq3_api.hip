@@ -22,13 +22,16 @@ extern "C" const char* fq3_last_error(void) { return g_err.c_str(); }
 extern "C" void fq3_set_error_(const char* msg) { g_err = msg ? msg : ""; }   // used by the codec TU
 extern "C" int fq3_abi_version(void) { return FQ3_ABI_VERSION; }
 
-static int dmalloc(fq3_ctx* c, void** p, size_t bytes) {
+static int dmalloc(fq3_ctx* c, void** p, size_t bytes, bool zero = true) {
     HIPCHK(hipMalloc(p, bytes));
-    HIPCHK(hipMemset(*p, 0, bytes));
+    // (a legacy-stream memset is illegal while ANOTHER host thread captures a graph on a blocking stream: workspaces that
+    //  are allocated lazily -- possibly next to another context's capture -- are therefore never zeroed; they are fully
+    //  written before they are read)
+    if (zero) HIPCHK(hipMemset(*p, 0, bytes));
     c->allocs.push_back(*p);
     return 0;
 }
-int fq3_dmalloc_(fq3_ctx* c, void** p, size_t bytes) { return dmalloc(c, p, bytes); }
+int fq3_dmalloc_(fq3_ctx* c, void** p, size_t bytes) { return dmalloc(c, p, bytes, false); }
 
 static bool dims_ok(const fq3_stack_dims& d) {
     return d.head_dim == kHeadDim && d.hidden % 8 == 0 && d.inter % 8 == 0 && d.n_heads % d.n_kv_heads == 0 &&

@@ -103,7 +103,8 @@ class HipSpeechTokenizer:
             self._bound["rope.sin"] = sn.to(self.device).contiguous()
         for name, t in self._bound.items():
             L.check(self.lib.fq3_codec_bind(self.h, name.encode(), t.data_ptr(), t.numel()))
-        L.check(self.lib.fq3_codec_finalize(self.h, None))
+        with torch.cuda.device(self.device):
+            L.check(self.lib.fq3_codec_finalize(self.h, torch.cuda.current_stream(self.device).cuda_stream))
 
     def num_samples(self, n_frames: int) -> int:
         return int(self.lib.fq3_codec_num_samples(self.h, int(n_frames)))
