@@ -600,8 +600,8 @@ def main():
                                                            "passes, talker 28 layers, heads, samplers)")
             # HBM-side traffic of one frame: separate `rocprofv3 --pmc FETCH_SIZE` pass (x2 gfx950 correction), not collected in
             # this run: the 15 predictor weight passes re-read their 157 MB through the fabric every pass
-            rl["traffic"] = 3.37e9
-            rl["traffic_source"] = "measured_offline: profiles/r01_pmc_fetch_size.txt (FETCH_SIZE x2, 8 profiled frames)"
+            rl["traffic"] = 3.455e9
+            rl["traffic_source"] = "measured_offline: profiles/r02_pmc_fetch_size.txt (rocprofv3 --pmc FETCH_SIZE, own pass, x2 gfx950 correction, 24 profiled frames)"
             out["roofline"] = rl
         if c3 is not None:
             if "error" in c3:
