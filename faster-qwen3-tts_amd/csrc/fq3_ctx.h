@@ -39,6 +39,7 @@ struct fq3_ctx {
                                   // single-token passes); parity-tested both ways; 2.06 vs 2.11 ms/frame with the v4 kernels
     int opt_pred_attn = 1;        // code predictor: one-wave-per-head register-only attention writing the final head output (FQ3_PRED_ATTN=0: generic split-KV kernel + merge)
     int opt_rmax = 2;             // GEMV rows-per-wave cap
+    int opt_flash_prefill = 1;    // bf16 prefill attention on the matrix cores (0: the per-row wave kernel)
     int prefill_mode = 0;         // 0 auto (MFMA), 1 token walk
     bool talker_wave = true;      // talker sampler variant baked into the captured graph
     fq3_sampling pred_sampling{0.9f, 50, 1.0f, 1, 1.0f};

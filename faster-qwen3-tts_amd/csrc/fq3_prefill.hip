@@ -110,6 +110,151 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(const T* qkv, const T
         for (int i = 0; i < 8; ++i) DT<T>::st(op + c * 8 + i, o[i] / l);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Flash-style causal attention on the matrix cores (bf16 contexts; long prompts: BASELINE configs[4], 4k tokens).
+// One workgroup = one q head x 64 queries (16 per wave); key tiles of 64 keys stream through LDS (K row-major, V
+// TRANSPOSED so that both MFMAs read 16-byte fragments); S = Q K^T and O += P V on v_mfma_f32_16x16x32_bf16, online
+// softmax in fp32 on the accumulator layout (row statistics by DPP inside the 16-lane groups).  The probabilities enter
+// the second MFMA as bf16, which the oracle's fp32 softmax(QK^T) V does not round: P is therefore split into a bf16 high
+// part and a bf16 residual (two MFMAs), leaving a 2^-16 relative error instead of 2^-9 -- below the one rounding to T of
+// the output.  The next tile's K/V global loads are issued before the current tile's arithmetic (register staging).
+// fp32 contexts keep prefill_attn_kernel (exact fp32 products).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kFaQ = 64, kFaK = 64, kFaKLd = kHeadDim + 8, kFaVLd = kFaK + 8, kFaPLd = kFaK + 8;
+
+__global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* qkv, const bf16_t* kcache, const bf16_t* vcache, bf16_t* out,
+                                                            int max_seq, int L, int n_pad, int NH, int NKV, float scale) {
+    constexpr int HD = kHeadDim;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[kFaK * kFaKLd];            // [key][dim]
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[HD * kFaVLd];              // [dim][key]
+    __shared__ __attribute__((aligned(16))) bf16_t Ps[4][2][16 * kFaPLd];        // per wave: P high / residual, [query][key]
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.y, g = h / (NH / NKV), per = NH + 2 * NKV;
+    const int q0 = blockIdx.x * kFaQ;
+    const bf16_t* kc = kcache + (size_t)g * max_seq * HD;
+    const bf16_t* vc = vcache + (size_t)g * max_seq * HD;
+    // Q fragments of this wave's 16 rows (A operand: row = fr, dims fq*8 + 32*ks), kept in registers
+    const int qrow = q0 + wave * 16 + fr;
+    const int qrc = qrow < L ? qrow : L - 1;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8_t*>(qkv + (size_t)qrc * per * HD + (size_t)h * HD + ks * 32 + fq * 8);
+    f32x4_t o[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) o[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m[4], l[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m[r] = -1e30f; l[r] = 0.f; }
+    const int q_hi = min(q0 + kFaQ, L) - 1;                              // last query of the workgroup
+    const int t_lo = n_pad / kFaK, t_hi = q_hi / kFaK;                    // key tiles [t_lo, t_hi]
+    // staging registers: thread -> key (tid & 63), 16-byte chunks (tid >> 6) + 4 j of that key's K and V rows
+    const int skey = tid & 63, sch = tid >> 6;
+    u32x4 kst[4], vst[4];
+    auto issue = [&](int tile) {
+        int key = tile * kFaK + skey;
+        key = key < max_seq ? key : max_seq - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kst[j] = *reinterpret_cast<const u32x4*>(kc + (size_t)key * HD + (sch + 4 * j) * 8);
+            vst[j] = *reinterpret_cast<const u32x4*>(vc + (size_t)key * HD + (sch + 4 * j) * 8);
+        }
+    };
+    issue(t_lo);
+    const float sl2 = scale * 1.4426950408889634f;                        // softmax in base 2: exp(x) = exp2(x * log2 e)
+    for (int tile = t_lo; tile <= t_hi; ++tile) {
+        __syncthreads();                                                  // everyone is done reading the previous tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<u32x4*>(&Ks[skey * kFaKLd + (sch + 4 * j) * 8]) = kst[j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)                                    // transposed store: dim-major image of V
+                Vt[((sch + 4 * j) * 8 + i) * kFaVLd + skey] = (bf16_t)((vst[j][i >> 1] >> (16 * (i & 1))) & 0xffffu);
+        }
+        __syncthreads();
+        if (tile < t_hi) issue(tile + 1);                                 // next tile's loads fly under the MFMAs
+        // ---- S = Q K^T: 4 key blocks of 16 ----
+        f32x4_t sacc[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            sacc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&Ks[(nb * 16 + fr) * kFaKLd + ks * 32 + fq * 8]);
+                sacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, sacc[nb], 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax (accumulator layout: column = key nb*16 + fr, row = query fq*4 + r) ----
+        float p[4][4], alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + wave * 16 + fq * 4 + r;
+            float mx = -1e30f;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int key = tile * kFaK + nb * 16 + fr;
+                const bool ok = key <= qi && key >= n_pad;
+                const float v = ok ? sacc[nb][r] * sl2 : -1e30f;
+                p[nb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = row16_max(mx);
+            const float mn = fmaxf(m[r], mx);
+            alpha[r] = exp2f(m[r] - mn);
+            float rs = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const float e = p[nb][r] > -1e29f ? exp2f(p[nb][r] - mn) : 0.f;
+                p[nb][r] = e;
+                rs += e;
+            }
+            rs = row16_sum(rs);
+            l[r] = l[r] * alpha[r] + rs;
+            m[r] = mn;
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[d][r] *= alpha[r];
+        // ---- P -> LDS as bf16 high part + bf16 residual, [query][key] (this wave's private region) ----
+        bf16_t* ph = Ps[wave][0];
+        bf16_t* pl = Ps[wave][1];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = p[nb][r];
+                const bf16_t hi = f_to_bf16(v);
+                ph[(fq * 4 + r) * kFaPLd + nb * 16 + fr] = hi;
+                pl[(fq * 4 + r) * kFaPLd + nb * 16 + fr] = f_to_bf16(v - bf16_to_f(hi));
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                               // lgkmcnt(0): the wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        // ---- O += P V: A = P [query fr][keys fq*8 + 32 ks], B = V^T [dim db*16 + fr][keys fq*8 + 32 ks] ----
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8_t pah = *reinterpret_cast<const bf16x8_t*>(&ph[fr * kFaPLd + ks * 32 + fq * 8]);
+            const bf16x8_t pal = *reinterpret_cast<const bf16x8_t*>(&pl[fr * kFaPLd + ks * 32 + fq * 8]);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(&Vt[(d * 16 + fr) * kFaVLd + ks * 32 + fq * 8]);
+                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pah, vf, o[d], 0, 0, 0);
+                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pal, vf, o[d], 0, 0, 0);
+            }
+        }
+    }
+    // ---- normalise, one rounding, store (left-padded query rows are zeros, like prefill_attn_kernel) ----
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + wave * 16 + fq * 4 + r;
+        if (qi >= L) continue;
+        const float inv = (qi >= n_pad && l[r] > 0.f) ? 1.0f / l[r] : 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) out[((size_t)qi * NH + h) * HD + d * 16 + fr] = f_to_bf16(o[d][r] * inv);
+    }
+}
+
 template <typename T>
 GemmArgs lin(const void* A, int M, int K, const void* W, int N, void* Y) {
     GemmArgs a{}; a.A = A; a.lda = K; a.M = M; a.a_rows = M; a.n_taps = 1; a.tap_off[0] = 0; a.Cin = K; a.W = W; a.N = N;
@@ -144,8 +289,17 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
         hipLaunchKernelGGL((qk_norm_rope_kv_kernel<T>), dim3((L * (NH + 2 * NKV) + 3) / 4), dim3(256), 0, s, QKV, (const T*)w.q_norm,
                            (const T*)w.k_norm, d.rms_eps, c->wt.talker_cos, c->wt.talker_sin, c->wt.talker_rope_len, c->rope_delta,
                            (T*)c->tk.k[i], (T*)c->tk.v[i], c->tk.max_seq, L, n_pad, NH, NKV);
-        hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((L * NH + 3) / 4), dim3(256), 0, s, (const T*)QKV, (const T*)c->tk.k[i],
-                           (const T*)c->tk.v[i], ATT, c->tk.max_seq, L, n_pad, NH, NKV, scale);
+        if constexpr (sizeof(T) == 2) {
+            if (c->opt_flash_prefill)
+                hipLaunchKernelGGL(flash_prefill_kernel, dim3((L + kFaQ - 1) / kFaQ, NH), dim3(256), 0, s, (const bf16_t*)QKV, (const bf16_t*)c->tk.k[i],
+                                   (const bf16_t*)c->tk.v[i], (bf16_t*)ATT, c->tk.max_seq, L, n_pad, NH, NKV, scale);
+            else
+                hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((L * NH + 3) / 4), dim3(256), 0, s, (const T*)QKV, (const T*)c->tk.k[i],
+                                   (const T*)c->tk.v[i], ATT, c->tk.max_seq, L, n_pad, NH, NKV, scale);
+        } else {
+            hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((L * NH + 3) / 4), dim3(256), 0, s, (const T*)QKV, (const T*)c->tk.k[i],
+                               (const T*)c->tk.v[i], ATT, c->tk.max_seq, L, n_pad, NH, NKV, scale);
+        }
         { GemmArgs a = lin<T>(ATT, L, QD, w.o, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
         hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((L + 3) / 4), dim3(256), 0, s, (const T*)X, (const T*)w.post_norm, XN, 0, L, H, d.rms_eps);
         gemm<T>(lin<T>(XN, L, H, w.gate_up, 2 * I, GU), s);

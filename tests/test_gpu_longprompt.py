@@ -1,0 +1,74 @@
+"""GPU: BASELINE configs[4] shape -- a 4096-token prompt at the real 1.7B layer dims (2 layers): matrix-core prefill with
+the flash-style attention kernel, then decode steps over a > 4096-key cache, against golden vectors of the CPU oracle
+(oracle/make_golden_longprompt.py).  fp32 contexts (exact-product kernels) to 2e-4 of the scale; bf16 to bf16 resolution
+(0.025 x scale, the same bound as the short-prompt tests), with the flash kernel additionally held to the per-row wave
+kernel (same inputs, fp32 softmax in both; only the summation order differs)."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fq3hip.weights import synth_weights, synth_prompt
+from oracle.make_golden_longprompt import config, L
+
+
+@pytest.mark.parametrize("tag,dtype", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+def test_prefill_4096_and_decode_over_long_cache(tag, dtype, golden_dir):
+    from fq3hip.engine import Fq3Engine
+    g = np.load(os.path.join(golden_dir, "longprompt.npz"))
+    cfg = config()
+    W = synth_weights(cfg, 0, dtype, parts=("talker", "predictor"))
+    tie, tam, _, _, _ = synth_prompt(cfg, L, 4, 0, dtype=dtype)
+    x = (tie * 30).to(dtype)[0].cuda().contiguous()
+    eng = Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=L + 8, max_frames=8)
+    tol = (lambda ref: 2e-4 * max(1.0, float(np.abs(ref).max()))) if dtype == torch.float32 else \
+          (lambda ref: 0.025 * max(1.0, float(np.abs(ref).max())))
+    results = {}
+    for flash in ((1, 0) if dtype == torch.bfloat16 else (1,)):
+        eng.set_option("flash_prefill", flash)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        logits, hidden = eng.prefill(x)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0)
+        lg, hd = logits.float().cpu().numpy(), hidden.float().cpu().numpy()
+        assert np.abs(hd - g[f"hidden_{tag}"]).max() <= tol(g[f"hidden_{tag}"]), (tag, flash)
+        assert np.abs(lg - g[f"logits_{tag}"]).max() <= tol(g[f"logits_{tag}"]), (tag, flash)
+        results[flash] = (lg, hd, ms)
+        print(f"[longprompt] {tag} flash={flash}: prefill({L} tokens, 2 layers at 1.7B dims) {ms:.1f} ms, "
+              f"max |hidden - oracle| {np.abs(hd - g[f'hidden_{tag}']).max():.4f}")
+        gen = torch.Generator().manual_seed(3)
+        for step in range(2):
+            xs = torch.randn(1, 1, cfg.talker.hidden_size, generator=gen).to(dtype)
+            h = eng.talker_step(xs.view(-1).cuda(), L + step).float().cpu().numpy()
+            assert np.abs(h - g[f"step{step}_{tag}"]).max() <= tol(g[f"step{step}_{tag}"]), (tag, flash, step)
+    if dtype == torch.bfloat16:
+        # flash (bf16 P split into high + residual) vs the wave kernel (fp32 P): at most one bf16 ulp apart anywhere
+        d = np.abs(results[1][1] - results[0][1]).max()
+        assert d <= 2.0 ** -7 * max(1.0, float(np.abs(results[0][1]).max())), d
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "longprompt_prefill.txt"), "w") as f:
+            f.write(f"prefill {L} tokens, 2 talker layers at 1.7B dims, bf16: flash MFMA attention {results[1][2]:.1f} ms, wave kernel {results[0][2]:.1f} ms\n")
+
+
+def test_flash_prefill_left_padded_matches_wave_kernel():
+    """n_pad > 0 across a tile boundary (n_pad = 70): padded keys are never attended, padded query rows are zeros."""
+    from fq3hip.engine import Fq3Engine
+    cfg = config()
+    dtype = torch.bfloat16
+    W = synth_weights(cfg, 0, dtype, parts=("talker", "predictor"))
+    tie, _, _, _, _ = synth_prompt(cfg, 300, 4, 0, dtype=dtype)
+    x = (tie * 30).to(dtype)[0].cuda().contiguous()
+    eng = Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=320, max_frames=8)
+    outs = []
+    for flash in (1, 0):
+        eng.set_option("flash_prefill", flash)
+        logits, hidden = eng.prefill(x, n_pad=70)
+        outs.append((logits.float().cpu(), hidden.float().cpu()))
+    assert (outs[0][1] - outs[1][1]).abs().max() <= 2.0 ** -7 * max(1.0, float(outs[1][1].abs().max()))
+    assert (outs[0][0] - outs[1][0]).abs().max() <= 2.0 ** -6 * max(1.0, float(outs[1][0].abs().max()))
