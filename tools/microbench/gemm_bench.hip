@@ -1,0 +1,83 @@
+// Micro-benchmark of the product's implicit-GEMM kernel (csrc/codec_kernels.cuh, through gemm_launch's own tile choice) on the
+// shapes the path runs: prefill GEMMs (200 and 4096 tokens), codec convs (full 370-frame decode and a streaming chunk), and
+// 4096^3 for comparison with published ladders.  Development aid; prints TFLOP/s per shape.  usage: gemm_bench [reps]
+#include "../../faster-qwen3-tts_amd/csrc/codec_kernels.cuh"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+using namespace fq3;
+
+static uint16_t f_to_bf16_host(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+static float bf16_to_f_host(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
+
+struct Shape { const char* name; int M, N, Cin, taps, dil; };
+
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 10;
+    std::vector<Shape> shapes = {
+        {"square 4096^3", 4096, 4096, 4096, 1, 1},
+        {"prefill4k qkv  (1.7B)", 4096, 4096, 2048, 1, 1},
+        {"prefill4k gate_up", 4096, 12288, 2048, 1, 1},
+        {"prefill4k down", 4096, 2048, 6144, 1, 1},
+        {"prefill200 qkv (0.6B)", 200, 4096, 1024, 1, 1},
+        {"prefill200 gate_up", 200, 6144, 1024, 1, 1},
+        {"prefill200 down", 200, 1024, 3072, 1, 1},
+        {"codec370 dec.0 k7", 1480, 1536, 1024, 7, 1},
+        {"codec370 b1 conv1 k7", 11832, 768, 768, 7, 1},
+        {"codec370 b2 conv1 k7", 59155, 384, 384, 7, 3},
+        {"codec370 b3 conv1 k7", 236616, 192, 192, 7, 9},
+        {"codec370 b4 conv1 k7", 709845, 96, 96, 7, 1},
+        {"codec370 b4 conv2 k1", 709845, 96, 96, 1, 1},
+        {"chunk13 dec.0 k7", 52, 1536, 1024, 7, 1},
+        {"chunk13 b1 conv1 k7", 416, 768, 768, 7, 1},
+        {"chunk13 b4 conv1 k7", 24960, 96, 96, 7, 1},
+    };
+    hipStream_t s; hipStreamCreate(&s);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (auto& sh : shapes) {
+        const size_t K = (size_t)sh.taps * sh.Cin;
+        const size_t na = (size_t)sh.M * sh.Cin, nw = (size_t)sh.N * K, ny = (size_t)sh.M * sh.N;
+        std::vector<uint16_t> ha(na), hw(nw);
+        uint32_t x = 12345;
+        auto rnd = [&]() { x = x * 1664525u + 1013904223u; return x >> 16; };
+        for (auto& v : ha) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 128.f);
+        for (auto& v : hw) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 1024.f);
+        void *A, *W, *Y;
+        hipMalloc(&A, na * 2); hipMalloc(&W, nw * 2); hipMalloc(&Y, ny * 2);
+        hipMemcpy(A, ha.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(W, hw.data(), nw * 2, hipMemcpyHostToDevice);
+        GemmArgs a{};
+        a.A = A; a.lda = sh.Cin; a.M = sh.M; a.a_rows = sh.M; a.n_taps = sh.taps; a.Cin = sh.Cin; a.W = W; a.N = sh.N;
+        for (int i = 0; i < sh.taps; ++i) a.tap_off[i] = -(sh.taps - 1 - i) * sh.dil;
+        a.bias_mod = sh.N; a.Y = Y; a.ldy = sh.N;
+        gemm_launch<bf16_t>(a, s);
+        hipStreamSynchronize(s);
+        hipEventRecord(e0, s);
+        for (int r = 0; r < reps; ++r) gemm_launch<bf16_t>(a, s);
+        hipEventRecord(e1, s);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+        // spot check of 16 outputs against a host dot product
+        std::vector<uint16_t> hy(ny);
+        hipMemcpy(hy.data(), Y, ny * 2, hipMemcpyDeviceToHost);
+        double maxerr = 0;
+        for (int t = 0; t < 16; ++t) {
+            const int m = (int)(((uint64_t)t * 7919 + 13) % sh.M), n = (int)(((uint64_t)t * 104729 + 7) % sh.N);
+            double acc = 0;
+            for (int tap = 0; tap < sh.taps; ++tap) {
+                const int ar = m + a.tap_off[tap];
+                if (ar < 0 || ar >= sh.M) continue;
+                for (int c = 0; c < sh.Cin; ++c) acc += (double)bf16_to_f_host(ha[(size_t)ar * sh.Cin + c]) * bf16_to_f_host(hw[(size_t)n * K + (size_t)tap * sh.Cin + c]);
+            }
+            const double got = bf16_to_f_host(hy[(size_t)m * sh.N + n]);
+            const double err = fabs(got - acc) / (fabs(acc) + 1.0);
+            if (err > maxerr) maxerr = err;
+        }
+        const double fl = 2.0 * sh.M * sh.N * K;
+        printf("%-24s M=%7d N=%5d K=%5zu  %9.3f us  %8.1f TFLOP/s  check %.2e %s\n", sh.name, sh.M, sh.N, K, ms * 1e3, fl / (ms * 1e-3) / 1e12,
+               maxerr, maxerr < 2e-2 ? "ok" : "MISMATCH");
+        hipFree(A); hipFree(W); hipFree(Y);
+    }
+    return 0;
+}
