@@ -6,7 +6,7 @@ import sys
 
 from fq3hip import __version__  # noqa: F401
 
-for _m in ("model", "generate", "streaming", "sampling", "talker_graph", "predictor_graph"):
+for _m in ("model", "generate", "streaming", "sampling", "talker_graph", "predictor_graph", "cli"):
     sys.modules[f"{__name__}.{_m}"] = importlib.import_module(f"fq3hip.{_m}")
 
 

@@ -1,0 +1,62 @@
+"""WAV / PCM helpers shared by the CLI and the HTTP server (callers either side of the hot path).
+
+The reference writes files with ``soundfile`` (``faster_qwen3_tts/cli.py:48-50``) and streams 16-bit PCM behind a WAV header
+of unknown length (``examples/openai_server.py:93-119``).  ``soundfile`` is not part of this image, so files go through the
+standard library's ``wave`` module (16-bit PCM, what ``sf.write`` produces for float input by default)."""
+from __future__ import annotations
+
+import io
+import os
+import struct
+import wave
+from typing import Tuple
+
+import numpy as np
+
+
+def to_pcm16(pcm: np.ndarray) -> bytes:
+    """float waveform in [-1, 1] -> raw 16-bit little-endian PCM (examples/openai_server.py:93-95)."""
+    return np.clip(np.asarray(pcm, dtype=np.float32) * 32768, -32768, 32767).astype("<i2").tobytes()
+
+
+def wav_header(sample_rate: int, data_len: int = 0xFFFFFFFF) -> bytes:
+    """RIFF/WAVE header for mono 16-bit PCM; ``data_len = 0xFFFFFFFF`` marks a stream of unknown size
+    (examples/openai_server.py:98-113)."""
+    n_channels, bits = 1, 16
+    byte_rate = sample_rate * n_channels * bits // 8
+    riff = 0xFFFFFFFF if data_len == 0xFFFFFFFF else 36 + data_len
+    return (b"RIFF" + struct.pack("<I", riff) + b"WAVE" + b"fmt " +
+            struct.pack("<IHHIIHH", 16, 1, n_channels, sample_rate, byte_rate, n_channels * bits // 8, bits) +
+            b"data" + struct.pack("<I", data_len))
+
+
+def to_wav_bytes(pcm: np.ndarray, sample_rate: int) -> bytes:
+    raw = to_pcm16(pcm)
+    return wav_header(sample_rate, len(raw)) + raw
+
+
+def write_wav(path: str, pcm: np.ndarray, sample_rate: int) -> None:
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(int(sample_rate))
+        w.writeframes(to_pcm16(pcm))
+
+
+def read_wav(path: str) -> Tuple[np.ndarray, int]:
+    """PCM WAV (8/16/32-bit integer) -> (mono float32 in [-1, 1], sample_rate)."""
+    with wave.open(str(path), "rb") as w:
+        sr, n, ch, sw = w.getframerate(), w.getnframes(), w.getnchannels(), w.getsampwidth()
+        raw = w.readframes(n)
+    if sw == 2:
+        a = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif sw == 4:
+        a = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif sw == 1:
+        a = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise ValueError(f"unsupported WAV sample width {sw}")
+    if ch > 1:
+        a = a.reshape(-1, ch).mean(axis=1)
+    return a, sr

@@ -223,14 +223,47 @@ class FasterQwen3TTS:
         return vcp, ref_ids, using_icl
 
     def _load_ref_audio_with_silence(self, ref_audio, silence_secs: float = 0.5):
-        """model.py:278-293 (needs ``soundfile``; only reached when raw reference audio is analysed)."""
-        import soundfile as sf
-        audio, sr = sf.read(str(ref_audio), dtype="float32", always_2d=False)
-        if audio.ndim > 1:
-            audio = audio.mean(axis=1)
+        """model.py:278-293.  ``soundfile`` when it is installed, otherwise the standard-library WAV reader."""
+        try:
+            import soundfile as sf
+            audio, sr = sf.read(str(ref_audio), dtype="float32", always_2d=False)
+            if audio.ndim > 1:
+                audio = audio.mean(axis=1)
+        except ImportError:
+            from .audio_io import read_wav
+            audio, sr = read_wav(str(ref_audio))
         if silence_secs > 0:
             audio = np.concatenate([audio, np.zeros(int(silence_secs * sr), dtype=np.float32)])
         return audio, sr
+
+    def set_voice_ref_cache(self, directory) -> None:
+        """Serve ``ref_audio=...`` calls from an on-disk cache of precomputed voice-clone prompts (``fq3hip/voice_cache.py``;
+        the role the reference's ``qwentts_ref_cache_dir`` plays for its GGML backend, ``ggml_backend.py:403-471``)."""
+        from .voice_cache import VoiceRefCache
+        self._voice_ref_cache = VoiceRefCache(directory) if directory else None
+
+    def _cached_voice_prompt(self, ref_audio, ref_text: str, xvec_only: bool, append_silence: bool):
+        cache = getattr(self, "_voice_ref_cache", None)
+        if cache is None:
+            return None
+        from .voice_cache import cache_key
+        silence = 0.5 if (append_silence and not xvec_only) else 0.0
+        audio, sr = self._load_ref_audio_with_silence(ref_audio, silence_secs=silence)
+        if sr != 24000:
+            from scipy.signal import resample_poly
+            from math import gcd
+            g = gcd(int(sr), 24000)
+            audio = resample_poly(audio, 24000 // g, int(sr) // g).astype(np.float32)
+        ident = f"{getattr(self.model.model, 'tts_model_type', 'base')}-{getattr(self.model.model, 'tts_model_size', '')}"
+        key, meta = cache_key(audio, append_silence=silence > 0, model_identity=ident)
+        hit = cache.load(key, meta)
+        if hit is None:
+            return None
+        spk = torch.from_numpy(hit["ref_spk_embedding"])
+        if xvec_only or hit["ref_code"] is None:
+            return dict(ref_code=[None], ref_spk_embedding=[spk], x_vector_only_mode=[True], icl_mode=[False]), None
+        return (dict(ref_code=[torch.from_numpy(hit["ref_code"])], ref_spk_embedding=[spk], x_vector_only_mode=[False],
+                     icl_mode=[True]), hit["ref_text"] or ref_text)
 
     def _resolve_voice_clone_prompt_from_reference(self, input_ids, ref_audio, ref_text: str, xvec_only: bool,
                                                    append_silence: bool):
@@ -239,7 +272,14 @@ class FasterQwen3TTS:
         if key in self._voice_prompt_cache:
             vcp, ref_ids = self._voice_prompt_cache[key]
             return vcp, ref_ids, using_icl
-        if xvec_only:
+        cached = self._cached_voice_prompt(ref_audio, ref_text, xvec_only, append_silence)
+        if cached is not None:
+            vcp, rt = cached
+            using_icl = bool(vcp["icl_mode"][0])
+            if using_icl and not rt:
+                raise ValueError("ref_text is required when voice_clone_prompt uses ICL mode.")
+            ref_ids = [self._ref_ids(rt) if using_icl else None]
+        elif xvec_only:
             items = self.model.create_voice_clone_prompt(ref_audio=str(ref_audio), ref_text="", x_vector_only_mode=True)
             vcp = dict(ref_code=[None], ref_spk_embedding=[items[0].ref_spk_embedding], x_vector_only_mode=[True],
                        icl_mode=[False])

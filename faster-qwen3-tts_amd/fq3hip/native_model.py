@@ -221,8 +221,10 @@ class NativeQwen3TTS:
     def create_voice_clone_prompt(self, ref_audio=None, ref_text: str = "", x_vector_only_mode: bool = False):
         raise NotImplementedError(
             "Reference-audio analysis (speaker encoder + speech-tokenizer encoder) is not part of the MI355X "
-            "fast path yet (SURVEY.md section 8f row 1). Pass voice_clone_prompt=dict(ref_spk_embedding=[...], "
-            "ref_code=[...], x_vector_only_mode=[...], icl_mode=[...]) computed once with upstream qwen-tts.")
+            "fast path (SURVEY.md section 8f row 1; DESIGN.md section 7). Pass voice_clone_prompt=dict(ref_spk_embedding=[...], "
+            "ref_code=[...], x_vector_only_mode=[...], icl_mode=[...]) computed once with upstream qwen-tts, or export it "
+            "into a voice-reference cache (fq3hip.voice_cache.export_voice_clone_prompt) and call "
+            "FasterQwen3TTS.set_voice_ref_cache(dir): ref_audio=... is then served from disk.")
 
     @staticmethod
     def _prompt_items_to_voice_clone_prompt(items: List[Any]) -> Dict[str, Any]:

@@ -1,0 +1,160 @@
+"""CPU: the callers and formats either side of the hot path: WAV / PCM framing, the on-disk
+voice-reference cache, the CLI (sub-commands, validation, the stdin serve loop) and the OpenAI-compatible endpoint with the
+reference's request / response contract (examples/openai_server.py:77-265), over scripted model objects."""
+import io
+import json
+import os
+import struct
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from fq3hip import audio_io, cli
+from fq3hip.voice_cache import VoiceRefCache, cache_key, export_voice_clone_prompt
+
+
+# ---- audio framing -----------------------------------------------------------------------------------------------
+def test_wav_header_and_pcm16():
+    h = audio_io.wav_header(24000)
+    assert len(h) == 44 and h[:4] == b"RIFF" and h[8:12] == b"WAVE" and h[36:40] == b"data"
+    assert struct.unpack("<I", h[4:8])[0] == 0xFFFFFFFF and struct.unpack("<I", h[40:44])[0] == 0xFFFFFFFF      # streaming: unknown size
+    fmt = struct.unpack("<IHHIIHH", h[16:36])
+    assert fmt == (16, 1, 1, 24000, 48000, 2, 16)
+    pcm = np.array([0.0, 0.5, -0.5, 2.0, -2.0], np.float32)
+    raw = np.frombuffer(audio_io.to_pcm16(pcm), dtype="<i2")
+    assert raw.tolist() == [0, 16384, -16384, 32767, -32768]
+    b = audio_io.to_wav_bytes(pcm, 24000)
+    assert struct.unpack("<I", b[40:44])[0] == 10 and struct.unpack("<I", b[4:8])[0] == 46
+    with wave.open(io.BytesIO(b)) as w:
+        assert w.getframerate() == 24000 and w.getnframes() == 5
+
+
+def test_write_read_wav_roundtrip(tmp_path):
+    x = (np.sin(np.arange(2400) / 20.0) * 0.5).astype(np.float32)
+    p = str(tmp_path / "sub" / "a.wav")
+    audio_io.write_wav(p, x, 24000)
+    y, sr = audio_io.read_wav(p)
+    assert sr == 24000 and y.shape == x.shape and np.abs(y - x).max() < 1.0 / 32768 + 1e-6
+
+
+# ---- voice-reference cache -----------------------------------------------------------------------------------------
+def test_voice_cache_roundtrip_and_staleness(tmp_path):
+    audio = np.linspace(-1, 1, 24000, dtype=np.float32)
+    key, meta = cache_key(audio, append_silence=True, model_identity="base-0b6")
+    key2, _ = cache_key(audio, append_silence=False, model_identity="base-0b6")
+    key3, _ = cache_key(audio * 0.5, append_silence=True, model_identity="base-0b6")
+    assert len(key) == 64 and len({key, key2, key3}) == 3 and cache_key(audio, append_silence=True, model_identity="base-0b6")[0] == key
+    c = VoiceRefCache(tmp_path / "voices")
+    spk = torch.randn(1024)
+    codes = torch.randint(0, 2048, (37, 16))
+    assert c.load(key, meta) is None
+    c.save(key, meta, spk, codes, ref_text="hello there")
+    assert sorted(p.suffix for p in (tmp_path / "voices").iterdir()) == [".json", ".rvq", ".spk"]
+    hit = c.load(key, meta)
+    assert np.array_equal(hit["ref_spk_embedding"], spk.numpy()) and np.array_equal(hit["ref_code"], codes.numpy())
+    assert hit["ref_text"] == "hello there"
+    assert c.load(key, dict(meta, model_identity="other")) is None          # metadata mismatch = stale entry
+    c.save(key2, cache_key(audio, append_silence=False, model_identity="base-0b6")[1], spk, None)       # x-vector only entry
+    assert c.load(key2)["ref_code"] is None
+    # upstream prompt item -> entry
+    from types import SimpleNamespace
+    k = export_voice_clone_prompt(c, audio, SimpleNamespace(ref_spk_embedding=spk, ref_code=codes, ref_text="t"), append_silence=True,
+                                  model_identity="base-0b6")
+    assert k == key
+
+
+# ---- CLI ---------------------------------------------------------------------------------------------------------------
+class _ScriptedModel:
+    sample_rate = 24000
+
+    def __init__(self):
+        self.calls = []
+
+    def _wave(self, text):
+        return np.full(240 * max(1, len(text)), 0.25, np.float32)
+
+    def generate_voice_clone(self, text, **kw):
+        self.calls.append(("clone", text, kw))
+        return [self._wave(text)], 24000
+
+    def generate_voice_clone_streaming(self, text, chunk_size=12, **kw):
+        self.calls.append(("clone_stream", text, kw))
+        w = self._wave(text)
+        for i in range(0, len(w), 1000):
+            yield w[i:i + 1000], 24000, {"chunk_index": i // 1000}
+
+    def generate_voice_clone_batch(self, texts, lanes=8, **kw):
+        self.calls.append(("clone_batch", list(texts), dict(kw, lanes=lanes)))
+        return [([self._wave(t)], 24000) for t in texts]
+
+    def generate_custom_voice(self, text, speaker, **kw):
+        self.calls.append(("custom", text, dict(kw, speaker=speaker)))
+        return [self._wave(text)], 24000
+
+    def generate_voice_design(self, text, instruct, **kw):
+        self.calls.append(("design", text, dict(kw, instruct=instruct)))
+        return [self._wave(text)], 24000
+
+
+def test_cli_parser_and_validation(capsys):
+    p = cli.build_parser()
+    a = p.parse_args(["clone", "--text", "hi", "--output", "o.wav", "--ref-audio", "r.wav", "--ref-text", "t", "--streaming", "--chunk-size", "8"])
+    assert a.mode == "clone" and a.streaming and a.chunk_size == 8 and a.temperature == 0.9 and a.top_k == 50 and a.repetition_penalty == 1.05
+    for argv, msg in ((["clone", "--text", "x", "--output", "o.wav"], "requires --ref-audio"),
+                      (["clone", "--text", "x", "--output", "o.wav", "--ref-audio", "r.wav"], "--ref-text is required"),
+                      (["clone", "--text", "x", "--output", "o.wav", "--ref-spk", "a.spk"], "GGML backend"),
+                      (["custom", "--text", "x", "--output", "o.wav"], "--speaker is required"),
+                      (["design", "--text", "x", "--output", "o.wav"], "--instruct is required")):
+        with pytest.raises(SystemExit) as e:
+            cli.cmd_once(p.parse_args(argv), model=_ScriptedModel())
+        assert e.value.code == 2 and msg in capsys.readouterr().out
+
+
+def test_cli_once_and_serve_loop(tmp_path, capsys):
+    p = cli.build_parser()
+    m = _ScriptedModel()
+    out = str(tmp_path / "one.wav")
+    cli.cmd_once(p.parse_args(["clone", "--text", "hello", "--output", out, "--ref-audio", "r.wav", "--ref-text", "t"]), model=m)
+    y, sr = audio_io.read_wav(out)
+    assert sr == 24000 and len(y) == 240 * 5 and m.calls[0][0] == "clone" and m.calls[0][2]["do_sample"] is True
+    cli.cmd_once(p.parse_args(["design", "--text", "abc", "--output", out, "--instruct", "calm", "--greedy"]), model=m)
+    assert m.calls[-1][0] == "design" and m.calls[-1][2]["do_sample"] is False
+    # serve: one line at a time (reference behaviour), streaming mode
+    d = str(tmp_path / "serve1")
+    a = p.parse_args(["serve", "--ref-audio", "r.wav", "--ref-text", "t", "--output-dir", d, "--streaming"])
+    cli.cmd_serve(a, model=m, lines=["first\n", "\n", "second line\n", "quit\n", "never\n"])
+    assert sorted(os.listdir(d)) == ["out_0001.wav", "out_0002.wav"]
+    assert [c[0] for c in m.calls[-2:]] == ["clone_stream", "clone_stream"]
+    # serve --lanes 3: waiting lines are decoded together through the batch entry point
+    d2 = str(tmp_path / "serve2")
+    a = p.parse_args(["serve", "--ref-audio", "r.wav", "--ref-text", "t", "--output-dir", d2, "--lanes", "3"])
+    cli.cmd_serve(a, model=m, lines=["a\n", "bb\n", "ccc\n", "dddd\n", "exit\n"])
+    assert sorted(os.listdir(d2)) == [f"out_000{i}.wav" for i in (1, 2, 3, 4)]
+    batch_calls = [c for c in m.calls if c[0] == "clone_batch"]
+    assert batch_calls[0][1] == ["a", "bb", "ccc"] and batch_calls[0][2]["lanes"] == 3
+    assert "Wrote" in capsys.readouterr().out
+
+
+# ---- OpenAI-compatible endpoint (lock scheduler, scripted model) -----------------------------------------------------------
+def test_openai_speech_endpoint_contract():
+    from fastapi.testclient import TestClient
+    from fq3hip.server import create_app
+    m = _ScriptedModel()
+    voices = {"alloy": {"ref_audio": "a.wav", "ref_text": "t", "language": "English"}}
+    client = TestClient(create_app(m, voices, default_voice="alloy", scheduler="lock"))
+    assert client.get("/health").json()["status"] == "ok"
+    r = client.post("/v1/audio/speech", json={"model": "tts-1", "input": "hello world", "voice": "alloy", "response_format": "wav"})
+    assert r.status_code == 200 and r.headers["content-type"].startswith("audio/wav")
+    body = r.content
+    assert body[:4] == b"RIFF" and struct.unpack("<I", body[40:44])[0] == 0xFFFFFFFF        # streamed WAV: unknown length
+    pcm = np.frombuffer(body[44:], dtype="<i2")
+    assert len(pcm) == 240 * len("hello world") and abs(int(pcm[0]) - 8192) <= 1
+    r = client.post("/v1/audio/speech", json={"input": "abc", "voice": "unknown-voice", "response_format": "pcm"})      # falls back to the default voice
+    assert r.status_code == 200 and r.headers["content-type"].startswith("audio/pcm") and len(r.content) == 2 * 240 * 3
+    assert m.calls[-1][2]["ref_audio"] == "a.wav" and m.calls[-1][2]["language"] == "English"
+    assert client.post("/v1/audio/speech", json={"input": "   ", "voice": "alloy"}).status_code == 400
+    assert client.post("/v1/audio/speech", json={"input": "x", "voice": "alloy", "response_format": "flac"}).status_code == 400
+    client2 = TestClient(create_app(m, voices, default_voice=None, scheduler="lock"))
+    assert client2.post("/v1/audio/speech", json={"input": "x", "voice": "nobody"}).status_code == 400
