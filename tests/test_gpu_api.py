@@ -165,6 +165,20 @@ def test_prefill_kv_import_from_hf_style_cache(model_and_weights):
     tiny = Fq3Engine(cfg, W, device="cuda", dtype=torch.float32, max_seq_len=32, max_frames=8)
     with pytest.raises(RuntimeError, match="Input is too long"):
         TalkerGraph(tiny).prefill_kv(cache)
+    # and against the ORACLE: a cache computed on the CPU by the oracle's prefill (the upstream talker.forward the
+    # reference hands to prefill_kv, generate.py:107-137) is imported, then one decode step must equal the oracle's
+    from oracle import qwen3tts_oracle as O
+    orc = O.OracleTTS(cfg, {k: v.float().cpu() for k, v in W.items()}, max_seq_len=64)
+    orc.prefill(x.cpu().unsqueeze(0), torch.ones(1, 37, dtype=torch.long))
+    ocache = [(orc.tcache.k[li][:37].permute(1, 0, 2).unsqueeze(0).contiguous(), orc.tcache.v[li][:37].permute(1, 0, 2).unsqueeze(0).contiguous())
+              for li in range(cfg.talker.num_hidden_layers)]
+    eng3 = Fq3Engine(cfg, W, device="cuda", dtype=torch.float32, max_seq_len=64, max_frames=8)
+    tg3 = TalkerGraph(eng3)
+    assert tg3.prefill_kv([(k.cuda(), v.cuda()) for k, v in ocache]) == 37
+    tg3.set_generation_state(torch.ones(1, 37, dtype=torch.long), None)
+    got3 = tg3.run(step_in.view(1, 1, -1), 37).view(-1).float().cpu()
+    ref3 = orc.talker_step(step_in.cpu().view(1, 1, -1), 37).view(-1)
+    assert (got3 - ref3).abs().max() <= 2e-4 * max(1.0, float(ref3.abs().max()))
 
 
 @pytest.mark.parametrize("kind", ["custom_voice", "voice_design"])
