@@ -62,6 +62,22 @@ __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, Lane
     attn_decode_body<T, REP>(a);
 }
 
+// Split-KV merge of the talker attention as its own launch (one thread per 8 head dims per lane, all slot loads in flight
+// at once), so that the o_proj after it is a plain GEMV: the merge inside the batch GEMV prologue walks 8 chunk tasks per
+// thread with one dependent round trip each (11.7-13.4 us per launch); merge + plain o_proj measured 8.2 us for the pair and
+// is bit-identical (tools/microbench/kernel_chain.hip).
+template <typename T>
+__global__ __launch_bounds__(256) void combine_batch_kernel(const float* part, size_t part_stride, int n_part, int rep, int q_dim,
+                                                            T* out, int out_stride) {
+    const int e0 = (blockIdx.x * 256 + threadIdx.x) * 8, l = blockIdx.y;
+    if (e0 >= q_dim) return;
+    CombineRegs cr;
+    combine_load(cr, part + (size_t)l * part_stride, e0, rep, n_part);
+    float f[8];
+    combine_finish<T>(cr, n_part, f);
+    DT<T>::st8(out + (size_t)l * out_stride + e0, f);
+}
+
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void sample_pred_batch_kernel(LaneTab t, const T* logits, size_t logit_stride, int V, int cb,
                                                                int G, const T* next_emb, T* next_in, int H) {

@@ -217,8 +217,10 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
             if (rep == 1) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 1>), grid, dim3(256), 0, s, a, b->tkv[i], b->tab, b->qkvm, b->rope_now, b->part_stride);
             else if (rep == 2) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 2>), grid, dim3(256), 0, s, a, b->tkv[i], b->tab, b->qkvm, b->rope_now, b->part_stride);
             else hipLaunchKernelGGL((attn_decode_batch_kernel<T, 4>), grid, dim3(256), 0, s, a, b->tkv[i], b->tab, b->qkvm, b->rope_now, b->part_stride);
-            o.part = b->part; o.part_stride = b->part_stride; o.n_part = c->tk.workers;
-            if (int r = launch_gemv_batch<PRO_COMBINE, EPI_RESIDUAL>(c, o, s)) return r;
+            hipLaunchKernelGGL((combine_batch_kernel<T>), dim3((q_dim / 8 + 255) / 256, B), dim3(256), 0, s, (const float*)b->part, b->part_stride,
+                               c->tk.workers, rep, q_dim, (T*)b->attn_out, b->qkvm);
+            o.x = b->attn_out; o.x_stride = b->qkvm;
+            if (int r = launch_gemv_batch<PRO_PLAIN, EPI_RESIDUAL>(c, o, s)) return r;
         } else {
             int rp = src.pos_imm; const int rl = c->wt.pred_rope_len;
             rp = rp < 0 ? 0 : (rp >= rl ? rl - 1 : rp);

@@ -99,21 +99,7 @@ static void check_lane_ops() {
     report("DPP / permlane-swap lane reductions", e, 1e-3);
 }
 
-// CANDIDATE for the next round (harness only): split-KV merge of all lanes as its own tiny launch, one 8-dim chunk per
-// thread (a single round trip), so that the batched talker o_proj can be a PLAIN GEMV.  The merge prologue inside
-// gemv_batch_kernel walks 8 chunk-tasks per thread one after the other (8 dependent round trips, 11.6-13.3 us per launch).
-template <typename T>
-__global__ __launch_bounds__(256) void combine_batch_kernel(const float* part, size_t part_stride, int n_part, int rep, int q_dim,
-                                                            T* out, int out_stride) {
-    const int e0 = (blockIdx.x * 256 + threadIdx.x) * 8, l = blockIdx.y;
-    if (e0 >= q_dim) return;
-    CombineRegs cr;
-    combine_load(cr, part + (size_t)l * part_stride, e0, rep, n_part);
-    float f[8];
-    combine_finish<T>(cr, n_part, f);
-    DT<T>::st8(out + (size_t)l * out_stride + e0, f);
-}
-
+// (combine_batch_kernel -- the split-KV merge as its own launch -- now lives in csrc/batch_kernels.cuh: shipped in round 2)
 __global__ void empty_kernel(const float* p) { if (p == nullptr) __builtin_trap(); }
 
 int main(int argc, char** argv) {
@@ -375,8 +361,8 @@ int main(int argc, char** argv) {
             run_v(4, 0, 8, yb); run_merge(); run_plain(0, ym); CHK(hipStreamSynchronize(st));
             auto a0 = fetch_bf16(yb, (size_t)8 * 8192), a2 = fetch_bf16(ym, (size_t)8 * 8192);
             int bad = 0; for (int m = 0; m < 8; ++m) for (int r = 0; r < H; ++r) bad += a0[(size_t)m * 8192 + r] != a2[(size_t)m * 8192 + r];
-            report("candidate merge kernel + PLAIN o_proj == COMBINE o_proj (B=8)", bad, 0.5);
-            chain("batch  B=8 candidate: merge kernel, then PLAIN o_proj (2 launches per step)", N, [&](int j) { if (j & 1) run_plain(j / 2, ym); else run_merge(); });
+            report("merge kernel + PLAIN o_proj == COMBINE o_proj (B=8)", bad, 0.5);
+            chain("batch  B=8 product: merge kernel, then PLAIN o_proj (2 launches per step)", N, [&](int j) { if (j & 1) run_plain(j / 2, ym); else run_merge(); });
         }
     }
     return g_fail ? 1 : 0;
