@@ -58,6 +58,59 @@ __global__ void snake_consts_kernel(const T* alpha, const T* beta, T* a_out, T* 
     DT<T>::st(ib_out + c, DT<T>::rnd(1.0f / DT<T>::rnd(b + 1e-9f)));
 }
 
+// Epilogue shared by the GEMM kernels.  C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
+template <typename T, int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane) {
+    T* Y = reinterpret_cast<T*>(a.Y);
+    T* Y2 = reinterpret_cast<T*>(a.Y2);
+    if (a.act == 2) {
+        // SwiGLU: tile j even = gate columns, j odd = the matching up columns (16-row interleave of the packed weight)
+        if constexpr (TN >= 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int np = n0 + wc * (BN / 2) + j * 16;             // physical column of the gate tile
+                    if (np >= a.N) continue;
+                    const int no = np / 2 + (lane & 15);                    // logical output column
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                        if (m >= a.M) continue;
+                        const float g = DT<T>::rnd(acc[i][j][r]), u = DT<T>::rnd(acc[i][j + 1][r]);
+                        DT<T>::st(Y + (size_t)m * a.ldy + no, DT<T>::rnd(g / (1.0f + expf(-g))) * u);
+                    }
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * (BN / 2) + j * 16 + (lane & 15);
+            if (n >= a.N) continue;
+            const int ch = n % a.bias_mod;
+            const float b = a.bias ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + ch) : 0.f;
+            const float sc = a.scale ? DT<T>::ld(reinterpret_cast<const T*>(a.scale) + n) : 1.f;
+            float sa = 0.f, sib = 0.f;
+            if (Y2) { sa = DT<T>::ld(reinterpret_cast<const T*>(a.sn_a) + ch); sib = DT<T>::ld(reinterpret_cast<const T*>(a.sn_ib) + ch); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                if (m >= a.M) continue;
+                float v = DT<T>::rnd(acc[i][j][r] + b);
+                if (a.act == 1) v = DT<T>::rnd(gelu_exact(v));
+                if (a.act == 3) v = DT<T>::rnd(v / (1.0f + expf(-v)));
+                if (a.scale) v = DT<T>::rnd(sc * v);
+                if (a.res) v = v + DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)m * a.ldr + n);
+                v = DT<T>::rnd(v);
+                if (Y) DT<T>::st(Y + (size_t)m * a.ldy + n, v);
+                if (Y2) DT<T>::st(Y2 + (size_t)m * a.ldy + n, snake_apply<T>(v, sa, sib));
+            }
+        }
+}
+
 // BM x BN output tile per workgroup, 4 waves as 2 x 2, each wave (BM/2) x (BN/2) = TM x TN MFMA tiles, K step 32,
 // double-buffered LDS (one barrier per step) fed by a PF-deep REGISTER prefetch: the global loads of step s + PF are
 // issued while step s is multiplied, so PF tiles (not one) are in flight per workgroup.  The streaming chunks make most
@@ -175,61 +228,124 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
             __syncthreads();
         }
     }
-    // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-    T* Y = reinterpret_cast<T*>(a.Y);
-    T* Y2 = reinterpret_cast<T*>(a.Y2);
-    if (a.act == 2) {
-        // SwiGLU: tile j even = gate columns, j odd = the matching up columns (16-row interleave of the packed weight)
-        if constexpr (TN >= 2) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; j += 2) {
-                    const int np = n0 + wc * (BN / 2) + j * 16;             // physical column of the gate tile
-                    if (np >= a.N) continue;
-                    const int no = np / 2 + (lane & 15);                    // logical output column
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
-                        if (m >= a.M) continue;
-                        const float g = DT<T>::rnd(acc[i][j][r]), u = DT<T>::rnd(acc[i][j + 1][r]);
-                        DT<T>::st(Y + (size_t)m * a.ldy + no, DT<T>::rnd(g / (1.0f + expf(-g))) * u);
-                    }
-                }
-        }
-        return;
-    }
+    gemm_epilogue<T, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
+}
+
+// Large-M variant (bf16): 128 x 64 tile, K step 64, operands copied global -> LDS by the DMA path (global_load_lds, 16 bytes
+// per lane: no staging registers, no ds_write pass), two LDS stages, one barrier per step.  The LDS image of a DMA copy is
+// lane-linear (wave-uniform base + lane * 16), so rows are exactly 128 bytes with no padding; bank conflicts are avoided by
+// swizzling the SOURCE address: LDS chunk c of row r holds global chunk c ^ ((r >> 1) & 7), which spreads the 16 rows of
+// an MFMA fragment read over all 64 banks.  Rows that must read as zeros (causal left pad, rows past M) are pointed at a
+// zero page.  The MFMA sequence per output element is the same ascending-K chain of 32-wide products as in
+// conv_gemm_kernel, so both kernels produce bit-identical results (tail decodes stay identical to full decodes).
+// Requires Cin % 64 == 0 (a K step never straddles a tap).
+static __device__ u32x4 g_gemm_zero_page[8];      // 128 zero bytes (one copy per translation unit)
+
+template <int BN, int STAGES>
+__global__ __launch_bounds__(256) void glds_gemm_kernel(GemmArgs a) {
+    static_assert(STAGES == 2 || STAGES == 3, "two or three LDS stages");
+    typedef bf16_t T;
+    constexpr int BM = 128, BK = 64, TM = 4, TN = BN / 32, NPB = BN / 32;     // NPB: 16-byte copy slots per thread for the B tile
+    extern __shared__ __attribute__((aligned(128))) unsigned char glds_smem[];
+    T* As = reinterpret_cast<T*>(glds_smem);                                  // [STAGES][BM * BK]
+    T* Bs = As + STAGES * BM * BK;                                            // [STAGES][BN * BK]
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = a.m_lo + blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int K = a.n_taps * a.Cin, nsteps = K / BK;
+    const T* A = reinterpret_cast<const T*>(a.A);
+    const T* W = reinterpret_cast<const T*>(a.W);
+    const T* zero = reinterpret_cast<const T*>(g_gemm_zero_page);
+    f32x4_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wc * (BN / 2) + j * 16 + (lane & 15);
-            if (n >= a.N) continue;
-            const int ch = n % a.bias_mod;
-            const float b = a.bias ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + ch) : 0.f;
-            const float sc = a.scale ? DT<T>::ld(reinterpret_cast<const T*>(a.scale) + n) : 1.f;
-            float sa = 0.f, sib = 0.f;
-            if (Y2) { sa = DT<T>::ld(reinterpret_cast<const T*>(a.sn_a) + ch); sib = DT<T>::ld(reinterpret_cast<const T*>(a.sn_ib) + ch); }
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // this thread's copy slots: slot = p * 256 + tid -> row = slot >> 3, LDS chunk = slot & 7, source chunk = chunk ^ swz(row)
+    int arow[4], asrc[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
-                if (m >= a.M) continue;
-                float v = DT<T>::rnd(acc[i][j][r] + b);
-                if (a.act == 1) v = DT<T>::rnd(gelu_exact(v));
-                if (a.act == 3) v = DT<T>::rnd(v / (1.0f + expf(-v)));
-                if (a.scale) v = DT<T>::rnd(sc * v);
-                if (a.res) v = v + DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)m * a.ldr + n);
-                v = DT<T>::rnd(v);
-                if (Y) DT<T>::st(Y + (size_t)m * a.ldy + n, v);
-                if (Y2) DT<T>::st(Y2 + (size_t)m * a.ldy + n, snake_apply<T>(v, sa, sib));
-            }
+    for (int p = 0; p < 4; ++p) {
+        const int slot = p * 256 + tid, r = slot >> 3, c = slot & 7;
+        arow[p] = m0 + r;
+        asrc[p] = (c ^ ((r >> 1) & 7)) * 8;
+    }
+    const T* wsrc[NPB];
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+        const int slot = p * 256 + tid, r = slot >> 3, c = slot & 7;
+        int n = n0 + r;
+        n = n < a.N ? n : a.N - 1;
+        wsrc[p] = W + (size_t)n * K + (c ^ ((r >> 1) & 7)) * 8;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    auto issue = [&](int step, int buf) {
+        const int k0 = step * BK;
+        const int tap = k0 / a.Cin, ci = k0 - tap * a.Cin;
+        const int toff = a.tap_off[tap];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int ar = arow[p] + toff;
+            const bool ok = arow[p] < a.M && ar >= 0 && ar < a.a_rows;
+            const T* src = ok ? A + (size_t)ar * a.lda + ci + asrc[p] : zero;
+            __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(As + buf * BM * BK + (p * 256 + wave * 64) * 8), 16, 0, 0);
         }
+#pragma unroll
+        for (int p = 0; p < NPB; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(wsrc[p] + k0), (lds_ptr)(Bs + buf * BN * BK + (p * 256 + wave * 64) * 8), 16, 0, 0);
+    };
+    issue(0, 0);
+    if (STAGES == 3 && nsteps > 1) issue(1, 1);
+    int buf = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // this wave's copies of stage s have landed (with three stages the copies of stage s + 1 may stay in flight)
+        if (STAGES == 3 && s + 1 < nsteps) {
+            if constexpr (BN == 64) __builtin_amdgcn_s_waitcnt(0x0f76); else __builtin_amdgcn_s_waitcnt(0x0f78);       // vmcnt(6) | vmcnt(8)
+        } else __builtin_amdgcn_s_waitcnt(0x0f70);                                                                    // vmcnt(0)
+        __builtin_amdgcn_s_barrier();                    // ... and everybody's; everybody is also done reading the stage refilled next
+        if (s + STAGES - 1 < nsteps) issue(s + STAGES - 1, (buf + STAGES - 1) % STAGES);       // flies under this step's MFMAs
+        const T* as = As + buf * BM * BK;
+        const T* bs = Bs + buf * BN * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wr * 64 + i * 16 + fr;
+                af[i] = *reinterpret_cast<const bf16x8_t*>(as + r * BK + (((ks * 4 + fq) ^ ((r >> 1) & 7)) * 8));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wc * (BN / 2) + j * 16 + fr;
+                bfr[j] = *reinterpret_cast<const bf16x8_t*>(bs + r * BK + (((ks * 4 + fq) ^ ((r >> 1) & 7)) * 8));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+    }
+    gemm_epilogue<T, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
+}
+
+template <int BN, int STAGES>
+inline void glds_go(const GemmArgs& a, hipStream_t s) {
+    const int rows = a.M - a.m_lo;
+    const size_t shm = (size_t)STAGES * (128 + BN) * 64 * 2;
+    auto kern = glds_gemm_kernel<BN, STAGES>;
+    if (shm > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, (rows + 127) / 128), dim3(256), shm, s, a);
 }
 
 // ---- host-side launch: tile shape per layer ---------------------------------------------------------------------
 template <typename T, int BM, int BN>
 inline void gemm_go(const GemmArgs& a, hipStream_t s) {
-    constexpr int PF = (BM + BN) > 128 ? 4 : 8;         // register-prefetch depth: 4 tiles of a big shape, 8 of a small one
+    // register-prefetch depth: the small tiles serve skinny layers (few workgroups, long K) and need 8 tiles in flight; the
+    // 128x64 tile runs with >= 2 workgroups per CU, where 2 is best (530 / 498 / 441 TFLOP/s at PF = 2 / 4 / 8, 4096^3)
+    constexpr int PF = (BM + BN) > 160 ? 2 : ((BM + BN) > 128 ? 4 : 8);
     dim3 grid((a.N + BN - 1) / BN, (a.M - a.m_lo + BM - 1) / BM);
     hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, PF>), grid, dim3(256), 0, s, a);
 }
@@ -244,7 +360,9 @@ inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
         // 80-110 (130 VGPRs / 40 KB LDS leave 3 workgroups per CU against 5: the one-barrier K step is latency-bound, so
         // residency beats arithmetic intensity here) -- the 128x128 shape is therefore not used.
         const bool n64 = a.N % 64 == 0 || a.N >= 512;
-        if (n64 && wgs(128, 64) >= 512) gemm_go<T, 128, 64>(a, s);
+        if (a.N % 64 == 0 && a.Cin % 64 == 0 && wgs(128, 64) >= 512) {
+            glds_go<64, 2>(a, s);
+        } else if (n64 && wgs(128, 64) >= 512) gemm_go<T, 128, 64>(a, s);
         else if (a.act != 2 && !n64 && wgs(128, 32) >= 256) gemm_go<T, 128, 32>(a, s);
         else if (n64 && (wgs(64, 64) >= 256 || a.act == 2)) gemm_go<T, 64, 64>(a, s);
         else if (a.act == 2) gemm_go<T, 64, 64>(a, s);
@@ -380,7 +498,6 @@ __global__ __launch_bounds__(256) void swa_attn_kernel(const T* qkv, T* out, int
     const float l = wave_sum(p[0] + p[1]);
     float o0 = 0.f, o1 = 0.f;
     const T* vbase = qkv + (size_t)k_lo * 3 * QD + 2 * QD + (size_t)h * HD;
-#pragma unroll 8
     for (int j = 0; j < nk; ++j) {
         const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j < 64 ? p[0] : p[1]), j & 63));
         const T* vp = vbase + (size_t)j * 3 * QD;

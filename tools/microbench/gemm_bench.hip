@@ -36,6 +36,44 @@ int main(int argc, char** argv) {
     };
     hipStream_t s; hipStreamCreate(&s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    if (argc > 2) {        // variant sweep on 4096 x 4096 x 4096: tile shape x prefetch depth
+        const int M = 4096, N = 4096, K = 4096;
+        void *A, *W, *Y;
+        hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&W, (size_t)N * K * 2); hipMalloc(&Y, (size_t)M * N * 2);
+        hipMemset(A, 0x3c, (size_t)M * K * 2); hipMemset(W, 0x3c, (size_t)N * K * 2);
+        GemmArgs a{};
+        a.A = A; a.lda = K; a.M = M; a.a_rows = M; a.n_taps = 1; a.Cin = K; a.W = W; a.N = N; a.bias_mod = N; a.Y = Y; a.ldy = N;
+        auto run = [&](const char* name, auto kern, int bm, int bn) {
+            dim3 grid((N + bn - 1) / bn, (M + bm - 1) / bm);
+            hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, a);
+            hipStreamSynchronize(s);
+            hipEventRecord(e0, s);
+            for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, a);
+            hipEventRecord(e1, s); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+            printf("%-28s %9.3f us  %8.1f TFLOP/s\n", name, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
+        };
+        auto rung = [&](const char* name, auto go) {
+            go(a, s); hipStreamSynchronize(s);
+            hipEventRecord(e0, s);
+            for (int r = 0; r < reps; ++r) go(a, s);
+            hipEventRecord(e1, s); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+            printf("%-28s %9.3f us  %8.1f TFLOP/s\n", name, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
+        };
+        rung("glds 128x64 2 stages", glds_go<64, 2>);
+        rung("glds 128x64 3 stages", glds_go<64, 3>);
+        rung("glds 128x128 2 stages", glds_go<128, 2>);
+        rung("glds 128x128 3 stages", glds_go<128, 3>);
+        run("128x64 PF=2", conv_gemm_kernel<bf16_t, 128, 64, 2>, 128, 64);
+        run("128x64 PF=4", conv_gemm_kernel<bf16_t, 128, 64, 4>, 128, 64);
+        run("128x64 PF=8", conv_gemm_kernel<bf16_t, 128, 64, 8>, 128, 64);
+        run("64x64 PF=4", conv_gemm_kernel<bf16_t, 64, 64, 4>, 64, 64);
+        run("64x64 PF=8", conv_gemm_kernel<bf16_t, 64, 64, 8>, 64, 64);
+        run("128x128 PF=2", conv_gemm_kernel<bf16_t, 128, 128, 2>, 128, 128);
+        run("128x128 PF=4", conv_gemm_kernel<bf16_t, 128, 128, 4>, 128, 128);
+        return 0;
+    }
     for (auto& sh : shapes) {
         const size_t K = (size_t)sh.taps * sh.Cin;
         const size_t na = (size_t)sh.M * sh.Cin, nw = (size_t)sh.N * K, ny = (size_t)sh.M * sh.N;
