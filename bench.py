@@ -97,13 +97,13 @@ def prefill_gemm_flops(cfg, L: int) -> float:
 # ------------------------------------------------------------------------------------------------------------------
 # GPU runner
 # ------------------------------------------------------------------------------------------------------------------
-def build_model(device, size="0p6b", frames=FRAMES):
+def build_model(device, size="0p6b", frames=FRAMES, max_seq_len=2048):
     from fq3hip.config import qwen3_tts_0p6b, qwen3_tts_1p7b
     from fq3hip.weights import synth_weights
     from fq3hip.model import FasterQwen3TTS
     cfg = qwen3_tts_0p6b() if size == "0p6b" else qwen3_tts_1p7b()
     W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor", "codec", "text"), codec_normalized=True)
-    model = FasterQwen3TTS.from_weights(cfg, W, device=device, dtype=torch.bfloat16, max_seq_len=2048,
+    model = FasterQwen3TTS.from_weights(cfg, W, device=device, dtype=torch.bfloat16, max_seq_len=max_seq_len,
                                         codec_max_frames=REF_FRAMES + frames + 16, max_frames=frames + 8)
     model._bench_weights = W
     return cfg, model
@@ -433,7 +433,7 @@ def cpu_baseline(cfg, frames=6, budget_s=45.0):
 def model_1p7b_block(device):
     """BASELINE configs[2]: the 1.7B shapes (talker hidden 2048 / intermediate 6144, predictor with projection), single
     stream: RTF / TTFA over 2 utterances + the decode-frame roofline; and 8 lock-step lanes (configs[3]'s model)."""
-    cfg, model = build_model(device, "1p7b")
+    cfg, model = build_model(device, "1p7b", max_seq_len=6144)
     req = build_request(cfg, device)
     one_utterance(model, req, 900)
     prompt = prepared_prompt(model, req)
@@ -443,6 +443,28 @@ def model_1p7b_block(device):
            "rtf": round(float(np.mean([n * FRAME_S / w for _, w, n, _ in res])), 3),
            "ttfa_ms_p50": round(1000 * float(np.median([t for t, _, _, _ in res])), 2),
            "decode_ms_per_frame": round(frame_ms, 4), "roofline": frame_roofline(cfg, frame_ms, p_mid)}
+    try:
+        # BASELINE configs[4] shape: a 4096-token prompt (synthetic embeddings) through the matrix-core prefill
+        from fq3hip.weights import synth_prompt
+        eng = model.talker_graph.engine
+        x = (synth_prompt(cfg, 4096, 4, 0, dtype=torch.bfloat16)[0][0] * 30).to(torch.bfloat16).to(device).contiguous()
+        eng.prefill(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        eng.prefill(x)
+        e1.record()
+        torch.cuda.synchronize()
+        pms = e0.elapsed_time(e1)
+        t = cfg.talker
+        gemm_fl = prefill_gemm_flops(cfg, 4096)
+        attn_fl = 4.0 * (4096 * 4097 / 2) * t.head_dim * t.num_attention_heads * t.num_hidden_layers
+        out["prefill_4096"] = {"workload": "configs[4] shape: 4096-token prompt, 28 layers at 1.7B dims, flash MFMA attention + glds GEMMs",
+                               "ms": round(pms, 2), "gemm_tflop": round(gemm_fl / 1e12, 2), "attention_tflop": round(attn_fl / 1e12, 2),
+                               "achieved": round((gemm_fl + attn_fl) / (pms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round((gemm_fl + attn_fl) / (pms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "bound": "mfma"}
+    except Exception as e:
+        out["prefill_4096"] = {"error": repr(e)}
     try:
         ms, p = batched_frame_time(model, cfg, prompt, lanes=8)
         out["batched_b8"] = {"ms_per_lockstep_frame": round(ms, 3), "value": round(8 * 80.0 / ms, 1),
