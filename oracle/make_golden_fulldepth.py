@@ -48,9 +48,37 @@ def run_case(size: str, dtype: torch.dtype, frames: int = FRAMES):
                 p_top1=np.asarray(orc.pred_top1, np.float32).reshape(frames, 15)), dt
 
 
+SAMPLED_FRAMES = 12
+SAMPLED_SEED = 21
+
+
+def sampled_noise(cfg, frames: int = SAMPLED_FRAMES, seed: int = SAMPLED_SEED):
+    """Exp(1) variates shared by the oracle and the GPU run (CPU generator: identical on every machine)."""
+    g = torch.Generator().manual_seed(seed)
+    tn = torch.empty(frames + 1, cfg.talker.vocab_size).exponential_(1, generator=g)
+    pn = torch.empty(frames, cfg.num_code_groups - 1, cfg.predictor.vocab_size).exponential_(1, generator=g)
+    return tn, pn
+
+
+def run_sampled_case(frames: int = SAMPLED_FRAMES):
+    """0.6B fp32, product-default sampling (T 0.9, top-k 50, repetition penalty 1.05, min_new 2; predictor T 0.9 / top-k 50)
+    with pre-drawn noise: the whole sampler + penalty path at the real vocabulary sizes inside the full-depth loop."""
+    cfg = qwen3_tts_0p6b()
+    W = synth_weights(cfg, 0, torch.float32, parts=("talker", "predictor"))
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, PROMPT, TRAILING, 0, dtype=torch.float32)
+    tn, pn = sampled_noise(cfg, frames)
+    orc = O.OracleTTS(cfg, W, max_seq_len=PROMPT + frames + 8)
+    sp = O.SamplingParams(max_new_tokens=frames, min_new_tokens=frames)
+    with torch.inference_mode():
+        codes = orc.generate(tie, tam, tth, tpe, sp, talker_noise=tn, pred_noise=pn)
+    assert codes.shape == (frames, 16)
+    return codes.numpy().astype(np.int32)
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
-    out = {}
+    out = {"0p6b_f32_sampled_codes": run_sampled_case()}
+    print("sampled 0.6B fp32:", out["0p6b_f32_sampled_codes"][:2].tolist())
     for size in ("0p6b", "1p7b"):
         for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
             r, dt = run_case(size, dtype)

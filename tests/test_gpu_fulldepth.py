@@ -107,3 +107,35 @@ def test_free_running_bf16_prefix_matches(golden_dir):
     _note("0p6b_bf16_free_running_prefix", [first_bad, int(same.size)])
     if first_bad < same.size:
         assert margin[first_bad] / TF.bf16_ulp(top1[first_bad:first_bad + 1])[0] <= K_ULP
+
+
+def test_full_depth_sampled_fp32_exact(golden_dir):
+    """Product-default SAMPLING (T 0.9, top-k 50, repetition penalty 1.05; predictor T 0.9 / top-k 50) at full depth and the
+    real vocabulary sizes, fp32, with the oracle's pre-drawn Exp(1) noise: the free-running hipGraph loop must reproduce
+    the oracle's ids exactly (golden: oracle/make_golden_fulldepth.py::run_sampled_case)."""
+    from fq3hip.engine import Fq3Engine
+    from oracle.make_golden_fulldepth import sampled_noise, SAMPLED_FRAMES, PROMPT, TRAILING
+    g = np.load(os.path.join(golden_dir, "fulldepth.npz"))
+    ref = g["0p6b_f32_sampled_codes"].astype(np.int64)
+    cfg = qwen3_tts_0p6b()
+    dtype = torch.float32
+    W = synth_weights(cfg, 0, dtype, parts=("talker", "predictor"))
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, PROMPT, TRAILING, 0, dtype=dtype)
+    tn, pn = sampled_noise(cfg)
+    frames = SAMPLED_FRAMES
+    eng = Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=PROMPT + frames + 8, max_frames=frames + 8)
+    del W
+    eng.set_predictor_sampling(do_sample=True, top_k=50, top_p=1.0, temperature=0.9)
+    kw = dict(temperature=0.9, top_k=50, top_p=1.0, do_sample=True)
+    V = cfg.talker.vocab_size
+    logits, hidden = eng.prefill(tie[0].cuda().contiguous())
+    tok = eng.sample(logits, sup_lo=V - 1024, sup_hi=V, keep_id=cfg.codec_eos_token_id, suppress_eos=True, noise=tn[0].cuda().contiguous(), **kw)
+    eng.decode_begin(first_token=int(tok), prefill_len=PROMPT, gen_step=0, past_hidden=hidden, trailing_text=tth[0].cuda().contiguous(),
+                     tts_pad_embed=tpe.view(-1).cuda().contiguous(), repetition_penalty=1.05, min_new_tokens=frames,
+                     max_new_tokens=frames, talker_noise=tn[1:].contiguous().cuda(), pred_noise=pn.contiguous().cuda(),
+                     noise_frames=frames, **kw)
+    eng.graph_capture()
+    eng.decode_frames(frames)
+    n, _ = eng.decode_poll()
+    codes = eng.decode_codes(0, n).cpu().numpy()
+    assert codes.shape == ref.shape and np.array_equal(codes, ref), int((codes != ref).sum())
