@@ -37,6 +37,9 @@ struct GemmArgs {
     void* Y; int ldy;                                 // primary output (may be null when only Y2 is wanted)
     int act;                                          // 0 none, 1 exact GELU, 2 SwiGLU over 16-column [gate|up] groups, 3 SiLU
     const void* sn_a; const void* sn_ib; void* Y2;    // optional second output: SnakeBeta(stored value), channel n % bias_mod
+    // split-K (single-tap GEMMs with few rows, e.g. the 200-token prefill's o_proj / down): workgroup z multiplies channel
+    // slice z and stores fp32 partials to ws[z][m - m_lo][n]; splitk_reduce_kernel sums them in order and runs the epilogue
+    float* ws; long ws_floats; int ksplit;
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -61,6 +64,21 @@ __global__ void snake_consts_kernel(const T* alpha, const T* beta, T* a_out, T* 
 // Epilogue shared by the GEMM kernels.  C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
 template <typename T, int BM, int BN, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane) {
+    if (a.ksplit > 1) {
+        float* ws = a.ws + (size_t)blockIdx.z * (size_t)(a.M - a.m_lo) * a.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wc * (BN / 2) + j * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                    if (n < a.N && m < a.M) ws[(size_t)(m - a.m_lo) * a.N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     T* Y = reinterpret_cast<T*>(a.Y);
     T* Y2 = reinterpret_cast<T*>(a.Y2);
     if (a.act == 2) {
@@ -130,10 +148,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m0 = a.m_lo + blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wr = wave >> 1, wc = wave & 1;
-    const int K = a.n_taps * a.Cin;
-    const int nsteps = K / BK;
+    const int ldw = a.n_taps * a.Cin;                   // weight row stride
     const T* A = reinterpret_cast<const T*>(a.A);
     const T* W = reinterpret_cast<const T*>(a.W);
+    int Cin = a.Cin;
+    if (a.ksplit > 1) { Cin = a.Cin / a.ksplit; A += blockIdx.z * Cin; W += blockIdx.z * Cin; }     // single-tap only: a channel slice
+    const int K = a.n_taps * Cin;
+    const int nsteps = K / BK;
     constexpr int EPT = 16 / sizeof(T);                 // elements per 16-byte access
     constexpr int TPR = BK / EPT;                       // threads per tile row
     constexpr int RPP = 256 / TPR;                      // rows per pass
@@ -151,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     for (int p = 0; p < NPB; ++p) {
         int n = n0 + lr + p * RPP;
         n = n < a.N ? n : a.N - 1;
-        wrow[p] = W + (size_t)n * K + lc;
+        wrow[p] = W + (size_t)n * ldw + lc;
     }
     u32x4 areg[PF][NPA], breg[PF][NPB];
     // issue cursor (step being loaded) and stage cursor (step being written to LDS): (tap, channel offset) walk K in order
@@ -165,8 +186,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
             areg[slot][p] = *reinterpret_cast<const u32x4*>(A + (size_t)ar * a.lda + i_ci + lc);
         }
 #pragma unroll
-        for (int p = 0; p < NPB; ++p) breg[slot][p] = *reinterpret_cast<const u32x4*>(wrow[p] + (size_t)i_tap * a.Cin + i_ci);
-        if (i_step + 1 < nsteps) { ++i_step; i_ci += BK; if (i_ci >= a.Cin) { i_ci = 0; ++i_tap; } }
+        for (int p = 0; p < NPB; ++p) breg[slot][p] = *reinterpret_cast<const u32x4*>(wrow[p] + (size_t)i_tap * Cin + i_ci);
+        if (i_step + 1 < nsteps) { ++i_step; i_ci += BK; if (i_ci >= Cin) { i_ci = 0; ++i_tap; } }
         else i_step = nsteps;                           // further issues re-read the last tile; staged as zeros
     };
     auto stage = [&](int slot, int buf) {               // slot -> LDS[buf]; rows outside the problem and tail steps become zeros
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
             const int r = lr + p * RPP;
             if (r < BN) *reinterpret_cast<u32x4*>(&Bs[buf][r * LD + lc]) = breg[slot][p];
         }
-        ++s_step; s_ci += BK; if (s_ci >= a.Cin) { s_ci = 0; if (s_tap + 1 < a.n_taps) ++s_tap; }
+        ++s_step; s_ci += BK; if (s_ci >= Cin) { s_ci = 0; if (s_tap + 1 < a.n_taps) ++s_tap; }
     };
 #pragma unroll
     for (int d = 0; d < PF; ++d) issue(d);
@@ -340,6 +361,27 @@ inline void glds_go(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, (rows + 127) / 128), dim3(256), shm, s, a);
 }
 
+// second pass of a split-K GEMM: sum the slices in index order (deterministic), then the ordinary epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs a) {
+    const int rows = a.M - a.m_lo;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)rows * a.N) return;
+    const int mm = (int)(e / a.N), n = (int)(e % a.N), m = a.m_lo + mm;
+    float sum = 0.f;
+    for (int z = 0; z < a.ksplit; ++z) sum += a.ws[(size_t)z * rows * a.N + e];
+    const int ch = n % a.bias_mod;
+    float v = DT<T>::rnd(sum + (a.bias ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + ch) : 0.f));
+    if (a.act == 1) v = DT<T>::rnd(gelu_exact(v));
+    if (a.act == 3) v = DT<T>::rnd(v / (1.0f + expf(-v)));
+    if (a.scale) v = DT<T>::rnd(DT<T>::ld(reinterpret_cast<const T*>(a.scale) + n) * v);
+    if (a.res) v = v + DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)m * a.ldr + n);
+    v = DT<T>::rnd(v);
+    if (a.Y) DT<T>::st(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + n, v);
+    if (a.Y2) DT<T>::st(reinterpret_cast<T*>(a.Y2) + (size_t)m * a.ldy + n,
+                        snake_apply<T>(v, DT<T>::ld(reinterpret_cast<const T*>(a.sn_a) + ch), DT<T>::ld(reinterpret_cast<const T*>(a.sn_ib) + ch)));
+}
+
 // ---- host-side launch: tile shape per layer ---------------------------------------------------------------------
 template <typename T, int BM, int BN>
 inline void gemm_go(const GemmArgs& a, hipStream_t s) {
@@ -356,6 +398,22 @@ inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
     if constexpr (sizeof(T) == 4) { gemm_go<T, 64, 64>(a, s); return; }      // fp32 = parity mode, one shape
     else {
         auto wgs = [&](int bm, int bn) { return (long)((rows + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+        // few rows, one tap, long K, narrow N (the 200-token prefill's o_proj / down): split K over workgroups, two passes.
+        // Only where the caller lends a workspace: the codec does not (a tail decode must stay bit-identical to a full one).
+        if (a.ws && a.n_taps == 1 && a.act != 2 && wgs(64, 32) < 384 && a.Cin >= 1536) {
+            int S = 0;
+            for (int cand : {8, 6, 4, 3, 2})
+                if (a.Cin % (cand * 32) == 0 && a.Cin / (cand * 32) >= 12 && wgs(64, 32) * cand <= 1024 &&
+                    (long)cand * rows * a.N <= a.ws_floats) { S = cand; break; }
+            if (S > 1) {
+                GemmArgs b = a;
+                b.ksplit = S;
+                dim3 grid((a.N + 31) / 32, (rows + 63) / 64, S);
+                hipLaunchKernelGGL((conv_gemm_kernel<T, 64, 32, 8>), grid, dim3(256), 0, s, b);
+                hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)(((size_t)rows * a.N + 255) / 256)), dim3(256), 0, s, b);
+                return;
+            }
+        }
         // Measured on MI355X (tools/microbench/gemm_bench.hip): the 128x64 tile reaches 390 TFLOP/s where 128x128 stays at
         // 80-110 (130 VGPRs / 40 KB LDS leave 3 workgroups per CU against 5: the one-barrier K step is latency-bound, so
         // residency beats arithmetic intensity here) -- the 128x128 shape is therefore not used.

@@ -53,7 +53,7 @@ struct fq3_ctx {
     void *pw_x = nullptr, *pw_h = nullptr;
     int pw_cap = 0;
     // MFMA prefill workspace (lazily allocated, sized for max_seq_len rows)
-    void *pf_x = nullptr, *pf_xn = nullptr, *pf_qkv = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_act = nullptr;
+    void *pf_x = nullptr, *pf_xn = nullptr, *pf_qkv = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_act = nullptr, *pf_ws = nullptr;
 };
 
 

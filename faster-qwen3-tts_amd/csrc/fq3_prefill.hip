@@ -260,6 +260,7 @@ GemmArgs lin(const void* A, int M, int K, const void* W, int N, void* Y) {
     GemmArgs a{}; a.A = A; a.lda = K; a.M = M; a.a_rows = M; a.n_taps = 1; a.tap_off[0] = 0; a.Cin = K; a.W = W; a.N = N;
     a.bias_mod = N; a.Y = Y; a.ldy = N; return a;
 }
+constexpr long kPrefillWsFloats = 8L << 20;       // split-K partials of the short-prompt GEMMs (32 MB)
 template <typename T> void gemm(const GemmArgs& a, hipStream_t s) { gemm_launch<T>(a, s); }
 
 template <typename T>
@@ -277,6 +278,7 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
         if ((r = fq3_dmalloc_(c, &c->pf_att, rows * QD * c->esz))) return r;
         if ((r = fq3_dmalloc_(c, &c->pf_gu, rows * 2 * I * c->esz))) return r;
         if ((r = fq3_dmalloc_(c, &c->pf_act, rows * I * c->esz))) return r;
+        if ((r = fq3_dmalloc_(c, &c->pf_ws, (size_t)kPrefillWsFloats * sizeof(float)))) return r;
     }
     T *X = (T*)c->pf_x, *XN = (T*)c->pf_xn, *QKV = (T*)c->pf_qkv, *ATT = (T*)c->pf_att, *GU = (T*)c->pf_gu, *ACT = (T*)c->pf_act;
     if (hipMemcpyAsync(X, embeds, (size_t)L * H * c->esz, hipMemcpyDeviceToDevice, s) != hipSuccess)
@@ -300,11 +302,11 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
             hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((L * NH + 3) / 4), dim3(256), 0, s, (const T*)QKV, (const T*)c->tk.k[i],
                                (const T*)c->tk.v[i], ATT, c->tk.max_seq, L, n_pad, NH, NKV, scale);
         }
-        { GemmArgs a = lin<T>(ATT, L, QD, w.o, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
+        { GemmArgs a = lin<T>(ATT, L, QD, w.o, H, X); a.res = X; a.ldr = H; a.ws = (float*)c->pf_ws; a.ws_floats = kPrefillWsFloats; gemm<T>(a, s); }
         hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((L + 3) / 4), dim3(256), 0, s, (const T*)X, (const T*)w.post_norm, XN, 0, L, H, d.rms_eps);
         gemm<T>(lin<T>(XN, L, H, w.gate_up, 2 * I, GU), s);
         hipLaunchKernelGGL((silu_mul_kernel<T>), dim3((unsigned)(((size_t)L * I + 255) / 256)), dim3(256), 0, s, (const T*)GU, ACT, L, I);
-        { GemmArgs a = lin<T>(ACT, L, I, w.down, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
+        { GemmArgs a = lin<T>(ACT, L, I, w.down, H, X); a.res = X; a.ldr = H; a.ws = (float*)c->pf_ws; a.ws_floats = kPrefillWsFloats; gemm<T>(a, s); }
     }
     // final norm of the last row only -> past_hidden; logits through the decode-path head GEMV
     hipLaunchKernelGGL((rmsnorm_kernel<T>), dim3(1), dim3(256), 0, s, (const T*)X + (size_t)(L - 1) * H, (const T*)c->wt.talker_final_norm,

@@ -12,7 +12,7 @@ using namespace fq3;
 static uint16_t f_to_bf16_host(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static float bf16_to_f_host(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
 
-struct Shape { const char* name; int M, N, Cin, taps, dil; };
+struct Shape { const char* name; int M, N, Cin, taps, dil; bool ws; };
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 10;
@@ -24,6 +24,8 @@ int main(int argc, char** argv) {
         {"prefill200 qkv (0.6B)", 200, 4096, 1024, 1, 1},
         {"prefill200 gate_up", 200, 6144, 1024, 1, 1},
         {"prefill200 down", 200, 1024, 3072, 1, 1},
+        {"prefill200 o     +splitK", 200, 1024, 2048, 1, 1, true},
+        {"prefill200 down  +splitK", 200, 1024, 3072, 1, 1, true},
         {"codec370 dec.0 k7", 1480, 1536, 1024, 7, 1},
         {"codec370 b1 conv1 k7", 11832, 768, 768, 7, 1},
         {"codec370 b2 conv1 k7", 59155, 384, 384, 7, 3},
@@ -89,6 +91,8 @@ int main(int argc, char** argv) {
         a.A = A; a.lda = sh.Cin; a.M = sh.M; a.a_rows = sh.M; a.n_taps = sh.taps; a.Cin = sh.Cin; a.W = W; a.N = sh.N;
         for (int i = 0; i < sh.taps; ++i) a.tap_off[i] = -(sh.taps - 1 - i) * sh.dil;
         a.bias_mod = sh.N; a.Y = Y; a.ldy = sh.N;
+        void* ws = nullptr;
+        if (sh.ws) { hipMalloc(&ws, (size_t)(8 << 20) * 4); a.ws = (float*)ws; a.ws_floats = 8 << 20; }
         gemm_launch<bf16_t>(a, s);
         hipStreamSynchronize(s);
         hipEventRecord(e0, s);
@@ -115,7 +119,7 @@ int main(int argc, char** argv) {
         const double fl = 2.0 * sh.M * sh.N * K;
         printf("%-24s M=%7d N=%5d K=%5zu  %9.3f us  %8.1f TFLOP/s  check %.2e %s\n", sh.name, sh.M, sh.N, K, ms * 1e3, fl / (ms * 1e-3) / 1e12,
                maxerr, maxerr < 2e-2 ? "ok" : "MISMATCH");
-        hipFree(A); hipFree(W); hipFree(Y);
+        hipFree(A); hipFree(W); hipFree(Y); if (ws) hipFree(ws);
     }
     return 0;
 }
