@@ -35,14 +35,27 @@ struct GemmArgs {
     const void* scale;                                // optional per-n multiplier after the activation
     const void* res; int ldr;                         // optional residual [M][ldr]
     void* Y; int ldy;                                 // primary output (may be null when only Y2 is wanted)
-    int act;                                          // 0 none, 1 exact GELU, 2 SwiGLU over 16-column [gate|up] groups, 3 SiLU
+    int act;                                          // 0 none, 1 exact GELU, 2 SwiGLU over 16-column [gate|up] groups, 3 SiLU,
+                                                      // 4 ReLU, 5 ELU, 6 tanh(ReLU), 7 sigmoid, 8 log(max(v, 1e-5)) (reference-audio analysis)
     const void* sn_a; const void* sn_ib; void* Y2;    // optional second output: SnakeBeta(stored value), channel n % bias_mod
+    int act2;                                         // second output's function: 0 SnakeBeta (sn_a / sn_ib), 1 ELU
     // split-K (single-tap GEMMs with few rows, e.g. the 200-token prefill's o_proj / down): workgroup z multiplies channel
     // slice z and stores fp32 partials to ws[z][m - m_lo][n]; splitk_reduce_kernel sums them in order and runs the epilogue
     float* ws; long ws_floats; int ksplit;
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// the activations only the reference-audio analysers use (act >= 4), kept out of line of the codec's epilogue
+__device__ __forceinline__ float act_extra(int act, float v) {
+    switch (act) {
+        case 4: return fmaxf(v, 0.f);
+        case 5: return elu1(v);
+        case 6: return tanhf(fmaxf(v, 0.f));
+        case 7: return 1.0f / (1.0f + expf(-v));
+        default: return logf(fmaxf(v, 1e-5f));
+    }
+}
 
 // SnakeBeta on an already T-rounded value, each Torch op rounded to T (modeling :3566-3580):
 // x + (1 / (exp(beta) + 1e-9)) * sin(x * exp(alpha))^2; a = rnd(exp(alpha)), ib = rnd(1 / rnd(rnd(exp(beta)) + 1e-9))
@@ -112,7 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
             const float b = a.bias ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + ch) : 0.f;
             const float sc = a.scale ? DT<T>::ld(reinterpret_cast<const T*>(a.scale) + n) : 1.f;
             float sa = 0.f, sib = 0.f;
-            if (Y2) { sa = DT<T>::ld(reinterpret_cast<const T*>(a.sn_a) + ch); sib = DT<T>::ld(reinterpret_cast<const T*>(a.sn_ib) + ch); }
+            if (Y2 && a.act2 == 0) { sa = DT<T>::ld(reinterpret_cast<const T*>(a.sn_a) + ch); sib = DT<T>::ld(reinterpret_cast<const T*>(a.sn_ib) + ch); }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
@@ -120,11 +133,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
                 float v = DT<T>::rnd(acc[i][j][r] + b);
                 if (a.act == 1) v = DT<T>::rnd(gelu_exact(v));
                 if (a.act == 3) v = DT<T>::rnd(v / (1.0f + expf(-v)));
+                if (a.act >= 4) v = DT<T>::rnd(act_extra(a.act, v));
                 if (a.scale) v = DT<T>::rnd(sc * v);
                 if (a.res) v = v + DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)m * a.ldr + n);
                 v = DT<T>::rnd(v);
                 if (Y) DT<T>::st(Y + (size_t)m * a.ldy + n, v);
-                if (Y2) DT<T>::st(Y2 + (size_t)m * a.ldy + n, snake_apply<T>(v, sa, sib));
+                if (Y2) DT<T>::st(Y2 + (size_t)m * a.ldy + n, a.act2 ? DT<T>::rnd(elu1(v)) : snake_apply<T>(v, sa, sib));
             }
         }
 }

@@ -70,6 +70,17 @@ class CodecConfig(C.Structure):
                 ("upsample_rates", i32 * 8), ("decoder_dim", i32), ("max_frames", i32)]
 
 
+class RefEncConfig(C.Structure):
+    _fields_ = [("num_filters", i32), ("n_ratios", i32), ("ratios", i32 * 8), ("kernel_size", i32), ("last_kernel_size", i32),
+                ("residual_kernel_size", i32), ("n_residual_layers", i32), ("dilation_growth_rate", i32), ("compress", i32),
+                ("hidden", i32), ("n_layers", i32), ("n_heads", i32), ("head_dim", i32), ("inter", i32), ("sliding_window", i32),
+                ("norm_eps", C.c_float), ("num_quantizers", i32), ("num_semantic", i32), ("codebook_size", i32),
+                ("codebook_dim", i32), ("max_positions", i32), ("mel_dim", i32), ("n_fft", i32), ("hop", i32),
+                ("n_bins_padded", i32), ("n_enc", i32), ("enc_channels", i32 * 8), ("enc_kernel_sizes", i32 * 8),
+                ("enc_dilations", i32 * 8), ("attn_channels", i32), ("res2net_scale", i32), ("se_channels", i32),
+                ("enc_dim", i32)]
+
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 SIGNATURES = {
     "fq3_last_error": (C.c_char_p, []),
@@ -114,6 +125,13 @@ SIGNATURES = {
     "fq3_codec_num_samples": (C.c_int64, [vp, C.c_int]),
     "fq3_codec_decode": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "fq3_codec_decode_tail": (C.c_int, [vp, vp, C.c_int, C.c_int64, vp, vp]),
+    "fq3_refenc_create": (C.c_int, [C.POINTER(RefEncConfig), C.POINTER(vp)]),
+    "fq3_refenc_destroy": (C.c_int, [vp]),
+    "fq3_refenc_bind": (C.c_int, [vp, C.c_char_p, vp, C.c_int64]),
+    "fq3_refenc_finalize": (C.c_int, [vp, vp]),
+    "fq3_refenc_num_frames": (C.c_int64, [vp, C.c_int64]),
+    "fq3_refenc_encode": (C.c_int, [vp, vp, C.c_int64, vp, vp]),
+    "fq3_refenc_speaker": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp]),
 }
 
 _lib = None

@@ -74,12 +74,82 @@ class CodecConfig:
 
 
 @dataclass
+class RefAudioConfig:
+    """Reference-audio analysers run once per new reference clip (reference ``model.py:430-447`` -> upstream
+    ``create_voice_clone_prompt``): the speech tokenizer's ENCODER and the speaker encoder.
+
+    Encoder defaults = the Mimi configuration (``transformers/models/mimi/configuration_mimi.py``: upstream's 12 Hz
+    tokenizer encoder subclasses ``MimiModel`` and keeps the first 16 of its 32 quantizers) [recalled]; speaker defaults =
+    the ECAPA-TDNN of ``modeling_qwen2_5_omni.py:2630-2707`` over a 128-bin log-mel (n_fft 1024, hop 256, 0-12 kHz,
+    BigVGAN-style) [recalled].  ``enc_dim`` equals the talker's hidden size."""
+
+    # speech-tokenizer encoder
+    num_filters: int = 64
+    ratios: Tuple[int, ...] = (4, 5, 6, 8)            # encoder order (= reversed Mimi ``upsampling_ratios``)
+    kernel_size: int = 7
+    last_kernel_size: int = 3
+    residual_kernel_size: int = 3
+    num_residual_layers: int = 1
+    dilation_growth_rate: int = 2
+    compress: int = 2
+    hidden_size: int = 512
+    num_hidden_layers: int = 8
+    num_attention_heads: int = 8
+    head_dim: int = 64
+    intermediate_size: int = 2048
+    sliding_window: int = 250
+    norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    layer_scale_initial_scale: float = 0.01
+    num_quantizers: int = 16                           # ``encoder_valid_num_quantizers``
+    num_semantic_quantizers: int = 1
+    codebook_size: int = 2048
+    codebook_dim: int = 256
+    max_positions: int = 8000                          # 25 Hz frames (320 s)
+    sample_rate: int = 24000
+    # speaker encoder
+    mel_dim: int = 128
+    n_fft: int = 1024
+    hop_size: int = 256
+    fmin: float = 0.0
+    fmax: float = 12000.0
+    enc_channels: Tuple[int, ...] = (512, 512, 512, 512, 1536)
+    enc_kernel_sizes: Tuple[int, ...] = (5, 3, 3, 3, 1)
+    enc_dilations: Tuple[int, ...] = (1, 2, 3, 4, 1)
+    enc_attention_channels: int = 128
+    enc_res2net_scale: int = 8
+    enc_se_channels: int = 128
+    enc_dim: int = 1024
+
+    @property
+    def n_bins_padded(self) -> int:
+        return (self.n_fft // 2 + 1 + 31) // 32 * 32
+
+    @property
+    def samples_per_frame(self) -> int:
+        n = 2
+        for r in self.ratios:
+            n *= r
+        return n
+
+
+def tiny_ref_audio_config() -> RefAudioConfig:
+    """Small shapes (same structure) for CPU-speed oracle pins and quick GPU parity."""
+    return RefAudioConfig(num_filters=64, ratios=(2, 3, 4), hidden_size=64, num_hidden_layers=2, num_attention_heads=2,
+                          head_dim=32, intermediate_size=128, sliding_window=12, num_quantizers=4, codebook_size=256,
+                          codebook_dim=32, max_positions=512, mel_dim=32, n_fft=256, hop_size=64,
+                          enc_channels=(256, 256, 256, 512), enc_kernel_sizes=(5, 3, 3, 1), enc_dilations=(1, 2, 3, 1),
+                          enc_attention_channels=32, enc_res2net_scale=8, enc_se_channels=32, enc_dim=64)
+
+
+@dataclass
 class TTSConfig:
     talker: StackConfig = field(default_factory=StackConfig)
     predictor: StackConfig = field(
         default_factory=lambda: StackConfig(num_hidden_layers=5, vocab_size=2048)
     )
     codec: CodecConfig = field(default_factory=CodecConfig)
+    ref_audio: RefAudioConfig = field(default_factory=RefAudioConfig)
     num_code_groups: int = 16
     codec_eos_token_id: int = 2150
     codec_pad_id: int = 2148
@@ -120,6 +190,7 @@ def qwen3_tts_1p7b() -> TTSConfig:
         predictor=StackConfig(num_hidden_layers=5, vocab_size=2048),
         predictor_has_projection=True,
         tts_model_size="1b7",
+        ref_audio=RefAudioConfig(enc_dim=2048),
     )
     return cfg
 
@@ -146,6 +217,8 @@ def tiny_test_config(hidden: int = 256, layers: int = 2, pred_layers: int = 2,
         tts_pad_token_id=500, tts_bos_token_id=501, tts_eos_token_id=502,
         predictor_has_projection=(ph != hidden),
     )
+    cfg.ref_audio = tiny_ref_audio_config()
+    cfg.ref_audio.enc_dim = hidden
     return cfg
 
 
@@ -187,4 +260,26 @@ def from_hf_config(d: dict) -> TTSConfig:
             if k in dc:
                 base[k] = tuple(dc[k]) if isinstance(dc[k], list) else dc[k]
         cfg.codec = CodecConfig(**base)
+    ra = asdict(cfg.ref_audio)
+    ra["enc_dim"] = cfg.talker.hidden_size
+    ec = d.get("encoder_config") or {}
+    for k in ("num_filters", "kernel_size", "last_kernel_size", "residual_kernel_size", "dilation_growth_rate", "compress",
+              "hidden_size", "num_hidden_layers", "num_attention_heads", "head_dim", "intermediate_size", "sliding_window",
+              "norm_eps", "num_semantic_quantizers", "codebook_size", "codebook_dim", "layer_scale_initial_scale"):
+        if ec.get(k) is not None:
+            ra[k] = ec[k]
+    if ec.get("num_residual_layers") is not None:
+        ra["num_residual_layers"] = ec["num_residual_layers"]
+    if ec.get("upsampling_ratios"):
+        ra["ratios"] = tuple(reversed(ec["upsampling_ratios"]))
+    if d.get("encoder_valid_num_quantizers"):
+        ra["num_quantizers"] = int(d["encoder_valid_num_quantizers"])
+    sc = d.get("speaker_encoder_config") or {}
+    for k in ("mel_dim", "enc_dim", "enc_attention_channels", "enc_res2net_scale", "enc_se_channels"):
+        if sc.get(k) is not None:
+            ra[k] = sc[k]
+    for k in ("enc_channels", "enc_kernel_sizes", "enc_dilations"):
+        if sc.get(k):
+            ra[k] = tuple(sc[k])
+    cfg.ref_audio = RefAudioConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in ra.items()})
     return cfg

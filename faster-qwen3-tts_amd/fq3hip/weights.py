@@ -16,7 +16,7 @@ from typing import Dict, Iterable, Optional
 
 import torch
 
-from .config import TTSConfig, StackConfig, CodecConfig, from_hf_config
+from .config import TTSConfig, StackConfig, CodecConfig, RefAudioConfig, from_hf_config
 
 Weights = Dict[str, torch.Tensor]
 
@@ -132,6 +132,88 @@ def _codec(w: Weights, g: _Gen, c: CodecConfig, normalized: bool = False):
     # [-1, 1] (std ~0.15) and the final clamp does not hide kernel errors from the parity tests
     w[f"{d}.{n + 2}.conv.weight"] = g.normal(1, cl, 7, std=(cl * 7) ** -0.5 * (0.06 if normalized else 0.0033))
     w[f"{d}.{n + 2}.conv.bias"] = g.normal(1, std=0.01)
+
+
+def synth_ref_audio_weights(rc: RefAudioConfig, seed: int = 0, device: str = "cpu") -> Weights:
+    """Seeded fp32 weights for the reference-audio analysers, under the checkpoint names: the speech tokenizer's encoder
+    as ``encoder.<MimiModel state-dict name>`` and the speaker encoder as ``speaker_encoder.<ECAPA state-dict name>``
+    [recalled prefixes].  Conv/linear ~ N(0, 1/fan_in); layer scales 0.5 (0.01 would hide the transformer); codebooks
+    as (embed_sum, cluster_usage) pairs like ``MimiEuclideanCodebook`` stores them."""
+    w: Weights = {}
+    g = _Gen(seed * 1000 + 5)
+    conv = lambda co, ci, k: g.normal(co, ci, k, std=(ci * k) ** -0.5)
+    bias = lambda n: g.normal(n, std=0.05)
+    E = "encoder.encoder.layers"
+    C = rc.num_filters
+    w[f"{E}.0.conv.weight"] = conv(C, 1, rc.kernel_size) * 4.0          # waveforms are O(0.1): lift them to O(1)
+    w[f"{E}.0.conv.bias"] = bias(C)
+    li = 1
+    for r in rc.ratios:
+        for j in range(rc.num_residual_layers):
+            w[f"{E}.{li}.block.1.conv.weight"] = conv(C // rc.compress, C, rc.residual_kernel_size)
+            w[f"{E}.{li}.block.1.conv.bias"] = bias(C // rc.compress)
+            w[f"{E}.{li}.block.3.conv.weight"] = conv(C, C // rc.compress, 1)
+            w[f"{E}.{li}.block.3.conv.bias"] = bias(C)
+            li += 1
+        li += 1
+        w[f"{E}.{li}.conv.weight"] = conv(2 * C, C, 2 * r)
+        w[f"{E}.{li}.conv.bias"] = bias(2 * C)
+        li += 1
+        C *= 2
+    li += 1
+    H = rc.hidden_size
+    w[f"{E}.{li}.conv.weight"] = conv(H, C, rc.last_kernel_size)
+    w[f"{E}.{li}.conv.bias"] = bias(H)
+    QD = rc.num_attention_heads * rc.head_dim
+    for l in range(rc.num_hidden_layers):
+        p = f"encoder.encoder_transformer.layers.{l}"
+        for n in ("q_proj", "k_proj", "v_proj"):
+            w[f"{p}.self_attn.{n}.weight"] = g.linear(QD, H)
+        w[f"{p}.self_attn.o_proj.weight"] = g.linear(H, QD)
+        w[f"{p}.mlp.fc1.weight"] = g.linear(rc.intermediate_size, H)
+        w[f"{p}.mlp.fc2.weight"] = g.linear(H, rc.intermediate_size)
+        for n in ("input_layernorm", "post_attention_layernorm"):
+            w[f"{p}.{n}.weight"] = g.gain(H)
+            w[f"{p}.{n}.bias"] = bias(H)
+        w[f"{p}.self_attn_layer_scale.scale"] = 0.5 + g.normal(H, std=0.05)
+        w[f"{p}.mlp_layer_scale.scale"] = 0.5 + g.normal(H, std=0.05)
+    w["encoder.downsample.conv.weight"] = conv(H, H, 4)
+    D, K = rc.codebook_dim, rc.codebook_size
+    for name, n in (("semantic", rc.num_semantic_quantizers), ("acoustic", rc.num_quantizers - rc.num_semantic_quantizers)):
+        q = f"encoder.quantizer.{name}_residual_vector_quantizer"
+        w[f"{q}.input_proj.weight"] = conv(D, H, 1)
+        for i in range(n):
+            usage = 0.5 + 1.5 * torch.rand(K, generator=g.g)
+            # residual scales shrink level by level in a trained RVQ; keep every level's codebook comparable to its input
+            w[f"{q}.layers.{i}.codebook.embed_sum"] = g.normal(K, D, std=0.8 ** i) * usage[:, None]
+            w[f"{q}.layers.{i}.codebook.cluster_usage"] = usage
+    S = "speaker_encoder"
+    ch, ks = rc.enc_channels, rc.enc_kernel_sizes
+    w[f"{S}.blocks.0.conv.weight"] = conv(ch[0], rc.mel_dim, ks[0]) * 0.25      # log-mels are O(5)
+    w[f"{S}.blocks.0.conv.bias"] = bias(ch[0])
+    for b in range(1, len(ch) - 1):
+        B = f"{S}.blocks.{b}"
+        cs = ch[b] // rc.enc_res2net_scale
+        for t in ("tdnn1", "tdnn2"):
+            w[f"{B}.{t}.conv.weight"] = conv(ch[b], ch[b], 1)
+            w[f"{B}.{t}.conv.bias"] = bias(ch[b])
+        for i in range(rc.enc_res2net_scale - 1):
+            w[f"{B}.res2net_block.blocks.{i}.conv.weight"] = conv(cs, cs, ks[b])
+            w[f"{B}.res2net_block.blocks.{i}.conv.bias"] = bias(cs)
+        w[f"{B}.se_block.conv1.weight"] = conv(rc.enc_se_channels, ch[b], 1)
+        w[f"{B}.se_block.conv1.bias"] = bias(rc.enc_se_channels)
+        w[f"{B}.se_block.conv2.weight"] = conv(ch[b], rc.enc_se_channels, 1)
+        w[f"{B}.se_block.conv2.bias"] = bias(ch[b])
+    cm = ch[-1]
+    w[f"{S}.mfa.conv.weight"] = conv(cm, cm, 1)
+    w[f"{S}.mfa.conv.bias"] = bias(cm)
+    w[f"{S}.asp.tdnn.conv.weight"] = conv(rc.enc_attention_channels, 3 * cm, 1)
+    w[f"{S}.asp.tdnn.conv.bias"] = bias(rc.enc_attention_channels)
+    w[f"{S}.asp.conv.weight"] = conv(cm, rc.enc_attention_channels, 1) * 4.0     # a peaked attention, so the softmax matters
+    w[f"{S}.asp.conv.bias"] = bias(cm)
+    w[f"{S}.fc.weight"] = conv(rc.enc_dim, 2 * cm, 1)
+    w[f"{S}.fc.bias"] = bias(rc.enc_dim)
+    return {k: v.to(device) for k, v in w.items()}
 
 
 def synth_weights(cfg: TTSConfig, seed: int = 0, dtype: torch.dtype = torch.bfloat16,

@@ -271,6 +271,42 @@ int fq3_codec_decode(fq3_codec* c, const int64_t* codes, int T, float* pcm, void
  * recomputed; the values are bit-identical to the corresponding tail of fq3_codec_decode's output. */
 int fq3_codec_decode_tail(fq3_codec* c, const int64_t* codes, int T, int64_t first_sample, float* pcm, void* stream);
 
+/* ---- reference-audio analysis (create_voice_clone_prompt, model.py:415-463 -> upstream qwen_tts) -----------------------
+ * What the reference runs once per new (ref_audio, ref_text) pair and then caches (model.py:424-463):
+ *   speech_tokenizer.encode(ref_wav)  -> ref_code  int64 [T, 16]   (the 12.5 Hz tokenizer's ENCODER: SEANet conv stack,
+ *       8-layer causal transformer, stride-2 conv, split residual VQ -- the Mimi architecture, transformers
+ *       models/mimi/modeling_mimi.py:450-492, :782-928, :1030-1138, :1231-1268)
+ *   extract_speaker_embedding(wav)    -> ref_spk_embedding [enc_dim] (log-mel front end + ECAPA-TDNN, transformers
+ *       models/qwen2_5_omni/modeling_qwen2_5_omni.py:2412-2707 is the readable sibling)
+ * fp32 only; either half may be left unbound.  Weight names are the checkpoint names under "encoder." / "speaker_encoder."
+ * in the layouts fq3hip/refenc.py packs (documented in csrc/fq3_refenc.hip). */
+typedef struct fq3_refenc fq3_refenc;
+typedef struct fq3_refenc_config {
+    /* speech-tokenizer encoder */
+    int32_t num_filters;                     /* 64 */
+    int32_t n_ratios; int32_t ratios[8];     /* strides in encoder order (4, 5, 6, 8) */
+    int32_t kernel_size, last_kernel_size, residual_kernel_size, n_residual_layers, dilation_growth_rate, compress;   /* 7 3 3 1 2 2 */
+    int32_t hidden, n_layers, n_heads, head_dim, inter, sliding_window;     /* 512 8 8 64 2048 250 */
+    float   norm_eps;                        /* 1e-5 */
+    int32_t num_quantizers, num_semantic, codebook_size, codebook_dim;      /* 16 1 2048 256 */
+    int32_t max_positions;                   /* rows of the "encoder.rope.cos/sin" tables (25 Hz frames) */
+    /* speaker encoder */
+    int32_t mel_dim, n_fft, hop, n_bins_padded;   /* 128 1024 256 544 (n_fft/2 + 1 rounded up to a multiple of 32) */
+    int32_t n_enc; int32_t enc_channels[8], enc_kernel_sizes[8], enc_dilations[8];   /* 5: 512 512 512 512 1536 / 5 3 3 3 1 / 1 2 3 4 1 */
+    int32_t attn_channels, res2net_scale, se_channels, enc_dim;             /* 128 8 128 1024|2048 */
+} fq3_refenc_config;
+int fq3_refenc_create(const fq3_refenc_config* cfg, fq3_refenc** out);
+int fq3_refenc_destroy(fq3_refenc* r);
+int fq3_refenc_bind(fq3_refenc* r, const char* name, const void* ptr, int64_t numel);
+int fq3_refenc_finalize(fq3_refenc* r, void* stream);
+/* number of 12.5 Hz frames the encoder produces for n_samples of 24 kHz audio (MimiModel.get_encoded_length, :1270-1284) */
+int64_t fq3_refenc_num_frames(const fq3_refenc* r, int64_t n_samples);
+/* pcm float32[n] (device, 24 kHz mono) -> codes int64[num_frames][num_quantizers] (device) */
+int fq3_refenc_encode(fq3_refenc* r, const float* pcm, int64_t n, int64_t* codes, void* stream);
+/* pcm float32[n] (device, 24 kHz mono) -> embed float32[enc_dim] (device); mel (optional, may be null) receives the
+ * log-mel frames float32[n / hop][mel_dim] the encoder consumed */
+int fq3_refenc_speaker(fq3_refenc* r, const float* pcm, int64_t n, float* embed, float* mel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
