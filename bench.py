@@ -430,6 +430,68 @@ def cpu_baseline(cfg, frames=6, budget_s=45.0):
             "ms_per_frame": round(1000 * t_codes / n, 1)}
 
 
+def reference_wave(seconds: float, seed: int = 31) -> np.ndarray:
+    """A speech-like synthetic clip (harmonics with a slow envelope + noise), 24 kHz mono float32."""
+    n = int(24000 * seconds)
+    t = np.arange(n, dtype=np.float64) / 24000.0
+    rng = np.random.default_rng(seed)
+    x = sum(a * np.sin(2 * np.pi * f * t + p) for a, f, p in ((0.2, 180.0, 0.0), (0.12, 360.0, 0.5), (0.08, 1240.0, 1.1), (0.04, 3100.0, 2.0)))
+    x = x * (0.55 + 0.45 * np.sin(2 * np.pi * 2.5 * t)) + 0.02 * rng.standard_normal(n)
+    return x.astype(np.float32)
+
+
+def ref_analysis_block(cfg, device, seconds=10.0, reps=10):
+    """SURVEY section 8f row 1, second half: what the reference does once per new reference clip (model.py:430-447,
+    upstream create_voice_clone_prompt) -- speech-tokenizer encoder + speaker encoder -- on the HIP analysers, for a
+    `seconds` clip + the 0.5 s of appended silence; and the same arithmetic through the CPU oracle (fp32 Torch)."""
+    from fq3hip.refenc import HipRefAudioAnalyzer
+    from fq3hip.weights import synth_ref_audio_weights
+    rc = cfg.ref_audio
+    W = synth_ref_audio_weights(rc, 0)
+    an = HipRefAudioAnalyzer(rc, W, device=str(device))
+    wav = np.concatenate([reference_wave(seconds), np.zeros(12000, np.float32)])
+    x = torch.from_numpy(wav).to(device)
+    an.encode(x); an.speaker_embedding(x)
+    torch.cuda.synchronize()
+
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    enc_ms, spk_ms = timed(lambda: an.encode(x)), timed(lambda: an.speaker_embedding(x))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        codes = an.encode(wav); emb = an.speaker_embedding(wav)        # host buffer in: PCIe-inclusive
+        torch.cuda.synchronize()
+    host_ms = 1000 * (time.perf_counter() - t0) / reps
+    out = {"clip_s": seconds + 0.5, "frames": int(codes.shape[0]), "tokenizer_encoder_ms": round(enc_ms, 3), "speaker_encoder_ms": round(spk_ms, 3),
+           "both_from_host_buffer_ms": round(host_ms, 3), "dtype": "f32",
+           "what": "fq3_refenc_encode + fq3_refenc_speaker (Mimi-shape encoder: 64..1024-channel SEANet, 8 x 512-d layers, 16 x 2048 RVQ; "
+                   "128-bin log-mel + ECAPA-TDNN 512/1536 channels); synthetic seeded weights"}
+    try:
+        from oracle import refenc_oracle as RO                            # CPU baseline leg of this block
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        xc = torch.from_numpy(wav)
+        t0 = time.perf_counter()
+        with torch.inference_mode():
+            ref_codes, margins = RO.tokenizer_encode(W, rc, xc, return_all=True)[:2]
+            ref_emb, _ = RO.speaker_embedding(W, rc, xc)
+        out["cpu_oracle_ms"] = round(1000 * (time.perf_counter() - t0), 1)
+        same = (codes.cpu() == ref_codes)
+        out["parity"] = {"ids_identical": int(same.sum()), "ids": int(same.numel()),
+                         "first_level_identical": int(same[:, 0].sum()), "frames": int(same.shape[0]),
+                         "speaker_embedding_max_abs_diff": float((emb.cpu() - ref_emb).abs().max()),
+                         "note": "ids after a near-tie arg-min of a frame's residual chain may differ (tests/test_gpu_refenc.py attributes them)"}
+    except Exception as e:
+        out["cpu_oracle_ms"] = {"error": repr(e)}
+    return out
+
+
 def model_1p7b_block(device):
     """BASELINE configs[2]: the 1.7B shapes (talker hidden 2048 / intermediate 6144, predictor with projection), single
     stream: RTF / TTFA over 2 utterances + the decode-frame roofline; and 8 lock-step lanes (configs[3]'s model)."""
@@ -573,6 +635,7 @@ def main():
     if solo and args.concurrent > 1:
         guarded("concurrent_utterances_one_gpu", lambda: concurrent_throughput(cfg, model, req, device, streams=args.concurrent))
     if solo:
+        guarded("reference_audio_analysis", lambda: ref_analysis_block(cfg, device))
         guarded("parity_bf16_frames", lambda: parity_note(cfg, model))
         guarded("roofline_mfma", lambda: measure_mfma(cfg, model, prompt))
     if solo and args.batch > 1:

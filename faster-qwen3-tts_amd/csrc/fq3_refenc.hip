@@ -67,7 +67,8 @@ extern "C" int fq3_refenc_create(const fq3_refenc_config* cfg, fq3_refenc** out)
     if (!ok) return rfail(FQ3_EUNSUPPORTED, "every channel count must be a multiple of 32 (MFMA K step)");
     if (g.head_dim != 32 && g.head_dim != 64 && g.head_dim != 128) return rfail(FQ3_EUNSUPPORTED, "encoder head_dim must be 32, 64 or 128");
     if (g.sliding_window < 1 || g.sliding_window > 256) return rfail(FQ3_EUNSUPPORTED, "encoder sliding_window must be in 1..256");
-    if (g.codebook_size % 256 || g.codebook_size > 256 * kRvqMaxPerThread) return rfail(FQ3_EUNSUPPORTED, "codebook_size must be a multiple of 256, at most 4096");
+    if (g.codebook_size != 256 && g.codebook_size != 512 && g.codebook_size != 1024 && g.codebook_size != 2048 && g.codebook_size != 4096)
+        return rfail(FQ3_EUNSUPPORTED, "codebook_size must be 256, 512, 1024, 2048 or 4096");
     if (g.num_quantizers > 32 || g.num_semantic < 1 || g.num_semantic >= g.num_quantizers) return rfail(FQ3_EINVAL, "quantizer counts");
     if (g.n_fft % g.hop || g.n_fft / g.hop > kMaxTaps || g.kernel_size > kMaxTaps) return rfail(FQ3_EUNSUPPORTED, "n_fft must be a small multiple of hop");
     if (g.n_bins_padded < g.n_fft / 2 + 1) return rfail(FQ3_EINVAL, "n_bins_padded < n_fft/2 + 1");
@@ -281,7 +282,14 @@ extern "C" int fq3_refenc_encode(fq3_refenc* r, const float* pcm, int64_t n, int
     if (err) return err;
     RvqEncArgs ra{}; ra.nq = g.num_quantizers; ra.n_sem = g.num_semantic; ra.K = K; ra.D = D;
     for (int lv = 0; lv < g.num_quantizers; ++lv) { ra.emb[lv] = r->books + (size_t)lv * 2 * K * D; ra.embT[lv] = ra.emb[lv] + (size_t)K * D; }
-    hipLaunchKernelGGL(rvq_encode_kernel, dim3(T5, 2), dim3(256), D * sizeof(float), s, ra, (const float*)Dd, codes);
+#define FQ3_RVQ(V, P) hipLaunchKernelGGL((rvq_encode_kernel<V, P>), dim3(T5, 2), dim3(256), D * sizeof(float), s, ra, (const float*)Dd, codes)
+    switch (K) {
+        case 256: FQ3_RVQ(1, 1); break;
+        case 512: FQ3_RVQ(1, 2); break;
+        case 1024: FQ3_RVQ(4, 1); break;
+        case 2048: FQ3_RVQ(4, 2); break;
+        default: FQ3_RVQ(4, 4); break;
+    }
     RHIP(hipGetLastError());
     return FQ3_OK;
 }
@@ -355,7 +363,7 @@ extern "C" int fq3_refenc_speaker(fq3_refenc* r, const float* pcm, int64_t n, fl
         }
         tdnn(r, s, R, Cb, nullptr, 0, F, Cb, 1, 1, W(Bk + "tdnn2.conv.weight"), W(Bk + "tdnn2.conv.bias"), Cb, V, Cb, 4, padbuf);
         // squeeze-excitation: mean over time -> 1x1 -> ReLU -> 1x1 -> sigmoid -> channel gate, + block input
-        hipLaunchKernelGGL(col_stats_kernel, dim3((Cb + 63) / 64), dim3(256), 0, s, (const float*)V, Cb, (const float*)nullptr, 0, mean, (float*)nullptr, F, Cb, 0.f);
+        hipLaunchKernelGGL(col_stats_kernel, dim3((Cb + 63) / 64), dim3(64 * kStatSlices), 0, s, (const float*)V, Cb, (const float*)nullptr, 0, mean, (float*)nullptr, F, Cb, 0.f);
         { GemmArgs a = gemm(mean, Cb, 1, 1, Cb, W(Bk + "se_block.conv1.weight"), g.se_channels, W(Bk + "se_block.conv1.bias"), gate1, g.se_channels); a.act = 4; if (err) return err; gemm_launch<float>(a, s); }
         { GemmArgs a = gemm(gate1, g.se_channels, 1, 1, g.se_channels, W(Bk + "se_block.conv2.weight"), Cb, W(Bk + "se_block.conv2.bias"), gate, Cb); a.act = 7; if (err) return err; gemm_launch<float>(a, s); }
         float* dst = Cat + (size_t)(b - 1) * Cb;
@@ -368,11 +376,11 @@ extern "C" int fq3_refenc_speaker(fq3_refenc* r, const float* pcm, int64_t n, fl
     float* ms = vec + 3 * Cm;           // [mean | std] (2 Cm)
     float* bias2 = vec + 5 * Cm;        // [Ac]
     float* pooled = vec + 6 * Cm;       // [mean | std] (2 Cm)
-    hipLaunchKernelGGL(col_stats_kernel, dim3((Cm + 63) / 64), dim3(256), 0, s, (const float*)Hm, Cm, (const float*)nullptr, 0, ms, ms + Cm, F, Cm, 1e-12f);
+    hipLaunchKernelGGL(col_stats_kernel, dim3((Cm + 63) / 64), dim3(64 * kStatSlices), 0, s, (const float*)Hm, Cm, (const float*)nullptr, 0, ms, ms + Cm, F, Cm, 1e-12f);
     { GemmArgs a = gemm(ms, 2 * Cm, 1, 1, 2 * Cm, W(S + "asp.tdnn.conv.weight_ms"), Ac, W(S + "asp.tdnn.conv.bias"), bias2, Ac); if (err) return err; gemm_launch<float>(a, s); }
     { GemmArgs a = gemm(Hm, Cm, F, F, Cm, W(S + "asp.tdnn.conv.weight_h"), Ac, bias2, A1, Ac); a.act = 6; if (err) return err; gemm_launch<float>(a, s); }
     { GemmArgs a = gemm(A1, Ac, F, F, Ac, W(S + "asp.conv.weight"), Cm, W(S + "asp.conv.bias"), Lg, Cm); if (err) return err; gemm_launch<float>(a, s); }
-    hipLaunchKernelGGL(col_stats_kernel, dim3((Cm + 63) / 64), dim3(256), 0, s, (const float*)Hm, Cm, (const float*)Lg, Cm, pooled, pooled + Cm, F, Cm, 1e-12f);
+    hipLaunchKernelGGL(col_stats_kernel, dim3((Cm + 63) / 64), dim3(64 * kStatSlices), 0, s, (const float*)Hm, Cm, (const float*)Lg, Cm, pooled, pooled + Cm, F, Cm, 1e-12f);
     { GemmArgs a = gemm(pooled, 2 * Cm, 1, 1, 2 * Cm, W(S + "fc.weight"), g.enc_dim, W(S + "fc.bias"), embed, g.enc_dim); if (err) return err; gemm_launch<float>(a, s); }
     RHIP(hipGetLastError());
     return FQ3_OK;

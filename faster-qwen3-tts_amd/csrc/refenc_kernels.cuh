@@ -112,34 +112,47 @@ __global__ void codebook_prepare_kernel(const float* __restrict__ embed_sum, con
 // Residual vector quantisation of one frame by one workgroup (modeling_mimi.py:1062-1079): per level, nearest codebook
 // row in Euclidean distance (first index on ties, torch.argmin), residual -= that row.  blockIdx.y = 0: the semantic
 // quantizer (levels [0, n_sem), input columns [0, D)); 1: the acoustic one (levels [n_sem, nq), columns [D, 2D)).
-// Each thread owns K / 256 codes and walks the D dims of the TRANSPOSED codebook (coalesced across threads).
+// Each thread owns PER groups of VEC consecutive codes (K = 256 * VEC * PER) and walks the D dims of the TRANSPOSED
+// codebook: a wave reads VEC * 256 contiguous bytes per load, no branch sits between the loads (the compiler keeps
+// them in flight), and the d loop is unrolled so that 4 * PER loads per thread overlap -- the scan is bound by the
+// codebook bytes a CU can pull from L2 (2 MB per level at K = 2048, D = 256).
 struct RvqEncArgs { const float* emb[32]; const float* embT[32]; int nq; int n_sem; int K; int D; };
-constexpr int kRvqMaxPerThread = 16;       // K <= 4096
+template <int VEC, int PER>
 __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqEncArgs a, const float* __restrict__ proj /*[T][2D]*/, int64_t* __restrict__ codes /*[T][nq]*/) {
     extern __shared__ float rsm[];
     float* res = rsm;                       // [D]
     __shared__ float best_d[4]; __shared__ int best_i[4]; __shared__ int winner;
     const int t = blockIdx.x, part = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lvl0 = part == 0 ? 0 : a.n_sem, lvl1 = part == 0 ? a.n_sem : a.nq;
-    const int D = a.D, K = a.K, per = K / 256;
+    const int D = a.D, K = a.K;
     for (int d = tid; d < D; d += 256) res[d] = proj[(size_t)t * 2 * D + (size_t)part * D + d];
     __syncthreads();
     for (int lv = lvl0; lv < lvl1; ++lv) {
-        const float* eT = a.embT[lv];
-        float acc[kRvqMaxPerThread];
+        const float* eT = a.embT[lv] + tid * VEC;
+        float acc[PER][VEC];
 #pragma unroll
-        for (int j = 0; j < kRvqMaxPerThread; ++j) acc[j] = 0.f;
+        for (int j = 0; j < PER; ++j)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[j][v] = 0.f;
+#pragma unroll 4
         for (int d = 0; d < D; ++d) {
             const float r = res[d];
-            const float* row = eT + (size_t)d * K + tid;
+            const float* row = eT + (size_t)d * K;
 #pragma unroll
-            for (int j = 0; j < kRvqMaxPerThread; ++j)
-                if (j < per) { const float df = r - row[j * 256]; acc[j] = fmaf(df, df, acc[j]); }
+            for (int j = 0; j < PER; ++j) {
+                float e[VEC];
+                if constexpr (VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(row + j * 1024); e[0] = q.x; e[1] = q.y; e[2] = q.z; e[3] = q.w; }
+                else e[0] = row[j * 256];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { const float df = r - e[v]; acc[j][v] = fmaf(df, df, acc[j][v]); }
+            }
         }
         float bd = INFINITY; int bi = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < kRvqMaxPerThread; ++j)
-            if (j < per && acc[j] < bd) { bd = acc[j]; bi = tid + j * 256; }         // ascending index within a thread: first minimum kept
+        for (int j = 0; j < PER; ++j)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                if (acc[j][v] < bd) { bd = acc[j][v]; bi = j * 256 * VEC + tid * VEC + v; }     // ascending index: first minimum kept
         // wave argmin (distance, then index), then across the 4 waves
         for (int off = 32; off >= 1; off >>= 1) {
             const float od = __shfl_xor(bd, off); const int oi = __shfl_xor(bi, off);
@@ -169,13 +182,14 @@ __global__ void dft_mag_kernel(const float* __restrict__ spec, float* __restrict
     mag[i] = sqrtf(re * re + im * im + 1e-9f);
 }
 
-// Per-channel statistics over time of x [T][ldx] (channels [0, C)), 64 channels x 4 time slices per workgroup.
+// Per-channel statistics over time of x [T][ldx] (channels [0, C)), 64 channels x 16 time slices per workgroup.
 //   logits == nullptr: uniform weights 1/T (SE mean; the pooling layer's global context)
 //   logits != nullptr: weights = softmax over time of logits[:, c] (attentive statistics pooling)
 // mean[c] = sum w x, std[c] = sqrt(max(sum w (x - mean)^2, eps)); either output may be null.
-__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ logits, int ldl,
+constexpr int kStatSlices = 16;
+__global__ __launch_bounds__(64 * kStatSlices) void col_stats_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ logits, int ldl,
                                                         float* __restrict__ mean, float* __restrict__ stdv, int T, int C, float eps) {
-    __shared__ float red[4][64];
+    __shared__ float red[kStatSlices][64];
     const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     const bool ok = c < C;
@@ -184,21 +198,21 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
         red[part][cl] = v;
         __syncthreads();
         float r = red[0][cl];
-        for (int p = 1; p < 4; ++p) r = is_max ? fmaxf(r, red[p][cl]) : r + red[p][cl];
+        for (int p = 1; p < kStatSlices; ++p) r = is_max ? fmaxf(r, red[p][cl]) : r + red[p][cl];
         __syncthreads();
         return r;
     };
     float mx = 0.f, denom = (float)T;
     if (logits) {
         float m = -INFINITY;
-        for (int t = part; t < T; t += 4) m = fmaxf(m, logits[(size_t)t * ldl + cc]);
+        for (int t = part; t < T; t += kStatSlices) m = fmaxf(m, logits[(size_t)t * ldl + cc]);
         mx = reduce(m, true);
         float s = 0.f;
-        for (int t = part; t < T; t += 4) s += expf(logits[(size_t)t * ldl + cc] - mx);
+        for (int t = part; t < T; t += kStatSlices) s += expf(logits[(size_t)t * ldl + cc] - mx);
         denom = reduce(s, false);
     }
     float s1 = 0.f;
-    for (int t = part; t < T; t += 4) {
+    for (int t = part; t < T; t += kStatSlices) {
         const float w = logits ? expf(logits[(size_t)t * ldl + cc] - mx) / denom : 1.0f / denom;
         s1 = fmaf(w, x[(size_t)t * ldx + cc], s1);
     }
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
     if (ok && part == 0 && mean) mean[c] = mu;
     if (!stdv) return;
     float s2 = 0.f;
-    for (int t = part; t < T; t += 4) {
+    for (int t = part; t < T; t += kStatSlices) {
         const float w = logits ? expf(logits[(size_t)t * ldl + cc] - mx) / denom : 1.0f / denom;
         const float d = x[(size_t)t * ldx + cc] - mu;
         s2 = fmaf(w, d * d, s2);

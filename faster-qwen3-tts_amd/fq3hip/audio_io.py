@@ -60,3 +60,14 @@ def read_wav(path: str) -> Tuple[np.ndarray, int]:
     if ch > 1:
         a = a.reshape(-1, ch).mean(axis=1)
     return a, sr
+
+
+def resample(audio: np.ndarray, sr: int, target_sr: int) -> np.ndarray:
+    """Polyphase resampling on the host (``scipy.signal.resample_poly``).  Upstream resamples reference clips with librosa
+    (soxr); the filters differ, so clips that are not already at ``target_sr`` give slightly different analyser inputs."""
+    if int(sr) == int(target_sr):
+        return np.asarray(audio, dtype=np.float32)
+    from math import gcd
+    from scipy.signal import resample_poly
+    g = gcd(int(sr), int(target_sr))
+    return resample_poly(np.asarray(audio, dtype=np.float64), int(target_sr) // g, int(sr) // g).astype(np.float32)

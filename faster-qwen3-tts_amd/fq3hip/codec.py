@@ -106,6 +106,26 @@ class HipSpeechTokenizer:
         with torch.cuda.device(self.device):
             L.check(self.lib.fq3_codec_finalize(self.h, torch.cuda.current_stream(self.device).cuda_stream))
 
+    def attach_encoder(self, analyzer) -> None:
+        """Give the tokenizer its encode half (``fq3hip.refenc.HipRefAudioAnalyzer``)."""
+        self._analyzer = analyzer
+
+    def encode(self, audio, sr: int = None):
+        """Upstream ``speech_tokenizer.encode(audio, sr)`` [recalled]: -> object with ``audio_codes`` = list of
+        ``LongTensor[T, 16]``.  ``audio`` is one waveform (or a list of them) at ``sr`` Hz."""
+        from types import SimpleNamespace
+        an = getattr(self, "_analyzer", None)
+        if an is None:
+            raise NotImplementedError("this speech tokenizer was built without encoder.* weights")
+        from .audio_io import resample
+        import numpy as np
+        items = audio if isinstance(audio, (list, tuple)) else [audio]
+        out = []
+        for a in items:
+            a = np.asarray(a.detach().cpu().numpy() if hasattr(a, "detach") else a, dtype=np.float32).reshape(-1)
+            out.append(an.encode(resample(a, int(sr or self.sample_rate), self.sample_rate)))
+        return SimpleNamespace(audio_codes=out)
+
     def num_samples(self, n_frames: int) -> int:
         return int(self.lib.fq3_codec_num_samples(self.h, int(n_frames)))
 

@@ -137,7 +137,7 @@ def tiny_ref_audio_config() -> RefAudioConfig:
     """Small shapes (same structure) for CPU-speed oracle pins and quick GPU parity."""
     return RefAudioConfig(num_filters=64, ratios=(2, 3, 4), hidden_size=64, num_hidden_layers=2, num_attention_heads=2,
                           head_dim=32, intermediate_size=128, sliding_window=12, num_quantizers=4, codebook_size=256,
-                          codebook_dim=32, max_positions=512, mel_dim=32, n_fft=256, hop_size=64,
+                          codebook_dim=32, max_positions=2048, mel_dim=32, n_fft=256, hop_size=64,
                           enc_channels=(256, 256, 256, 512), enc_kernel_sizes=(5, 3, 3, 1), enc_dilations=(1, 2, 3, 1),
                           enc_attention_channels=32, enc_res2net_scale=8, enc_se_channels=32, enc_dim=64)
 
@@ -219,6 +219,7 @@ def tiny_test_config(hidden: int = 256, layers: int = 2, pred_layers: int = 2,
     )
     cfg.ref_audio = tiny_ref_audio_config()
     cfg.ref_audio.enc_dim = hidden
+    cfg.ref_audio.num_quantizers = cfg.num_code_groups          # reference codes feed the 16-group prompt builder
     return cfg
 
 

@@ -265,6 +265,20 @@ class FasterQwen3TTS:
         return (dict(ref_code=[torch.from_numpy(hit["ref_code"])], ref_spk_embedding=[spk], x_vector_only_mode=[False],
                      icl_mode=[True]), hit["ref_text"] or ref_text)
 
+    def _store_voice_prompt(self, ref_audio, item, xvec_only: bool, append_silence: bool) -> None:
+        """Write a freshly analysed reference through to the on-disk cache (when one is set), so that the next process
+        serves it without running the analysers (the reference's GGML backend does the same, ggml_backend.py:448-465)."""
+        cache = getattr(self, "_voice_ref_cache", None)
+        if cache is None:
+            return
+        from .audio_io import resample
+        from .voice_cache import export_voice_clone_prompt
+        silence = 0.5 if (append_silence and not xvec_only) else 0.0
+        audio, sr = self._load_ref_audio_with_silence(ref_audio, silence_secs=silence)
+        ident = f"{getattr(self.model.model, 'tts_model_type', 'base')}-{getattr(self.model.model, 'tts_model_size', '')}"
+        export_voice_clone_prompt(cache, resample(audio, sr, 24000), item, append_silence=silence > 0, model_identity=ident,
+                                  ref_text=getattr(item, "ref_text", None) or "")
+
     def _resolve_voice_clone_prompt_from_reference(self, input_ids, ref_audio, ref_text: str, xvec_only: bool,
                                                    append_silence: bool):
         using_icl = not xvec_only
@@ -284,12 +298,14 @@ class FasterQwen3TTS:
             vcp = dict(ref_code=[None], ref_spk_embedding=[items[0].ref_spk_embedding], x_vector_only_mode=[True],
                        icl_mode=[False])
             ref_ids = [None] * len(input_ids)
+            self._store_voice_prompt(ref_audio, items[0], xvec_only, append_silence)
         else:
             audio = self._load_ref_audio_with_silence(ref_audio, silence_secs=0.5 if append_silence else 0.0)
             items = self.model.create_voice_clone_prompt(ref_audio=audio, ref_text=ref_text)
             vcp = self.model._prompt_items_to_voice_clone_prompt(items)
             rt = items[0].ref_text
             ref_ids = [self._ref_ids(rt) if rt else None]
+            self._store_voice_prompt(ref_audio, items[0], xvec_only, append_silence)
         self._voice_prompt_cache[key] = (vcp, ref_ids)
         return vcp, ref_ids, using_icl
 

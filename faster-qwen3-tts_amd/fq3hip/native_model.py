@@ -10,14 +10,16 @@ plain weight table so that ``FasterQwen3TTS`` and the decode loops run without `
   code embedding sum): HIP (``fq3_text_project`` / ``fq3_prompt_rows``, driven by ``fq3hip/prompt.py``); the
   module-style accessors below (``get_text_embeddings``, ``text_projection``, ``generate_icl_prompt``) keep the
   attribute surface the reference's generic code path reaches for;
-* reference-audio analysis (speaker encoder, speech-tokenizer *encoder*): not implemented; callers
-  pass a precomputed ``voice_clone_prompt`` (the reference supports exactly that, model.py:320-411).
+* reference-audio analysis (speaker encoder, speech-tokenizer *encoder*): HIP (``fq3hip/refenc.py`` over
+  ``csrc/fq3_refenc.hip``) when the weight table carries ``encoder.*`` / ``speaker_encoder.*`` tensors; otherwise callers
+  pass a precomputed ``voice_clone_prompt`` (the reference supports exactly that, model.py:320-411) or a voice cache.
 
 ``generate_icl_prompt`` / the chat templates restate upstream behaviour from memory of
 ``qwen_tts/core/models/modeling_qwen3_tts.py`` [recalled, unverifiable offline].
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Any, Dict, List, Optional
@@ -169,6 +171,17 @@ class NativeQwen3TTS:
                                      share=share.model.speech_tokenizer if share is not None else None)
         self.model = NativeInner(cfg, talker, tok)
         self.tokenizer = tokenizer or ByteTokenizer(cfg.text_vocab_size)
+        # reference-audio analysers (first call per reference clip): one instance per GPU, shared by every lane
+        self.ref_analyzer = None
+        if share is not None and getattr(share, "ref_analyzer", None) is not None and share.device == self.device:
+            self.ref_analyzer = share.ref_analyzer
+        else:
+            ref = {k: v for k, v in weights.items() if k.startswith(("encoder.", "speaker_encoder."))}
+            if ref:
+                from .refenc import HipRefAudioAnalyzer
+                self.ref_analyzer = HipRefAudioAnalyzer(cfg.ref_audio, ref, device=device)
+        if tok is not None and self.ref_analyzer is not None and self.ref_analyzer.has_encoder:
+            tok.attach_encoder(self.ref_analyzer)
 
     # ---- text helpers (upstream chat templates, [recalled]) ----------------------------------------
     @staticmethod
@@ -218,13 +231,44 @@ class NativeQwen3TTS:
                 raise ValueError(f"Unsupported speaker {s!r}; supported: {sorted(ok)}")
 
     # ---- voice-clone prompt handling -----------------------------------------------------------------------
+    def _reference_wave(self, ref_audio) -> "np.ndarray":
+        """``ref_audio``: a WAV path, ``(waveform, sample_rate)`` (what the reference passes, model.py:443-447) or a
+        waveform already at the model rate -> mono float32 at 24 kHz."""
+        import numpy as np
+        from .audio_io import read_wav, resample
+        rate = self.cfg.ref_audio.sample_rate
+        if isinstance(ref_audio, (str, os.PathLike)):
+            audio, sr = read_wav(str(ref_audio))
+        elif isinstance(ref_audio, (tuple, list)) and len(ref_audio) == 2 and not np.isscalar(ref_audio[0]):
+            audio, sr = ref_audio
+        else:
+            audio, sr = ref_audio, rate
+        audio = np.asarray(audio.detach().cpu().numpy() if hasattr(audio, "detach") else audio, dtype=np.float32)
+        if audio.ndim > 1:
+            audio = audio.mean(axis=-1) if audio.shape[-1] <= 8 else audio.mean(axis=0)
+        return resample(audio, int(sr), rate)
+
     def create_voice_clone_prompt(self, ref_audio=None, ref_text: str = "", x_vector_only_mode: bool = False):
-        raise NotImplementedError(
-            "Reference-audio analysis (speaker encoder + speech-tokenizer encoder) is not part of the MI355X "
-            "fast path (SURVEY.md section 8f row 1; DESIGN.md section 7). Pass voice_clone_prompt=dict(ref_spk_embedding=[...], "
-            "ref_code=[...], x_vector_only_mode=[...], icl_mode=[...]) computed once with upstream qwen-tts, or export it "
-            "into a voice-reference cache (fq3hip.voice_cache.export_voice_clone_prompt) and call "
-            "FasterQwen3TTS.set_voice_ref_cache(dir): ref_audio=... is then served from disk.")
+        """Upstream ``Qwen3TTSModel.create_voice_clone_prompt`` [recalled] over the HIP analysers: the x-vector always,
+        the reference codes in ICL mode (``x_vector_only_mode=False``, which needs ``ref_text``)."""
+        an = self.ref_analyzer
+        if an is None or not an.has_speaker:
+            raise NotImplementedError(
+                "This weight table has no speaker_encoder.* / encoder.* tensors, so reference audio cannot be analysed here. "
+                "Pass voice_clone_prompt=dict(ref_spk_embedding=[...], ref_code=[...], x_vector_only_mode=[...], icl_mode=[...]) "
+                "or serve ref_audio from a voice-reference cache (FasterQwen3TTS.set_voice_ref_cache).")
+        if ref_audio is None:
+            raise ValueError("ref_audio is required")
+        icl = not x_vector_only_mode
+        if icl and not ref_text:
+            raise ValueError("ref_text is required when x_vector_only_mode=False (ICL mode).")
+        if icl and not an.has_encoder:
+            raise NotImplementedError("ICL mode needs the speech tokenizer's encoder.* tensors; use x_vector_only_mode=True")
+        wav = self._reference_wave(ref_audio)
+        spk = an.speaker_embedding(wav).to(self.dtype)
+        codes = an.encode(wav) if icl else None
+        return [VoiceClonePromptItem(ref_code=codes, ref_spk_embedding=spk, x_vector_only_mode=bool(x_vector_only_mode),
+                                     icl_mode=icl, ref_text=ref_text if icl else None)]
 
     @staticmethod
     def _prompt_items_to_voice_clone_prompt(items: List[Any]) -> Dict[str, Any]:

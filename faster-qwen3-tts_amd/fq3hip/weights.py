@@ -291,7 +291,11 @@ def load_hf_checkpoint(path: str, dtype: torch.dtype = torch.bfloat16, device: s
     tok_dir = os.path.join(path, "speech_tokenizer")
     if os.path.isdir(tok_dir) and os.path.exists(os.path.join(tok_dir, "config.json")):
         with open(os.path.join(tok_dir, "config.json")) as f:
-            cfg_dict["decoder_config"] = json.load(f).get("decoder_config")
+            tok_cfg = json.load(f)
+        cfg_dict["decoder_config"] = tok_cfg.get("decoder_config")
+        cfg_dict["encoder_config"] = tok_cfg.get("encoder_config")
+        if tok_cfg.get("encoder_valid_num_quantizers"):
+            cfg_dict["encoder_valid_num_quantizers"] = tok_cfg["encoder_valid_num_quantizers"]
     cfg = from_hf_config(cfg_dict)
     w: Weights = {}
 
@@ -303,6 +307,10 @@ def load_hf_checkpoint(path: str, dtype: torch.dtype = torch.bfloat16, device: s
                         k = k[len(strip):]
                     # the EuclideanCodebook statistics stay fp32 until the division below (upstream divides in fp32)
                     keep32 = k.endswith("._codebook.embedding_sum") or k.endswith("._codebook.cluster_usage")
+                    # the reference-audio analysers run in fp32 from the stored values (fq3hip/refenc.py)
+                    if k.startswith(("encoder.", "speaker_encoder.")):
+                        w[k] = v.to(device)
+                        continue
                     w[k] = v.to(dtype=(torch.float32 if keep32 else dtype) if v.is_floating_point() else v.dtype).to(device)
 
     ingest(path)
