@@ -271,12 +271,15 @@ def from_hf_config(d: dict) -> TTSConfig:
             ra[k] = ec[k]
     if ec.get("num_residual_layers") is not None:
         ra["num_residual_layers"] = ec["num_residual_layers"]
+    if ec.get("max_position_embeddings") is not None:
+        ra["max_positions"] = int(ec["max_position_embeddings"])
     if ec.get("upsampling_ratios"):
         ra["ratios"] = tuple(reversed(ec["upsampling_ratios"]))
     if d.get("encoder_valid_num_quantizers"):
         ra["num_quantizers"] = int(d["encoder_valid_num_quantizers"])
     sc = d.get("speaker_encoder_config") or {}
-    for k in ("mel_dim", "enc_dim", "enc_attention_channels", "enc_res2net_scale", "enc_se_channels"):
+    # the mel front end's parameters are constants in upstream's code; accepted here when a config carries them
+    for k in ("mel_dim", "enc_dim", "enc_attention_channels", "enc_res2net_scale", "enc_se_channels", "n_fft", "hop_size", "fmin", "fmax"):
         if sc.get(k) is not None:
             ra[k] = sc[k]
     for k in ("enc_channels", "enc_kernel_sizes", "enc_dilations"):

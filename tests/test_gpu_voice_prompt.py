@@ -93,3 +93,29 @@ def test_speech_tokenizer_encode_duck_type_and_errors(tmp_path):
         m.model.create_voice_clone_prompt(ref_audio=(x, 24000), ref_text="")
     with pytest.raises(ValueError, match="ref_audio is required"):
         m.model.create_voice_clone_prompt(ref_audio=None, ref_text="x")
+
+
+def test_from_pretrained_checkpoint_directory_serves_ref_audio(tmp_path):
+    """The reference's primary call sequence -- from_pretrained(dir) then generate_voice_clone(text, language,
+    ref_audio=wav, ref_text=...) -- over a checkpoint directory in the (recalled) upstream layout."""
+    import os
+    from fq3hip import audio_io
+    from fq3hip.model import FasterQwen3TTS
+    from tests.test_loader import _write_checkpoint
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, torch.float32, parts=("talker", "predictor", "codec", "text"))
+    W.update(synth_ref_audio_weights(cfg.ref_audio, 4))
+    root = str(tmp_path / "ckpt")
+    os.makedirs(root)
+    _write_checkpoint(root, cfg, W)
+    m = FasterQwen3TTS.from_pretrained(root, device="cuda", dtype=torch.float32, max_seq_len=512)
+    assert m.model.ref_analyzer is not None and m.model.ref_analyzer.has_encoder and m.model.ref_analyzer.has_speaker
+    m.predictor_graph.do_sample = False
+    m.predictor_graph.top_k = 0
+    wav = str(tmp_path / "ref.wav")
+    audio_io.write_wav(wav, make_wave(48 * 20, seed=8).numpy(), 24000)
+    a, sr = m.generate_voice_clone(text="Hello there.", language="English", ref_audio=wav, ref_text="the reference", **KW)
+    # same answer as the in-memory model of the other tests given the same weights
+    _, _, m2 = _model(True)
+    b, _ = m2.generate_voice_clone(text="Hello there.", language="English", ref_audio=wav, ref_text="the reference", **KW)
+    assert sr == 24000 and len(a[0]) > 1000 and np.array_equal(a[0], b[0])
