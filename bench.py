@@ -282,14 +282,15 @@ def batched_run(model, prompt, n_utt, lanes=8, frames=FRAMES, seed0=2000, sync=N
     sync()
     t0 = time.perf_counter()
     n_frames, lens = 0, [0] * n_utt
+    voc = model._side_vocoder()                       # what generate_voice_clone_batch uses: codec + D2H copy on a side stream
     for rid, codes, timing in dec.run(reqs):
         if codes is None:
             continue
         full = torch.cat([ref_codes.to(codes.device), codes], dim=0) if ref_codes is not None else codes
-        audio_list, _sr = m.speech_tokenizer.decode({"audio_codes": full.unsqueeze(0)})
-        a = audio_list[0].cpu() if hasattr(audio_list[0], "cpu") else audio_list[0]
-        lens[rid] = int(len(a))
+        voc.submit(rid, full, ref_len=ref_codes.shape[0] if ref_codes is not None else 0)
         n_frames += codes.shape[0]
+    for rid, a in voc.collect():                      # every waveform on the host before the clock stops
+        lens[rid] = int(len(a))
     sync()
     return n_frames * FRAME_S, time.perf_counter() - t0, lens
 

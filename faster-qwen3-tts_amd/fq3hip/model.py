@@ -29,6 +29,49 @@ def _to_numpy(a) -> np.ndarray:
     return a.flatten() if hasattr(a, "flatten") else a
 
 
+class _SideVocoder:
+    """Non-streaming vocoding of whole utterances off the decode stream (batched generation): ``submit`` enqueues the codec
+    decode + the device-to-pinned-host copy on a side stream after the codes are ready, ``collect`` waits and returns the
+    waveforms in submission order.  Tokenizers without ``decode_tensor`` (a foreign ``speech_tokenizer``) are decoded
+    synchronously through the upstream call."""
+
+    def __init__(self, tok, device):
+        self.tok = tok
+        self.sample_rate = int(getattr(tok, "sample_rate", 24000))
+        self.dev = torch.device(device) if not isinstance(device, torch.device) else device
+        self.async_ok = torch.cuda.is_available() and hasattr(tok, "decode_tensor")
+        self.stream = torch.cuda.Stream(device=self.dev) if self.async_ok else None
+        self.items: list = []
+
+    def submit(self, key, codes: torch.Tensor, ref_len: int = 0) -> None:
+        """``ref_len`` > 0: the first ``ref_len`` frames are the ICL reference; only the waveform after their share
+        (``int(ref_len / T * n_samples)``, model.py:927-930) is produced."""
+        if not self.async_ok or not hasattr(self.tok, "num_samples_total"):
+            lst, _rate = self.tok.decode({"audio_codes": codes.unsqueeze(0)})
+            a = _to_numpy(lst[0])
+            self.items.append((key, a[int(ref_len / max(codes.shape[0], 1) * len(a)):] if ref_len > 0 else a, None, None))
+            return
+        cut = int(ref_len / max(codes.shape[0], 1) * self.tok.num_samples_total(codes.shape[0])) if ref_len > 0 else 0
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        codes.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            pcm = self.tok.decode_tensor(codes, cut)
+            host = torch.empty(pcm.shape, dtype=torch.float32, pin_memory=True)
+            host.copy_(pcm, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.items.append((key, host, ev, pcm))          # pcm kept alive until its copy has completed
+
+    def collect(self):
+        for key, host, ev, _pcm in self.items:
+            if ev is None:
+                yield key, host
+            else:
+                ev.synchronize()
+                yield key, host.numpy().copy()
+        self.items = []
+
+
 class FasterQwen3TTS:
     """Qwen3-TTS with a hipGraph-captured, hand-written HIP decode path (drop-in for the CUDA-graph wrapper)."""
 
@@ -447,14 +490,21 @@ class FasterQwen3TTS:
             return [np.zeros(1, dtype=np.float32)], self.sample_rate
         # ICL: the reference codes go in front so the decoder has acoustic context (model.py:919-937)
         codes = torch.cat([ref_codes.to(codec_ids.device), codec_ids], dim=0) if ref_codes is not None else codec_ids
-        audio_list, sr = m.speech_tokenizer.decode({"audio_codes": codes.unsqueeze(0)})
         ref_len = ref_codes.shape[0] if ref_codes is not None else 0
-        out = []
-        for a in audio_list:
-            a = _to_numpy(a)
-            if ref_len > 0:
-                a = a[int(ref_len / max(codes.shape[0], 1) * len(a)):]
-            out.append(a)
+        tok = m.speech_tokenizer
+        if ref_len > 0 and hasattr(tok, "decode_tensor") and hasattr(tok, "num_samples_total"):
+            # the reference decodes ref + generated frames and cuts the reference's share (model.py:927-930); the HIP
+            # decoder produces only that tail (bit-identical to the slice, fq3_codec_decode_tail)
+            cut = int(ref_len / max(codes.shape[0], 1) * tok.num_samples_total(codes.shape[0]))
+            out, sr = [_to_numpy(tok.decode_tensor(codes, cut))], tok.sample_rate
+        else:
+            audio_list, sr = tok.decode({"audio_codes": codes.unsqueeze(0)})
+            out = []
+            for a in audio_list:
+                a = _to_numpy(a)
+                if ref_len > 0:
+                    a = a[int(ref_len / max(codes.shape[0], 1) * len(a)):]
+                out.append(a)
         n = timing["steps"]
         total = timing["prefill_ms"] / 1000 + timing["decode_s"]
         logger.info("Generated %.2fs audio in %.2fs (%.1fms/step, RTF: %.2f)", n / 12.5, total, timing["ms_per_step"],
@@ -595,6 +645,11 @@ class FasterQwen3TTS:
         self._batch_cache = (lanes, dec)
         return dec
 
+    def _side_vocoder(self):
+        """Vocoder for finished utterances of a batched run: decodes on its own HIP stream (the lock-step decode of the
+        remaining / next utterances goes on meanwhile) and copies the waveform to pinned host memory asynchronously."""
+        return _SideVocoder(self.model.model.speech_tokenizer, self.device)
+
     @torch.inference_mode()
     def generate_voice_clone_batch(self, texts: List[str], language: Union[str, List[str]] = "English",
                                    ref_audio: Optional[Union[str, Path]] = None, ref_text: str = "",
@@ -623,23 +678,19 @@ class FasterQwen3TTS:
                 instruct=instruct)
             reqs.append(BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(gen_kwargs)))
             ref_codes_of[i] = rc
-        m = self.model.model
         out: List[Optional[Tuple[list, int]]] = [None] * len(texts)
+        voc = self._side_vocoder()
         for rid, codec_ids, _timing in self._batch_decoder(lanes).run(reqs):
             if codec_ids is None:
                 out[rid] = ([np.zeros(1, dtype=np.float32)], self.sample_rate)
                 continue
             rc = ref_codes_of[rid]
             codes = torch.cat([rc.to(codec_ids.device), codec_ids], dim=0) if rc is not None else codec_ids
-            audio_list, sr = m.speech_tokenizer.decode({"audio_codes": codes.unsqueeze(0)})
-            ref_len = rc.shape[0] if rc is not None else 0
-            wavs = []
-            for a in audio_list:
-                a = _to_numpy(a)
-                if ref_len > 0:
-                    a = a[int(ref_len / max(codes.shape[0], 1) * len(a)):]
-                wavs.append(a)
-            out[rid] = (wavs, sr)
+            # side stream; the next frames of the other lanes are not held up.  The reference's share of the waveform is cut
+            # (model.py:927-930) by not producing it
+            voc.submit(rid, codes, ref_len=rc.shape[0] if rc is not None else 0)
+        for rid, a in voc.collect():
+            out[rid] = ([a], voc.sample_rate)
         return out
 
     @torch.inference_mode()
