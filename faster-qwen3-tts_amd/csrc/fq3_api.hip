@@ -403,6 +403,41 @@ extern "C" int fq3_kv_export(fq3_ctx* c, int layer, void* k, void* v, int L, voi
     return FQ3_OK;
 }
 
+// KV rows [0, L) of every talker layer, context to context, in one launch: grid (2 * layers, kv heads)
+struct KvAdoptTab { void* dst[128]; const void* src[128]; };
+template <typename T>
+__global__ __launch_bounds__(256) void kv_adopt_kernel(KvAdoptTab t, int L, int dst_seq, int src_seq) {
+    const int which = blockIdx.x, h = blockIdx.y;
+    const u32x4* s = reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(t.src[which]) + (size_t)h * src_seq * kHeadDim);
+    u32x4* d = reinterpret_cast<u32x4*>(reinterpret_cast<T*>(t.dst[which]) + (size_t)h * dst_seq * kHeadDim);
+    const int n16 = L * kHeadDim * (int)sizeof(T) / 16;
+    for (int i = threadIdx.x; i < n16; i += 256) d[i] = s[i];
+}
+
+extern "C" int fq3_kv_adopt(fq3_ctx* dst, const fq3_ctx* src, int L, void* stream) {
+    if (!dst || !src) return fail(FQ3_EINVAL, "null ctx");
+    const auto &a = dst->cfg, &b = src->cfg;
+    if (a.dtype != b.dtype || a.talker.n_layers != b.talker.n_layers || a.talker.n_kv_heads != b.talker.n_kv_heads)
+        return fail(FQ3_EINVAL, "fq3_kv_adopt: contexts of different shape");
+    if (L < 0 || L > src->tk.max_seq) return fail(FQ3_EINVAL, "fq3_kv_adopt: L outside the source cache");
+    if (L > dst->tk.max_seq) {
+        char m[256];
+        snprintf(m, sizeof m, "Input is too long: prefill has %d tokens but max_seq_len=%d. Use shorter text or shorter reference audio.", L, a.max_seq_len);
+        return fail(FQ3_ETOOLONG, m);
+    }
+    const int nl = a.talker.n_layers;
+    if (2 * nl > 128) return fail(FQ3_EUNSUPPORTED, "fq3_kv_adopt: more than 64 layers");
+    if (L == 0) return FQ3_OK;
+    KvAdoptTab t{};
+    for (int l = 0; l < nl; ++l) { t.dst[2 * l] = dst->tk.k[l]; t.src[2 * l] = src->tk.k[l]; t.dst[2 * l + 1] = dst->tk.v[l]; t.src[2 * l + 1] = src->tk.v[l]; }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(2 * nl, a.talker.n_kv_heads);
+    if (a.dtype == FQ3_BF16) hipLaunchKernelGGL((kv_adopt_kernel<bf16_t>), grid, dim3(256), 0, s, t, L, dst->tk.max_seq, src->tk.max_seq);
+    else hipLaunchKernelGGL((kv_adopt_kernel<float>), grid, dim3(256), 0, s, t, L, dst->tk.max_seq, src->tk.max_seq);
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
 static int final_norm(fq3_ctx* c, bool talker, const void* x, void* y, hipStream_t s) {
     const fq3_stack_dims& d = talker ? c->cfg.talker : c->cfg.predictor;
     const void* w = talker ? c->wt.talker_final_norm : c->wt.predictor_final_norm;

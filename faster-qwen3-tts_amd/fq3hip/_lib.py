@@ -91,6 +91,7 @@ SIGNATURES = {
     "fq3_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "fq3_kv_import": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp]),
     "fq3_kv_export": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp]),
+    "fq3_kv_adopt": (C.c_int, [vp, vp, C.c_int, vp]),
     "fq3_set_generation_state": (C.c_int, [vp, C.c_int, C.c_int]),
     "fq3_talker_step": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "fq3_prefill": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),

@@ -1,5 +1,7 @@
 """Continuous batching over ``Fq3Batch`` (``fq3_batch_*``): several utterances decode in lock-step over one weight
-stream; a finished lane is re-armed with the next request at a frame boundary.
+stream; a finished lane is re-armed with the next request at a frame boundary.  With ``staging`` contexts the next
+requests are prefilled on a side stream WHILE the batch decodes (their KV rows move into the freed lane with one
+``fq3_kv_adopt`` launch), so admission costs the running lanes a few tens of microseconds instead of a prefill.
 
 No reference equivalent -- the reference decodes one utterance at a time (``talker_graph.py:46`` /
 ``predictor_graph.py:70`` fix batch = 1 and ``examples/openai_server.py:71`` serialises requests with a lock); the
@@ -12,11 +14,11 @@ from __future__ import annotations
 import time
 from collections import deque
 from dataclasses import dataclass, field
-from typing import Any, Dict, Iterable, Iterator, List, Optional, Tuple
+from typing import Any, Callable, Dict, Iterable, Iterator, List, Optional, Tuple
 
 import torch
 
-from .generate import NOISE_RING, _prefill_and_arm, _refill
+from .generate import NOISE_RING, _arm_decode, _prefill_and_arm, _prefill_first_token, _refill
 from .predictor_graph import PredictorGraph
 from .talker_graph import TalkerGraph
 
@@ -49,12 +51,27 @@ class _Lane:
     prefill_ms: float = 0.0
 
 
+@dataclass
+class _Stage:
+    """A spare context a pending request is prefilled into (side stream) before a lane is free."""
+    engine: Any
+    req: Optional[BatchRequest] = None
+    kw: Optional[Dict[str, Any]] = None
+    token: int = 0
+    hidden: Optional[torch.Tensor] = None
+    n_rows: int = 0
+    ready: Any = None            # event: prefill + first token done (side stream)
+    released: Any = None         # event: the lane has copied the KV rows out (main stream)
+    t0: float = 0.0
+    prefill_ms: float = 0.0
+
+
 class BatchDecoder:
     """Drives up to ``len(engines)`` lanes.  ``engines[1:]`` must share ``engines[0]``'s weights
     (``Fq3Engine(..., share=engines[0])``)."""
 
     def __init__(self, engines: List[Any], predictor_policy: Optional[Dict[str, Any]] = None, poll_every: int = 8,
-                 use_graph: bool = True, batch_factory=None):
+                 use_graph: bool = True, batch_factory=None, staging: Optional[List[Any]] = None):
         if batch_factory is None:
             from .engine import Fq3Batch as batch_factory
         policy = predictor_policy or dict(do_sample=True, top_k=50, top_p=1.0, temperature=0.9)
@@ -63,6 +80,9 @@ class BatchDecoder:
         self.poll_every = max(1, int(poll_every))
         self.use_graph = use_graph
         self._captured = False
+        # spare contexts (same weights, not part of the lock-step batch) for prefilling ahead of admission
+        self.stages = [_Stage(e) for e in (staging or [])]
+        self._side = None
 
     def set_predictor_policy(self, **policy):
         for ln in self.lanes:
@@ -70,12 +90,17 @@ class BatchDecoder:
                 setattr(ln.predictor_graph, k, v)
 
     # ------------------------------------------------------------------------------------------------------------
-    def _arm(self, ln: _Lane, req: BatchRequest):
+    @staticmethod
+    def _kwargs(ln_pg, req: BatchRequest) -> Dict[str, Any]:
         kw = dict(max_new_tokens=2048, min_new_tokens=2, temperature=0.9, top_k=50, top_p=1.0, do_sample=True,
                   repetition_penalty=1.05)
         kw.update(req.gen_kwargs)
-        if float(kw["top_p"]) < 1.0 or float(ln.predictor_graph.top_p) < 1.0:
+        if float(kw["top_p"]) < 1.0 or float(ln_pg.top_p) < 1.0:
             raise NotImplementedError("batched decode supports top_p >= 1.0 only; use the single-stream path for nucleus sampling")
+        return kw
+
+    def _arm(self, ln: _Lane, req: BatchRequest):
+        kw = self._kwargs(ln.predictor_graph, req)
         t0 = time.time()
         _eng, tn, pn, max_frames = _prefill_and_arm(
             req.talker, req.talker_input_embeds, req.attention_mask, req.trailing_text_hiddens, req.tts_pad_embed,
@@ -83,6 +108,55 @@ class BatchDecoder:
             kw["temperature"], kw["top_k"], kw["top_p"], kw["do_sample"], kw["repetition_penalty"], use_graph=False)
         ln.req, ln.tn, ln.pn, ln.issued, ln.max_frames = req, tn, pn, 0, max_frames
         ln.t_arm, ln.prefill_ms = t0, (time.time() - t0) * 1000
+
+    def _on_gpu(self, engine) -> bool:
+        return torch.cuda.is_available() and getattr(engine.device, "type", "cpu") == "cuda"
+
+    def _stage(self, st: _Stage, req: BatchRequest, req_ready=None):
+        """Prefill + first token of ``req`` into the spare context, on the side stream (the host waits for the token, the
+        main stream -- with lock-step frames already queued -- does not)."""
+        kw = self._kwargs(self.lanes[0].predictor_graph, req)
+        t0 = time.time()
+        args = (st.engine, req.talker_input_embeds, req.attention_mask, req.config, kw["min_new_tokens"], kw["temperature"],
+                kw["top_k"], kw["top_p"], kw["do_sample"])
+        if self._on_gpu(st.engine):
+            dev = st.engine.device
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            if req_ready is not None:
+                self._side.wait_event(req_ready)                        # the request's tensors were produced on the main stream
+            else:
+                self._side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._side):
+                if st.released is not None:
+                    self._side.wait_event(st.released)                  # the previous tenant's KV rows have been copied out
+                token, hidden, n_rows, _ = _prefill_first_token(*args)
+                st.ready = torch.cuda.Event()
+                st.ready.record(self._side)
+        else:
+            token, hidden, n_rows, _ = _prefill_first_token(*args)
+        st.req, st.kw, st.token, st.hidden, st.n_rows = req, kw, token, hidden, n_rows
+        st.t0, st.prefill_ms = t0, (time.time() - t0) * 1000
+
+    def _admit(self, ln: _Lane, st: _Stage):
+        """Hand a staged request to a free lane at a frame boundary: one KV copy launch + the arm kernel."""
+        req, kw = st.req, st.kw
+        gpu = self._on_gpu(ln.engine)
+        if gpu:
+            main = torch.cuda.current_stream(ln.engine.device)
+            main.wait_event(st.ready)
+            st.hidden.record_stream(main)
+        ln.engine.kv_adopt(st.engine, st.n_rows)
+        if gpu:
+            st.released = torch.cuda.Event()
+            st.released.record(main)
+        _eng, tn, pn, max_frames = _arm_decode(
+            req.talker, req.config, st.token, st.hidden, st.n_rows, req.attention_mask, req.trailing_text_hiddens, req.tts_pad_embed,
+            ln.predictor_graph, ln.talker_graph, kw["max_new_tokens"], kw["min_new_tokens"], kw["temperature"], kw["top_k"],
+            kw["top_p"], kw["do_sample"], kw["repetition_penalty"], use_graph=False)
+        ln.req, ln.tn, ln.pn, ln.issued, ln.max_frames = req, tn, pn, 0, max_frames
+        ln.t_arm, ln.prefill_ms = st.t0, st.prefill_ms
+        st.req, st.kw, st.hidden = None, None, None
 
     def _finish(self, ln: _Lane, n: int) -> Tuple[Any, Optional[torch.Tensor], Dict[str, float]]:
         codes = ln.engine.decode_codes(0, n) if n > 0 else None
@@ -94,28 +168,85 @@ class BatchDecoder:
         return rid, codes, timing
 
     @torch.inference_mode()
-    def run(self, requests: Iterable[BatchRequest], on_error: str = "raise"
+    def run(self, requests: Iterable[BatchRequest], on_error: str = "raise",
+            source: Optional[Callable[[], Optional[BatchRequest]]] = None
             ) -> Iterator[Tuple[Any, Optional[torch.Tensor], Dict[str, Any]]]:
         """Yields ``(rid, codes LongTensor[T, 16] or None, timing)`` as utterances finish (not in request order).
         ``on_error="yield"``: a request that cannot be armed (prompt longer than ``max_seq_len``, nucleus sampling, ...)
         is reported as ``(rid, None, {"error": repr(exc), "steps": 0})`` and the other lanes keep going; the default
-        re-raises, like the single-utterance entry points."""
+        re-raises, like the single-utterance entry points.  ``source``: polled without blocking at every frame boundary
+        for requests that arrived after the call (``None`` = nothing waiting): a server's inbox."""
         if on_error not in ("raise", "yield"):
             raise ValueError("on_error must be 'raise' or 'yield'")
-        pending = deque(requests)
+        gpu = self._on_gpu(self.lanes[0].engine)
+
+        def stamped(req):
+            """(request, event after which its tensors are ready): recorded on the main stream when the request arrives, so
+            a side-stream prefill waits for THAT, not for the lock-step frames queued later."""
+            ev = None
+            if gpu and self.stages:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.lanes[0].engine.device))
+            return req, ev
+
+        pending = deque(stamped(r) for r in requests)
         free = deque(self.lanes)
         active: List[_Lane] = []
-        while pending or active:
-            while pending and free:                                   # admit at a frame boundary
-                ln = free.popleft()
-                req = pending.popleft()
+        idle = deque(self.stages)
+        ready: deque = deque()
+        failed: List[Tuple[Any, Dict[str, Any]]] = []
+
+        def pull():
+            while source is not None and len(pending) < len(self.lanes) + len(self.stages):
+                r = source()
+                if r is None:
+                    break
+                pending.append(stamped(r))
+
+        def stage_ahead(limit: int = 1 << 30):
+            # while lanes decode, only a couple of prefills per batch of queued frames: the host waits for each staged
+            # request's first token, and the main stream must not run dry meanwhile
+            while pending and idle and limit > 0:
+                limit -= 1
+                st, (req, ev) = idle.popleft(), pending.popleft()
                 try:
-                    self._arm(ln, req)
+                    self._stage(st, req, ev)
+                except Exception as exc:
+                    idle.appendleft(st)
+                    if on_error == "raise":
+                        raise
+                    failed.append((req.rid, {"error": repr(exc), "steps": 0}))
+                    continue
+                ready.append(st)
+
+        while True:
+            pull()
+            if not (pending or active or ready):
+                break
+            if self.stages and not active and not ready:
+                stage_ahead()                                         # nothing is decoding: nothing to overlap with
+            while failed:
+                rid, info = failed.pop(0)
+                yield rid, None, info
+            while free and (ready or (pending and not self.stages)):  # admit at a frame boundary
+                ln = free.popleft()
+                try:
+                    if ready:
+                        st = ready.popleft()
+                        rid = st.req.rid
+                        try:
+                            self._admit(ln, st)
+                        finally:
+                            idle.append(st)
+                    else:
+                        req, _ev = pending.popleft()
+                        rid = req.rid
+                        self._arm(ln, req)
                 except Exception as exc:
                     free.appendleft(ln)
                     if on_error == "raise":
                         raise
-                    yield req.rid, None, {"error": repr(exc), "steps": 0}
+                    yield rid, None, {"error": repr(exc), "steps": 0}
                     continue
                 if ln.max_frames <= 0:
                     yield self._finish(ln, 0)
@@ -133,9 +264,12 @@ class BatchDecoder:
                 if ln.issued % NOISE_RING == 0:
                     _refill(ln.engine, ln.tn, ln.pn)
                 step = min(step, NOISE_RING - ln.issued % NOISE_RING, max(ln.max_frames - ln.issued, 1))
+            pull()                                                    # stamp new arrivals before the frames are queued
             self.batch.frames(step)
             for ln in active:
                 ln.issued += step
+            if self.stages:
+                stage_ahead(limit=max(1, self.poll_every // 4))       # prefills fly under the frames queued above
             still = []
             for ln in active:
                 n, done = ln.engine.decode_poll()                     # first poll waits for the stream, the rest are free

@@ -183,6 +183,10 @@ class Fq3Engine:
         L.check(self.lib.fq3_kv_export(self.ctx, layer, k.data_ptr(), v.data_ptr(), int(Lk), self._stream()))
         return k, v
 
+    def kv_adopt(self, src: "Fq3Engine", Lk: int):
+        """Take over the first ``Lk`` KV rows of every talker layer from another context (``fq3_kv_adopt``)."""
+        L.check(self.lib.fq3_kv_adopt(self.ctx, src.ctx, int(Lk), self._stream()))
+
     def talker_step(self, embeds: torch.Tensor, position: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         H = self.cfg.talker.hidden_size
         self._chk(embeds, H, "talker_step embeds")

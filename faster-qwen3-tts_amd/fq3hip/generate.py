@@ -26,22 +26,29 @@ def _refill(engine, talker_noise, pred_noise):
         pred_noise.exponential_(1)
 
 
-def _prefill_and_arm(talker, talker_input_embeds, attention_mask, trailing_text_hiddens, tts_pad_embed, config,
-                     predictor_graph, talker_graph, max_new_tokens, min_new_tokens, temperature, top_k, top_p,
-                     do_sample, repetition_penalty, use_graph):
-    eng = talker_graph.engine
+def _prefill_first_token(eng, talker_input_embeds, attention_mask, config, min_new_tokens, temperature, top_k, top_p, do_sample):
+    """=== PREFILL (generate.py:107-134) === on ``eng``: KV rows written, first codebook-0 token sampled.
+    Returns (token, past_hidden, prompt_rows, n_pad)."""
     dt, dev = eng.dtype, eng.device
     eos_id = config.codec_eos_token_id
     V = config.vocab_size
     n_pad = int((attention_mask[0] == 0).sum()) if attention_mask is not None else 0
     x = talker_input_embeds[0].to(device=dev, dtype=dt).contiguous()
-    # === PREFILL (generate.py:107-134) ===
     logits, hidden = eng.prefill(x, n_pad=n_pad)
     first_noise = torch.empty(V, dtype=dt, device=dev).exponential_(1) if do_sample else None
     token = eng.sample(logits, temperature=temperature, top_k=top_k, top_p=top_p, do_sample=do_sample,
                        sup_lo=max(0, V - 1024), sup_hi=V, keep_id=eos_id, suppress_eos=min_new_tokens > 0,
                        noise=first_noise)
-    prefill_len = talker_graph.prefill_kv(int(x.shape[0]))
+    return int(token), hidden, int(x.shape[0]), n_pad
+
+
+def _arm_decode(talker, config, token, hidden, n_rows, attention_mask, trailing_text_hiddens, tts_pad_embed, predictor_graph, talker_graph,
+                max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty, use_graph):
+    """Arms the on-device loop of ``talker_graph.engine`` behind a prefill whose KV rows are already in its cache."""
+    eng = talker_graph.engine
+    dt, dev = eng.dtype, eng.device
+    V = config.vocab_size
+    prefill_len = talker_graph.prefill_kv(n_rows)
     rope_deltas = getattr(talker, "rope_deltas", None)
     talker_graph.set_generation_state(attention_mask, rope_deltas)
     need_pred_noise = bool(predictor_graph.do_sample)
@@ -61,6 +68,16 @@ def _prefill_and_arm(talker, talker_input_embeds, attention_mask, trailing_text_
     else:
         eng.graph_reset()
     return eng, tn, pn, max_frames
+
+
+def _prefill_and_arm(talker, talker_input_embeds, attention_mask, trailing_text_hiddens, tts_pad_embed, config,
+                     predictor_graph, talker_graph, max_new_tokens, min_new_tokens, temperature, top_k, top_p,
+                     do_sample, repetition_penalty, use_graph):
+    token, hidden, n_rows, _n_pad = _prefill_first_token(talker_graph.engine, talker_input_embeds, attention_mask, config,
+                                                         min_new_tokens, temperature, top_k, top_p, do_sample)
+    return _arm_decode(talker, config, token, hidden, n_rows, attention_mask, trailing_text_hiddens, tts_pad_embed, predictor_graph,
+                       talker_graph, max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty,
+                       use_graph)
 
 
 def run_frames(eng, tn, pn, issued: int, count: int):

@@ -627,22 +627,26 @@ class FasterQwen3TTS:
                                                repetition_penalty))
 
     # ---- batched generation (extension: the reference has no multi-utterance entry point) ---------------------------------
-    def _batch_decoder(self, lanes: int):
-        """Lazily builds ``lanes`` decode contexts over this model's single weight replica and the scheduler on top."""
+    def _batch_decoder(self, lanes: int, staging: Optional[int] = None):
+        """Lazily builds ``lanes`` decode contexts over this model's single weight replica, ``staging`` spare contexts
+        (default: as many as lanes) that the next requests are prefilled into while the batch decodes, and the
+        scheduler on top."""
         from .batching import BatchDecoder
         from .engine import Fq3Engine
         lanes = max(1, min(int(lanes), 8))
+        staging = lanes if staging is None else max(0, int(staging))
         cached = getattr(self, "_batch_cache", None)
-        if cached is not None and cached[0] == lanes:
+        if cached is not None and cached[0] == (lanes, staging):
             return cached[1]
         first = self.talker_graph.engine
-        engines = [first] + [Fq3Engine(first.cfg, first.weights, device=str(first.device), dtype=first.dtype,
-                                       max_seq_len=first.max_seq_len, max_frames=first.max_frames, share=first)
-                             for _ in range(lanes - 1)]
+        mk = lambda: Fq3Engine(first.cfg, first.weights, device=str(first.device), dtype=first.dtype,
+                               max_seq_len=first.max_seq_len, max_frames=first.max_frames, share=first)
+        engines = [first] + [mk() for _ in range(lanes - 1)]
         pg = self.predictor_graph
         dec = BatchDecoder(engines, predictor_policy=dict(do_sample=pg.do_sample, top_k=pg.top_k, top_p=pg.top_p,
-                                                          temperature=pg.temperature))
-        self._batch_cache = (lanes, dec)
+                                                          temperature=pg.temperature),
+                           staging=[mk() for _ in range(staging)])
+        self._batch_cache = ((lanes, staging), dec)
         return dec
 
     def _side_vocoder(self):

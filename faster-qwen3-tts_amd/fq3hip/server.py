@@ -57,15 +57,6 @@ class BatchWorker:
         self.inbox.put((voice_cfg, text, out))
         return out
 
-    def _requests(self, first):
-        """Generator feeding BatchDecoder.run: the first request, then whatever is waiting each time a lane frees up."""
-        yield first
-        while True:
-            try:
-                yield self.inbox.get_nowait()
-            except queue.Empty:
-                return
-
     def _run(self):
         import torch
         from .batching import BatchRequest
@@ -75,22 +66,43 @@ class BatchWorker:
             if first is None:
                 return
             waiting: Dict[int, Any] = {}
+            counter = [0]
             try:
                 with torch.inference_mode():
-                    def reqs():
-                        for i, (cfg, text, out) in enumerate(self._requests(first)):
+                    def prepare(item):
+                        """(voice cfg, text, reply queue) -> BatchRequest, or None when the request failed before decoding."""
+                        cfg, text, out = item
+                        try:
+                            inner, talker, config, tie, tam, tth, tpe, rc = m._prepare_generation(
+                                text=text, language=cfg.get("language", "Auto"), ref_audio=cfg.get("ref_audio"),
+                                ref_text=cfg.get("ref_text", ""), voice_clone_prompt=cfg.get("voice_clone_prompt"),
+                                non_streaming_mode=False)
+                        except Exception as exc:
+                            out.put(exc)
+                            return None
+                        i = counter[0]
+                        counter[0] += 1
+                        waiting[i] = (out, rc)
+                        kw = m._gen_kwargs(int(cfg.get("max_new_tokens", 2048)), 2, 0.9, 50, 1.0, True, 1.05)
+                        return BatchRequest(i, talker, tie, tam, tth, tpe, config, kw)
+
+                    def source():
+                        """Polled by the scheduler at every frame boundary: requests that arrived while the batch was decoding."""
+                        while True:
                             try:
-                                inner, talker, config, tie, tam, tth, tpe, rc = m._prepare_generation(
-                                    text=text, language=cfg.get("language", "Auto"), ref_audio=cfg.get("ref_audio"),
-                                    ref_text=cfg.get("ref_text", ""), voice_clone_prompt=cfg.get("voice_clone_prompt"),
-                                    non_streaming_mode=False)
-                            except Exception as exc:
-                                out.put(exc)
-                                continue
-                            waiting[i] = (out, rc)
-                            kw = m._gen_kwargs(int(cfg.get("max_new_tokens", 2048)), 2, 0.9, 50, 1.0, True, 1.05)
-                            yield BatchRequest(i, talker, tie, tam, tth, tpe, config, kw)
-                    for rid, codes, timing in m._batch_decoder(self.lanes).run(reqs(), on_error="yield"):
+                                item = self.inbox.get_nowait()
+                            except queue.Empty:
+                                return None
+                            if item is None:                   # shutdown marker: finish what is running, then stop
+                                self.inbox.put(None)
+                                return None
+                            req = prepare(item)
+                            if req is not None:
+                                return req
+
+                    head = prepare(first)
+                    for rid, codes, timing in m._batch_decoder(self.lanes).run([head] if head is not None else [], on_error="yield",
+                                                                               source=source):
                         out, rc = waiting.pop(rid)
                         if codes is None:
                             out.put(RuntimeError(timing.get("error", "generation returned no tokens")))

@@ -116,6 +116,10 @@ int fq3_bind_weights(fq3_ctx* ctx, const fq3_weight_table* table);
 int fq3_kv_import(fq3_ctx* ctx, int layer, const void* k, const void* v, int L, void* stream);
 /* Test hook: copy static KV slots [0, L) of one layer back out in the same layout. */
 int fq3_kv_export(fq3_ctx* ctx, int layer, void* k, void* v, int L, void* stream);
+/* Copies the KV rows [0, L) of every talker layer from `src` to `dst` (same shapes; max_seq_len may differ) in one launch.
+ * No reference equivalent: it lets a server prefill the next request into a spare context while the lock-step batch keeps
+ * decoding, and hand the result to whichever lane frees up (fq3hip/batching.py).  FQ3_ETOOLONG if L > dst's max_seq_len. */
+int fq3_kv_adopt(fq3_ctx* dst, const fq3_ctx* src, int L, void* stream);
 
 /* TalkerGraph.set_generation_state (talker_graph.py:172-196): left-pad count of the prompt mask and
  * the rope delta; replaces the 2048-row additive mask table with two integers. */

@@ -111,3 +111,56 @@ def test_bad_request_can_be_reported_without_stopping_the_others(sched):
     assert out[1][0] is None and "NotImplementedError" in out[1][1]["error"] and out[1][1]["steps"] == 0
     with pytest.raises(ValueError):
         list(dec.run([], on_error="ignore"))
+
+
+def test_staged_admission_prefills_ahead_and_reuses_spare_contexts(monkeypatch):
+    """With spare contexts the scheduler prefills pending requests while lanes decode, admits them with kv_adopt + arm,
+    recycles the spare context, and still routes / budgets every utterance like the direct path."""
+    log = []
+
+    class Eng(FakeLaneEngine):
+        def kv_adopt(self, src, n_rows):
+            log.append(("adopt", self.idx, src.idx, n_rows))
+
+    lanes = [Eng(log, i) for i in range(2)]
+    spares = [Eng(log, 10 + i) for i in range(2)]
+
+    def fake_prefill(eng, tie, tam, config, min_new, temperature, top_k, top_p, do_sample):
+        if getattr(config, "bad", False):
+            raise RuntimeError("Input is too long")
+        log.append(("prefill", eng.idx, config.rid, sum(e.frames for e in lanes)))
+        return 7, torch.zeros(8), tie.shape[1], 0
+
+    def fake_arm(talker, config, token, hidden, n_rows, tam, tth, tpe, pg, tg, max_new, min_new, temperature, top_k, top_p, do_sample, rp, use_graph):
+        eng = tg.engine
+        cfg = eng.next_cfg
+        eng.frames, eng.budget, eng.eos_after, eng.rid = 0, int(max_new), cfg.eos_after, cfg.rid
+        log.append(("arm", eng.idx, cfg.rid))
+        return eng, torch.zeros(1), torch.zeros(1), int(max_new)
+
+    monkeypatch.setattr(Bt, "_prefill_first_token", fake_prefill)
+    monkeypatch.setattr(Bt, "_arm_decode", fake_arm)
+    monkeypatch.setattr(Bt, "_refill", lambda eng, tn, pn: None)
+    monkeypatch.setattr(Bt, "TalkerGraph", lambda e: SimpleNamespace(engine=e))
+    monkeypatch.setattr(Bt, "PredictorGraph", lambda e, **kw: SimpleNamespace(engine=e, top_p=kw.get("top_p", 1.0)))
+    dec = Bt.BatchDecoder(lanes, poll_every=8, batch_factory=FakeBatch, staging=spares)
+    orig_admit = dec._admit
+
+    def admit(ln, st):
+        ln.engine.next_cfg = st.req.config
+        return orig_admit(ln, st)
+
+    dec._admit = admit
+    reqs = [_req(0, 24), _req(1, 40), _req(2, 16), _req(3, 8), _req(4, 8)]
+    reqs[3].config.bad = True
+    late = [_req(5, 8)]
+    out = {rid: (c, t) for rid, c, t in dec.run(reqs, on_error="yield", source=lambda: late.pop() if late else None)}
+    assert {r: (None if out[r][0] is None else out[r][0].shape[0]) for r in out} == {0: 24, 1: 40, 2: 16, 3: None, 4: 8, 5: 8}
+    assert "too long" in out[3][1]["error"]
+    prefills = [e for e in log if e[0] == "prefill"]
+    assert [p[2] for p in prefills] == [0, 1, 2, 4, 5]                       # request order, the bad one never staged
+    assert all(p[1] >= 10 for p in prefills)                                 # always into a spare context, never into a lane
+    assert prefills[2][3] > 0 and prefills[3][3] > 0                         # requests 2 and 4 were prefilled while lanes were decoding
+    adopts = [e for e in log if e[0] == "adopt"]
+    assert len(adopts) == 5 and {a[2] for a in adopts} == {10, 11}           # spare contexts recycled
+    assert [a[1] for a in adopts[:2]] == [0, 1] and all(a[3] == 4 for a in adopts)
