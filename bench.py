@@ -295,6 +295,27 @@ def batched_run(model, prompt, n_utt, lanes=8, frames=FRAMES, seed0=2000, sync=N
     return n_frames * FRAME_S, time.perf_counter() - t0, lens
 
 
+def batched_streaming_run(model, req, lanes=8, n_utt=16):
+    """Streaming AND batched through the public entry point (generate_voice_clone_batch_streaming): `n_utt` requests handed
+    over at once, `lanes` lock-step lanes, every utterance vocoded chunk by chunk on the side stream.  TTFA = time from the
+    call to an utterance's first audio chunk on the host (first wave = the requests that get a lane immediately)."""
+    torch.manual_seed(4242)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    first, samples = {}, 0
+    for i, audio, sr, tm in model.generate_voice_clone_batch_streaming(
+            [req["text"]] * n_utt, language=req["language"], ref_text=req["ref_text"], voice_clone_prompt=req["voice_clone_prompt"],
+            instruct=req["instruct"], chunk_size=CHUNK, max_new_tokens=FRAMES, min_new_tokens=FRAMES, lanes=lanes):
+        first.setdefault(i, time.perf_counter() - t0)
+        samples += len(audio)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    wave = sorted(first[i] for i in range(min(lanes, n_utt)))
+    return {"utterances": n_utt, "lanes": lanes, "value": round(samples / 24000.0 / wall, 3),
+            "unit": "x real-time (aggregate audio s / wall s; tokenise + prompt build + staged prefill + lock-step decode + streaming vocoder)",
+            "ttfa_ms_first_wave_p50": round(1000 * float(np.median(wave)), 2), "ttfa_ms_first_wave_max": round(1000 * wave[-1], 2)}
+
+
 def batched_groups_run(cfg, model, prompt, device, n_utt, groups=2, lanes=8):
     """Batching AND concurrency: `groups` independent lock-step batches of `lanes` lanes each (own contexts, own hipGraph,
     own HIP stream and host thread; ONE weight replica) decode at the same time.  A lock-step frame is still a chain of
@@ -649,6 +670,11 @@ def main():
                    "unit": "x real-time (aggregate audio s / wall s, one GPU, prefill + lock-step decode + non-streaming vocoder per finished utterance)",
                    "ms_per_lockstep_frame": round(ms, 3), "decode_only_value": round(lanes * 80.0 / ms, 1),
                    "roofline": frame_roofline(cfg, ms, p, lanes=lanes, what=f"batched decode-frame hipGraph, {lanes} lanes, matrix-core GEMVs (default)")}
+            try:
+                batched_streaming_run(model, req, lanes, lanes)                        # warm-up
+                out["streaming"] = batched_streaming_run(model, req, lanes, 2 * lanes)
+            except Exception as e:
+                out["streaming"] = {"error": repr(e)}
             try:
                 ms2, p2 = batched_frame_time(model, cfg, prompt, lanes, mfma=0)
                 out["valu_gemv"] = {"ms_per_lockstep_frame": round(ms2, 3), "decode_only_value": round(lanes * 80.0 / ms2, 1),

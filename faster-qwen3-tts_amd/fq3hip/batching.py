@@ -46,6 +46,7 @@ class _Lane:
     tn: Optional[torch.Tensor] = None
     pn: Optional[torch.Tensor] = None
     issued: int = 0
+    emitted: int = 0             # frames already handed out as partial chunks (chunk_frames mode)
     max_frames: int = 0
     t_arm: float = 0.0
     prefill_ms: float = 0.0
@@ -109,6 +110,14 @@ class BatchDecoder:
         ln.req, ln.tn, ln.pn, ln.issued, ln.max_frames = req, tn, pn, 0, max_frames
         ln.t_arm, ln.prefill_ms = t0, (time.time() - t0) * 1000
 
+    def _mark(self, engine):
+        """Event after which the code tensors just read out are complete (recorded before further frames are queued)."""
+        if not self._on_gpu(engine):
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(engine.device))
+        return ev
+
     def _on_gpu(self, engine) -> bool:
         return torch.cuda.is_available() and getattr(engine.device, "type", "cpu") == "cuda"
 
@@ -158,24 +167,37 @@ class BatchDecoder:
         ln.t_arm, ln.prefill_ms = st.t0, st.prefill_ms
         st.req, st.kw, st.hidden = None, None, None
 
-    def _finish(self, ln: _Lane, n: int) -> Tuple[Any, Optional[torch.Tensor], Dict[str, float]]:
-        codes = ln.engine.decode_codes(0, n) if n > 0 else None
+    def _finish(self, ln: _Lane, n: int, chunked: bool = False) -> Tuple[Any, Optional[torch.Tensor], Dict[str, float]]:
+        first = ln.emitted if chunked else 0
+        if n > first:
+            codes = ln.engine.decode_codes(first, n - first)
+        elif chunked and n > 0:                      # every frame already went out as a partial chunk
+            codes = torch.empty(0, ln.engine.cfg.num_code_groups, dtype=torch.long, device=ln.engine.device)
+        else:
+            codes = None
         wall = time.time() - ln.t_arm
         timing = {"prefill_ms": ln.prefill_ms, "decode_s": max(wall - ln.prefill_ms / 1000, 0.0), "steps": n,
                   "ms_per_step": (1000 * wall / n) if n else 0.0, "steps_per_s": (n / wall) if wall > 0 else 0.0}
+        if chunked:
+            timing.update(is_final=True, total_steps_so_far=n)
         rid = ln.req.rid
-        ln.req, ln.tn, ln.pn = None, None, None
+        ln.req, ln.tn, ln.pn, ln.emitted = None, None, None, 0
         return rid, codes, timing
 
     @torch.inference_mode()
     def run(self, requests: Iterable[BatchRequest], on_error: str = "raise",
-            source: Optional[Callable[[], Optional[BatchRequest]]] = None
+            source: Optional[Callable[[], Optional[BatchRequest]]] = None, chunk_frames: Optional[int] = None
             ) -> Iterator[Tuple[Any, Optional[torch.Tensor], Dict[str, Any]]]:
         """Yields ``(rid, codes LongTensor[T, 16] or None, timing)`` as utterances finish (not in request order).
         ``on_error="yield"``: a request that cannot be armed (prompt longer than ``max_seq_len``, nucleus sampling, ...)
         is reported as ``(rid, None, {"error": repr(exc), "steps": 0})`` and the other lanes keep going; the default
         re-raises, like the single-utterance entry points.  ``source``: polled without blocking at every frame boundary
-        for requests that arrived after the call (``None`` = nothing waiting): a server's inbox."""
+        for requests that arrived after the call (``None`` = nothing waiting): a server's inbox.
+        ``chunk_frames``: streaming mode -- besides the final event every utterance yields partial events
+        ``(rid, codes of the next whole chunks, {"is_final": False, "total_steps_so_far": n})`` as its frames complete, and
+        its final event (``"is_final": True``) carries only the frames not handed out before (``None`` when the utterance
+        produced no frame at all, an empty tensor when everything was already handed out)."""
+        chunked = chunk_frames is not None and int(chunk_frames) > 0
         if on_error not in ("raise", "yield"):
             raise ValueError("on_error must be 'raise' or 'yield'")
         gpu = self._on_gpu(self.lanes[0].engine)
@@ -195,6 +217,8 @@ class BatchDecoder:
         idle = deque(self.stages)
         ready: deque = deque()
         failed: List[Tuple[Any, Dict[str, Any]]] = []
+        outbox: List[Tuple[Any, Any, Dict[str, Any]]] = []            # streaming-mode events waiting for the next frames to be queued
+        now: List[Tuple[Any, Any, Dict[str, Any]]] = []
 
         def pull():
             while source is not None and len(pending) < len(self.lanes) + len(self.stages):
@@ -249,7 +273,7 @@ class BatchDecoder:
                     yield rid, None, {"error": repr(exc), "steps": 0}
                     continue
                 if ln.max_frames <= 0:
-                    yield self._finish(ln, 0)
+                    yield self._finish(ln, 0, chunked)
                     free.append(ln)
                     continue
                 active.append(ln)
@@ -268,14 +292,39 @@ class BatchDecoder:
             self.batch.frames(step)
             for ln in active:
                 ln.issued += step
+            # streaming mode: the chunks found by the previous poll go out only now, with the next frames already queued, so
+            # that whatever the consumer does with them (vocoding) overlaps the decode instead of stalling it
+            while outbox:
+                yield outbox.pop(0)
             if self.stages:
                 stage_ahead(limit=max(1, self.poll_every // 4))       # prefills fly under the frames queued above
             still = []
             for ln in active:
                 n, done = ln.engine.decode_poll()                     # first poll waits for the stream, the rest are free
-                if done or ln.issued >= ln.max_frames:
-                    yield self._finish(ln, n)
+                fin = done or ln.issued >= ln.max_frames
+                if chunked:
+                    # whole chunks, one event each (a poll can complete several); a finished utterance's last event carries
+                    # the remainder (at most one chunk) and the timing
+                    c = int(chunk_frames)
+                    upto = n if fin else (n // c) * c
+                    while (upto - ln.emitted > c) if fin else (upto - ln.emitted >= c):
+                        codes = ln.engine.decode_codes(ln.emitted, c)
+                        ln.emitted += c
+                        outbox.append((ln.req.rid, codes, {"is_final": False, "total_steps_so_far": ln.emitted,
+                                                           "codes_ready_event": self._mark(ln.engine)}))
+                if fin:
+                    ev = self._finish(ln, n, chunked)
+                    if chunked and ev[1] is not None:
+                        ev[2]["codes_ready_event"] = self._mark(ln.engine)
+                    (outbox.append if chunked else now.append)(ev)
                     free.append(ln)
                 else:
                     still.append(ln)
             active = still
+            while now:
+                yield now.pop(0)
+            if not active and not ready and not pending:              # nothing left to overlap with
+                while outbox:
+                    yield outbox.pop(0)
+        while outbox:
+            yield outbox.pop(0)

@@ -72,6 +72,80 @@ class _SideVocoder:
         self.items = []
 
 
+class StreamingVocoder:
+    """The reference's streaming windowing (``faster_qwen3_tts/model.py:1048-1137``) as a state machine over code chunks:
+    phase 1 re-decodes everything (reference codes in front) until >= max(25, chunk) frames exist and calibrates samples
+    per frame; phase 2 decodes [25 context frames + the new chunk] and drops the context.  With the HIP tokenizer only the
+    samples that are kept are produced (``decode_tensor(codes, first_sample)``: bit-identical to slicing the full decode)
+    and the codec runs on ``side_stream`` so that it overlaps the next frames' decode kernels."""
+
+    CONTEXT_FRAMES = 25
+
+    def __init__(self, tok, ref_codes, chunk_size: int, device, side_stream=None):
+        self.tok, self.ref_codes, self.side = tok, ref_codes, side_stream
+        self.dev = torch.device(device) if not isinstance(device, torch.device) else device
+        self.min_cal = max(self.CONTEXT_FRAMES, int(chunk_size))
+        self.all_codes: List[torch.Tensor] = []
+        self.prev_len, self.spf = 0, None
+
+    def _vocode(self, codes_in, first_sample, ev):
+        """waveform[first_sample:] of codes_in (host array)."""
+        if self.side is None:
+            lst, rate = self.tok.decode({"audio_codes": codes_in.unsqueeze(0)})
+            return _to_numpy(lst[0])[first_sample:], rate
+        if ev is not None:
+            self.side.wait_event(ev)
+        else:
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.side):
+            out = _to_numpy(self.tok.decode_tensor(codes_in, first_sample))      # .cpu() synchronises the side stream only
+        return out, self.tok.sample_rate
+
+    def _cat(self, parts, ev):
+        if self.side is None:
+            return torch.cat(parts, dim=0)
+        with torch.cuda.stream(self.side):
+            if ev is not None:
+                self.side.wait_event(ev)
+            else:
+                self.side.wait_stream(torch.cuda.current_stream(self.dev))
+            return torch.cat(parts, dim=0)
+
+    def push(self, chunk: torch.Tensor, ready_event=None):
+        """``chunk`` LongTensor[n_new, 16] (device) -> (new audio as a host array, sample_rate)."""
+        if self.side is not None:
+            chunk.record_stream(self.side)
+        self.all_codes.append(chunk)
+        n_new = chunk.shape[0]
+        flat = self._cat(self.all_codes, ready_event)
+        n_total = flat.shape[0]
+        if self.spf is None:
+            rc = self.ref_codes
+            inp = self._cat([rc.to(flat.device), flat], ready_event) if rc is not None else flat
+            ref_len = rc.shape[0] if rc is not None else 0
+            if self.side is not None:
+                # model.py:1095-1100 without materialising what is thrown away: audio[cut:][prev_len:]
+                n_audio = self.tok.num_samples_total(inp.shape[0])
+                cut = int(ref_len / max(inp.shape[0], 1) * n_audio) if ref_len else 0
+                new_audio, sr = self._vocode(inp, cut + self.prev_len, ready_event)
+                gen_len = n_audio - cut
+            else:
+                audio, sr = self._vocode(inp, 0, ready_event)
+                if ref_len:
+                    audio = audio[int(ref_len / max(inp.shape[0], 1) * len(audio)):]
+                new_audio = audio[self.prev_len:]
+                gen_len = len(audio)
+            self.prev_len = gen_len
+            if n_total >= self.min_cal:
+                self.spf = gen_len / n_total
+        else:
+            start = max(0, n_total - n_new - self.CONTEXT_FRAMES)
+            window = flat[start:]
+            n_ctx = window.shape[0] - n_new
+            new_audio, sr = self._vocode(window, int(round(n_ctx * self.spf)) if n_ctx > 0 else 0, ready_event)
+        return new_audio, sr
+
+
 class FasterQwen3TTS:
     """Qwen3-TTS with a hipGraph-captured, hand-written HIP decode path (drop-in for the CUDA-graph wrapper)."""
 
@@ -511,91 +585,38 @@ class FasterQwen3TTS:
                     (n / 12.5) / total if total > 0 else 0)
         return out, sr
 
+    def _vocoder_stream(self, tok):
+        """The HIP stream every streaming vocoder of this model runs on (one codec workspace -> one stream), or None for a
+        foreign tokenizer that is decoded synchronously."""
+        use_side = torch.cuda.is_available() and hasattr(tok, "decode_tensor") and hasattr(tok, "num_samples_total")
+        if not use_side:
+            return None
+        if getattr(self, "_voc_stream", None) is None:
+            dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
+            # FQ3_VOC_PRIORITY (development knob): HIP stream priority of the vocoder stream (larger = lower)
+            prio = os.environ.get("FQ3_VOC_PRIORITY")
+            self._voc_stream = torch.cuda.Stream(device=dev) if prio is None else torch.cuda.Stream(device=dev, priority=int(prio))
+        return self._voc_stream
+
+    def streaming_vocoder(self, ref_codes, chunk_size: int) -> "StreamingVocoder":
+        """A fresh windowing state for one utterance (used by the streaming entry points and by the batch server)."""
+        tok = self.model.model.speech_tokenizer
+        return StreamingVocoder(tok, ref_codes, chunk_size, self.device, self._vocoder_stream(tok))
+
     def _run_streaming(self, m, talker, config, tie, tam, tth, tpe, ref_codes, gen_kwargs, chunk_size: int,
                        parity_mode: bool = False):
-        """model.py:1048-1137: phase 1 re-decodes everything until >= max(25, chunk) frames exist and
-        calibrates samples/frame; phase 2 decodes [25 context frames + new chunk] and drops the context."""
+        """model.py:1048-1137: the decode loop yields code chunks, ``StreamingVocoder`` turns each into the audio the
+        reference's windowing would emit for it."""
         from .streaming import fast_generate_streaming, parity_generate_streaming
         tok = m.speech_tokenizer
-        context_frames = 25
-        min_cal = max(context_frames, chunk_size)
-        all_codes: List[torch.Tensor] = []
-        prev_len, spf = 0, None
+        voc = StreamingVocoder(tok, ref_codes, chunk_size, self.device, self._vocoder_stream(tok))
         fn = parity_generate_streaming if parity_mode else fast_generate_streaming
         stream = fn(talker=talker, talker_input_embeds=tie, attention_mask=tam, trailing_text_hiddens=tth,
                     tts_pad_embed=tpe, config=config, predictor_graph=self.predictor_graph,
                     talker_graph=self.talker_graph, chunk_size=chunk_size, **gen_kwargs)
-        dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
-        use_side = torch.cuda.is_available() and hasattr(tok, "decode_tensor") and hasattr(tok, "num_samples_total")
-        if use_side and getattr(self, "_voc_stream", None) is None:
-            # FQ3_VOC_PRIORITY (development knob): HIP stream priority of the vocoder stream (larger = lower)
-            prio = os.environ.get("FQ3_VOC_PRIORITY")
-            self._voc_stream = torch.cuda.Stream(device=dev) if prio is None else torch.cuda.Stream(device=dev, priority=int(prio))
         for chunk, timing in stream:
             ev = timing.pop("codes_ready_event", None)
-            if use_side:
-                chunk.record_stream(self._voc_stream)
-            all_codes.append(chunk)
-            n_new = chunk.shape[0]
-
-            def vocode(codes_in, first_sample=0):
-                """waveform[first_sample:] of codes_in (host array).  The HIP tokenizer produces only that tail
-                (fq3_codec_decode_tail: bit-identical to slicing the full decode, but only the rows the tail depends on
-                are recomputed); any other tokenizer decodes everything and is sliced here."""
-                if not use_side:
-                    lst, rate = tok.decode({"audio_codes": codes_in.unsqueeze(0)})
-                    return _to_numpy(lst[0])[first_sample:], rate
-                # the codec runs on its own stream so that it overlaps the next chunk's decode kernels
-                side = self._voc_stream
-                if ev is not None:
-                    side.wait_event(ev)
-                else:
-                    side.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side):
-                    out = _to_numpy(tok.decode_tensor(codes_in, first_sample))      # .cpu() synchronises the side stream only
-                return out, tok.sample_rate
-
-            def n_samples(n_frames):
-                return tok.num_samples_total(n_frames) if use_side else None
-
-            if use_side:
-                with torch.cuda.stream(self._voc_stream):
-                    if ev is not None:
-                        self._voc_stream.wait_event(ev)
-                    flat = torch.cat(all_codes, dim=0)
-            else:
-                flat = torch.cat(all_codes, dim=0)
-            n_total = flat.shape[0]
-            if spf is None:
-                if ref_codes is not None:
-                    if use_side:
-                        with torch.cuda.stream(self._voc_stream):
-                            inp = torch.cat([ref_codes.to(flat.device), flat], dim=0)
-                    else:
-                        inp = torch.cat([ref_codes.to(flat.device), flat], dim=0)
-                else:
-                    inp = flat
-                ref_len = ref_codes.shape[0] if ref_codes is not None else 0
-                n_audio = n_samples(inp.shape[0])
-                if n_audio is not None:
-                    # model.py:1095-1100 without materialising what is thrown away: audio[cut:][prev_len:]
-                    cut = int(ref_len / max(inp.shape[0], 1) * n_audio) if ref_len else 0
-                    new_audio, sr = vocode(inp, cut + prev_len)
-                    gen_len = n_audio - cut
-                else:
-                    audio, sr = vocode(inp)
-                    if ref_len:
-                        audio = audio[int(ref_len / max(inp.shape[0], 1) * len(audio)):]
-                    new_audio = audio[prev_len:]
-                    gen_len = len(audio)
-                prev_len = gen_len
-                if n_total >= min_cal:
-                    spf = gen_len / n_total
-            else:
-                start = max(0, n_total - n_new - context_frames)
-                window = flat[start:]
-                n_ctx = window.shape[0] - n_new
-                new_audio, sr = vocode(window, int(round(n_ctx * spf)) if n_ctx > 0 else 0)
+            new_audio, sr = voc.push(chunk, ev)
             yield new_audio, sr, timing
 
     @staticmethod
@@ -696,6 +717,47 @@ class FasterQwen3TTS:
         for rid, a in voc.collect():
             out[rid] = ([a], voc.sample_rate)
         return out
+
+    @torch.inference_mode()
+    def generate_voice_clone_batch_streaming(self, texts: List[str], language: Union[str, List[str]] = "English",
+                                             ref_audio: Optional[Union[str, Path]] = None, ref_text: str = "",
+                                             max_new_tokens: int = 2048, min_new_tokens: int = 2, temperature: float = 0.9,
+                                             top_k: int = 50, top_p: float = 1.0, do_sample: bool = True,
+                                             repetition_penalty: float = 1.05, chunk_size: int = 12, xvec_only: bool = False,
+                                             non_streaming_mode: Optional[bool] = None, append_silence: bool = True,
+                                             instruct: Optional[str] = None,
+                                             voice_clone_prompt: Optional[Union[Dict[str, Any], List[Any]]] = None,
+                                             lanes: int = 8) -> Generator[Tuple[int, np.ndarray, int, dict], None, None]:
+        """Streaming AND batched: the texts decode in lock-step lanes (as :meth:`generate_voice_clone_batch`) and every
+        ``chunk_size`` frames of any utterance yield ``(text_index, audio_chunk, sample_rate, timing)`` -- per utterance
+        exactly the chunks :meth:`generate_voice_clone_streaming` would produce for it (same windowing state machine).
+        ``timing``: ``chunk_index``, ``total_steps_so_far``, ``is_final``."""
+        from .batching import BatchRequest
+        nsm = self._resolve_non_streaming_mode(non_streaming_mode, default=False)
+        langs = language if isinstance(language, (list, tuple)) else [language] * len(texts)
+        if len(langs) != len(texts):
+            raise ValueError("language must be one string or one per text")
+        gen_kwargs = self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty)
+        reqs, vocs, n_chunks = [], {}, {}
+        for i, (text, lang) in enumerate(zip(texts, langs)):
+            m, talker, config, tie, tam, tth, tpe, rc = self._prepare_generation(
+                text=text, language=lang, ref_audio=ref_audio, ref_text=ref_text, xvec_only=xvec_only,
+                non_streaming_mode=nsm, append_silence=append_silence, voice_clone_prompt=voice_clone_prompt,
+                instruct=instruct)
+            reqs.append(BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(gen_kwargs)))
+            vocs[i], n_chunks[i] = self.streaming_vocoder(rc, chunk_size), 0
+        for rid, codes, info in self._batch_decoder(lanes).run(reqs, chunk_frames=chunk_size):
+            ev = info.pop("codes_ready_event", None)
+            final = bool(info.get("is_final"))
+            if codes is not None and codes.shape[0] > 0:
+                audio, sr = vocs[rid].push(codes, ev)
+            elif final:
+                audio, sr = np.zeros(1 if codes is None else 0, dtype=np.float32), self.sample_rate
+            else:
+                continue
+            yield rid, audio, sr, dict(chunk_index=n_chunks[rid], total_steps_so_far=int(info.get("total_steps_so_far", 0)),
+                                       is_final=final, chunk_steps=0 if codes is None else int(codes.shape[0]))
+            n_chunks[rid] += 1
 
     @torch.inference_mode()
     def generate_voice_clone_streaming(self, text: str, language: str, ref_audio: Optional[Union[str, Path]] = None,

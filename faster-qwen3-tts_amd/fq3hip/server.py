@@ -44,7 +44,10 @@ class SpeechRequest(BaseModel):
 
 
 class BatchWorker:
-    """One thread owns the model; ``submit`` returns a future-like queue that receives (audio, sr) or an exception."""
+    """One thread owns the model and runs the continuous-batching decoder in streaming mode.  ``submit`` returns a queue that
+    receives the utterance's PCM chunks (``np.ndarray``) as they are vocoded, then ``BatchWorker.DONE`` -- or an exception."""
+
+    DONE = object()
 
     def __init__(self, model, lanes: int = 8):
         self.model, self.lanes = model, max(1, min(int(lanes), 8))
@@ -53,7 +56,7 @@ class BatchWorker:
         self.thread.start()
 
     def submit(self, voice_cfg: dict, text: str) -> "queue.Queue":
-        out: "queue.Queue" = queue.Queue(maxsize=1)
+        out: "queue.Queue" = queue.Queue()
         self.inbox.put((voice_cfg, text, out))
         return out
 
@@ -82,7 +85,8 @@ class BatchWorker:
                             return None
                         i = counter[0]
                         counter[0] += 1
-                        waiting[i] = (out, rc)
+                        chunk = int(cfg.get("chunk_size", 12))
+                        waiting[i] = (out, m.streaming_vocoder(rc, chunk))
                         kw = m._gen_kwargs(int(cfg.get("max_new_tokens", 2048)), 2, 0.9, 50, 1.0, True, 1.05)
                         return BatchRequest(i, talker, tie, tam, tth, tpe, config, kw)
 
@@ -101,18 +105,19 @@ class BatchWorker:
                                 return req
 
                     head = prepare(first)
-                    for rid, codes, timing in m._batch_decoder(self.lanes).run([head] if head is not None else [], on_error="yield",
-                                                                               source=source):
-                        out, rc = waiting.pop(rid)
-                        if codes is None:
-                            out.put(RuntimeError(timing.get("error", "generation returned no tokens")))
-                            continue
-                        full = torch.cat([rc.to(codes.device), codes], 0) if rc is not None else codes
-                        wavs, sr = m.model.model.speech_tokenizer.decode({"audio_codes": full.unsqueeze(0)})
-                        a = wavs[0].float().cpu().numpy() if hasattr(wavs[0], "cpu") else np.asarray(wavs[0])
-                        if rc is not None:
-                            a = a[int(rc.shape[0] / max(full.shape[0], 1) * len(a)):]
-                        out.put((a, sr))
+                    chunk_frames = int(first[0].get("chunk_size", 12))
+                    for rid, codes, info in m._batch_decoder(self.lanes).run([head] if head is not None else [], on_error="yield",
+                                                                             source=source, chunk_frames=chunk_frames):
+                        out, voc = waiting[rid]
+                        final = bool(info.get("is_final")) or "error" in info
+                        if "error" in info or (codes is None and final and info.get("steps", 0) == 0):
+                            out.put(RuntimeError(info.get("error", "generation returned no tokens")))
+                        elif codes is not None and codes.shape[0] > 0:
+                            audio, _sr = voc.push(codes, info.get("codes_ready_event"))
+                            out.put(np.asarray(audio, dtype=np.float32))
+                        if final:
+                            out.put(self.DONE)
+                            waiting.pop(rid, None)
             except Exception as exc:            # a failed batch answers everyone who is still waiting
                 for out, _ in waiting.values():
                     out.put(exc)
@@ -183,12 +188,37 @@ def create_app(model, voices: Dict[str, dict], default_voice: Optional[str] = No
         loop = asyncio.get_event_loop()
         if worker is not None:
             box = worker.submit(cfg, req.input)
-            res = await loop.run_in_executor(None, box.get)
-            if isinstance(res, Exception):
-                raise HTTPException(status_code=500, detail=repr(res))
-            audio, sr = res
-            body = to_wav_bytes(audio, sr) if fmt == "wav" else to_pcm16(audio)
-            return Response(content=body, media_type=CONTENT_TYPES[fmt])
+
+            async def batch_stream():
+                first = True
+                while True:
+                    item = await loop.run_in_executor(None, box.get)
+                    if item is BatchWorker.DONE:
+                        break
+                    if isinstance(item, Exception):
+                        if first:
+                            raise HTTPException(status_code=500, detail=repr(item))
+                        logger.error("generation failed mid-stream: %r", item)
+                        break
+                    if first and fmt == "wav":
+                        yield wav_header(sample_rate)      # unknown data length: streaming
+                    first = False
+                    yield to_pcm16(item)
+
+            # pull the first event before answering, so that a request that fails outright is a 500, not an empty 200
+            gen = batch_stream()
+            try:
+                head = await gen.__anext__()
+            except StopAsyncIteration:
+                head = None
+
+            async def replay():
+                if head is not None:
+                    yield head
+                async for raw in gen:
+                    yield raw
+
+            return StreamingResponse(replay(), media_type=CONTENT_TYPES[fmt])
 
         async def audio_stream():
             if fmt == "wav":

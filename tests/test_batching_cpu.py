@@ -164,3 +164,20 @@ def test_staged_admission_prefills_ahead_and_reuses_spare_contexts(monkeypatch):
     adopts = [e for e in log if e[0] == "adopt"]
     assert len(adopts) == 5 and {a[2] for a in adopts} == {10, 11}           # spare contexts recycled
     assert [a[1] for a in adopts[:2]] == [0, 1] and all(a[3] == 4 for a in adopts)
+
+
+def test_chunked_streaming_events(sched):
+    """chunk_frames mode: whole chunks go out as they complete, the final event carries only the rest."""
+    dec, engines, log, refills = sched
+    events = list(dec.run([_req(0, 20), _req(1, 40, eos_after=13), _req(2, 16)], chunk_frames=8))
+    per = {}
+    for rid, codes, info in events:
+        per.setdefault(rid, []).append((None if codes is None else codes.shape[0], info["is_final"], info["total_steps_so_far"]))
+    assert per[0] == [(8, False, 8), (8, False, 16), (4, True, 20)]
+    assert per[1] == [(8, False, 8), (5, True, 13)]                      # EOS inside the second chunk
+    assert per[2] == [(8, False, 8), (8, True, 16)]                      # finished exactly at the polled boundary: no empty tail event needed
+    finals = [info for _rid, _c, info in events if info["is_final"]]
+    assert all("prefill_ms" in f and "steps" in f for f in finals)
+    # default mode is unchanged: one event per utterance with all frames
+    out = list(dec.run([_req(5, 12)]))
+    assert len(out) == 1 and out[0][1].shape[0] == 12 and "is_final" not in out[0][2]

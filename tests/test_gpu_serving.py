@@ -104,6 +104,40 @@ def test_openai_endpoint_batch_scheduler_takes_concurrent_requests(model):
         assert r is not None and r.status_code == 200, None if r is None else r.text
         body = r.content
         n = struct.unpack("<I", body[40:44])[0]
-        assert body[:4] == b"RIFF" and n == len(body) - 44 and n > 2000          # complete WAV with its real length
+        # the batch scheduler streams every utterance chunk by chunk: WAV header of unknown length, as the reference's server
+        assert body[:4] == b"RIFF" and n == 0xFFFFFFFF and len(body) - 44 > 2000 and (len(body) - 44) % 2 == 0
     r = client.post("/v1/audio/speech", json={"input": "pcm please", "voice": "alloy", "response_format": "pcm"})
     assert r.status_code == 200 and len(r.content) > 2000 and len(r.content) % 2 == 0
+
+
+def test_batch_streaming_equals_single_stream_streaming(model):
+    """generate_voice_clone_batch_streaming: per utterance the same chunks (sizes and samples) as
+    generate_voice_clone_streaming, while the utterances share lock-step lanes (greedy fp32: lanes are bit-identical to the
+    single-stream decode)."""
+    cfg = model._cfg_for_test
+    spk, codes = _voice(cfg)
+    vcp = dict(ref_code=[codes], ref_spk_embedding=[spk], x_vector_only_mode=[False], icl_mode=[True])
+    kw = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0, repetition_penalty=1.0, min_new_tokens=0, ref_text="the reference",
+              voice_clone_prompt=vcp, chunk_size=4)
+    model.predictor_graph.do_sample = False
+    model.predictor_graph.top_k = 0
+    texts = ["First line.", "A second, rather longer line of text.", "Three.", "And the fourth one."]
+    budgets = 23                                   # not a multiple of the chunk size: the last chunk is a remainder
+    single = []
+    for t in texts:
+        single.append([(a.copy(), tm["is_final"]) for a, _sr, tm in model.generate_voice_clone_streaming(text=t, language="English",
+                                                                                                      max_new_tokens=budgets, **kw)])
+    got = {i: [] for i in range(len(texts))}
+    order = []
+    for i, a, sr, tm in model.generate_voice_clone_batch_streaming(texts, language="English", max_new_tokens=budgets, lanes=3, **kw):
+        assert sr == 24000
+        got[i].append((a, tm["is_final"], tm["chunk_index"]))
+        order.append(i)
+    assert len(set(order[:6])) == 3               # the first chunks of the three lanes arrive interleaved, not utterance by utterance
+    for i in range(len(texts)):
+        ref = [c for c in single[i] if len(c[0]) > 0]
+        mine = [c for c in got[i] if len(c[0]) > 0]
+        assert len(mine) == len(ref) and [c[2] for c in got[i]] == list(range(len(got[i])))
+        for (a, _f), (b, _g, _k) in zip(ref, mine):
+            assert a.shape == b.shape and np.array_equal(a, b)
+        assert got[i][-1][1] is True and all(not c[1] for c in got[i][:-1])
