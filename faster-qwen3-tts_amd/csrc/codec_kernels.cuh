@@ -143,6 +143,76 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
         }
 }
 
+// The same per-element epilogue (bias, activation, scale, residual, one rounding, second output) for a kernel that walks its
+// outputs from LDS instead of from the MFMA register layout (big_gemm_kernel).  Not for act == 2 (SwiGLU pairs columns).
+template <typename T>
+__device__ __forceinline__ void epilogue_elem(const GemmArgs& a, float accv, int m, int n) {
+    const int ch = n % a.bias_mod;
+    const float b = a.bias ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + ch) : 0.f;
+    float v = DT<T>::rnd(accv + b);
+    if (a.act == 1) v = DT<T>::rnd(gelu_exact(v));
+    if (a.act == 3) v = DT<T>::rnd(v / (1.0f + expf(-v)));
+    if (a.act >= 4) v = DT<T>::rnd(act_extra(a.act, v));
+    if (a.scale) v = DT<T>::rnd(DT<T>::ld(reinterpret_cast<const T*>(a.scale) + n) * v);
+    if (a.res) v = v + DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)m * a.ldr + n);
+    v = DT<T>::rnd(v);
+    if (a.Y) DT<T>::st(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + n, v);
+    if (a.Y2) {
+        float y2;
+        if (a.act2) y2 = DT<T>::rnd(elu1(v));
+        else y2 = snake_apply<T>(v, DT<T>::ld(reinterpret_cast<const T*>(a.sn_a) + ch), DT<T>::ld(reinterpret_cast<const T*>(a.sn_ib) + ch));
+        DT<T>::st(reinterpret_cast<T*>(a.Y2) + (size_t)m * a.ldy + n, y2);
+    }
+}
+
+// Four consecutive columns of one output row (what a lane holds when the MFMA is issued with its operands swapped): the
+// general epilogue, out of line so that a kernel can call it from a fully unrolled loop over 32 accumulator tiles.
+struct EpiArgs {
+    const bf16_t* bias; int bias_mod; const bf16_t* scale; const bf16_t* res; int ldr; bf16_t* Y; int ldy; bf16_t* Y2;
+    const bf16_t* sn_a; const bf16_t* sn_ib; int act, act2, M, N;
+};
+__device__ __noinline__ void epi_store4(EpiArgs e, f32x4_t acc, int m, int n) {
+    typedef bf16_t T;
+    if (m >= e.M || n >= e.N) return;
+    if (n + 3 < e.N && (e.ldy & 3) == 0 && (!e.res || (e.ldr & 3) == 0) && (e.bias_mod & 3) == 0) {
+        const int ch = n % e.bias_mod;
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (e.res) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(e.res + (size_t)m * e.ldr + n);
+            rv[0] = __uint_as_float(rr.x << 16); rv[1] = __uint_as_float(rr.x & 0xFFFF0000u);
+            rv[2] = __uint_as_float(rr.y << 16); rv[3] = __uint_as_float(rr.y & 0xFFFF0000u);
+        }
+        float v[4], v2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float x = DT<T>::rnd(acc[c] + (e.bias ? DT<T>::ld(e.bias + ch + c) : 0.f));
+            if (e.act == 1) x = DT<T>::rnd(gelu_exact(x));
+            if (e.act == 3) x = DT<T>::rnd(x / (1.0f + expf(-x)));
+            if (e.act >= 4) x = DT<T>::rnd(act_extra(e.act, x));
+            if (e.scale) x = DT<T>::rnd(DT<T>::ld(e.scale + n + c) * x);
+            if (e.res) x = x + rv[c];
+            v[c] = DT<T>::rnd(x);
+            v2[c] = 0.f;
+            if (e.Y2) v2[c] = e.act2 ? DT<T>::rnd(elu1(v[c])) : snake_apply<T>(v[c], DT<T>::ld(e.sn_a + ch + c), DT<T>::ld(e.sn_ib + ch + c));
+        }
+        if (e.Y) *reinterpret_cast<uint2*>(e.Y + (size_t)m * e.ldy + n) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        if (e.Y2) *reinterpret_cast<uint2*>(e.Y2 + (size_t)m * e.ldy + n) = uint2{pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3])};
+        return;
+    }
+    for (int c = 0; c < 4 && n + c < e.N; ++c) {            // ragged right edge / unaligned leading dimensions
+        const int nn = n + c, ch = nn % e.bias_mod;
+        float x = DT<T>::rnd(acc[c] + (e.bias ? DT<T>::ld(e.bias + ch) : 0.f));
+        if (e.act == 1) x = DT<T>::rnd(gelu_exact(x));
+        if (e.act == 3) x = DT<T>::rnd(x / (1.0f + expf(-x)));
+        if (e.act >= 4) x = DT<T>::rnd(act_extra(e.act, x));
+        if (e.scale) x = DT<T>::rnd(DT<T>::ld(e.scale + nn) * x);
+        if (e.res) x = x + DT<T>::ld(e.res + (size_t)m * e.ldr + nn);
+        x = DT<T>::rnd(x);
+        if (e.Y) DT<T>::st(e.Y + (size_t)m * e.ldy + nn, x);
+        if (e.Y2) DT<T>::st(e.Y2 + (size_t)m * e.ldy + nn, e.act2 ? DT<T>::rnd(elu1(x)) : snake_apply<T>(x, DT<T>::ld(e.sn_a + ch), DT<T>::ld(e.sn_ib + ch)));
+    }
+}
+
 // BM x BN output tile per workgroup, 4 waves as 2 x 2, each wave (BM/2) x (BN/2) = TM x TN MFMA tiles, K step 32,
 // double-buffered LDS (one barrier per step) fed by a PF-deep REGISTER prefetch: the global loads of step s + PF are
 // issued while step s is multiplied, so PF tiles (not one) are in flight per workgroup.  The streaming chunks make most
@@ -375,6 +445,236 @@ inline void glds_go(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, (rows + 127) / 128), dim3(256), shm, s, a);
 }
 
+// Largest-M variant (bf16): 256 x 256 tile, 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 block of 8 x 4 MFMA tiles
+// (one LDS byte feeds 2.7x the arithmetic of the 128 x 64 tile), K step 32, operands by global_load_lds into a RING OF FOUR
+// 32 KB stages: the copies of K steps t + 1 .. t + 3 are in flight while step t is multiplied, the wait before a step is
+// a counted vmcnt(8) (never 0 in the steady state) and there is ONE barrier per step -- it both publishes stage t and
+// proves that stage t - 1 (refilled right after it) has been read by everybody.  One workgroup per CU (128 KB LDS), two
+// waves per SIMD.  LDS rows are 64 B (four 16-byte chunks); LDS chunk c of row r holds global chunk c ^ ((-(r >> 2)) & 3),
+// which makes the 16-lane groups of a ds_read_b128 fragment read hit 16 distinct bank quads.  blockIdx is remapped so that
+// the workgroups of one XCD (every 8th id) cover a compact range of tiles (shared A / W panels stay in that XCD's L2).
+// Per output element the same ascending chain of 32-wide MFMA products as conv_gemm_kernel: bit-identical results.
+constexpr int kBigBM = 256, kBigBN = 256, kBigBK = 32, kBigStages = 4;
+template <int ST, bool TR>
+__global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, int tiles_total) {
+    typedef bf16_t T;
+    constexpr int BM = kBigBM, BN = kBigBN, BK = kBigBK, TM = 8, TN = 4;
+    static_assert(ST == 4, "ring of four stages");
+    extern __shared__ __attribute__((aligned(128))) unsigned char big_smem[];
+    T* As = reinterpret_cast<T*>(big_smem);                                   // [ST][BM * BK]
+    T* Bs = As + ST * BM * BK;                                                // [ST][BN * BK]
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware tile id (bijective also when the tile count is not a multiple of 8)
+    const int orig = blockIdx.x, xcd = orig & 7, q = tiles_total >> 3, r8 = tiles_total & 7;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int m0 = a.m_lo + (tile / tiles_x) * BM, n0 = (tile % tiles_x) * BN;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int K = a.n_taps * a.Cin, nsteps = K / BK;
+    const T* A = reinterpret_cast<const T*>(a.A);
+    const T* W = reinterpret_cast<const T*>(a.W);
+    const T* zero = reinterpret_cast<const T*>(g_gemm_zero_page);
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // copy slots: slot = p * 512 + tid -> row = slot >> 2, LDS chunk = slot & 3, source chunk = chunk ^ swz(row)
+    int arow[2], asrc[2];
+    const T* wsrc[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int slot = p * 512 + tid, r = slot >> 2, c = slot & 3;
+        const int sc = (c ^ ((0 - (r >> 2)) & 3)) * 8;
+        arow[p] = m0 + r;
+        asrc[p] = sc;
+        int n = n0 + r;
+        n = n < a.N ? n : a.N - 1;
+        wsrc[p] = W + (size_t)n * K + sc;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    auto issue = [&](int step, int buf) {
+        const int k0 = step * BK;
+        const int tap = k0 / a.Cin, ci = k0 - tap * a.Cin;
+        const int toff = a.tap_off[tap];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int ar = arow[p] + toff;
+            const bool ok = arow[p] < a.M && ar >= 0 && ar < a.a_rows;
+            const T* src = ok ? A + (size_t)ar * a.lda + ci + asrc[p] : zero;
+            __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(As + buf * BM * BK + (p * 512 + wave * 64) * 8), 16, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(wsrc[p] + k0), (lds_ptr)(Bs + buf * BN * BK + (p * 512 + wave * 64) * 8), 16, 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < ST - 1; ++d) issue(d < nsteps ? d : nsteps - 1, d);          // a short K re-copies its last step (never read)
+    const int swz = ((0 - (fr >> 2)) & 3);
+    const int a_off = (wr * 128 + fr) * BK + ((fq ^ swz) * 8);                       // + i * 16 * BK
+    const int b_off = (wc * 64 + fr) * BK + ((fq ^ swz) * 8);                        // + j * 16 * BK
+    // Fragments are double-buffered in registers: while step s is multiplied from `cur`, the fragments of step s + 1 are
+    // read into `nxt`, so no MFMA waits for LDS.  Iteration s: vmcnt(4) = my copies of step s + 1 have landed (only step
+    // s + 2's four may stay in flight); the barrier publishes them and proves that everybody's reads of step s - 1 are done
+    // (they fed the MFMAs of iteration s - 1); then step s + 3 is copied into the stage step s - 1 used.
+    bf16x8_t fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto load_frags = [&](bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN], int stage) {
+        const T* as = As + stage * BM * BK + a_off;
+        const T* bs = Bs + stage * BN * BK + b_off;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(bs + j * 16 * BK);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(as + i * 16 * BK);
+    };
+    auto body = [&](bf16x8_t (&ca)[TM], bf16x8_t (&cb)[TN], bf16x8_t (&na)[TM], bf16x8_t (&nb)[TN], int s) {
+        __builtin_amdgcn_s_waitcnt(0x0f74);                                          // vmcnt(4)
+        __builtin_amdgcn_s_barrier();
+        {
+            const int nx = s + ST - 1;
+            issue(nx < nsteps ? nx : nsteps - 1, (s + ST - 1) & (ST - 1));           // redundant re-copy past the end: never read
+        }
+        load_frags(na, nb, (s + 1) & (ST - 1));                                      // step s + 1 (garbage after the last step: unused)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[j], ca[i], acc[i][j], 0, 0, 0)      // operands swapped: C^T tile
+                               : __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+        // schedule: the 4 copies first, then one fragment read between every two MFMAs (left alone the compiler sinks all 12
+        // reads behind the 32 MFMAs and the next step starts by waiting for them)
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                           // VMEM (the LDS-DMA copies)
+#pragma unroll
+        for (int k = 0; k < TM + TN; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // one DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                       // two MFMAs
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 2 * (TM + TN), 0);
+    };
+    __builtin_amdgcn_s_waitcnt(0x0f78);                                              // vmcnt(8): my copies of step 0
+    __builtin_amdgcn_s_barrier();
+    load_frags(fa0, fb0, 0);
+    for (int s = 0; s < nsteps; s += 2) {
+        body(fa0, fb0, fa1, fb1, s);
+        if (s + 1 < nsteps) body(fa1, fb1, fa0, fb0, s + 1);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);                  // the tail's redundant copies must not outlive the workgroup's LDS
+    if constexpr (TR) {
+    // Variant TR (wide, plain outputs: the prefill's qkv / gate_up): the MFMAs ran with swapped operands, so each accumulator
+    // tile is the TRANSPOSE of the usual layout: a lane holds 4 consecutive output COLUMNS (n = j * 16 + fq * 4 + r) of one
+    // row (m = i * 16 + fr) -> 8-byte stores straight from the registers.  Plain outputs are stored inline; anything else
+    // goes through one out-of-line call per tile, which keeps the 32-tile loop small enough to unroll (a loop over `acc`
+    // that is not unrolled sends the accumulators to scratch).
+    const bool plain = a.act == 0 && !a.scale && !a.res && !a.Y2 && a.Y && (a.ldy & 3) == 0 && (a.bias_mod & 3) == 0;
+    const EpiArgs e{reinterpret_cast<const T*>(a.bias), a.bias_mod, reinterpret_cast<const T*>(a.scale), reinterpret_cast<const T*>(a.res), a.ldr,
+                    reinterpret_cast<T*>(a.Y), a.ldy, reinterpret_cast<T*>(a.Y2), reinterpret_cast<const T*>(a.sn_a),
+                    reinterpret_cast<const T*>(a.sn_ib), a.act, a.act2, a.M, a.N};
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int m = m0 + wr * 128 + i * 16 + fr, n = n0 + wc * 64 + j * 16 + fq * 4;
+            if (plain && n + 3 < a.N) {
+                if (m < a.M) {
+                    f32x4_t t = acc[i][j];
+                    if (a.bias) {
+                        const int ch = n % a.bias_mod;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) t[c] += DT<T>::ld(reinterpret_cast<const T*>(a.bias) + ch + c);
+                    }
+                    *reinterpret_cast<uint2*>(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + n) = uint2{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
+                }
+            } else {
+                epi_store4(e, acc[i][j], m, n);
+            }
+        }
+    } else {
+    // Variant !TR (tall outputs with the full epilogue: the codec's convs): through LDS, in two halves of 4 x 4 MFMA tiles.
+    // Each wave parks 64 x 64 fp32 values in its own 16 KB region (static register indices only), then walks them with 4
+    // columns per lane and 4 rows per wave instruction: 128 contiguous bytes per output row, per-column constants hoisted.
+    __syncthreads();
+    float* park = reinterpret_cast<float*>(big_smem) + wave * (64 * 64);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    park[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * 4 + i][j][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        const int mb = m0 + wr * 128 + half * 64;
+        const int nq = n0 + wc * 64 + (lane & 15) * 4;                   // this lane's 4 consecutive columns
+        const bool vec_ok = (a.ldy & 3) == 0 && (!a.res || (a.ldr & 3) == 0) && nq + 3 < a.N && a.bias_mod >= 4 && (a.bias_mod & 3) == 0;
+        if (vec_ok) {
+            const int ch = nq % a.bias_mod;
+            float b[4], sc[4], sa[4], sib[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                b[c] = a.bias ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + ch + c) : 0.f;
+                sc[c] = a.scale ? DT<T>::ld(reinterpret_cast<const T*>(a.scale) + nq + c) : 1.f;
+                sa[c] = (a.Y2 && !a.act2) ? DT<T>::ld(reinterpret_cast<const T*>(a.sn_a) + ch + c) : 0.f;
+                sib[c] = (a.Y2 && !a.act2) ? DT<T>::ld(reinterpret_cast<const T*>(a.sn_ib) + ch + c) : 0.f;
+            }
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 4 + (lane >> 4), m = mb + row;
+                if (m >= a.M) break;                                     // rows ascend with `it` for every lane group
+                const f32x4_t pv = *reinterpret_cast<const f32x4_t*>(park + row * 64 + (lane & 15) * 4);
+                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.res) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(a.res) + (size_t)m * a.ldr + nq);
+                    rv[0] = __uint_as_float(rr.x << 16); rv[1] = __uint_as_float(rr.x & 0xFFFF0000u);
+                    rv[2] = __uint_as_float(rr.y << 16); rv[3] = __uint_as_float(rr.y & 0xFFFF0000u);
+                }
+                float v[4], v2[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float x = DT<T>::rnd(pv[c] + b[c]);
+                    if (a.act == 1) x = DT<T>::rnd(gelu_exact(x));
+                    if (a.act == 3) x = DT<T>::rnd(x / (1.0f + expf(-x)));
+                    if (a.act >= 4) x = DT<T>::rnd(act_extra(a.act, x));
+                    if (a.scale) x = DT<T>::rnd(sc[c] * x);
+                    if (a.res) x = x + rv[c];
+                    v[c] = DT<T>::rnd(x);
+                    v2[c] = 0.f;
+                    if (a.Y2) v2[c] = a.act2 ? DT<T>::rnd(elu1(v[c])) : snake_apply<T>(v[c], sa[c], sib[c]);
+                }
+                if (a.Y) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + nq) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (a.Y2) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(a.Y2) + (size_t)m * a.ldy + nq) = uint2{pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3])};
+            }
+        } else {
+            const int n = n0 + wc * 64 + lane;
+            if (n < a.N)
+                for (int row = 0; row < 64; ++row) {
+                    const int m = mb + row;
+                    if (m >= a.M) break;
+                    epilogue_elem<T>(a, park[row * 64 + lane], m, n);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();                 // before the second half overwrites the region
+    }
+    }
+}
+
+template <bool TR>
+inline void big_go_t(const GemmArgs& a, hipStream_t s) {
+    const int rows = a.M - a.m_lo;
+    const int tx = (a.N + kBigBN - 1) / kBigBN, ty = (rows + kBigBM - 1) / kBigBM;
+    const size_t shm = (size_t)kBigStages * (kBigBM + kBigBN) * kBigBK * 2;
+    static bool attr = false;
+    auto kern = big_gemm_kernel<kBigStages, TR>;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = true; }
+    hipLaunchKernelGGL(kern, dim3(tx * ty), dim3(512), shm, s, a, tx, tx * ty);
+}
+// wide plain outputs (prefill qkv / gate_up: 980 vs 872 TFLOP/s) store straight from the transposed accumulators; tall outputs
+// with the full epilogue (codec convs: 661 vs 584) go through the LDS walk with 128-byte row stores
+inline void big_go(const GemmArgs& a, hipStream_t s) {
+    const bool plain = a.act == 0 && !a.scale && !a.res && !a.Y2;
+    if (plain && a.N >= 1024 && a.N % kBigBN == 0) big_go_t<true>(a, s); else big_go_t<false>(a, s);
+}
+
 // second pass of a split-K GEMM: sum the slices in index order (deterministic), then the ordinary epilogue
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs a) {
@@ -432,6 +732,14 @@ inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
         // 80-110 (130 VGPRs / 40 KB LDS leave 3 workgroups per CU against 5: the one-barrier K step is latency-bound, so
         // residency beats arithmetic intensity here) -- the 128x128 shape is therefore not used.
         const bool n64 = a.N % 64 == 0 || a.N >= 512;
+        // 256 x 256 ring-of-four tile (932 TFLOP/s at 4096^3 on random operands against 622 for the 128 x 64 glds tile): one
+        // workgroup per CU, so it pays only when the tiles are well filled AND the last wave of workgroups is mostly full
+        if (a.act != 2 && a.Cin % 32 == 0) {
+            const long tx = (a.N + kBigBN - 1) / kBigBN, ty = (rows + kBigBM - 1) / kBigBM, tiles = tx * ty;
+            const double fill = (double)rows * a.N / ((double)tiles * kBigBM * kBigBN);
+            const double eff = (double)tiles / (double)(((tiles + 255) / 256) * 256);
+            if (tiles >= 64 && fill * eff >= 0.66) { big_go(a, s); return; }
+        }
         if (a.N % 64 == 0 && a.Cin % 64 == 0 && wgs(128, 64) >= 512) {
             glds_go<64, 2>(a, s);
         } else if (n64 && wgs(128, 64) >= 512) gemm_go<T, 128, 64>(a, s);

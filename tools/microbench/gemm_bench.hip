@@ -18,6 +18,8 @@ int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 10;
     std::vector<Shape> shapes = {
         {"square 4096^3", 4096, 4096, 4096, 1, 1},
+        {"big-tile overhead probe", 4096, 4096, 128, 1, 1},
+        {"big-tile odd step count", 4096, 4096, 96 * 7, 1, 1},
         {"prefill4k qkv  (1.7B)", 4096, 4096, 2048, 1, 1},
         {"prefill4k gate_up", 4096, 12288, 2048, 1, 1},
         {"prefill4k down", 4096, 2048, 6144, 1, 1},
@@ -63,6 +65,30 @@ int main(int argc, char** argv) {
             float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
             printf("%-28s %9.3f us  %8.1f TFLOP/s\n", name, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
         };
+        {   // big tile vs the register-staged kernel on random operands: must agree bit for bit (same MFMA chain per element)
+            std::vector<uint16_t> ha((size_t)M * K), hw((size_t)N * K);
+            uint32_t x = 777;
+            auto rnd = [&]() { x = x * 1664525u + 1013904223u; return x >> 16; };
+            for (auto& v : ha) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 128.f);
+            for (auto& v : hw) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 1024.f);
+            hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice); hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+            void* Y2; hipMalloc(&Y2, (size_t)M * N * 2);
+            glds_go<64, 2>(a, s);
+            GemmArgs b = a; b.Y = Y2;
+            big_go(b, s);
+            hipStreamSynchronize(s);
+            std::vector<uint16_t> y1((size_t)M * N), y2((size_t)M * N);
+            hipMemcpy(y1.data(), Y, y1.size() * 2, hipMemcpyDeviceToHost); hipMemcpy(y2.data(), Y2, y2.size() * 2, hipMemcpyDeviceToHost);
+            size_t bad = 0, first = 0;
+            for (size_t i = 0; i < y1.size(); ++i) if (y1[i] != y2[i]) { if (!bad) first = i; ++bad; }
+            printf("big 256x256 vs glds 128x64 on random operands: %zu / %zu elements differ%s\n", bad, y1.size(), bad ? "  <-- MISMATCH" : " (bit-identical)");
+            if (bad) printf("  first at row %zu col %zu: %04x vs %04x\n", first / N, first % N, y1[first], y2[first]);
+            hipFree(Y2);
+            rung("big 256x256 ring-4 (random)", big_go);
+            rung("glds 128x64 2 st (random)", glds_go<64, 2>);
+            hipMemset(A, 0x3c, (size_t)M * K * 2); hipMemset(W, 0x3c, (size_t)N * K * 2);
+        }
+        rung("big 256x256 ring-4", big_go);
         rung("glds 128x64 2 stages", glds_go<64, 2>);
         rung("glds 128x64 3 stages", glds_go<64, 3>);
         rung("glds 128x128 2 stages", glds_go<128, 2>);
