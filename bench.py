@@ -543,7 +543,7 @@ def model_1p7b_block(device):
         t = cfg.talker
         gemm_fl = prefill_gemm_flops(cfg, 4096)
         attn_fl = 4.0 * (4096 * 4097 / 2) * t.head_dim * t.num_attention_heads * t.num_hidden_layers
-        out["prefill_4096"] = {"workload": "configs[4] shape: 4096-token prompt, 28 layers at 1.7B dims, flash MFMA attention + glds GEMMs",
+        out["prefill_4096"] = {"workload": "configs[4] shape: 4096-token prompt, 28 layers at 1.7B dims, flash MFMA attention + 256x256 ring / glds GEMMs",
                                "ms": round(pms, 2), "gemm_tflop": round(gemm_fl / 1e12, 2), "attention_tflop": round(attn_fl / 1e12, 2),
                                "achieved": round((gemm_fl + attn_fl) / (pms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round((gemm_fl + attn_fl) / (pms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "bound": "mfma"}
