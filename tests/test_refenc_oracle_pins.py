@@ -139,3 +139,42 @@ def test_mel_front_end_tables():
     b2 = RO.slaney_mel(rc.sample_rate, rc.n_fft, rc.mel_dim, rc.fmin, rc.fmax)
     assert torch.allclose(basis[:, : rc.n_fft // 2 + 1], b2, atol=1e-7)
     assert (b2.sum(1) > 0).all()
+
+
+def test_strided_conv_packing_is_a_two_tap_gemm_over_the_row_view():
+    """Host logic of fq3hip/refenc.py: a causal conv with k = 2r, stride r equals a 2-tap stride-1 GEMM over the
+    [T/r][r*C] view of the (zero-tailed) input with the packed weight [Cout][2][r*Cin] -- what csrc/fq3_refenc.hip runs."""
+    from fq3hip.refenc import pack_ref_audio_weights
+    rc = tiny_ref_audio_config()
+    W = synth_ref_audio_weights(rc, 3)
+    P = pack_ref_audio_weights(W, rc)
+    g = torch.Generator().manual_seed(1)
+    li, C = 1, rc.num_filters
+    for r in rc.ratios:
+        li += rc.num_residual_layers + 1
+        name = f"encoder.encoder.layers.{li}.conv"
+        for T in (5 * r, 5 * r + 1, 7 * r - 1):
+            x = torch.randn(1, C, T, generator=g, dtype=torch.float64)
+            ref = RO.mimi_conv1d(x, W[name + ".weight"].double(), W[name + ".bias"].double(), stride=r)[0].t()     # [T', 2C]
+            Tn = -(-T // r)
+            rows = torch.zeros(Tn * r, C, dtype=torch.float64)
+            rows[:T] = x[0].t()
+            view = rows.reshape(Tn, r * C)
+            prev = torch.cat([torch.zeros(1, r * C, dtype=torch.float64), view[:-1]], 0)                            # tap offset -1 (causal)
+            pw = P[name + ".weight"].double()                                                                        # [2C, 2, r*C]
+            got = prev @ pw[:, 0].t() + view @ pw[:, 1].t() + W[name + ".bias"].double()
+            assert got.shape == ref.shape == (Tn, 2 * C)
+            assert torch.allclose(got, ref, atol=1e-10), (r, T)
+        li += 1
+        C *= 2
+    # the stride-2 conv after the transformer: replicate padding = 2 copies of the first row, the last row repeated to even length
+    H = rc.hidden_size
+    for T in (6, 7):
+        x = torch.randn(1, H, T, generator=g, dtype=torch.float64)
+        ref = RO.mimi_conv1d(x, W["encoder.downsample.conv.weight"].double(), None, stride=2, pad_mode="replicate")[0].t()
+        T5 = (T + 1) // 2
+        idx = torch.clamp(torch.arange(2 + 2 * T5) - 2, 0, T - 1)
+        padded = x[0].t()[idx].reshape(1 + T5, 2 * H)
+        pw = P["encoder.downsample.conv.weight"].double()
+        got = padded[:-1] @ pw[:, 0].t() + padded[1:] @ pw[:, 1].t()
+        assert torch.allclose(got, ref, atol=1e-10), T
