@@ -158,3 +158,87 @@ def test_openai_speech_endpoint_contract():
     assert client.post("/v1/audio/speech", json={"input": "x", "voice": "alloy", "response_format": "flac"}).status_code == 400
     client2 = TestClient(create_app(m, voices, default_voice=None, scheduler="lock"))
     assert client2.post("/v1/audio/speech", json={"input": "x", "voice": "nobody"}).status_code == 400
+
+
+# ---- OpenAI-compatible endpoint, batch scheduler (scripted model + scripted lock-step decoder) ---------------------------------
+class _ScriptedBatchModel(_ScriptedModel):
+    """What BatchWorker needs from a model: _prepare_generation, _gen_kwargs, streaming_vocoder, _batch_decoder(...).run."""
+
+    class _Voc:
+        def __init__(self):
+            self.n = 0
+
+        def push(self, codes, ready_event=None):
+            self.n += 1
+            return np.full(100 * int(codes.shape[0]), 0.5, np.float32), 24000
+
+    class _Dec:
+        def __init__(self, owner):
+            self.owner = owner
+
+        def run(self, requests, on_error="raise", source=None, chunk_frames=None):
+            import torch
+            pending = list(requests)
+            self.owner.calls.append(("run", chunk_frames))
+            while pending:
+                req = pending.pop(0)
+                n = len(req.gen_kwargs["text"])
+                if req.gen_kwargs["text"] == "boom":
+                    yield req.rid, None, {"error": "RuntimeError('Input is too long')", "steps": 0}
+                else:
+                    done = 0
+                    while n - done > chunk_frames:
+                        done += chunk_frames
+                        yield req.rid, torch.zeros(chunk_frames, 16, dtype=torch.long), {"is_final": False, "total_steps_so_far": done}
+                    yield req.rid, torch.zeros(n - done, 16, dtype=torch.long), {"is_final": True, "total_steps_so_far": n, "steps": n}
+                while source is not None:                    # requests that arrived meanwhile join the same run
+                    r = source()
+                    if r is None:
+                        break
+                    pending.append(r)
+
+    def _prepare_generation(self, text, **kw):
+        if text == "bad voice":
+            raise ValueError("ref_text is required")
+        self.calls.append(("prepare", text, kw))
+        return None, None, None, text, None, None, None, None
+
+    @staticmethod
+    def _gen_kwargs(*a):
+        return {}
+
+    def streaming_vocoder(self, rc, chunk):
+        return self._Voc()
+
+    def _batch_decoder(self, lanes):
+        return self._Dec(self)
+
+
+def test_openai_endpoint_batch_scheduler_streams_and_reports_errors(monkeypatch):
+    from fastapi.testclient import TestClient
+    import fq3hip.batching as Bt
+    from fq3hip.server import create_app
+
+    class Req:                                            # BatchRequest stand-in keeping the text for the scripted decoder
+        def __init__(self, rid, talker, tie, tam, tth, tpe, config, kw):
+            self.rid, self.gen_kwargs = rid, dict(kw, text=tie)
+
+    monkeypatch.setattr(Bt, "BatchRequest", Req)
+    m = _ScriptedBatchModel()
+    voices = {"alloy": {"voice_clone_prompt": {"x": 1}, "ref_text": "t", "language": "English", "chunk_size": 4}}
+    client = TestClient(create_app(m, voices, default_voice="alloy", scheduler="batch", lanes=2))
+    assert client.get("/health").json()["scheduler"] == "batch"
+    r = client.post("/v1/audio/speech", json={"input": "ten chars!", "voice": "alloy", "response_format": "wav"})
+    assert r.status_code == 200 and r.content[:4] == b"RIFF" and struct.unpack("<I", r.content[40:44])[0] == 0xFFFFFFFF
+    pcm = np.frombuffer(r.content[44:], dtype="<i2")
+    assert len(pcm) == 100 * 10 and abs(int(pcm[0]) - 16384) <= 1            # chunks of 4 + 4 + 2 frames, 100 samples each
+    assert ("run", 4) in m.calls
+    r = client.post("/v1/audio/speech", json={"input": "abcde", "voice": "alloy", "response_format": "pcm"})
+    assert r.status_code == 200 and len(r.content) == 2 * 100 * 5
+    # a request the decoder rejects, and one that fails before decoding, are 500s with the reason; the worker survives both
+    r = client.post("/v1/audio/speech", json={"input": "boom", "voice": "alloy"})
+    assert r.status_code == 500 and "too long" in r.text
+    r = client.post("/v1/audio/speech", json={"input": "bad voice", "voice": "alloy"})
+    assert r.status_code == 500 and "ref_text is required" in r.text
+    r = client.post("/v1/audio/speech", json={"input": "ok", "voice": "alloy", "response_format": "pcm"})
+    assert r.status_code == 200 and len(r.content) == 2 * 100 * 2
