@@ -455,11 +455,14 @@ inline void glds_go(const GemmArgs& a, hipStream_t s) {
 // the workgroups of one XCD (every 8th id) cover a compact range of tiles (shared A / W panels stay in that XCD's L2).
 // Per output element the same ascending chain of 32-wide MFMA products as conv_gemm_kernel: bit-identical results.
 constexpr int kBigBM = 256, kBigBN = 256, kBigBK = 32, kBigStages = 4;
-template <int ST, bool TR>
+template <int ST, bool TR, int BN>
 __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, int tiles_total) {
     typedef bf16_t T;
-    constexpr int BM = kBigBM, BN = kBigBN, BK = kBigBK, TM = 8, TN = 4;
+    // BN = 256: wave block 128 x 64 (8 x 4 tiles).  BN = 128 (TR only; N = 2048 at M = 4096 would fill half the CUs with 256-wide
+    // tiles): wave block 128 x 32 (8 x 2 tiles), 3 copies per thread and step.
+    constexpr int BM = kBigBM, BK = kBigBK, TM = 8, TN = BN / 64, WN = BN / 4, NPB = BN / 128, CP = 2 + NPB;
     static_assert(ST == 4, "ring of four stages");
+    static_assert(BN == 256 || (BN == 128 && TR), "256-wide tiles, or 128-wide with the register epilogue");
     extern __shared__ __attribute__((aligned(128))) unsigned char big_smem[];
     T* As = reinterpret_cast<T*>(big_smem);                                   // [ST][BM * BK]
     T* Bs = As + ST * BM * BK;                                                // [ST][BN * BK]
@@ -481,16 +484,18 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // copy slots: slot = p * 512 + tid -> row = slot >> 2, LDS chunk = slot & 3, source chunk = chunk ^ swz(row)
     int arow[2], asrc[2];
-    const T* wsrc[2];
+    const T* wsrc[NPB];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int slot = p * 512 + tid, r = slot >> 2, c = slot & 3;
         const int sc = (c ^ ((0 - (r >> 2)) & 3)) * 8;
         arow[p] = m0 + r;
         asrc[p] = sc;
-        int n = n0 + r;
-        n = n < a.N ? n : a.N - 1;
-        wsrc[p] = W + (size_t)n * K + sc;
+        if (p < NPB) {
+            int n = n0 + r;
+            n = n < a.N ? n : a.N - 1;
+            wsrc[p] = W + (size_t)n * K + sc;
+        }
     }
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
@@ -506,14 +511,14 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
             __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(As + buf * BM * BK + (p * 512 + wave * 64) * 8), 16, 0, 0);
         }
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < NPB; ++p)
             __builtin_amdgcn_global_load_lds((gbl_ptr)(wsrc[p] + k0), (lds_ptr)(Bs + buf * BN * BK + (p * 512 + wave * 64) * 8), 16, 0, 0);
     };
 #pragma unroll
     for (int d = 0; d < ST - 1; ++d) issue(d < nsteps ? d : nsteps - 1, d);          // a short K re-copies its last step (never read)
     const int swz = ((0 - (fr >> 2)) & 3);
     const int a_off = (wr * 128 + fr) * BK + ((fq ^ swz) * 8);                       // + i * 16 * BK
-    const int b_off = (wc * 64 + fr) * BK + ((fq ^ swz) * 8);                        // + j * 16 * BK
+    const int b_off = (wc * WN + fr) * BK + ((fq ^ swz) * 8);                        // + j * 16 * BK
     // Fragments are double-buffered in registers: while step s is multiplied from `cur`, the fragments of step s + 1 are
     // read into `nxt`, so no MFMA waits for LDS.  Iteration s: vmcnt(4) = my copies of step s + 1 have landed (only step
     // s + 2's four may stay in flight); the barrier publishes them and proves that everybody's reads of step s - 1 are done
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
         for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(as + i * 16 * BK);
     };
     auto body = [&](bf16x8_t (&ca)[TM], bf16x8_t (&cb)[TN], bf16x8_t (&na)[TM], bf16x8_t (&nb)[TN], int s) {
-        __builtin_amdgcn_s_waitcnt(0x0f74);                                          // vmcnt(4)
+        if constexpr (CP == 4) __builtin_amdgcn_s_waitcnt(0x0f74); else __builtin_amdgcn_s_waitcnt(0x0f73);      // vmcnt(CP): one step's copies may stay in flight
         __builtin_amdgcn_s_barrier();
         {
             const int nx = s + ST - 1;
@@ -543,15 +548,16 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
         // schedule: the 4 copies first, then one fragment read between every two MFMAs (left alone the compiler sinks all 12
         // reads behind the 32 MFMAs and the next step starts by waiting for them)
-        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                           // VMEM (the LDS-DMA copies)
+        constexpr int PER = (TM * TN) / (TM + TN);                                   // MFMAs per fragment read: 2 (BN = 256) or 1
+        __builtin_amdgcn_sched_group_barrier(0x020, CP, 0);                          // VMEM (the LDS-DMA copies)
 #pragma unroll
         for (int k = 0; k < TM + TN; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // one DS read
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                       // two MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);                     // PER MFMAs
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 2 * (TM + TN), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - PER * (TM + TN), 0);
     };
-    __builtin_amdgcn_s_waitcnt(0x0f78);                                              // vmcnt(8): my copies of step 0
+    if constexpr (CP == 4) __builtin_amdgcn_s_waitcnt(0x0f78); else __builtin_amdgcn_s_waitcnt(0x0f76);          // vmcnt(2 CP): my copies of step 0
     __builtin_amdgcn_s_barrier();
     load_frags(fa0, fb0, 0);
     for (int s = 0; s < nsteps; s += 2) {
@@ -573,7 +579,7 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int m = m0 + wr * 128 + i * 16 + fr, n = n0 + wc * 64 + j * 16 + fq * 4;
+            const int m = m0 + wr * 128 + i * 16 + fr, n = n0 + wc * WN + j * 16 + fq * 4;
             if (plain && n + 3 < a.N) {
                 if (m < a.M) {
                     f32x4_t t = acc[i][j];
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
                 epi_store4(e, acc[i][j], m, n);
             }
         }
-    } else {
+    } else if constexpr (BN == 256) {
     // Variant !TR (tall outputs with the full epilogue: the codec's convs): through LDS, in two halves of 4 x 4 MFMA tiles.
     // Each wave parks 64 x 64 fp32 values in its own 16 KB region (static register indices only), then walks them with 4
     // columns per lane and 4 rows per wave instruction: 128 contiguous bytes per output row, per-column constants hoisted.
@@ -658,13 +664,13 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
     }
 }
 
-template <bool TR>
+template <bool TR, int BN>
 inline void big_go_t(const GemmArgs& a, hipStream_t s) {
     const int rows = a.M - a.m_lo;
-    const int tx = (a.N + kBigBN - 1) / kBigBN, ty = (rows + kBigBM - 1) / kBigBM;
-    const size_t shm = (size_t)kBigStages * (kBigBM + kBigBN) * kBigBK * 2;
+    const int tx = (a.N + BN - 1) / BN, ty = (rows + kBigBM - 1) / kBigBM;
+    const size_t shm = (size_t)kBigStages * (kBigBM + BN) * kBigBK * 2;
     static bool attr = false;
-    auto kern = big_gemm_kernel<kBigStages, TR>;
+    auto kern = big_gemm_kernel<kBigStages, TR, BN>;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = true; }
     hipLaunchKernelGGL(kern, dim3(tx * ty), dim3(512), shm, s, a, tx, tx * ty);
 }
@@ -672,7 +678,14 @@ inline void big_go_t(const GemmArgs& a, hipStream_t s) {
 // with the full epilogue (codec convs: 661 vs 584) go through the LDS walk with 128-byte row stores
 inline void big_go(const GemmArgs& a, hipStream_t s) {
     const bool plain = a.act == 0 && !a.scale && !a.res && !a.Y2;
-    if (plain && a.N >= 1024 && a.N % kBigBN == 0) big_go_t<true>(a, s); else big_go_t<false>(a, s);
+    if (plain && a.N >= 1024 && a.N % kBigBN == 0) big_go_t<true, kBigBN>(a, s); else big_go_t<false, kBigBN>(a, s);
+}
+// does a tiling into 256 x bn tiles use the chip well?  (fill of the tiles) x (fill of the last wave of workgroups)
+inline bool big_tiling_pays(int rows, int N, int bn) {
+    const long tx = (N + bn - 1) / bn, ty = (rows + kBigBM - 1) / kBigBM, tiles = tx * ty;
+    const double fill = (double)rows * N / ((double)tiles * kBigBM * bn);
+    const double eff = (double)tiles / (double)(((tiles + 255) / 256) * 256);
+    return tiles >= 64 && fill * eff >= 0.66;
 }
 
 // second pass of a split-K GEMM: sum the slices in index order (deterministic), then the ordinary epilogue
@@ -735,10 +748,9 @@ inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
         // 256 x 256 ring-of-four tile (932 TFLOP/s at 4096^3 on random operands against 622 for the 128 x 64 glds tile): one
         // workgroup per CU, so it pays only when the tiles are well filled AND the last wave of workgroups is mostly full
         if (a.act != 2 && a.Cin % 32 == 0) {
-            const long tx = (a.N + kBigBN - 1) / kBigBN, ty = (rows + kBigBM - 1) / kBigBM, tiles = tx * ty;
-            const double fill = (double)rows * a.N / ((double)tiles * kBigBM * kBigBN);
-            const double eff = (double)tiles / (double)(((tiles + 255) / 256) * 256);
-            if (tiles >= 64 && fill * eff >= 0.66) { big_go(a, s); return; }
+            if (big_tiling_pays(rows, a.N, kBigBN)) { big_go(a, s); return; }
+            // 256 x 128 tiles where the 256-wide ones would leave half the CUs idle (N = 2048 at M = 4096: o_proj / down at 1.7B)
+            if (rows >= 1024 && a.N % 128 == 0 && big_tiling_pays(rows, a.N, 128)) { big_go_t<true, 128>(a, s); return; }
         }
         if (a.N % 64 == 0 && a.Cin % 64 == 0 && wgs(128, 64) >= 512) {
             glds_go<64, 2>(a, s);

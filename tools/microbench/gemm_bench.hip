@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
         {"prefill4k qkv  (1.7B)", 4096, 4096, 2048, 1, 1},
         {"prefill4k gate_up", 4096, 12288, 2048, 1, 1},
         {"prefill4k down", 4096, 2048, 6144, 1, 1},
+        {"prefill4k o_proj", 4096, 2048, 2048, 1, 1},
         {"prefill200 qkv (0.6B)", 200, 4096, 1024, 1, 1},
         {"prefill200 gate_up", 200, 6144, 1024, 1, 1},
         {"prefill200 down", 200, 1024, 3072, 1, 1},
@@ -83,7 +84,16 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < y1.size(); ++i) if (y1[i] != y2[i]) { if (!bad) first = i; ++bad; }
             printf("big 256x256 vs glds 128x64 on random operands: %zu / %zu elements differ%s\n", bad, y1.size(), bad ? "  <-- MISMATCH" : " (bit-identical)");
             if (bad) printf("  first at row %zu col %zu: %04x vs %04x\n", first / N, first % N, y1[first], y2[first]);
+            {   // the 256 x 128 variant on the same operands
+                big_go_t<true, 128>(b, s);
+                hipStreamSynchronize(s);
+                hipMemcpy(y2.data(), Y2, y2.size() * 2, hipMemcpyDeviceToHost);
+                size_t bad2 = 0;
+                for (size_t i = 0; i < y1.size(); ++i) bad2 += y1[i] != y2[i];
+                printf("big 256x128 vs glds 128x64 on random operands: %zu / %zu elements differ%s\n", bad2, y1.size(), bad2 ? "  <-- MISMATCH" : " (bit-identical)");
+            }
             hipFree(Y2);
+            rung("big 256x128 ring-4 (random)", big_go_t<true, 128>);
             rung("big 256x256 ring-4 (random)", big_go);
             rung("glds 128x64 2 st (random)", glds_go<64, 2>);
             hipMemset(A, 0x3c, (size_t)M * K * 2); hipMemset(W, 0x3c, (size_t)N * K * 2);
