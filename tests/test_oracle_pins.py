@@ -114,3 +114,28 @@ def test_fulldepth_golden_is_the_oracle(golden_dir):
     assert np.array_equal(r["codes"], g["0p6b_f32_codes"][:3])
     assert np.allclose(r["t_margin"][:3], g["0p6b_f32_t_margin"][:3], atol=1e-4)
     assert np.allclose(r["p_top1"], g["0p6b_f32_p_top1"][:3], atol=1e-4)
+
+
+@pytest.mark.parametrize("sizes,ref_frames", [([8] * 6, 5), ([4, 4, 4, 4, 4, 4, 4, 4, 4, 3], 0), ([12, 12, 12, 7], 9), ([8, 16, 8, 8, 3], 4)])
+def test_product_streaming_vocoder_is_the_reference_windowing(sizes, ref_frames):
+    """fq3hip.model.StreamingVocoder (the state machine behind generate_voice_clone_streaming AND the batched streaming
+    paths, here on its synchronous foreign-tokenizer path) emits exactly what the restated reference windowing
+    (model.py:1052-1137) emits -- also for ragged chunk sizes, which only the batched scheduler produces."""
+    from fq3hip.model import StreamingVocoder
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, torch.float32, parts=("codec",))
+    tok = O.OracleSpeechTokenizer(cfg, W)
+    g = torch.Generator().manual_seed(3)
+    n = sum(sizes)
+    codes = torch.randint(0, cfg.codec.codebook_size, (n, 16), generator=g)
+    ref = torch.randint(0, cfg.codec.codebook_size, (ref_frames, 16), generator=g) if ref_frames else None
+    chunks, pos = [], 0
+    for k in sizes:
+        chunks.append(codes[pos:pos + k]); pos += k
+    want = list(O.streaming_vocode(tok, chunks, ref, sizes[0]))
+    voc = StreamingVocoder(tok, ref, sizes[0], "cpu", side_stream=None)
+    got = [voc.push(c)[0] for c in chunks]
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert voc.spf is not None or n < max(25, sizes[0])
