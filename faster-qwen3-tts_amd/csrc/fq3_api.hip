@@ -507,6 +507,42 @@ extern "C" int fq3_prefill(fq3_ctx* c, const void* embeds, int L, int n_pad, voi
     return FQ3_OK;
 }
 
+extern "C" int fq3_prefill_batch(fq3_ctx* const* ctxs, int n, const void* const* embeds, const int* L, const int* n_pad,
+                                 void* const* out_logits, void* const* out_hidden, void* stream) {
+    if (!ctxs || !embeds || !L || !n_pad || !out_hidden || n < 1 || n > 64) return fail(FQ3_EINVAL, "fq3_prefill_batch: bad argument");
+    long total = 0;
+    bool packed = true;
+    for (int q = 0; q < n; ++q) {
+        fq3_ctx* c = ctxs[q];
+        NEED_BOUND(c);
+        if (!embeds[q] || !out_hidden[q] || L[q] <= 0) return fail(FQ3_EINVAL, "fq3_prefill_batch: bad prompt");
+        if (L[q] > c->cfg.max_seq_len) {
+            char b[256];
+            snprintf(b, sizeof b, "Input is too long: prefill has %d tokens but max_seq_len=%d. Use shorter text or shorter reference audio.",
+                     L[q], c->cfg.max_seq_len);
+            return fail(FQ3_ETOOLONG, b);
+        }
+        if (n_pad[q] < 0 || n_pad[q] >= L[q]) return fail(FQ3_EINVAL, "n_pad");
+        total += L[q];
+        // one pass over the weights needs ONE set of weights, and the matrix-core path for every prompt
+        const fq3_ctx* c0 = ctxs[0];
+        packed = packed && c->cfg.dtype == c0->cfg.dtype && c->wt.codec_head == c0->wt.codec_head && c->tl.size() == c0->tl.size() &&
+                 !c->tl.empty() && c->tl[0].qkv == c0->tl[0].qkv && c->prefill_mode != 1 && L[q] - n_pad[q] >= 4;
+        for (int p = 0; p < q; ++p) if (ctxs[p] == c) return fail(FQ3_EINVAL, "fq3_prefill_batch: a context appears twice");
+    }
+    packed = packed && n > 1 && total <= ctxs[0]->cfg.max_seq_len;
+    if (!packed) {                                       // not packable: the n single prefills
+        for (int q = 0; q < n; ++q)
+            if (int r = fq3_prefill(ctxs[q], embeds[q], L[q], n_pad[q], out_logits ? out_logits[q] : nullptr, out_hidden[q], stream)) return r;
+        return FQ3_OK;
+    }
+    for (int q = 0; q < n; ++q)
+        if (int r = fq3_set_generation_state(ctxs[q], n_pad[q], -n_pad[q])) return r;
+    if (int r = fq3_prefill_batch_mfma_(ctxs, n, embeds, L, n_pad, out_logits, out_hidden, (hipStream_t)stream)) return r;
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
 int fq3_codec_head_launch_(fq3_ctx* c, const void* hidden, void* out_logits, hipStream_t s) {
     GemvArgs g{};
     g.W = c->wt.codec_head; g.N = c->cfg.talker.vocab; g.K = c->cfg.talker.hidden; g.x = hidden; g.y = out_logits;

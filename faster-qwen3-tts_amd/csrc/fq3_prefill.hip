@@ -5,6 +5,7 @@
 // Rounding points are those of the decode path (one rounding to T per Linear / norm / RoPE / residual add),
 // so prefill + decode match the oracle's matrix-form prefill.
 #include "fq3_ctx.h"
+#include <vector>
 #include "codec_kernels.cuh"
 
 using namespace fq3;
@@ -315,7 +316,83 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
     return 0;
 }
 
+// The same prefill for n prompts at once: everything row-wise (norms, the four GEMMs, SwiGLU) runs over the PACKED rows of all
+// prompts -- one pass over the layer's weights instead of n -- and only the sequence-specific steps run per prompt on its
+// slice of the packed rows: q/k norm + RoPE + KV write into that context's own cache, and causal attention over it.
+// Workspaces are those of ctxs[0] (sum of the lengths <= its max_seq_len).  Per element the arithmetic is that of
+// prefill_t; what can differ is the GEMM tile / split-K choice, which depends on the row count (bf16: last-bit level).
+template <typename T>
+int prefill_batch_t(fq3_ctx* const* cs, int n, const void* const* embeds, const int* L, const int* n_pad, void* const* out_logits,
+                    void* const* out_hidden, hipStream_t s) {
+    fq3_ctx* c = cs[0];
+    const fq3_stack_dims& d = c->cfg.talker;
+    const int H = d.hidden, I = d.inter, NH = d.n_heads, NKV = d.n_kv_heads;
+    const int QD = NH * kHeadDim, KVD = NKV * kHeadDim, per = QD + 2 * KVD;
+    if (H % 32 || I % 32) return fq3_fail_(FQ3_EUNSUPPORTED, "MFMA prefill needs hidden and intermediate sizes that are multiples of 32");
+    const size_t rows = (size_t)c->cfg.max_seq_len;
+    if (!c->pf_x) {
+        int r;
+        if ((r = fq3_dmalloc_(c, &c->pf_x, rows * H * c->esz))) return r;
+        if ((r = fq3_dmalloc_(c, &c->pf_xn, rows * H * c->esz))) return r;
+        if ((r = fq3_dmalloc_(c, &c->pf_qkv, rows * per * c->esz))) return r;
+        if ((r = fq3_dmalloc_(c, &c->pf_att, rows * QD * c->esz))) return r;
+        if ((r = fq3_dmalloc_(c, &c->pf_gu, rows * 2 * I * c->esz))) return r;
+        if ((r = fq3_dmalloc_(c, &c->pf_act, rows * I * c->esz))) return r;
+        if ((r = fq3_dmalloc_(c, &c->pf_ws, (size_t)kPrefillWsFloats * sizeof(float)))) return r;
+    }
+    T *X = (T*)c->pf_x, *XN = (T*)c->pf_xn, *QKV = (T*)c->pf_qkv, *ATT = (T*)c->pf_att, *GU = (T*)c->pf_gu, *ACT = (T*)c->pf_act;
+    std::vector<int> off(n + 1, 0);
+    for (int q = 0; q < n; ++q) off[q + 1] = off[q] + L[q];
+    const int Lt = off[n];
+    for (int q = 0; q < n; ++q)
+        if (hipMemcpyAsync(X + (size_t)off[q] * H, embeds[q], (size_t)L[q] * H * c->esz, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return fq3_fail_(FQ3_EHIP, "prefill: copy of the prompt embeddings failed");
+    const float scale = 1.0f / sqrtf((float)kHeadDim);
+    for (int i = 0; i < d.n_layers; ++i) {
+        const fq3_layer_weights& w = c->tl[i];
+        hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Lt + 3) / 4), dim3(256), 0, s, (const T*)X, (const T*)w.input_norm, XN, 0, Lt, H, d.rms_eps);
+        gemm<T>(lin<T>(XN, Lt, H, w.qkv, per, QKV), s);
+        for (int q = 0; q < n; ++q) {
+            fq3_ctx* cq = cs[q];
+            T* qkv = QKV + (size_t)off[q] * per;
+            T* att = ATT + (size_t)off[q] * QD;
+            const int Lq = L[q], pq = n_pad[q];
+            hipLaunchKernelGGL((qk_norm_rope_kv_kernel<T>), dim3((Lq * (NH + 2 * NKV) + 3) / 4), dim3(256), 0, s, qkv, (const T*)w.q_norm,
+                               (const T*)w.k_norm, d.rms_eps, c->wt.talker_cos, c->wt.talker_sin, c->wt.talker_rope_len, cq->rope_delta,
+                               (T*)cq->tk.k[i], (T*)cq->tk.v[i], cq->tk.max_seq, Lq, pq, NH, NKV);
+            bool flash = false;
+            if constexpr (sizeof(T) == 2) flash = c->opt_flash_prefill != 0;
+            if constexpr (sizeof(T) == 2) {
+                if (flash)
+                    hipLaunchKernelGGL(flash_prefill_kernel, dim3((Lq + kFaQ - 1) / kFaQ, NH), dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)cq->tk.k[i],
+                                       (const bf16_t*)cq->tk.v[i], (bf16_t*)att, cq->tk.max_seq, Lq, pq, NH, NKV, scale);
+            }
+            if (!flash)
+                hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((Lq * NH + 3) / 4), dim3(256), 0, s, (const T*)qkv, (const T*)cq->tk.k[i],
+                                   (const T*)cq->tk.v[i], att, cq->tk.max_seq, Lq, pq, NH, NKV, scale);
+        }
+        { GemmArgs a = lin<T>(ATT, Lt, QD, w.o, H, X); a.res = X; a.ldr = H; a.ws = (float*)c->pf_ws; a.ws_floats = kPrefillWsFloats; gemm<T>(a, s); }
+        hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Lt + 3) / 4), dim3(256), 0, s, (const T*)X, (const T*)w.post_norm, XN, 0, Lt, H, d.rms_eps);
+        gemm<T>(lin<T>(XN, Lt, H, w.gate_up, 2 * I, GU), s);
+        hipLaunchKernelGGL((silu_mul_kernel<T>), dim3((unsigned)(((size_t)Lt * I + 255) / 256)), dim3(256), 0, s, (const T*)GU, ACT, Lt, I);
+        { GemmArgs a = lin<T>(ACT, Lt, I, w.down, H, X); a.res = X; a.ldr = H; a.ws = (float*)c->pf_ws; a.ws_floats = kPrefillWsFloats; gemm<T>(a, s); }
+    }
+    for (int q = 0; q < n; ++q) {
+        hipLaunchKernelGGL((rmsnorm_kernel<T>), dim3(1), dim3(256), 0, s, (const T*)X + (size_t)(off[q + 1] - 1) * H, (const T*)c->wt.talker_final_norm,
+                           (T*)out_hidden[q], H, d.rms_eps);
+        if (out_logits && out_logits[q])
+            if (int r = fq3_codec_head_launch_(cs[q], out_hidden[q], out_logits[q], s)) return r;
+    }
+    return 0;
+}
+
 }  // namespace
+
+int fq3_prefill_batch_mfma_(fq3_ctx* const* cs, int n, const void* const* embeds, const int* L, const int* n_pad, void* const* out_logits,
+                            void* const* out_hidden, hipStream_t s) {
+    return cs[0]->cfg.dtype == FQ3_BF16 ? prefill_batch_t<bf16_t>(cs, n, embeds, L, n_pad, out_logits, out_hidden, s)
+                                        : prefill_batch_t<float>(cs, n, embeds, L, n_pad, out_logits, out_hidden, s);
+}
 
 int fq3_prefill_mfma_(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits, void* out_hidden, hipStream_t s) {
     return c->cfg.dtype == FQ3_BF16 ? prefill_t<bf16_t>(c, embeds, L, n_pad, out_logits, out_hidden, s)

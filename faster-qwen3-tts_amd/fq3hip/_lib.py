@@ -95,6 +95,8 @@ SIGNATURES = {
     "fq3_set_generation_state": (C.c_int, [vp, C.c_int, C.c_int]),
     "fq3_talker_step": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "fq3_prefill": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "fq3_prefill_batch": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(vp),
+                                    C.POINTER(vp), vp]),
     "fq3_set_prefill_mode": (C.c_int, [vp, C.c_int]),
     "fq3_codec_head": (C.c_int, [vp, vp, vp, vp]),
     "fq3_set_predictor_sampling": (C.c_int, [vp, C.POINTER(Sampling)]),

@@ -18,7 +18,7 @@ from typing import Any, Callable, Dict, Iterable, Iterator, List, Optional, Tupl
 
 import torch
 
-from .generate import NOISE_RING, _arm_decode, _prefill_and_arm, _prefill_first_token, _refill
+from .generate import NOISE_RING, _arm_decode, _prefill_and_arm, _prefill_first_token, _prefill_first_tokens_packed, _refill
 from .predictor_graph import PredictorGraph
 from .talker_graph import TalkerGraph
 
@@ -72,7 +72,7 @@ class BatchDecoder:
     (``Fq3Engine(..., share=engines[0])``)."""
 
     def __init__(self, engines: List[Any], predictor_policy: Optional[Dict[str, Any]] = None, poll_every: int = 8,
-                 use_graph: bool = True, batch_factory=None, staging: Optional[List[Any]] = None):
+                 use_graph: bool = True, batch_factory=None, staging: Optional[List[Any]] = None, packed_prefill: bool = False):
         if batch_factory is None:
             from .engine import Fq3Batch as batch_factory
         policy = predictor_policy or dict(do_sample=True, top_k=50, top_p=1.0, temperature=0.9)
@@ -84,6 +84,10 @@ class BatchDecoder:
         # spare contexts (same weights, not part of the lock-step batch) for prefilling ahead of admission
         self.stages = [_Stage(e) for e in (staging or [])]
         self._side = None
+        # opt-in: requests staged together share ONE pass over the weights (fq3_prefill_batch; parity-tested at the engine level,
+        # tests/test_gpu_decode.py, but its effect on first-wave TTFA has not been measured yet, so the scheduler default stays on
+        # one prefill per request)
+        self.packed_prefill = bool(packed_prefill)
 
     def set_predictor_policy(self, **policy):
         for ln in self.lanes:
@@ -124,28 +128,46 @@ class BatchDecoder:
     def _stage(self, st: _Stage, req: BatchRequest, req_ready=None):
         """Prefill + first token of ``req`` into the spare context, on the side stream (the host waits for the token, the
         main stream -- with lock-step frames already queued -- does not)."""
-        kw = self._kwargs(self.lanes[0].predictor_graph, req)
+        self._stage_many([(st, req, req_ready)])
+
+    def _stage_many(self, group):
+        """``[(spare context, request, ready event), ...]``: ONE packed prefill for the whole group when it has more than one
+        member (``fq3_prefill_batch``: the layer weights are read once, not once per request)."""
+        kws = [self._kwargs(self.lanes[0].predictor_graph, req) for _st, req, _ev in group]
         t0 = time.time()
-        args = (st.engine, req.talker_input_embeds, req.attention_mask, req.config, kw["min_new_tokens"], kw["temperature"],
-                kw["top_k"], kw["top_p"], kw["do_sample"])
-        if self._on_gpu(st.engine):
-            dev = st.engine.device
+        items = [(req.talker_input_embeds, req.attention_mask, req.config, kw["min_new_tokens"], kw["temperature"], kw["top_k"],
+                  kw["top_p"], kw["do_sample"]) for (_st, req, _ev), kw in zip(group, kws)]
+        engines = [st.engine for st, _req, _ev in group]
+
+        def run():
+            if len(group) == 1 or not self.packed_prefill:
+                return [_prefill_first_token(e, *it) for e, it in zip(engines, items)]
+            return _prefill_first_tokens_packed(engines, items)
+
+        if self._on_gpu(engines[0]):
+            dev = engines[0].device
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
-            if req_ready is not None:
-                self._side.wait_event(req_ready)                        # the request's tensors were produced on the main stream
-            else:
-                self._side.wait_stream(torch.cuda.current_stream(dev))
+            for _st, _req, ev in group:
+                if ev is not None:
+                    self._side.wait_event(ev)                           # the request's tensors were produced on the main stream
+                else:
+                    self._side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(self._side):
-                if st.released is not None:
-                    self._side.wait_event(st.released)                  # the previous tenant's KV rows have been copied out
-                token, hidden, n_rows, _ = _prefill_first_token(*args)
-                st.ready = torch.cuda.Event()
-                st.ready.record(self._side)
+                for st, _req, _ev in group:
+                    if st.released is not None:
+                        self._side.wait_event(st.released)              # the previous tenant's KV rows have been copied out
+                res = run()
+                done = torch.cuda.Event()
+                done.record(self._side)
+            for st, _req, _ev in group:
+                st.ready = done
         else:
-            token, hidden, n_rows, _ = _prefill_first_token(*args)
-        st.req, st.kw, st.token, st.hidden, st.n_rows = req, kw, token, hidden, n_rows
-        st.t0, st.prefill_ms = t0, (time.time() - t0) * 1000
+            res = run()
+        ms = (time.time() - t0) * 1000
+        for (st, req, _ev), kw, (token, hidden, n_rows, _pad) in zip(group, kws, res):
+            st.req, st.kw, st.token, st.hidden, st.n_rows = req, kw, token, hidden, n_rows
+            st.t0, st.prefill_ms = t0, ms
 
     def _admit(self, ln: _Lane, st: _Stage):
         """Hand a staged request to a free lane at a frame boundary: one KV copy launch + the arm kernel."""
@@ -228,20 +250,46 @@ class BatchDecoder:
                 pending.append(stamped(r))
 
         def stage_ahead(limit: int = 1 << 30):
-            # while lanes decode, only a couple of prefills per batch of queued frames: the host waits for each staged
-            # request's first token, and the main stream must not run dry meanwhile
+            # while lanes decode, only a couple of prefills per batch of queued frames: the host waits for the staged requests'
+            # first tokens, and the main stream must not run dry meanwhile.  Requests staged together are prefilled together.
+            group = []
             while pending and idle and limit > 0:
                 limit -= 1
                 st, (req, ev) = idle.popleft(), pending.popleft()
                 try:
-                    self._stage(st, req, ev)
+                    self._kwargs(self.lanes[0].predictor_graph, req)                  # reject (top-p) before it joins a group
                 except Exception as exc:
                     idle.appendleft(st)
                     if on_error == "raise":
                         raise
                     failed.append((req.rid, {"error": repr(exc), "steps": 0}))
                     continue
-                ready.append(st)
+                group.append((st, req, ev))
+            if not group:
+                return
+            try:
+                self._stage_many(group)
+                ready.extend(st for st, _r, _e in group)
+                return
+            except Exception:
+                if len(group) == 1:
+                    st, req, _ev = group[0]
+                    idle.appendleft(st)
+                    if on_error == "raise":
+                        raise
+                    import sys
+                    failed.append((req.rid, {"error": repr(sys.exc_info()[1]), "steps": 0}))
+                    return
+            # a packed group failed (one prompt too long, ...): stage its members one by one so that only the culprit fails
+            for st, req, ev in group:
+                try:
+                    self._stage_many([(st, req, ev)])
+                    ready.append(st)
+                except Exception as exc:
+                    idle.appendleft(st)
+                    if on_error == "raise":
+                        raise
+                    failed.append((req.rid, {"error": repr(exc), "steps": 0}))
 
         while True:
             pull()

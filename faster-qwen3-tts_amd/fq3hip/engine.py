@@ -203,6 +203,29 @@ class Fq3Engine:
                                      hid.data_ptr(), self._stream()))
         return logits, hid
 
+    @staticmethod
+    def prefill_batch(engines, embeds, n_pads=None):
+        """Several prompts in one pass over the weights (``fq3_prefill_batch``): ``embeds[i]`` [L_i, H] is prefilled into
+        ``engines[i]``'s cache.  Returns ``[(logits [V], hidden [H]), ...]``.  The engines must share one weight table."""
+        import ctypes as C
+        e0 = engines[0]
+        n = len(engines)
+        n_pads = list(n_pads) if n_pads is not None else [0] * n
+        H, V = e0.cfg.talker.hidden_size, e0.cfg.talker.vocab_size
+        outs = []
+        for e, x in zip(engines, embeds):
+            e._chk(x, x.shape[0] * H, "prefill embeds")
+            outs.append((e.new(V), e.new(H)))
+        vp = C.c_void_p
+        ctxs = (vp * n)(*[e.ctx for e in engines])
+        emb = (vp * n)(*[x.data_ptr() for x in embeds])
+        Ls = (C.c_int * n)(*[int(x.shape[0]) for x in embeds])
+        pads = (C.c_int * n)(*[int(p) for p in n_pads])
+        lg = (vp * n)(*[o[0].data_ptr() for o in outs])
+        hd = (vp * n)(*[o[1].data_ptr() for o in outs])
+        L.check(e0.lib.fq3_prefill_batch(ctxs, n, emb, Ls, pads, lg, hd, e0._stream()))
+        return outs
+
     def set_option(self, key: str, value: int):
         """Kernel-variant switch (``fq3_set_option``): weight_nt, pred_m2, pred_attn, rows_per_wave_max, prefill_mode."""
         L.check(self.lib.fq3_set_option(self.ctx, key.encode(), int(value)))

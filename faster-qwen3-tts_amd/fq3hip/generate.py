@@ -42,6 +42,26 @@ def _prefill_first_token(eng, talker_input_embeds, attention_mask, config, min_n
     return int(token), hidden, int(x.shape[0]), n_pad
 
 
+def _prefill_first_tokens_packed(engines, items):
+    """``_prefill_first_token`` for several requests at once: ONE packed prefill (``fq3_prefill_batch``: one pass over the
+    weights), then the first tokens sampled per request.  ``items[i]`` = the argument tuple ``_prefill_first_token`` takes
+    after the engine.  Returns one ``(token, past_hidden, prompt_rows, n_pad)`` per request."""
+    from .engine import Fq3Engine
+    xs, pads = [], []
+    for eng, (tie, tam, _config, *_rest) in zip(engines, items):
+        pads.append(int((tam[0] == 0).sum()) if tam is not None else 0)
+        xs.append(tie[0].to(device=eng.device, dtype=eng.dtype).contiguous())
+    outs = Fq3Engine.prefill_batch(engines, xs, pads)
+    toks = []
+    for eng, x, (logits, hidden), (tie, tam, config, min_new_tokens, temperature, top_k, top_p, do_sample) in zip(engines, xs, outs, items):
+        V = config.vocab_size
+        first_noise = torch.empty(V, dtype=eng.dtype, device=eng.device).exponential_(1) if do_sample else None
+        toks.append(eng.sample(logits, temperature=temperature, top_k=top_k, top_p=top_p, do_sample=do_sample,
+                               sup_lo=max(0, V - 1024), sup_hi=V, keep_id=config.codec_eos_token_id,
+                               suppress_eos=min_new_tokens > 0, noise=first_noise))
+    return [(int(t), o[1], int(x.shape[0]), p) for t, o, x, p in zip(toks, outs, xs, pads)]      # the first int() waits for all
+
+
 def _arm_decode(talker, config, token, hidden, n_rows, attention_mask, trailing_text_hiddens, tts_pad_embed, predictor_graph, talker_graph,
                 max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty, use_graph):
     """Arms the on-device loop of ``talker_graph.engine`` behind a prefill whose KV rows are already in its cache."""

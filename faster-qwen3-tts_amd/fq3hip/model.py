@@ -658,6 +658,9 @@ class FasterQwen3TTS:
         staging = lanes if staging is None else max(0, int(staging))
         cached = getattr(self, "_batch_cache", None)
         if cached is not None and cached[0] == (lanes, staging):
+            # the lanes follow this model's CURRENT predictor policy (it is copied into the loop state when a lane is armed)
+            pg = self.predictor_graph
+            cached[1].set_predictor_policy(do_sample=pg.do_sample, top_k=pg.top_k, top_p=pg.top_p, temperature=pg.temperature)
             return cached[1]
         first = self.talker_graph.engine
         mk = lambda: Fq3Engine(first.cfg, first.weights, device=str(first.device), dtype=first.dtype,

@@ -133,6 +133,13 @@ int fq3_talker_step(fq3_ctx* ctx, const void* embeds, int position, void* out_hi
  * [0,L); outputs last-position logits T[V] and post-norm hidden T[H].  n_pad = left padding. */
 int fq3_prefill(fq3_ctx* ctx, const void* embeds, int L, int n_pad, void* out_logits, void* out_hidden,
                 void* stream);
+/* The same prefill for n prompts with ONE pass over the weights: row-wise work (norms, GEMMs, SwiGLU) on the packed rows of
+ * all prompts, q/k norm + RoPE + KV write and causal attention per prompt into ctxs[q]'s own cache.  ctxs must share one
+ * weight table; workspaces are ctxs[0]'s (sum of L <= its max_seq_len) -- otherwise this is n fq3_prefill calls.  No
+ * reference equivalent (its prefill is one upstream forward per request, generate.py:107-118); used when a lock-step batch
+ * admits several requests at once.  out_logits may be null, or hold nulls. */
+int fq3_prefill_batch(fq3_ctx* const* ctxs, int n, const void* const* embeds, const int* L, const int* n_pad,
+                      void* const* out_logits, void* const* out_hidden, void* stream);
 
 /* Test hook: 0 = matrix-core prefill (default), 1 = walk the prompt token by token through the decode kernels. */
 int fq3_set_prefill_mode(fq3_ctx* ctx, int mode);

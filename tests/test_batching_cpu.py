@@ -138,12 +138,19 @@ def test_staged_admission_prefills_ahead_and_reuses_spare_contexts(monkeypatch):
         log.append(("arm", eng.idx, cfg.rid))
         return eng, torch.zeros(1), torch.zeros(1), int(max_new)
 
+    def fake_packed(engs, items):
+        if any(getattr(it[2], "bad", False) for it in items):
+            raise RuntimeError("Input is too long")           # a packed group fails as a whole; the scheduler then isolates the culprit
+        log.append(("packed", [e.idx for e in engs], [it[2].rid for it in items]))
+        return [fake_prefill(e, *it) for e, it in zip(engs, items)]
+
     monkeypatch.setattr(Bt, "_prefill_first_token", fake_prefill)
+    monkeypatch.setattr(Bt, "_prefill_first_tokens_packed", fake_packed)
     monkeypatch.setattr(Bt, "_arm_decode", fake_arm)
     monkeypatch.setattr(Bt, "_refill", lambda eng, tn, pn: None)
     monkeypatch.setattr(Bt, "TalkerGraph", lambda e: SimpleNamespace(engine=e))
     monkeypatch.setattr(Bt, "PredictorGraph", lambda e, **kw: SimpleNamespace(engine=e, top_p=kw.get("top_p", 1.0)))
-    dec = Bt.BatchDecoder(lanes, poll_every=8, batch_factory=FakeBatch, staging=spares)
+    dec = Bt.BatchDecoder(lanes, poll_every=8, batch_factory=FakeBatch, staging=spares, packed_prefill=True)
     orig_admit = dec._admit
 
     def admit(ln, st):
@@ -161,6 +168,9 @@ def test_staged_admission_prefills_ahead_and_reuses_spare_contexts(monkeypatch):
     assert [p[2] for p in prefills] == [0, 1, 2, 4, 5]                       # request order, the bad one never staged
     assert all(p[1] >= 10 for p in prefills)                                 # always into a spare context, never into a lane
     assert prefills[2][3] > 0 and prefills[3][3] > 0                         # requests 2 and 4 were prefilled while lanes were decoding
+    packed = [e for e in log if e[0] == "packed"]
+    assert packed[0][2] == [0, 1] and packed[0][1] == [10, 11]               # the first wave shares one pass over the weights
+    assert all(len(p[2]) >= 2 for p in packed)
     adopts = [e for e in log if e[0] == "adopt"]
     assert len(adopts) == 5 and {a[2] for a in adopts} == {10, 11}           # spare contexts recycled
     assert [a[1] for a in adopts[:2]] == [0, 1] and all(a[3] == 4 for a in adopts)

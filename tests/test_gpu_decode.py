@@ -448,3 +448,55 @@ def test_predictor_attention_kernel_variants(mode):
                 assert (lg.float().cpu() - o_logits.float()).abs().max() <= 5e-4
             else:
                 assert (lg[0].float().cpu() - o_logits[0].float()).abs().max() <= 0.15
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_packed_prefill_of_several_prompts(dtype):
+    """fq3_prefill_batch: three prompts of different lengths (one left-padded) in ONE pass over the weights, each into its
+    own context.  Against the ORACLE (logits / hidden / a decode step over the written KV) and against three single
+    prefills: fp32 bit-identical outputs and KV rows; bf16 within the oracle tolerance (the GEMM tile choice depends on
+    the row count).  Falls back to single prefills when the prompts do not fit one workspace."""
+    from fq3hip.engine import Fq3Engine
+    from oracle import qwen3tts_oracle as O
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, dtype)
+    first = _engine(cfg, W, dtype)
+    engs = [first] + [Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=96, max_frames=64, share=first) for _ in range(2)]
+    singles = [Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=96, max_frames=64, share=first) for _ in range(3)]
+    lens, pads = [24, 9, 40], [0, 3, 0]
+    prompts = []
+    for i, (Lp, p) in enumerate(zip(lens, pads)):
+        tie, tam, _, _, _ = synth_prompt(cfg, Lp, 4, 0, dtype=dtype, seed=50 + i)
+        tie = tie * 30
+        tam[0, :p] = 0
+        prompts.append((tie, tam))
+    xs = [t[0].cuda().contiguous() for t, _ in prompts]
+    outs = Fq3Engine.prefill_batch(engs, xs, pads)
+    nl = cfg.talker.num_hidden_layers
+    for i, ((tie, tam), (logits, hidden)) in enumerate(zip(prompts, outs)):
+        orc = O.OracleTTS(cfg, W, max_seq_len=96)
+        o_logits, o_hidden, _, Lo = orc.prefill(tie, tam)
+        assert Lo == lens[i]
+        assert (hidden.float().cpu() - o_hidden.float().view(-1)).abs().max() <= _tol(dtype, float(o_hidden.float().abs().max()))
+        assert (logits.float().cpu() - o_logits.float().view(-1)).abs().max() <= _tol(dtype, float(o_logits.float().abs().max()))
+        x = torch.randn(1, 1, cfg.talker.hidden_size, generator=torch.Generator().manual_seed(i)).to(dtype)
+        oh = orc.talker_step(x, Lo)
+        engs[i].set_generation_state(pads[i], -pads[i])
+        gh = engs[i].talker_step(x.view(-1).cuda(), Lo)              # attends over the KV rows the packed prefill wrote
+        assert (gh.float().cpu() - oh.float().view(-1)).abs().max() <= _tol(dtype, float(oh.float().abs().max()))
+        s_logits, s_hidden = singles[i].prefill(xs[i], n_pad=pads[i])
+        if dtype == torch.float32:
+            assert torch.equal(s_logits, logits) and torch.equal(s_hidden, hidden)
+            for layer in (0, nl - 1):
+                k1, v1 = engs[i].kv_export(layer, lens[i])
+                k2, v2 = singles[i].kv_export(layer, lens[i])
+                assert torch.equal(k1[:, pads[i]:], k2[:, pads[i]:]) and torch.equal(v1[:, pads[i]:], v2[:, pads[i]:])
+        else:
+            assert (s_hidden.float() - hidden.float()).abs().max() <= 0.03 * max(1.0, float(s_hidden.float().abs().max()))
+    # too many rows for one workspace (96): the call still answers, through single prefills
+    long_x = [torch.randn(50, cfg.talker.hidden_size, dtype=dtype, device="cuda") * 0.5 for _ in range(2)]
+    two = Fq3Engine.prefill_batch(engs[:2], long_x, [0, 0])
+    ref0 = singles[0].prefill(long_x[0])
+    assert torch.equal(two[0][1], ref0[1])
+    with pytest.raises(RuntimeError, match="Input is too long"):
+        Fq3Engine.prefill_batch(engs[:2], [torch.zeros(97, cfg.talker.hidden_size, dtype=dtype, device="cuda"), long_x[0]], [0, 0])
