@@ -106,3 +106,25 @@ def test_errors_and_partial_binding():
     del broken["encoder.encoder.layers.4.block.1.conv.weight"]
     with pytest.raises(KeyError):
         HipRefAudioAnalyzer(rc, broken)
+
+
+def test_against_transformers_module_outputs(golden_dir):
+    """tests/golden/refenc.npz holds what the transformers modules themselves (MimiModel.encode, ECAPA_TimeDelayNet) produced for
+    these seeds on CPU (oracle/make_golden_refenc.py): the HIP kernels against the modules, not against the restatement."""
+    import numpy as np
+    from fq3hip.refenc import HipRefAudioAnalyzer
+    g = np.load(os.path.join(golden_dir, "refenc.npz"))
+    rc = RefAudioConfig()
+    wseed, n, seed = (int(v) for v in g["enc_meta"])
+    an = HipRefAudioAnalyzer(rc, synth_ref_audio_weights(rc, wseed))
+    got = an.encode(make_wave(n, seed=seed)).cpu()
+    ref, margins = torch.from_numpy(g["enc_codes_mimi"].astype(np.int64)), torch.from_numpy(g["enc_margins"])
+    n_cmp, n_div = _compare_codes(rc, got, ref, margins)
+    print(f"vs MimiModel.encode: {int((got == ref).sum())}/{ref.numel()} ids identical, {n_div} chains diverged at near-ties")
+    assert n_div <= 2 and int((got == ref).sum()) >= ref.numel() - 40
+    wseed, n, seed = (int(v) for v in g["spk_meta"])
+    an2 = HipRefAudioAnalyzer(rc, synth_ref_audio_weights(rc, wseed))
+    emb, mel = an2.speaker_embedding(make_wave(n, seed=seed), return_mel=True)
+    want = torch.from_numpy(g["spk_xvector_ecapa"])
+    assert (emb.cpu() - want).abs().max() < 2e-3 * float(want.abs().max())
+    assert (mel[:8].cpu() - torch.from_numpy(g["spk_mel_first_frames"])).abs().max() < 5e-3

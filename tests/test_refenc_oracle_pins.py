@@ -178,3 +178,22 @@ def test_strided_conv_packing_is_a_two_tap_gemm_over_the_row_view():
         pw = P["encoder.downsample.conv.weight"].double()
         got = padded[:-1] @ pw[:, 0].t() + padded[1:] @ pw[:, 1].t()
         assert torch.allclose(got, ref, atol=1e-10), T
+
+
+def test_refenc_golden_fixture_is_what_the_modules_produce(golden_dir):
+    """tests/golden/refenc.npz (scored against by the GPU test) is reproduced here: the speaker half from the module itself,
+    the encoder half through the restatement (MimiModel on a 3.1 s clip at the real shapes is the slow part of
+    oracle/make_golden_refenc.py, which asserts their agreement when it writes the file)."""
+    g = np.load(os.path.join(golden_dir, "refenc.npz"))
+    rc = RefAudioConfig()
+    wseed, n, seed = (int(v) for v in g["spk_meta"])
+    W = synth_ref_audio_weights(rc, wseed)
+    with torch.no_grad():
+        emb, mel = RO.speaker_embedding(W, rc, make_wave(n, seed=seed))
+        ref = _ecapa(rc, W)(mel[None])[0]
+    assert np.allclose(ref.numpy(), g["spk_xvector_ecapa"], atol=1e-6) and np.allclose(mel[:8].numpy(), g["spk_mel_first_frames"], atol=1e-5)
+    wseed, n, seed = (int(v) for v in g["enc_meta"])
+    with torch.no_grad():
+        codes, margins = RO.tokenizer_encode(synth_ref_audio_weights(rc, wseed), rc, make_wave(n, seed=seed), return_all=True)[:2]
+    assert np.array_equal(codes.numpy(), g["enc_codes_mimi"].astype(np.int64))
+    assert np.allclose(margins.numpy(), g["enc_margins"], rtol=1e-3, atol=1e-7)
