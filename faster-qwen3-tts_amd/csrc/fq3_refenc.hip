@@ -185,7 +185,16 @@ extern "C" int fq3_refenc_encode(fq3_refenc* r, const float* pcm, int64_t n, int
     const int QD = g.n_heads * g.head_dim;
     int maxr = 2;
     for (int i = 0; i < g.n_ratios; ++i) maxr = std::max(maxr, g.ratios[i]);
-    const size_t big = (size_t)(n + maxr) * g.num_filters + 256;             // rows x channels never grows along the stack
+    size_t big = (size_t)(n + maxr) * g.num_filters + 256;                   // rows x channels never grows along the stack ...
+    {   // ... except for the zeroed tail of a strided conv's row view, which a stack of small ratios can push past it
+        int64_t t = n; size_t ch = (size_t)g.num_filters;
+        for (int i = 0; i < g.n_ratios; ++i) {
+            const int64_t tn = ceil_div(t, g.ratios[i]);
+            big = std::max(big, (size_t)(tn * g.ratios[i]) * ch + 256);
+            t = tn; ch *= 2;
+        }
+        big = std::max(big, (size_t)t * ch + 256);
+    }
     const size_t tr = (size_t)(t25 + 4) * std::max(std::max(3 * QD, g.inter), 2 * g.hidden) + 256;
     const size_t per = std::max(big, tr);
     if (ws_reserve(r, 4 * per + 1024, s)) return FQ3_EHIP;
