@@ -139,3 +139,41 @@ def test_left_pad_and_greedy_paths(patched):
     assert ("sample", False, False) in eng.log
     assert eng.begin["talker_noise"] is None and eng.begin["pred_noise"] is not None      # predictor policy is separate
     assert args[7].state[0] == 3
+
+
+def test_side_vocoder_synchronous_fallback_cuts_the_reference_share():
+    """_SideVocoder with a foreign tokenizer (no decode_tensor): decodes through the upstream call and cuts the ICL reference's
+    share of the waveform exactly like model.py:927-930; collect() returns the submissions in order."""
+    import numpy as np
+    import torch
+    from fq3hip.model import _SideVocoder
+
+    class Tok:
+        sample_rate = 24000
+
+        def decode(self, payload):
+            codes = payload["audio_codes"][0]
+            return [torch.arange(codes.shape[0] * 10, dtype=torch.float32)], 24000
+
+    voc = _SideVocoder(Tok(), "cpu")
+    assert not voc.async_ok
+    voc.submit("a", torch.zeros(7, 16, dtype=torch.long))
+    voc.submit("b", torch.zeros(10, 16, dtype=torch.long), ref_len=4)
+    out = list(voc.collect())
+    assert [k for k, _ in out] == ["a", "b"]
+    assert len(out[0][1]) == 70 and out[0][1][0] == 0
+    cut = int(4 / 10 * 100)
+    assert len(out[1][1]) == 100 - cut and out[1][1][0] == cut
+    assert list(voc.collect()) == []
+
+
+def test_new_public_entry_points_keep_the_single_stream_vocabulary():
+    import inspect
+    from fq3hip.model import FasterQwen3TTS
+    single = inspect.signature(FasterQwen3TTS.generate_voice_clone_streaming).parameters
+    batch = inspect.signature(FasterQwen3TTS.generate_voice_clone_batch_streaming).parameters
+    assert "language" in batch                      # one string or one per text; defaults to "English" like generate_voice_clone_batch
+    for name in ("ref_audio", "ref_text", "max_new_tokens", "min_new_tokens", "temperature", "top_k", "top_p", "do_sample",
+                 "repetition_penalty", "chunk_size", "xvec_only", "non_streaming_mode", "append_silence", "instruct", "voice_clone_prompt"):
+        assert name in batch and batch[name].default == single[name].default, name
+    assert list(batch)[1] == "texts" and batch["lanes"].default == 8
