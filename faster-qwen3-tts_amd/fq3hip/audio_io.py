@@ -44,8 +44,44 @@ def write_wav(path: str, pcm: np.ndarray, sample_rate: int) -> None:
         w.writeframes(to_pcm16(pcm))
 
 
+def load_audio(path) -> Tuple[np.ndarray, int]:
+    """Reference-clip loader shared by every caller (model.py:278-293 uses ``soundfile``): ``soundfile`` when it is
+    installed (FLAC, IEEE-float WAV, ...), otherwise the standard-library PCM WAV reader with a clear error for what it cannot
+    read.  -> (mono float32, sample_rate)."""
+    try:
+        import soundfile as sf
+    except ImportError:
+        return read_wav(str(path))
+    audio, sr = sf.read(str(path), dtype="float32", always_2d=False)
+    if audio.ndim > 1:
+        audio = audio.mean(axis=1)
+    return np.asarray(audio, dtype=np.float32), int(sr)
+
+
+def _wav_format_tag(path: str) -> int:
+    """wFormatTag of a RIFF/WAVE file (1 = integer PCM, 3 = IEEE float, 85 = MP3, 0xFFFE = extensible), -1 if not RIFF/WAVE."""
+    with open(path, "rb") as f:
+        head = f.read(12)
+        if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+            return -1
+        while True:
+            ck = f.read(8)
+            if len(ck) < 8:
+                return -1
+            cid, size = ck[:4], struct.unpack("<I", ck[4:])[0]
+            if cid == b"fmt ":
+                return struct.unpack("<H", f.read(2))[0]
+            f.seek(size + (size & 1), 1)
+
+
 def read_wav(path: str) -> Tuple[np.ndarray, int]:
     """PCM WAV (8/16/32-bit integer) -> (mono float32 in [-1, 1], sample_rate)."""
+    tag = _wav_format_tag(str(path))
+    if tag not in (1, 0xFFFE):
+        what = {-1: "not a RIFF/WAVE file", 3: "IEEE-float WAV (format tag 3)", 85: "MP3-in-WAV (format tag 85)"}.get(
+            tag, f"WAV format tag {tag}")
+        raise ValueError(f"{path}: {what} cannot be read without the 'soundfile' package (not in this image); "
+                         "convert the clip to 16-bit PCM WAV, or pass (waveform, sample_rate) / a voice_clone_prompt")
     with wave.open(str(path), "rb") as w:
         sr, n, ch, sw = w.getframerate(), w.getnframes(), w.getnchannels(), w.getsampwidth()
         raw = w.readframes(n)

@@ -23,6 +23,9 @@ from .predictor_graph import PredictorGraph
 from .talker_graph import TalkerGraph
 
 
+MAX_LANES = 16          # kMaxLanes of csrc/batch_kernels.cuh (fq3_batch_create refuses more)
+
+
 @dataclass
 class BatchRequest:
     """One utterance: the tensors ``fast_generate`` takes plus its sampling arguments."""
@@ -111,7 +114,7 @@ class BatchDecoder:
             req.talker, req.talker_input_embeds, req.attention_mask, req.trailing_text_hiddens, req.tts_pad_embed,
             req.config, ln.predictor_graph, ln.talker_graph, kw["max_new_tokens"], kw["min_new_tokens"],
             kw["temperature"], kw["top_k"], kw["top_p"], kw["do_sample"], kw["repetition_penalty"], use_graph=False)
-        ln.req, ln.tn, ln.pn, ln.issued, ln.max_frames = req, tn, pn, 0, max_frames
+        ln.req, ln.tn, ln.pn, ln.issued, ln.emitted, ln.max_frames = req, tn, pn, 0, 0, max_frames
         ln.t_arm, ln.prefill_ms = t0, (time.time() - t0) * 1000
 
     def _mark(self, engine):
@@ -185,7 +188,7 @@ class BatchDecoder:
             req.talker, req.config, st.token, st.hidden, st.n_rows, req.attention_mask, req.trailing_text_hiddens, req.tts_pad_embed,
             ln.predictor_graph, ln.talker_graph, kw["max_new_tokens"], kw["min_new_tokens"], kw["temperature"], kw["top_k"],
             kw["top_p"], kw["do_sample"], kw["repetition_penalty"], use_graph=False)
-        ln.req, ln.tn, ln.pn, ln.issued, ln.max_frames = req, tn, pn, 0, max_frames
+        ln.req, ln.tn, ln.pn, ln.issued, ln.emitted, ln.max_frames = req, tn, pn, 0, 0, max_frames
         ln.t_arm, ln.prefill_ms = st.t0, st.prefill_ms
         st.req, st.kw, st.hidden = None, None, None
 
@@ -233,6 +236,12 @@ class BatchDecoder:
                 ev.record(torch.cuda.current_stream(self.lanes[0].engine.device))
             return req, ev
 
+        # a previous run() may have been abandoned mid-utterance (a streaming consumer that stopped early, an exception in the
+        # caller): no lane carries a tenant, a partial-chunk counter or a staged request over into this one
+        for ln in self.lanes:
+            ln.req, ln.tn, ln.pn, ln.issued, ln.emitted = None, None, None, 0, 0
+        for st in self.stages:
+            st.req, st.kw, st.hidden = None, None, None
         pending = deque(stamped(r) for r in requests)
         free = deque(self.lanes)
         active: List[_Lane] = []
@@ -293,7 +302,7 @@ class BatchDecoder:
 
         while True:
             pull()
-            if not (pending or active or ready):
+            if not (pending or active or ready or failed):
                 break
             if self.stages and not active and not ready:
                 stage_ahead()                                         # nothing is decoding: nothing to overlap with
@@ -376,3 +385,6 @@ class BatchDecoder:
                     yield outbox.pop(0)
         while outbox:
             yield outbox.pop(0)
+        while failed:                                                 # belt and braces: no error event is ever dropped
+            rid, info = failed.pop(0)
+            yield rid, None, info

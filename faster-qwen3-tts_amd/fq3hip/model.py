@@ -9,8 +9,6 @@ decode loop state lives on the GPU.
 """
 from __future__ import annotations
 
-import os
-
 import logging
 from pathlib import Path
 from typing import Any, Dict, Generator, List, Optional, Tuple, Union
@@ -341,14 +339,8 @@ class FasterQwen3TTS:
 
     def _load_ref_audio_with_silence(self, ref_audio, silence_secs: float = 0.5):
         """model.py:278-293.  ``soundfile`` when it is installed, otherwise the standard-library WAV reader."""
-        try:
-            import soundfile as sf
-            audio, sr = sf.read(str(ref_audio), dtype="float32", always_2d=False)
-            if audio.ndim > 1:
-                audio = audio.mean(axis=1)
-        except ImportError:
-            from .audio_io import read_wav
-            audio, sr = read_wav(str(ref_audio))
+        from .audio_io import load_audio
+        audio, sr = load_audio(ref_audio)
         if silence_secs > 0:
             audio = np.concatenate([audio, np.zeros(int(silence_secs * sr), dtype=np.float32)])
         return audio, sr
@@ -359,25 +351,28 @@ class FasterQwen3TTS:
         from .voice_cache import VoiceRefCache
         self._voice_ref_cache = VoiceRefCache(directory) if directory else None
 
+    def _voice_cache_entry(self, ref_audio, xvec_only: bool, append_silence: bool):
+        """(audio at 24 kHz, key, metadata) of a reference clip: ONE construction for lookups and stores (same loader, same
+        resampler, the request's mode in the metadata), so that what is written is what is found."""
+        from .audio_io import resample
+        from .voice_cache import cache_key
+        silence = 0.5 if (append_silence and not xvec_only) else 0.0
+        audio, sr = self._load_ref_audio_with_silence(ref_audio, silence_secs=silence)
+        audio = resample(audio, sr, 24000)
+        ident = f"{getattr(self.model.model, 'tts_model_type', 'base')}-{getattr(self.model.model, 'tts_model_size', '')}"
+        key, meta = cache_key(audio, append_silence=silence > 0, model_identity=ident, mode="xvec" if xvec_only else "icl")
+        return audio, key, meta, silence > 0, ident
+
     def _cached_voice_prompt(self, ref_audio, ref_text: str, xvec_only: bool, append_silence: bool):
         cache = getattr(self, "_voice_ref_cache", None)
         if cache is None:
             return None
-        from .voice_cache import cache_key
-        silence = 0.5 if (append_silence and not xvec_only) else 0.0
-        audio, sr = self._load_ref_audio_with_silence(ref_audio, silence_secs=silence)
-        if sr != 24000:
-            from scipy.signal import resample_poly
-            from math import gcd
-            g = gcd(int(sr), 24000)
-            audio = resample_poly(audio, 24000 // g, int(sr) // g).astype(np.float32)
-        ident = f"{getattr(self.model.model, 'tts_model_type', 'base')}-{getattr(self.model.model, 'tts_model_size', '')}"
-        key, meta = cache_key(audio, append_silence=silence > 0, model_identity=ident)
+        _audio, key, meta, _sil, _ident = self._voice_cache_entry(ref_audio, xvec_only, append_silence)
         hit = cache.load(key, meta)
-        if hit is None:
+        if hit is None or (not xvec_only and hit["ref_code"] is None):      # an entry without codes cannot serve an ICL request
             return None
         spk = torch.from_numpy(hit["ref_spk_embedding"])
-        if xvec_only or hit["ref_code"] is None:
+        if xvec_only:
             return dict(ref_code=[None], ref_spk_embedding=[spk], x_vector_only_mode=[True], icl_mode=[False]), None
         return (dict(ref_code=[torch.from_numpy(hit["ref_code"])], ref_spk_embedding=[spk], x_vector_only_mode=[False],
                      icl_mode=[True]), hit["ref_text"] or ref_text)
@@ -388,12 +383,9 @@ class FasterQwen3TTS:
         cache = getattr(self, "_voice_ref_cache", None)
         if cache is None:
             return
-        from .audio_io import resample
         from .voice_cache import export_voice_clone_prompt
-        silence = 0.5 if (append_silence and not xvec_only) else 0.0
-        audio, sr = self._load_ref_audio_with_silence(ref_audio, silence_secs=silence)
-        ident = f"{getattr(self.model.model, 'tts_model_type', 'base')}-{getattr(self.model.model, 'tts_model_size', '')}"
-        export_voice_clone_prompt(cache, resample(audio, sr, 24000), item, append_silence=silence > 0, model_identity=ident,
+        audio, _key, _meta, sil, ident = self._voice_cache_entry(ref_audio, xvec_only, append_silence)
+        export_voice_clone_prompt(cache, audio, item, append_silence=sil, model_identity=ident,
                                   ref_text=getattr(item, "ref_text", None) or "")
 
     def _resolve_voice_clone_prompt_from_reference(self, input_ids, ref_audio, ref_text: str, xvec_only: bool,
@@ -593,8 +585,9 @@ class FasterQwen3TTS:
             return None
         if getattr(self, "_voc_stream", None) is None:
             dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
-            # FQ3_VOC_PRIORITY (development knob): HIP stream priority of the vocoder stream (larger = lower)
-            prio = os.environ.get("FQ3_VOC_PRIORITY")
+            # vocoder_stream_priority (attribute, default None = the device default): HIP stream priority of the vocoder
+            # stream, larger = lower.  Set it before the first streaming call.
+            prio = getattr(self, "vocoder_stream_priority", None)
             self._voc_stream = torch.cuda.Stream(device=dev) if prio is None else torch.cuda.Stream(device=dev, priority=int(prio))
         return self._voc_stream
 
@@ -654,7 +647,8 @@ class FasterQwen3TTS:
         scheduler on top."""
         from .batching import BatchDecoder
         from .engine import Fq3Engine
-        lanes = max(1, min(int(lanes), 8))
+        from .batching import MAX_LANES
+        lanes = max(1, min(int(lanes), MAX_LANES))
         staging = lanes if staging is None else max(0, int(staging))
         cached = getattr(self, "_batch_cache", None)
         if cached is not None and cached[0] == (lanes, staging):
@@ -688,7 +682,7 @@ class FasterQwen3TTS:
                                    instruct: Optional[str] = None,
                                    voice_clone_prompt: Optional[Union[Dict[str, Any], List[Any]]] = None,
                                    lanes: int = 8) -> List[Tuple[list, int]]:
-        """Voice cloning of several texts with one voice: up to ``lanes`` (<= 8) utterances decode in lock-step over
+        """Voice cloning of several texts with one voice: up to ``lanes`` (<= 16) utterances decode in lock-step over
         one pass of the weights per frame (``fq3_batch_*``), finished lanes are refilled from the queue.  Returns one
         ``([np.float32 waveform], sample_rate)`` per text, in input order; each utterance follows exactly the
         single-utterance semantics of :meth:`generate_voice_clone` (``top_p`` must be 1.0 on this path)."""

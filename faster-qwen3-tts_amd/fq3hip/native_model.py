@@ -235,10 +235,10 @@ class NativeQwen3TTS:
         """``ref_audio``: a WAV path, ``(waveform, sample_rate)`` (what the reference passes, model.py:443-447) or a
         waveform already at the model rate -> mono float32 at 24 kHz."""
         import numpy as np
-        from .audio_io import read_wav, resample
+        from .audio_io import load_audio, resample
         rate = self.cfg.ref_audio.sample_rate
         if isinstance(ref_audio, (str, os.PathLike)):
-            audio, sr = read_wav(str(ref_audio))
+            audio, sr = load_audio(str(ref_audio))          # same loader as model._load_ref_audio_with_silence
         elif isinstance(ref_audio, (tuple, list)) and len(ref_audio) == 2 and not np.isscalar(ref_audio[0]):
             audio, sr = ref_audio
         else:

@@ -8,7 +8,7 @@ objects hold a single static context.  Here there are two schedulers:
 * ``lock``   one request at a time, audio streamed chunk by chunk as it is generated (the reference's behaviour);
 * ``batch``  a worker thread owns the model and runs the continuous-batching decoder (``fq3hip/batching.py`` over
              ``fq3_batch_*``): requests that arrive while others are decoding join at the next frame boundary, up to
-             ``lanes`` (<= 8) utterances advance in lock-step over ONE pass of the weights per frame; each response is
+             ``lanes`` (<= 16) utterances advance in lock-step over ONE pass of the weights per frame; each response is
              sent when its utterance finishes.
 
 ``create_app(model, voices, ...)`` is the testable core; ``main()`` is the command line (same flags as the reference plus
@@ -49,8 +49,12 @@ class BatchWorker:
 
     DONE = object()
 
-    def __init__(self, model, lanes: int = 8):
-        self.model, self.lanes = model, max(1, min(int(lanes), 8))
+    def __init__(self, model, lanes: int = 8, chunk_size: int = 12):
+        from .batching import MAX_LANES
+        self.model, self.lanes = model, max(1, min(int(lanes), MAX_LANES))
+        # ONE chunk size for the whole server: the lock-step decoder hands out chunks of this many frames and every request's
+        # StreamingVocoder is built for the same number (a voice entry's own "chunk_size" only applies to the lock scheduler)
+        self.chunk_size = max(1, int(chunk_size))
         self.inbox: "queue.Queue" = queue.Queue()
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
@@ -85,8 +89,7 @@ class BatchWorker:
                             return None
                         i = counter[0]
                         counter[0] += 1
-                        chunk = int(cfg.get("chunk_size", 12))
-                        waiting[i] = (out, m.streaming_vocoder(rc, chunk))
+                        waiting[i] = (out, m.streaming_vocoder(rc, self.chunk_size))
                         kw = m._gen_kwargs(int(cfg.get("max_new_tokens", 2048)), 2, 0.9, 50, 1.0, True, 1.05)
                         return BatchRequest(i, talker, tie, tam, tth, tpe, config, kw)
 
@@ -105,7 +108,7 @@ class BatchWorker:
                                 return req
 
                     head = prepare(first)
-                    chunk_frames = int(first[0].get("chunk_size", 12))
+                    chunk_frames = self.chunk_size
                     for rid, codes, info in m._batch_decoder(self.lanes).run([head] if head is not None else [], on_error="yield",
                                                                              source=source, chunk_frames=chunk_frames):
                         out, voc = waiting[rid]
@@ -118,18 +121,27 @@ class BatchWorker:
                         if final:
                             out.put(self.DONE)
                             waiting.pop(rid, None)
+                # the scheduler is done: nobody may be left without an answer (a request it never reported would otherwise
+                # block its HTTP handler and an executor thread forever)
+                for out, _ in waiting.values():
+                    out.put(RuntimeError("the batch scheduler finished without an answer for this request"))
+                    out.put(self.DONE)
+                waiting.clear()
             except Exception as exc:            # a failed batch answers everyone who is still waiting
                 for out, _ in waiting.values():
                     out.put(exc)
+                    out.put(self.DONE)
+                waiting.clear()
 
 
-def create_app(model, voices: Dict[str, dict], default_voice: Optional[str] = None, scheduler: str = "lock", lanes: int = 8):
+def create_app(model, voices: Dict[str, dict], default_voice: Optional[str] = None, scheduler: str = "lock", lanes: int = 8,
+               chunk_size: int = 12):
     from fastapi import FastAPI, HTTPException
     from fastapi.responses import Response, StreamingResponse
 
     app = FastAPI(title="faster-qwen3-tts (MI355X) OpenAI-compatible API")
     lock = threading.Lock()
-    worker = BatchWorker(model, lanes) if scheduler == "batch" else None
+    worker = BatchWorker(model, lanes, chunk_size) if scheduler == "batch" else None
     sample_rate = int(getattr(model, "sample_rate", 24000))
 
     def resolve_voice(name: str) -> dict:
@@ -243,6 +255,7 @@ def main(argv=None):
     p.add_argument("--device", default="cuda")
     p.add_argument("--scheduler", default="batch", choices=["lock", "batch"])
     p.add_argument("--lanes", type=int, default=8)
+    p.add_argument("--chunk-size", type=int, default=12, help="frames per streamed chunk (batch scheduler: server-wide)")
     p.add_argument("--voice-cache", help="directory of precomputed voice prompts serving ref_audio entries")
     p.add_argument("--synthetic", choices=["0.6b", "1.7b"])
     args = p.parse_args(argv)
@@ -262,7 +275,7 @@ def main(argv=None):
                                        voice_cache=args.voice_cache))
     import uvicorn
     logging.basicConfig(level=logging.INFO)
-    uvicorn.run(create_app(model, voices, default_voice, args.scheduler, args.lanes), host=args.host, port=args.port)
+    uvicorn.run(create_app(model, voices, default_voice, args.scheduler, args.lanes, args.chunk_size), host=args.host, port=args.port)
 
 
 if __name__ == "__main__":

@@ -9,9 +9,11 @@ canonical metadata JSON that contains the audio's SHA-256, three files per entry
     <key>.json  the metadata the key was derived from (+ "ref_text")
 
 An entry is exactly one ``voice_clone_prompt`` item (what upstream ``create_voice_clone_prompt`` returns,
-reference ``model.py:430-451``).  Reference-audio *analysis* (speaker encoder + tokenizer encoder) is not part of the MI355X
-path, so entries are produced once elsewhere (``export_voice_clone_prompt`` below takes the upstream prompt item) and every
-later ``generate_voice_clone(ref_audio=...)`` call on this path is served from the cache.
+reference ``model.py:430-451``).  Entries are written through by ``FasterQwen3TTS`` the first time a reference clip is analysed
+(the HIP analysers, ``fq3hip/refenc.py``; or ``export_voice_clone_prompt`` below over an upstream prompt item) and every later
+``generate_voice_clone(ref_audio=...)`` call -- in this or another process -- is served from the cache.  The key's metadata
+carries the entry's *mode* (``"xvec"`` = speaker embedding only, ``"icl"`` = embedding + reference codes), so an x-vector-only
+entry never answers an ICL request.
 """
 from __future__ import annotations
 
@@ -24,15 +26,18 @@ from typing import Any, Dict, Optional, Tuple
 
 import numpy as np
 
-CACHE_VERSION = 1
+CACHE_VERSION = 2          # 2: the key metadata carries the entry's mode
 _RVQ_MAGIC = b"FQ3RVQ1\0"
 
 
-def cache_key(ref_audio_24k: np.ndarray, *, append_silence: bool, model_identity: str) -> Tuple[str, dict]:
-    """Same construction as the reference (``ggml_backend.py:403-416``): metadata dict -> canonical JSON -> SHA-256."""
+def cache_key(ref_audio_24k: np.ndarray, *, append_silence: bool, model_identity: str, mode: str = "icl") -> Tuple[str, dict]:
+    """Same construction as the reference (``ggml_backend.py:403-416``): metadata dict -> canonical JSON -> SHA-256.
+    ``mode``: ``"icl"`` (speaker embedding + reference codes) or ``"xvec"`` (speaker embedding only)."""
+    if mode not in ("icl", "xvec"):
+        raise ValueError("mode must be 'icl' or 'xvec'")
     audio = np.ascontiguousarray(np.asarray(ref_audio_24k, dtype=np.float32))
     meta = {"version": CACHE_VERSION, "model_identity": str(model_identity), "sample_rate": 24000, "dtype": "float32",
-            "n_samples": int(audio.shape[0]), "append_silence": bool(append_silence),
+            "n_samples": int(audio.shape[0]), "append_silence": bool(append_silence), "mode": mode,
             "audio_sha256": hashlib.sha256(audio.tobytes()).hexdigest()}
     payload = json.dumps(meta, sort_keys=True, separators=(",", ":")).encode("utf-8")
     return hashlib.sha256(payload).hexdigest(), meta
@@ -98,7 +103,9 @@ def export_voice_clone_prompt(cache: VoiceRefCache, ref_audio_24k: np.ndarray, i
                               model_identity: str, ref_text: str = "") -> str:
     """Store one upstream prompt item (attributes ``ref_spk_embedding``, ``ref_code``, ``ref_text``; reference
     ``model.py:336-352``) under the key of its audio.  Run once where upstream ``qwen-tts`` is available."""
-    key, meta = cache_key(ref_audio_24k, append_silence=append_silence, model_identity=model_identity)
+    ref_code = getattr(item, "ref_code", None)
+    key, meta = cache_key(ref_audio_24k, append_silence=append_silence, model_identity=model_identity,
+                          mode="icl" if ref_code is not None else "xvec")
     text = getattr(item, "ref_text", None) or ref_text
-    cache.save(key, meta, item.ref_spk_embedding, getattr(item, "ref_code", None), ref_text=text or "")
+    cache.save(key, meta, item.ref_spk_embedding, ref_code, ref_text=text or "")
     return key

@@ -191,3 +191,61 @@ def test_chunked_streaming_events(sched):
     # default mode is unchanged: one event per utterance with all frames
     out = list(dec.run([_req(5, 12)]))
     assert len(out) == 1 and out[0][1].shape[0] == 12 and "is_final" not in out[0][2]
+
+
+def test_abandoned_chunked_run_leaves_no_state_behind(sched):
+    """A streaming consumer that stops early (generator closed after two chunks) must not make the next utterance on that lane
+    lose its first frames: the partial-chunk counter is per tenant, not per lane."""
+    dec, engines, log, refills = sched
+    g = dec.run([_req(0, 40)], chunk_frames=8)
+    first = [next(g), next(g)]
+    assert [e[1].shape[0] for e in first] == [8, 8]
+    g.close()
+    events = list(dec.run([_req(1, 20)], chunk_frames=8))
+    assert [(e[1].shape[0], e[2]["is_final"]) for e in events] == [(8, False), (8, False), (4, True)]
+    assert sum(e[1].shape[0] for e in events) == 20
+    # and a lane whose run died on an exception is clean for the next caller, too
+    for ln in dec.lanes:
+        ln.emitted = 16
+    out = list(dec.run([_req(2, 12)]))
+    assert out[0][1].shape[0] == 12
+
+
+def test_late_failure_during_the_last_poll_is_still_reported(monkeypatch):
+    """on_error='yield': a request that fails while being staged under the LAST frames of the last active lane (nothing left
+    to decode afterwards) still produces its error event -- a server's reply queue would otherwise never be answered."""
+    log = []
+
+    class Eng(FakeLaneEngine):
+        def kv_adopt(self, src, n_rows):
+            pass
+
+    lanes, spares = [Eng(log, 0)], [Eng(log, 10)]
+
+    def fake_prefill(eng, tie, tam, config, min_new, temperature, top_k, top_p, do_sample):
+        if getattr(config, "bad", False):
+            raise RuntimeError("Input is too long")
+        return 7, torch.zeros(8), tie.shape[1], 0
+
+    def fake_arm(talker, config, token, hidden, n_rows, tam, tth, tpe, pg, tg, max_new, min_new, temperature, top_k, top_p, do_sample, rp, use_graph):
+        eng = tg.engine
+        eng.frames, eng.budget, eng.eos_after, eng.rid = 0, int(max_new), 10 ** 9, config.rid
+        return eng, torch.zeros(1), torch.zeros(1), int(max_new)
+
+    monkeypatch.setattr(Bt, "_prefill_first_token", fake_prefill)
+    monkeypatch.setattr(Bt, "_arm_decode", fake_arm)
+    monkeypatch.setattr(Bt, "_refill", lambda eng, tn, pn: None)
+    monkeypatch.setattr(Bt, "TalkerGraph", lambda e: SimpleNamespace(engine=e))
+    monkeypatch.setattr(Bt, "PredictorGraph", lambda e, **kw: SimpleNamespace(engine=e, top_p=kw.get("top_p", 1.0)))
+    dec = Bt.BatchDecoder(lanes, poll_every=8, batch_factory=FakeBatch, staging=spares)
+    bad = _req(9, 8)
+    bad.config.bad = True
+    polls = [0]
+
+    def source():                      # the bad request arrives just before request 0's only step (8 frames) is queued: it is
+        polls[0] += 1                  # staged -- and fails -- under those frames, and request 0 finishes in the same iteration
+        return bad if polls[0] == 2 else None
+
+    out = {rid: (c, t) for rid, c, t in dec.run([_req(0, 8)], on_error="yield", source=source)}
+    assert out[0][0].shape[0] == 8
+    assert 9 in out and out[9][0] is None and "too long" in out[9][1]["error"]

@@ -226,7 +226,7 @@ def test_openai_endpoint_batch_scheduler_streams_and_reports_errors(monkeypatch)
     monkeypatch.setattr(Bt, "BatchRequest", Req)
     m = _ScriptedBatchModel()
     voices = {"alloy": {"voice_clone_prompt": {"x": 1}, "ref_text": "t", "language": "English", "chunk_size": 4}}
-    client = TestClient(create_app(m, voices, default_voice="alloy", scheduler="batch", lanes=2))
+    client = TestClient(create_app(m, voices, default_voice="alloy", scheduler="batch", lanes=2, chunk_size=4))
     assert client.get("/health").json()["scheduler"] == "batch"
     r = client.post("/v1/audio/speech", json={"input": "ten chars!", "voice": "alloy", "response_format": "wav"})
     assert r.status_code == 200 and r.content[:4] == b"RIFF" and struct.unpack("<I", r.content[40:44])[0] == 0xFFFFFFFF
@@ -242,3 +242,67 @@ def test_openai_endpoint_batch_scheduler_streams_and_reports_errors(monkeypatch)
     assert r.status_code == 500 and "ref_text is required" in r.text
     r = client.post("/v1/audio/speech", json={"input": "ok", "voice": "alloy", "response_format": "pcm"})
     assert r.status_code == 200 and len(r.content) == 2 * 100 * 2
+
+
+def test_voice_cache_key_is_one_construction_for_lookup_and_store(tmp_path):
+    """A reference clip that is not at 24 kHz hits the entry its own analysis wrote (same loader + resampler on both sides), and an
+    x-vector-only entry never serves an ICL request (the mode is part of the key)."""
+    from types import SimpleNamespace
+    from fq3hip.audio_io import write_wav
+    from fq3hip.model import FasterQwen3TTS
+    clip = tmp_path / "ref16k.wav"
+    t = np.arange(16000, dtype=np.float32) / 16000.0
+    write_wav(str(clip), 0.3 * np.sin(2 * np.pi * 220.0 * t), 16000)
+    inner = SimpleNamespace(tts_model_type="base", tts_model_size="0b6", speech_tokenizer=None)
+    m = FasterQwen3TTS(SimpleNamespace(model=inner, sample_rate=24000), None, None, device="cpu")
+    m.set_voice_ref_cache(str(tmp_path / "voices"))
+    spk, codes = torch.randn(1024), torch.randint(0, 2048, (21, 16))
+    assert m._cached_voice_prompt(str(clip), "hi", False, True) is None
+    # an x-vector-only analysis is written through ...
+    m._store_voice_prompt(str(clip), SimpleNamespace(ref_spk_embedding=spk, ref_code=None, ref_text=None), True, True)
+    hit = m._cached_voice_prompt(str(clip), "", True, True)
+    assert hit is not None and hit[0]["x_vector_only_mode"] == [True] and torch.equal(hit[0]["ref_spk_embedding"][0], spk)
+    # ... and does NOT answer the ICL request for the same clip (it used to, silently dropping ref_text)
+    assert m._cached_voice_prompt(str(clip), "hi", False, False) is None
+    assert m._cached_voice_prompt(str(clip), "hi", False, True) is None
+    # the ICL analysis is then stored under its own key and found again: 16 kHz clip, resampled identically on both sides
+    m._store_voice_prompt(str(clip), SimpleNamespace(ref_spk_embedding=spk, ref_code=codes, ref_text="hi"), False, True)
+    vcp, rt = m._cached_voice_prompt(str(clip), "", False, True)
+    assert vcp["icl_mode"] == [True] and torch.equal(vcp["ref_code"][0], codes) and rt == "hi"
+    assert len(list((tmp_path / "voices").glob("*.json"))) == 2
+
+
+def test_wav_loader_names_what_it_cannot_read(tmp_path):
+    from fq3hip.audio_io import load_audio, write_wav
+    good = tmp_path / "a.wav"
+    write_wav(str(good), np.zeros(100, np.float32), 24000)
+    a, sr = load_audio(str(good))
+    assert sr == 24000 and a.shape == (100,)
+    bad = tmp_path / "f.wav"           # IEEE-float WAV header (format tag 3)
+    bad.write_bytes(b"RIFF" + struct.pack("<I", 36 + 16) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 3, 1, 24000, 96000, 4, 32) +
+                    b"data" + struct.pack("<I", 16) + np.zeros(4, "<f4").tobytes())
+    try:
+        import soundfile  # noqa: F401
+    except ImportError:
+        with pytest.raises(ValueError, match="IEEE-float"):
+            load_audio(str(bad))
+
+
+def test_batch_worker_answers_requests_the_scheduler_never_reported():
+    """Whatever the decoder does, every submitted request gets an answer and DONE (no HTTP handler is left blocked)."""
+    from fq3hip.server import BatchWorker
+
+    class Model(_ScriptedBatchModel):
+        class _Dec(_ScriptedBatchModel._Dec):
+            def run(self, requests, on_error="raise", source=None, chunk_frames=None):
+                for _r in requests:          # a scheduler that loses the request: no event at all
+                    pass
+                return
+                yield
+
+    w = BatchWorker(Model(), lanes=2, chunk_size=4)
+    box = w.submit({"voice_clone_prompt": {"x": 1}, "ref_text": "t"}, "hello")
+    first = box.get(timeout=10)
+    assert isinstance(first, Exception) and "without an answer" in str(first)
+    assert box.get(timeout=10) is BatchWorker.DONE
+    w.inbox.put(None)
