@@ -574,6 +574,24 @@ def _stub_utterance(seed):
     return 0.004 + 0.001 * (seed % 3), 0.01, FRAMES, rng.standard_normal(1000 + seed % 7).astype(np.float32)
 
 
+def self_launch(n: int) -> int:
+    """Re-run this command line as `n` ranks: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1
+    --master-port <free> bench.py <same arguments>`.  Returns the launcher's exit code (non-zero when any rank fails, e.g. when
+    the box has fewer than `n` GPUs)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -589,9 +607,18 @@ def main():
     ap.add_argument("--no-1p7b", action="store_true")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` (no launcher): start the N ranks ourselves -- one process per GPU under torchrun, loopback
+        # rendezvous -- and hand their exit code back.  Under torchrun (the driver's N > 1 form) this branch is never taken.
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); "
+                         f"use `python bench.py --gpus {args.gpus}` or torchrun --nproc-per-node {args.gpus}")
     stub = args.stub
     if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (there is no CPU path for the product)")

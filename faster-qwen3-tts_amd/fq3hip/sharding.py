@@ -20,9 +20,11 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
-def gather_arrays(local: np.ndarray, device="cpu") -> List[np.ndarray]:
-    """All ranks contribute one 1-D array (ragged); every rank gets the list ordered by rank."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def gather_arrays(local: np.ndarray, device="cpu", always_collective: bool = False) -> List[np.ndarray]:
+    """All ranks contribute one 1-D array (ragged); every rank gets the list ordered by rank.  A single rank needs no
+    collective and gets its array back, unless ``always_collective`` asks for the real ``all_gather`` pair anyway (how the
+    1-GPU test makes RCCL itself execute)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not always_collective):
         return [np.asarray(local)]
     world = dist.get_world_size()
     t = torch.as_tensor(np.ascontiguousarray(local)).to(device)

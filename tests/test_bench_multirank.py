@@ -46,3 +46,29 @@ def test_bench_two_ranks_gloo_stub():
 def test_bench_single_rank_stub_has_same_shape():
     d = _run(1, steps=1)
     assert d["n_gpus"] == 1 and d["config3_sharded_batched"]["utterances"] == 10
+
+
+def test_bench_gpus_flag_alone_launches_the_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT a launcher (the form README / DESIGN advertise and the driver's SCALE command
+    uses at N = 1): bench.py starts the two ranks itself and rank 0's line says n_gpus: 2."""
+    env = dict(os.environ, FQ3_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub",
+           "--config3-utterances", "6"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config3_sharded_batched"]["utterances"] == 6
+
+
+def test_bench_refuses_a_world_that_contradicts_gpus():
+    """Launched as 2 ranks but told --gpus 1: every rank exits non-zero instead of printing a line with the wrong n_gpus."""
+    env = dict(os.environ, FQ3_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--stub"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
