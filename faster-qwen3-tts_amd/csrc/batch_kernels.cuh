@@ -3,9 +3,11 @@
 // the weights per frame.  Every lane keeps its own single-stream context (KV caches, DecodeState, history, codes,
 // noise rings -- prefill and fq3_decode_begin are the single-stream entry points); only the per-frame chain is
 // replaced.  The lane-local kernels below are thin wrappers that point the single-stream bodies at lane `l`;
-// gemv_batch_kernel is the M = B GEMV: tokens prepared (RMSNorm / split-KV merge, T-rounded) cooperatively into
-// LDS, weight rows in registers, every wave walks the B tokens.  Same arithmetic, order and rounding as gemv_kernel,
-// so a lane's ids are bit-identical to the same utterance decoded alone (tests/test_gpu_batch.py).
+// gemv_batch_kernel is the M = B GEMV on the VALU: tokens prepared (RMSNorm, T-rounded) cooperatively into LDS in
+// groups of up to 8, weight rows in registers, every wave walks the tokens.  Same arithmetic, order and rounding as
+// gemv_kernel, so a lane's ids are bit-identical to the same utterance decoded alone (tests/test_gpu_batch.py).
+// The bf16 default is the pair of matrix-core kernels further down (one 16-column token tile per MFMA: up to 16 lanes
+// cost the same weight stream and the same MFMA count as 8).
 #pragma once
 #include "decode_kernels.cuh"
 #include "sampler.cuh"
@@ -13,7 +15,8 @@
 
 namespace fq3 {
 
-constexpr int kMaxLanes = 8;
+constexpr int kMaxLanes = 16;        // one v_mfma_f32_16x16x32_bf16 token tile
+constexpr int kGroupLanes = 8;       // VALU batch GEMV: tokens staged in LDS per pass over the register-resident weight rows
 
 struct LaneTab {
     DecodeState* st[kMaxLanes];
@@ -84,55 +87,66 @@ __global__ __launch_bounds__(256) void sample_pred_batch_kernel(LaneTab t, const
     const int l = blockIdx.x;
     SampleCfg c{};                       // policy comes from the lane's DecodeState
     c.rep_penalty = 1.0f; c.sup_lo = 0; c.sup_hi = 0; c.keep_id = -1; c.sup_extra = -1;
-    sample_pred_wave_body<T, NC>(t.st[l], logits + (size_t)l * logit_stride, V, cb, c, (const T*)nullptr, t.codes[l], G,
-                                 (int64_t*)nullptr, next_emb, next_in + (size_t)l * H, H);
+    // NUCLEUS = true: a lane whose policy asks for top_p < 1 takes the LDS sampler (sampler.cuh::sample_core) inside the same
+    // launch; the register-resident path of the other lanes is unchanged
+    sample_pred_wave_body<T, NC, true>(t.st[l], logits + (size_t)l * logit_stride, V, cb, c, (const T*)nullptr, t.codes[l], G,
+                                       (int64_t*)nullptr, next_emb, next_in + (size_t)l * H, H);
 }
 
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void sample_talker_batch_kernel(LaneTab t, const T* logits, int V, int G) {
     const int l = blockIdx.x;
-    sample_talker_wave_body<T, NC>(t.st[l], logits + (size_t)l * V, V, t.seen[l], G);
+    sample_talker_wave_body<T, NC, true>(t.st[l], logits + (size_t)l * V, V, t.seen[l], G);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 struct BatchGemvArgs {
     const void* W; int N; int K; int B;
-    const void* x; int x_stride;                   // T[B][x_stride]          (PRO_PLAIN / PRO_NORM)
+    const void* x; int x_stride;                   // T[B][x_stride]
     const void* norm_w; float eps;
     const void* bias;
     void* y; int y_stride;                         // T[B][y_stride]
     const void* res; int res_stride;               // T[B][res_stride]        (EPI_RESIDUAL), may alias y
     int up_off;
-    const float* part; size_t part_stride; int n_part; int rep;       // PRO_COMBINE: lane l's slots at part + l * part_stride
+    int group;                                     // VALU kernel: tokens per LDS pass (1..kGroupLanes; the launcher sizes the LDS for it)
     void* xn_out[kMaxLanes];                       // optional per-lane copy of the prepared token (codec_head -> past_hidden)
 };
 
-// One row per wave (4 rows per workgroup); B <= kMaxLanes is a launch argument, the loops are unrolled to kMaxLanes
-// and guarded (uniform branches), so one instantiation serves every batch size.
+// One row per wave (4 rows per workgroup), weight rows loaded ONCE; the B <= kMaxLanes tokens pass through LDS in groups of
+// `a.group` <= 8 (so that B x K never has to fit the 160 KB LDS at once: 16 lanes, fp32, K = 6144 would need 393 KB).  Loops
+// are unrolled to the group maximum and guarded by uniform branches, so one instantiation serves every batch size.
 template <typename T, int NCH, int PRO, int EPI>
 __global__ __launch_bounds__(256) void gemv_batch_kernel(BatchGemvArgs a) {
+    static_assert(PRO == PRO_PLAIN || PRO == PRO_NORM, "the split-KV merge is its own launch in the batch chain (combine_batch_kernel)");
     constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;
-    constexpr int TPW = kMaxLanes / 4;                          // tokens prepared per wave
+    constexpr int GT = kGroupLanes, TPW = GT / 4;               // tokens prepared per wave and group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* xs = reinterpret_cast<T*>(smem_raw);                     // [B][K], normalised / merged + rounded
+    T* xs = reinterpret_cast<T*>(smem_raw);                     // [group][K], normalised + rounded
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int K = a.K, B = a.B;
+    const int K = a.K, B = a.B, group = a.group;
     const T* W = reinterpret_cast<const T*>(a.W);
     const int row = blockIdx.x * 4 + wave;
     const int rowc = row < a.N ? row : a.N - 1;
 
-    // ---- 1. token loads: wave w prepares tokens w and w + 4 (clamped, unconditional) ----
+    // ---- 1. token loads of the first group: wave w prepares group tokens w and w + 4 (clamped, unconditional) ----
     Raw8<T> xraw[TPW][NCH], nraw[NCH];
-    if constexpr (PRO != PRO_COMBINE) {
+    auto issue_tokens = [&](int g0, int nb) {
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int off = j * 512 + lane * 8, offc = off < K ? off : 0;
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-                const int m = wave + 4 * t < B ? wave + 4 * t : B - 1;
+                const int m = g0 + (wave + 4 * t < nb ? wave + 4 * t : nb - 1);
                 ldraw<false>(xraw[t][j], reinterpret_cast<const T*>(a.x) + (size_t)m * a.x_stride + offc);
             }
-            if constexpr (PRO == PRO_NORM) ldraw<false>(nraw[j], reinterpret_cast<const T*>(a.norm_w) + offc);
+        }
+    };
+    issue_tokens(0, B < group ? B : group);
+    if constexpr (PRO == PRO_NORM) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int off = j * 512 + lane * 8;
+            ldraw<false>(nraw[j], reinterpret_cast<const T*>(a.norm_w) + (off < K ? off : 0));
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -147,34 +161,29 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(BatchGemvArgs a) {
             ldraw<false>(raw[h][j], wr + (off < K ? off : 0));
         }
     }
-    float resv[kMaxLanes];
-#pragma unroll
-    for (int m = 0; m < kMaxLanes; ++m) {
-        resv[m] = 0.f;
-        if constexpr (EPI == EPI_RESIDUAL) {
-            const int mc = m < B ? m : B - 1;
-            resv[m] = DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)mc * a.res_stride + rowc);
-        }
-    }
     const T* bp = a.bias ? reinterpret_cast<const T*>(a.bias) + rowc : W;
     const float bv = DT<T>::ld(bp);
     const float biasv = a.bias ? bv : 0.f;
     __builtin_amdgcn_sched_barrier(0);
-    // ---- 3. prepare the tokens while the weights fly; stage them in LDS ----
+
+#pragma unroll 1
+    for (int g0 = 0; g0 < B; g0 += group) {
+        const int nb = B - g0 < group ? B - g0 : group;
+        if (g0 > 0) issue_tokens(g0, nb);                       // later groups pay one exposed round trip (B > 8 only)
+        float resv[GT];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int m = wave + 4 * t;
-        const int mc = m < B ? m : B - 1;
-        float xr[NCH][8];
-        if constexpr (PRO == PRO_COMBINE) {
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int off = j * 512 + lane * 8;
-                CombineRegs cr;
-                combine_load(cr, a.part + (size_t)mc * a.part_stride, off < K ? off : 0, a.rep, a.n_part);
-                combine_finish<T>(cr, a.n_part, xr[j]);
+        for (int m = 0; m < GT; ++m) {
+            resv[m] = 0.f;
+            if constexpr (EPI == EPI_RESIDUAL) {
+                const int mc = g0 + (m < nb ? m : nb - 1);
+                resv[m] = DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)mc * a.res_stride + rowc);
             }
-        } else {
+        }
+        // ---- 3. prepare this group's tokens (the first group: while the weights fly); stage them in LDS ----
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int m = wave + 4 * t;
+            float xr[NCH][8];
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 if (j * 512 + lane * 8 >= K) zero(xraw[t][j]);
@@ -202,85 +211,92 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(BatchGemvArgs a) {
                     }
                 }
             }
-        }
-        if (m < B) {
-            T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[m]) : nullptr;
+            if (m < nb) {
+                T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[g0 + m]) : nullptr;
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int off = j * 512 + lane * 8;
-                if (off < K) {
-                    DT<T>::st8(xs + (size_t)m * K + off, xr[j]);
-                    if (xo) DT<T>::st8(xo + off, xr[j]);
+                for (int j = 0; j < NCH; ++j) {
+                    const int off = j * 512 + lane * 8;
+                    if (off < K) {
+                        DT<T>::st8(xs + (size_t)m * K + off, xr[j]);
+                        if (xo) DT<T>::st8(xo + off, xr[j]);
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
-    // ---- 4. walk the B tokens: same chunk order and fma chain as gemv_kernel's dot8 ----
-    float acc[kMaxLanes][NR];
+        __syncthreads();
+        // ---- 4. walk the group's tokens: same chunk order and fma chain as gemv_kernel's dot8 ----
+        float acc[GT][NR];
 #pragma unroll
-    for (int m = 0; m < kMaxLanes; ++m) {
+        for (int m = 0; m < GT; ++m) {
 #pragma unroll
-        for (int h = 0; h < NR; ++h) acc[m][h] = 0.f;
-        if (m < B) {
-            float xr[NCH][8];
+            for (int h = 0; h < NR; ++h) acc[m][h] = 0.f;
+            if (m < nb) {
+                float xr[NCH][8];
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int off = j * 512 + lane * 8;
-                Raw8<T> q;
-                ldraw<false>(q, xs + (size_t)m * K + (off < K ? off : 0));
-                if (off >= K) zero(q);
-                unpack(q, xr[j]);
-            }
+                for (int j = 0; j < NCH; ++j) {
+                    const int off = j * 512 + lane * 8;
+                    Raw8<T> q;
+                    ldraw<false>(q, xs + (size_t)m * K + (off < K ? off : 0));
+                    if (off >= K) zero(q);
+                    unpack(q, xr[j]);
+                }
 #pragma unroll
-            for (int h = 0; h < NR; ++h) {
-                float s = 0.f;
+                for (int h = 0; h < NR; ++h) {
+                    float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) s = dot8<T>(raw[h][j], xr[j], s);
-                acc[m][h] = s;
+                    for (int j = 0; j < NCH; ++j) s = dot8<T>(raw[h][j], xr[j], s);
+                    acc[m][h] = s;
+                }
             }
         }
-    }
 #pragma unroll
-    for (int m = 0; m < kMaxLanes; ++m)
+        for (int m = 0; m < GT; ++m)
 #pragma unroll
-        for (int h = 0; h < NR; ++h) acc[m][h] = wave_sum(acc[m][h]);
+            for (int h = 0; h < NR; ++h) acc[m][h] = wave_sum(acc[m][h]);
 #pragma unroll
-    for (int m = 0; m < kMaxLanes; ++m) {
-        float v;
-        if constexpr (EPI == EPI_SWIGLU) {
-            const float g = DT<T>::rnd(acc[m][0]);
-            const float u = DT<T>::rnd(acc[m][NR - 1]);
-            const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
-            v = sg * u;
-        } else {
-            v = DT<T>::rnd(acc[m][0] + biasv);
-            if constexpr (EPI == EPI_RESIDUAL) v = v + resv[m];
+        for (int m = 0; m < GT; ++m) {
+            float v;
+            if constexpr (EPI == EPI_SWIGLU) {
+                const float g = DT<T>::rnd(acc[m][0]);
+                const float u = DT<T>::rnd(acc[m][NR - 1]);
+                const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
+                v = sg * u;
+            } else {
+                v = DT<T>::rnd(acc[m][0] + biasv);
+                if constexpr (EPI == EPI_RESIDUAL) v = v + resv[m];
+            }
+            if (lane == 0 && row < a.N && m < nb) DT<T>::st(reinterpret_cast<T*>(a.y) + (size_t)(g0 + m) * a.y_stride + row, v);
         }
-        if (lane == 0 && row < a.N && m < B) DT<T>::st(reinterpret_cast<T*>(a.y) + (size_t)m * a.y_stride + row, v);
+        __syncthreads();                                        // the next group overwrites the LDS tokens
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The same M = B GEMV on the matrix cores (bf16 only; FQ3_BATCH_MFMA=1).  One workgroup = one tile of 16 weight rows
-// (x NR for SwiGLU); the 4 waves split K; v_mfma_f32_16x16x32_bf16 with A = weights (lane: row = lane & 15, k group =
-// lane >> 4: a 16-byte global load per lane IS the operand layout, no LDS hop), B = the prepared tokens from LDS
-// (lane: token = lane & 15, same k group), C[row = (lane >> 4) * 4 + reg][token]; layouts as in conv_gemm_kernel.
-// The fp32 accumulation order differs from the VALU kernels (<= ~1e-4 relative), so lanes are no longer bit-identical
-// to single-stream decoding: parity for this path is against the oracle with the bf16 tolerances.
-// Measured in the harness (profiles/r01_batch_gemv_prototype.txt): B=8 4.46 us per launch vs 7.30 us for the VALU kernel.
+// The same M = B GEMV on the matrix cores (bf16; the default).  One workgroup = one tile of 16 weight rows (x NR for
+// SwiGLU); the waves split K; v_mfma_f32_16x16x32_bf16 with A = weights (lane: row = lane & 15, k group = lane >> 4: a
+// 16-byte global load per lane IS the operand layout, no LDS hop), B = tokens (lane: token = lane & 15, same k group),
+// C[row = (lane >> 4) * 4 + reg][token]; layouts as in conv_gemm_kernel.  The tile carries 16 token columns whatever B is,
+// so 9..16 lanes cost the weight stream and the MFMA count of 1..8.  The fp32 accumulation order differs from the VALU
+// kernels (<= ~1e-4 relative), so lanes are not bit-identical to single-stream decoding: parity for this path is against
+// the oracle with the bf16 tolerances (tests/test_gpu_batch.py, tests/test_gpu_fulldepth.py).
+//   gemv_batch_mfma_norm_kernel   RMSNorm prologue (qkv, gate|up, heads; K = hidden <= 2048): tokens are normalised
+//                                 cooperatively (wave w: tokens w, w + 4, w + 8, w + 12) into a padded LDS panel
+//   gemv_batch_mfma_plain_kernel  no prologue (o_proj, down, projection; K up to 6144): the token fragments are loaded
+//                                 straight from global memory in operand layout -- no LDS panel (16 x 6144 bf16 would not
+//                                 fit), no barrier before the MFMAs; NW = 4 or 8 waves split K
+// Columns of tokens >= B hold a duplicate of token B - 1 and are never stored (an MFMA column depends on its own B column only).
 // ---------------------------------------------------------------------------------------------------------------
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int KSTEPS, int PRO, int EPI>           // K = KSTEPS * 128
-__global__ __launch_bounds__(256) void gemv_batch_mfma_kernel(BatchGemvArgs a) {
+template <int KSTEPS, int EPI>                    // K = KSTEPS * 128
+__global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs a) {
     typedef bf16_t T;
     constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr int K = KSTEPS * 128, KP = K + 8;                 // padded LDS row: 16 tokens x same k would share a bank
     constexpr int NCH = (K + 511) / 512;
     constexpr int TPW = kMaxLanes / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* xs = reinterpret_cast<T*>(smem_raw);                     // [B][KP]
+    T* xs = reinterpret_cast<T*>(smem_raw);                     // [16][KP]
     float* red = reinterpret_cast<float*>(smem_raw + (((size_t)kMaxLanes * KP * sizeof(T) + 15) & ~(size_t)15));   // [4][NR][64][4]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int fr = lane & 15, fq = lane >> 4, B = a.B;
@@ -289,17 +305,15 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_kernel(BatchGemvArgs a) {
 
     // ---- 1. token loads ----
     Raw8<T> xraw[TPW][NCH], nraw[NCH];
-    if constexpr (PRO != PRO_COMBINE) {
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int off = j * 512 + lane * 8, offc = off < K ? off : 0;
+    for (int j = 0; j < NCH; ++j) {
+        const int off = j * 512 + lane * 8, offc = off < K ? off : 0;
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int m = wave + 4 * t < B ? wave + 4 * t : B - 1;
-                ldraw<false>(xraw[t][j], reinterpret_cast<const T*>(a.x) + (size_t)m * a.x_stride + offc);
-            }
-            if constexpr (PRO == PRO_NORM) ldraw<false>(nraw[j], reinterpret_cast<const T*>(a.norm_w) + offc);
+        for (int t = 0; t < TPW; ++t) {
+            const int m = wave + 4 * t < B ? wave + 4 * t : B - 1;
+            ldraw<false>(xraw[t][j], reinterpret_cast<const T*>(a.x) + (size_t)m * a.x_stride + offc);
         }
+        ldraw<false>(nraw[j], reinterpret_cast<const T*>(a.norm_w) + offc);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- 2. this wave's K quarter of the 16 (x NR) weight rows, in A-operand layout ----
@@ -311,61 +325,43 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_kernel(BatchGemvArgs a) {
         for (int s = 0; s < KSTEPS; ++s)
             ldraw<false>(wreg[h][s], W + (size_t)(rowc + h * a.up_off) * K + wave * (K / 4) + s * 32 + fq * 8);
     // epilogue operands of wave 0: token = fr, rows row0 + fq * 4 + i
-    float resv[4], biasv[4];
-    {
-        const int tok = fr < B ? fr : 0;
+    float biasv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = row0 + fq * 4 + i < a.N ? row0 + fq * 4 + i : a.N - 1;
-            resv[i] = 0.f;
-            if constexpr (EPI == EPI_RESIDUAL) resv[i] = DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)tok * a.res_stride + r);
-            const T* bp = a.bias ? reinterpret_cast<const T*>(a.bias) + r : W;
-            const float bv = DT<T>::ld(bp);
-            biasv[i] = a.bias ? bv : 0.f;
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + fq * 4 + i < a.N ? row0 + fq * 4 + i : a.N - 1;
+        const T* bp = a.bias ? reinterpret_cast<const T*>(a.bias) + r : W;
+        const float bv = DT<T>::ld(bp);
+        biasv[i] = a.bias ? bv : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- 3. prepare tokens while the weights fly ----
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int m = wave + 4 * t;
-        const int mc = m < B ? m : B - 1;
         float xr[NCH][8];
-        if constexpr (PRO == PRO_COMBINE) {
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int off = j * 512 + lane * 8;
-                CombineRegs cr;
-                combine_load(cr, a.part + (size_t)mc * a.part_stride, off < K ? off : 0, a.rep, a.n_part);
-                combine_finish<T>(cr, a.n_part, xr[j]);
-            }
-        } else {
+        for (int j = 0; j < NCH; ++j) {
+            if (j * 512 + lane * 8 >= K) zero(xraw[t][j]);
+            unpack(xraw[t][j], xr[j]);
+        }
+        float ss = 0.f;
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                if (j * 512 + lane * 8 >= K) zero(xraw[t][j]);
-                unpack(xraw[t][j], xr[j]);
-            }
-            if constexpr (PRO == PRO_NORM) {
-                float ss = 0.f;
+        for (int j = 0; j < NCH; ++j)
 #pragma unroll
-                for (int j = 0; j < NCH; ++j)
+            for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
+        ss = wave_sum(ss);
+        const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
-                ss = wave_sum(ss);
-                const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+        for (int j = 0; j < NCH; ++j) {
+            float nw[8];
+            unpack(nraw[j], nw);
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) {
-                    float nw[8];
-                    unpack(nraw[j], nw);
-#pragma unroll
-                    for (int i = 0; i < 8; i += 2) {
-                        float u = xr[j][i] * rs, v = xr[j][i + 1] * rs;
-                        DT<T>::rnd2(u, v);
-                        u *= nw[i]; v *= nw[i + 1];
-                        DT<T>::rnd2(u, v);
-                        xr[j][i] = u; xr[j][i + 1] = v;
-                    }
-                }
+            for (int i = 0; i < 8; i += 2) {
+                float u = xr[j][i] * rs, v = xr[j][i + 1] * rs;
+                DT<T>::rnd2(u, v);
+                u *= nw[i]; v *= nw[i + 1];
+                DT<T>::rnd2(u, v);
+                xr[j][i] = u; xr[j][i + 1] = v;
             }
         }
         if (m < B) {
@@ -385,11 +381,10 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_kernel(BatchGemvArgs a) {
     f32x4 acc[NR];
 #pragma unroll
     for (int h = 0; h < NR; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int tokc = fr < B ? fr : 0;
+    const int tokc = fr < B ? fr : B - 1;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
-        u32x4 bq = *reinterpret_cast<const u32x4*>(xs + (size_t)tokc * KP + wave * (K / 4) + s * 32 + fq * 8);
-        if (fr >= B) bq = u32x4{0u, 0u, 0u, 0u};
+        const u32x4 bq = *reinterpret_cast<const u32x4*>(xs + (size_t)tokc * KP + wave * (K / 4) + s * 32 + fq * 8);
         const mfma_bf16x8 bfrag = __builtin_bit_cast(mfma_bf16x8, bq);
 #pragma unroll
         for (int h = 0; h < NR; ++h)
@@ -420,8 +415,63 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_kernel(BatchGemvArgs a) {
             v = sg * u;
         } else {
             v = DT<T>::rnd(tot[0][i] + biasv[i]);
-            if constexpr (EPI == EPI_RESIDUAL) v = v + resv[i];
         }
+        if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
+    }
+}
+
+template <int KSTEPS, int NW, int EPI>            // K = KSTEPS * 32 * NW; NW waves split K
+__global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGemvArgs a) {
+    typedef bf16_t T;
+    static_assert(EPI == EPI_STORE || EPI == EPI_RESIDUAL, "SwiGLU always follows an RMSNorm prologue");
+    constexpr int K = KSTEPS * 32 * NW;
+    __shared__ __attribute__((aligned(16))) float red[NW * 64 * 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int fr = lane & 15, fq = lane >> 4, B = a.B;
+    const T* W = reinterpret_cast<const T*>(a.W);
+    const int row0 = blockIdx.x * 16;
+    // ---- 1. token fragments (small, L2-resident) first, then the weight fragments: vmcnt retires in order, so the wait before
+    //         MFMA step s (its weight fragment) also covers every token fragment ----
+    const int tokc = fr < B ? fr : B - 1;
+    const T* xp = reinterpret_cast<const T*>(a.x) + (size_t)tokc * a.x_stride + wave * (K / NW) + fq * 8;
+    Raw8<T> breg[KSTEPS], wreg[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) ldraw<false>(breg[s], xp + s * 32);
+    __builtin_amdgcn_sched_barrier(0);
+    const int rowc = row0 + fr < a.N ? row0 + fr : a.N - 1;
+    const T* wp = W + (size_t)rowc * K + wave * (K / NW) + fq * 8;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) ldraw<false>(wreg[s], wp + s * 32);
+    float resv[4], biasv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + fq * 4 + i < a.N ? row0 + fq * 4 + i : a.N - 1;
+        resv[i] = 0.f;
+        if constexpr (EPI == EPI_RESIDUAL) resv[i] = DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)tokc * a.res_stride + r);
+        const T* bp = a.bias ? reinterpret_cast<const T*>(a.bias) + r : W;
+        const float bv = DT<T>::ld(bp);
+        biasv[i] = a.bias ? bv : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 2. MFMA over this wave's K share ----
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wreg[s].v), __builtin_bit_cast(mfma_bf16x8, breg[s].v), acc, 0, 0, 0);
+    // ---- 3. sum the NW shares (fixed order), epilogue on wave 0 ----
+    *reinterpret_cast<f32x4*>(red + ((size_t)wave * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4 t = *reinterpret_cast<const f32x4*>(red + (size_t)lane * 4);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += *reinterpret_cast<const f32x4*>(red + ((size_t)w * 64 + lane) * 4);
+    if (fr >= B) return;
+    const float tot[4] = {t.x, t.y, t.z, t.w};
+    T* yp = reinterpret_cast<T*>(a.y) + (size_t)fr * a.y_stride + row0 + fq * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = DT<T>::rnd(tot[i] + biasv[i]);
+        if constexpr (EPI == EPI_RESIDUAL) v = v + resv[i];
         if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
     }
 }

@@ -167,7 +167,29 @@ __global__ __launch_bounds__(256) void sample_api_wave_kernel(const T* logits, i
     if (threadIdx.x == 0) out[0] = tok;
 }
 
+// NUCLEUS (batched lanes): when the policy found in the loop state asks for top_p < 1 the logits already in registers are
+// spilled to LDS and the workgroup sampler of sampler.cuh (stable sort + cumulative cut, sampling.py:57-65) takes over; the
+// branch is uniform per workgroup (= per lane of the batch), so lanes with and without nucleus sampling share one launch.
 template <typename T, int NC>
+__device__ __forceinline__ int sample_nucleus_from_regs(Raw8<T> (&xraw)[NC], int V, const SampleCfg& c, const unsigned char* seen,
+                                                        const T* noise, SampleSmem& big) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        float f[8];
+        unpack(xraw[j], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = j * 2048 + threadIdx.x * 8 + i;
+            if (id < V) big.vals[id] = f[i];
+        }
+    }
+    __syncthreads();
+    const int tok = sample_core<T>(big, V, c, seen, noise);
+    __syncthreads();
+    return tok;
+}
+
+template <typename T, int NC, bool NUCLEUS = false>
 __device__ __forceinline__ void sample_pred_wave_body(const DecodeState* st, const T* logits, int V, int cb,
                                                       const SampleCfg& c_imm, const T* noise_imm, int* codes, int G,
                                                       int64_t* out64, const T* next_emb, T* next_in, int H) {
@@ -184,7 +206,14 @@ __device__ __forceinline__ void sample_pred_wave_body(const DecodeState* st, con
         if (st->pred_noise)
             noise = reinterpret_cast<const T*>(st->pred_noise) + ((size_t)(frame % st->noise_frames) * (G - 1) + cb) * V;
     }
-    int tok = sample_wave_core<T, NC>(xraw, V, c, nullptr, noise, sm);
+    int tok;
+    if constexpr (NUCLEUS) {
+        __shared__ SampleSmem big;
+        if (c.do_sample && c.top_p < 1.0f) tok = sample_nucleus_from_regs<T, NC>(xraw, V, c, nullptr, noise, big);
+        else tok = sample_wave_core<T, NC>(xraw, V, c, nullptr, noise, sm);
+    } else {
+        tok = sample_wave_core<T, NC>(xraw, V, c, nullptr, noise, sm);
+    }
     if (st) tok = forced_or(st, frame * G + 1 + cb, tok);
     if (threadIdx.x == 0) {
         if (codes) codes[(size_t)frame * G + 1 + cb] = tok;
@@ -209,7 +238,7 @@ __global__ __launch_bounds__(256) void sample_pred_wave_kernel(const DecodeState
     sample_pred_wave_body<T, NC>(st, logits, V, cb, c_imm, noise_imm, codes, G, out64, next_emb, next_in, H);
 }
 
-template <typename T, int NC>
+template <typename T, int NC, bool NUCLEUS = false>
 __device__ __forceinline__ void sample_talker_wave_body(DecodeState* st, const T* logits, int V, const unsigned char* seen, int G) {
     __shared__ BlkSmem sm;
     Raw8<T> xraw[NC];
@@ -223,7 +252,14 @@ __device__ __forceinline__ void sample_talker_wave_body(DecodeState* st, const T
     c.sup_extra = (frame + 1 < st->min_new) ? st->eos_id : -1;
     const T* noise = st->talker_noise
         ? reinterpret_cast<const T*>(st->talker_noise) + (size_t)(frame % st->noise_frames) * V : nullptr;
-    int tok = sample_wave_core<T, NC>(xraw, V, c, seen, noise, sm);
+    int tok;
+    if constexpr (NUCLEUS) {
+        __shared__ SampleSmem big;
+        if (c.do_sample && c.top_p < 1.0f) tok = sample_nucleus_from_regs<T, NC>(xraw, V, c, seen, noise, big);
+        else tok = sample_wave_core<T, NC>(xraw, V, c, seen, noise, sm);
+    } else {
+        tok = sample_wave_core<T, NC>(xraw, V, c, seen, noise, sm);
+    }
     tok = forced_or(st, (frame + 1) * G, tok);
     if (threadIdx.x == 0) { st->token = tok; st->frame = frame + 1; st->pos += 1; st->gen_step += 1; }
 }

@@ -103,8 +103,8 @@ class BatchDecoder:
         kw = dict(max_new_tokens=2048, min_new_tokens=2, temperature=0.9, top_k=50, top_p=1.0, do_sample=True,
                   repetition_penalty=1.05)
         kw.update(req.gen_kwargs)
-        if float(kw["top_p"]) < 1.0 or float(ln_pg.top_p) < 1.0:
-            raise NotImplementedError("batched decode supports top_p >= 1.0 only; use the single-stream path for nucleus sampling")
+        # nucleus sampling (top_p < 1, sampling.py:57-65) is a per-lane policy of the loop state: the batch sampler kernels
+        # branch to the LDS sorter for exactly the lanes that ask for it
         return kw
 
     def _arm(self, ln: _Lane, req: BatchRequest):
@@ -214,7 +214,7 @@ class BatchDecoder:
             source: Optional[Callable[[], Optional[BatchRequest]]] = None, chunk_frames: Optional[int] = None
             ) -> Iterator[Tuple[Any, Optional[torch.Tensor], Dict[str, Any]]]:
         """Yields ``(rid, codes LongTensor[T, 16] or None, timing)`` as utterances finish (not in request order).
-        ``on_error="yield"``: a request that cannot be armed (prompt longer than ``max_seq_len``, nucleus sampling, ...)
+        ``on_error="yield"``: a request that cannot be armed (prompt longer than ``max_seq_len``, ...)
         is reported as ``(rid, None, {"error": repr(exc), "steps": 0})`` and the other lanes keep going; the default
         re-raises, like the single-utterance entry points.  ``source``: polled without blocking at every frame boundary
         for requests that arrived after the call (``None`` = nothing waiting): a server's inbox.
@@ -266,7 +266,7 @@ class BatchDecoder:
                 limit -= 1
                 st, (req, ev) = idle.popleft(), pending.popleft()
                 try:
-                    self._kwargs(self.lanes[0].predictor_graph, req)                  # reject (top-p) before it joins a group
+                    self._kwargs(self.lanes[0].predictor_graph, req)                  # malformed sampling arguments fail here, before it joins a group
                 except Exception as exc:
                     idle.appendleft(st)
                     if on_error == "raise":

@@ -685,7 +685,7 @@ class FasterQwen3TTS:
         """Voice cloning of several texts with one voice: up to ``lanes`` (<= 16) utterances decode in lock-step over
         one pass of the weights per frame (``fq3_batch_*``), finished lanes are refilled from the queue.  Returns one
         ``([np.float32 waveform], sample_rate)`` per text, in input order; each utterance follows exactly the
-        single-utterance semantics of :meth:`generate_voice_clone` (``top_p`` must be 1.0 on this path)."""
+        single-utterance semantics of :meth:`generate_voice_clone`, nucleus sampling (``top_p < 1``) included."""
         from .batching import BatchRequest
         nsm = self._resolve_non_streaming_mode(non_streaming_mode, default=False)
         langs = language if isinstance(language, (list, tuple)) else [language] * len(texts)

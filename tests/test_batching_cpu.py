@@ -1,6 +1,6 @@
 """CPU: the continuous-batching scheduler (fq3hip/batching.py) against scripted fake lanes -- admission at frame
 boundaries, lock-step issue that never crosses a lane's noise-ring boundary, per-lane budgets, early EOS, lane re-use,
-result routing by request id, top-p rejection."""
+result routing by request id, error reporting."""
 from types import SimpleNamespace
 
 import pytest
@@ -51,7 +51,9 @@ def sched(monkeypatch):
     def fake_arm(talker, tie, tam, tth, tpe, config, pg, tg, max_new, min_new, temperature, top_k, top_p, do_sample, rp, use_graph):
         eng = tg.engine
         eng.frames, eng.budget, eng.eos_after, eng.rid = 0, int(max_new), config.eos_after, config.rid
-        log.append(("arm", eng.idx, config.rid))
+        if getattr(config, "bad", False):
+            raise RuntimeError("Input is too long")
+        log.append(("arm", eng.idx, config.rid, top_p))
         assert use_graph is False
         return eng, torch.zeros(1), torch.zeros(1), int(max_new)
 
@@ -95,20 +97,25 @@ def test_lock_step_never_crosses_a_noise_ring_boundary(sched):
     assert sum(dec.batch.calls[dec2_calls:]) == 100
 
 
-def test_zero_budget_and_top_p_rejection(sched):
+def test_zero_budget_and_top_p_passes_through(sched):
     dec, engines, log, refills = sched
     out = list(dec.run([_req(0, 0), _req(1, 5)]))
     assert out[0][0] == 0 and out[0][1] is None and out[0][2]["steps"] == 0
     assert out[1][0] == 1 and out[1][1].shape[0] == 5
-    with pytest.raises(NotImplementedError):
-        list(dec.run([_req(2, 5, top_p=0.9)]))
+    # nucleus sampling is a per-lane policy now (the batch sampler kernels honour it): the request is armed like any other
+    # and its top_p reaches the lane
+    out = list(dec.run([_req(2, 5, top_p=0.9)]))
+    assert out[0][1].shape[0] == 5
+    assert [e for e in log if e[0] == "arm"][-1][3] == 0.9
 
 
 def test_bad_request_can_be_reported_without_stopping_the_others(sched):
     dec, engines, log, refills = sched
-    out = {rid: (c, t) for rid, c, t in dec.run([_req(0, 12), _req(1, 5, top_p=0.5), _req(2, 9)], on_error="yield")}
+    bad = _req(1, 5)
+    bad.config.bad = True
+    out = {rid: (c, t) for rid, c, t in dec.run([_req(0, 12), bad, _req(2, 9)], on_error="yield")}
     assert out[0][0].shape[0] == 12 and out[2][0].shape[0] == 9
-    assert out[1][0] is None and "NotImplementedError" in out[1][1]["error"] and out[1][1]["steps"] == 0
+    assert out[1][0] is None and "too long" in out[1][1]["error"] and out[1][1]["steps"] == 0
     with pytest.raises(ValueError):
         list(dec.run([], on_error="ignore"))
 

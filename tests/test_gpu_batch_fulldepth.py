@@ -1,0 +1,160 @@
+"""Parity of the LOCK-STEP BATCH at the benchmarked configurations: full-depth 0.6B / 1.7B (28 talker + 5 predictor layers at
+the real shapes), 8 AND 16 lanes, the matrix-core batch GEMVs the bench line uses (the template instantiations selected by
+H = 1024 / 2048, I = 3072 / 6144: gemv_batch_mfma_norm_kernel<8|16, *>, gemv_batch_mfma_plain_kernel<8|12|24, 8, *>), every lane
+teacher-forced with golden oracle ids and every one of its 16 x frames decisions scored (oracle/teacher_forced.py).
+
+Lanes alternate between two golden utterances (tests/golden/fulldepth.npz: 200-row prompt, 24 frames;
+tests/golden/fulldepth_alt.npz: 137-row prompt, 16 frames -- other positions, a ragged last key tile), so the lanes of one
+batch sit at different positions and finish at different frames.
+
+Tolerances: bf16 -- a mismatch is accepted only where the ORACLE's own top-2 margin is <= K_ULP = 2 bf16 ulps of the winning
+logit (the largest margin of any mismatch ever observed on this path, single-stream or batched), and the matched fraction over
+all lanes must be >= 0.95; fp32 (VALU batch GEMVs, 16 lanes, 0.6B) -- every decision identical."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+K_ULP = 2.0
+MIN_MATCH = 0.95
+
+from fq3hip.config import qwen3_tts_0p6b, qwen3_tts_1p7b
+from fq3hip.weights import synth_weights, synth_prompt
+
+
+def _note(key, val):
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    p = os.path.join(d, "parity_batch_fulldepth.json")
+    cur = {}
+    if os.path.exists(p):
+        try:
+            cur = json.load(open(p))
+        except Exception:
+            cur = {}
+    cur[key] = val
+    json.dump(cur, open(p, "w"), indent=1)
+
+
+def _cases(golden_dir, cfg, size, tag, dtype):
+    """[(case dict, tie, tth, tpe)] for the two golden utterances of this model / dtype."""
+    from oracle import teacher_forced as TF
+    from oracle.make_golden_fulldepth_alt import alt_prompt
+    g = np.load(os.path.join(golden_dir, "fulldepth.npz"))
+    frames, plen, tlen = (int(x) for x in g["meta"])
+    tie, _tam, tth, tpe, _ = synth_prompt(cfg, plen, tlen, 0, dtype=dtype)
+    out = [(TF.load_case(g, f"{size}_{tag}"), tie, tth, tpe)]
+    ga = np.load(os.path.join(golden_dir, "fulldepth_alt.npz"))
+    if f"{size}_{tag}_codes" in ga:
+        tie2, _tam2, tth2, tpe2, _ = alt_prompt(cfg, dtype)
+        out.append((TF.load_case(ga, f"{size}_{tag}"), tie2, tth2, tpe2))
+    return out
+
+
+def _arm_forced(eng, cfg, case, tie, tth, tpe):
+    """prefill + decode_begin with the oracle's first token + teacher forcing; returns (HIP prefill decision, forced, decisions)."""
+    dev = eng.device
+    codes = case["codes"]
+    N, G = codes.shape
+    V, eos = cfg.talker.vocab_size, cfg.codec_eos_token_id
+    greedy = dict(temperature=1.0, top_k=0, top_p=1.0, do_sample=False)
+    logits, hidden = eng.prefill(tie[0].to(dev).contiguous())
+    tok0 = eng.sample(logits, sup_lo=max(0, V - 1024), sup_hi=V, keep_id=eos, suppress_eos=True, **greedy)
+    forced = torch.zeros(N + 1, G, dtype=torch.int32)
+    forced[:N] = torch.from_numpy(codes.astype(np.int32))
+    forced[N, 0] = int(codes[N - 1, 0])
+    forced = forced.to(dev).contiguous()
+    dec = torch.full((N + 1, G), -1, dtype=torch.int32, device=dev)
+    eng.decode_begin(first_token=int(codes[0, 0]), prefill_len=tie.shape[1], gen_step=0, past_hidden=hidden,
+                     trailing_text=tth[0].to(dev).contiguous(), tts_pad_embed=tpe.view(-1).to(dev).contiguous(),
+                     repetition_penalty=1.0, min_new_tokens=N, max_new_tokens=N, **greedy)
+    eng.decode_set_forced(forced, dec)
+    return int(tok0), forced, dec
+
+
+def _run_batch(engines, cfg, cases, B, mfma, graph=True):
+    from fq3hip.engine import Fq3Batch
+    from oracle import teacher_forced as TF
+    lanes = engines[:B]
+    batch = Fq3Batch(lanes)
+    batch.set_option("mfma", mfma)
+    armed = []
+    for i, e in enumerate(lanes):
+        case, tie, tth, tpe = cases[i % len(cases)]
+        armed.append((case,) + _arm_forced(e, cfg, case, tie, tth, tpe))
+    if graph:
+        batch.graph_capture()
+    batch.frames(max(c[0]["codes"].shape[0] for c in cases))
+    scores = []
+    for i, (e, (case, tok0, forced, dec)) in enumerate(zip(lanes, armed)):
+        N = case["codes"].shape[0]
+        n, _ = e.decode_poll()
+        assert n == N, (i, n, N)
+        assert np.array_equal(e.decode_codes(0, N).cpu().numpy(), case["codes"].astype(np.int64)), f"lane {i}: the forced ids were not the ones the loop continued with"
+        d = dec.cpu().numpy().astype(np.int64)[:N].copy()
+        d[0, 0] = tok0
+        scores.append(TF.score(d, case, K_ULP))
+        e.decode_set_forced(None, None)
+    batch.close()
+    return scores
+
+
+@pytest.mark.parametrize("size", ["0p6b", "1p7b"])
+def test_batch_full_depth_bf16_mfma_lanes_vs_oracle(size, golden_dir):
+    from fq3hip.engine import Fq3Engine
+    cfg = qwen3_tts_0p6b() if size == "0p6b" else qwen3_tts_1p7b()
+    dtype = torch.bfloat16
+    W = synth_weights(cfg, 0, dtype, parts=("talker", "predictor"))
+    cases = _cases(golden_dir, cfg, size, "bf16", dtype)
+    seq = max(c[1].shape[1] + c[0]["codes"].shape[0] for c in cases) + 8
+    frames = max(c[0]["codes"].shape[0] for c in cases) + 8
+    first = Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames)
+    del W
+    engines = [first] + [Fq3Engine(cfg, first.weights, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames, share=first) for _ in range(15)]
+    for e in engines:
+        e.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    for B in (8, 16):
+        scores = _run_batch(engines, cfg, cases, B, mfma=1)
+        tot = sum(s["total"] for s in scores); ok = sum(s["matched_decisions"] for s in scores)
+        worst = max(s["worst_mismatch_ulp"] for s in scores)
+        print(f"[parity] batch {size} bf16 mfma B={B}: {ok}/{tot} decisions identical, worst mismatch margin {worst} ulps, "
+              f"per lane {[s['matched_decisions'] for s in scores]}")
+        _note(f"{size}_bf16_mfma_B{B}", dict(matched=ok, total=tot, worst_mismatch_ulp=worst, k_ulp=K_ULP,
+                                              per_lane=[s["matched_decisions"] for s in scores],
+                                              unexplained=sum(s["unexplained"] for s in scores)))
+        assert all(s["unexplained"] == 0 for s in scores), scores
+        assert ok >= MIN_MATCH * tot, (ok, tot)
+        # lanes that decode the same utterance must agree with each other exactly (lock-step lanes do not interact)
+        for i in range(len(cases), B):
+            assert scores[i]["matched_decisions"] == scores[i % len(cases)]["matched_decisions"]
+    for e in engines[1:]:
+        e.close()
+    first.close()
+
+
+def test_batch_full_depth_fp32_16_lanes_exact(golden_dir):
+    """fp32 (VALU batch GEMVs, two LDS passes of 8 tokens each at 16 lanes): every decision of every lane identical to the oracle."""
+    from fq3hip.engine import Fq3Engine
+    cfg = qwen3_tts_0p6b()
+    dtype = torch.float32
+    W = synth_weights(cfg, 0, dtype, parts=("talker", "predictor"))
+    cases = _cases(golden_dir, cfg, "0p6b", "f32", dtype)
+    seq = max(c[1].shape[1] + c[0]["codes"].shape[0] for c in cases) + 8
+    frames = max(c[0]["codes"].shape[0] for c in cases) + 8
+    first = Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames)
+    del W
+    engines = [first] + [Fq3Engine(cfg, first.weights, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames, share=first) for _ in range(15)]
+    for e in engines:
+        e.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    scores = _run_batch(engines, cfg, cases, 16, mfma=0)
+    print(f"[parity] batch 0p6b f32 B=16: per lane {[s['matched_decisions'] for s in scores]} of {[s['total'] for s in scores]}")
+    _note("0p6b_f32_valu_B16", dict(matched=sum(s["matched_decisions"] for s in scores), total=sum(s["total"] for s in scores)))
+    for s in scores:
+        assert s["matched_decisions"] == s["total"], s
+    for e in engines[1:]:
+        e.close()
+    first.close()

@@ -273,52 +273,49 @@ int main(int argc, char** argv) {
 
     // ---- batched decode (csrc/batch_kernels.cuh): B tokens share one pass over the weights ----
     if (want("batch")) {
-        void* xb = dev_bf16((size_t)8 * 8192, 1.f);           // [B][8192] activations in
-        void* yb = dev_bf16((size_t)8 * 8192, 1.f);           // batch kernel out
-        void* y1 = dev_bf16((size_t)8 * 8192, 1.f);           // reference: B single-token launches of the product kernels
-        void* ym = dev_bf16((size_t)8 * 8192, 1.f);           // MFMA kernel out
+        constexpr int MB = kMaxLanes;
+        void* xb = dev_bf16((size_t)MB * 8192, 1.f);          // [B][8192] activations in
+        void* yb = dev_bf16((size_t)MB * 8192, 1.f);          // batch kernel out
+        void* y1 = dev_bf16((size_t)MB * 8192, 1.f);          // reference: B single-token launches of the product kernels
+        void* ym = dev_bf16((size_t)MB * 8192, 1.f);          // MFMA kernel out
         void* bias = dev_bf16(8192, 0.3f);
-        void* xn8 = dev_bf16((size_t)8 * 8192, 0.f);
-        float* part8 = (float*)dev_f32((size_t)8 * NKV * kMaxWorkers * 4 * kPartStride, 0.5f);
+        void* xn8 = dev_bf16((size_t)MB * 8192, 0.f);
+        const size_t pstride = (size_t)NKV * kMaxWorkers * 4 * kPartStride;
+        float* part8 = (float*)dev_f32((size_t)MB * pstride, 0.5f);
         {   // make the softmax denominators of the synthetic partial slots positive (l in [0.5, 1.5))
-            const size_t n = (size_t)8 * NKV * kMaxWorkers * 4 * kPartStride;
+            const size_t n = (size_t)MB * pstride;
             std::vector<float> hp(n); CHK(hipMemcpy(hp.data(), part8, n * 4, hipMemcpyDeviceToHost));
             for (size_t s0 = 0; s0 + kPartStride <= n; s0 += kPartStride) hp[s0 + kHeadDim + 1] = 1.0f + hp[s0 + kHeadDim + 1];
             CHK(hipMemcpy(part8, hp.data(), n * 4, hipMemcpyHostToDevice));
         }
-        const size_t pstride = (size_t)NKV * kMaxWorkers * 4 * kPartStride;
         auto bargs = [&](int kind, int i, int B, void* y) {
             BatchGemvArgs g{}; g.B = B; g.eps = 1e-6f; g.norm_w = norm_w; g.x = xb; g.x_stride = 8192; g.y = y; g.y_stride = 8192; g.res = xb; g.res_stride = 8192;
             if (kind == 0) { g.W = Wqkv[i % NL]; g.N = NQKV; g.K = H; }
             else if (kind == 1) { g.W = Wo[i % NL]; g.N = H; g.K = QD; }
             else if (kind == 2) { g.W = Wgu[i % NL]; g.N = I; g.K = H; g.up_off = I; }
             else if (kind == 3) { g.W = Wdn[i % NL]; g.N = H; g.K = I; }
-            else if (kind == 4) { g.W = Wo[i % NL]; g.N = H; g.K = QD; g.part = part8; g.part_stride = pstride; g.n_part = 8; g.rep = 2; }     // talker o_proj: split-KV merge
             else { g.W = Whead[i % NL]; g.N = Vp; g.K = H; g.bias = bias; for (int m = 0; m < B; ++m) g.xn_out[m] = (bf16_t*)xn8 + (size_t)m * 8192; } // head + bias + xn_out
             return g;
         };
         auto run_v = [&](int kind, int i, int B, void* y) {      // VALU batch kernel (bit-identical to single-token launches)
             BatchGemvArgs g = bargs(kind, i, B, y);
-            const int grid = (g.N + 3) / 4; const size_t shm = (size_t)B * g.K * 2;
+            g.group = B < kGroupLanes ? B : kGroupLanes;
+            const int grid = (g.N + 3) / 4; const size_t shm = (size_t)g.group * g.K * 2;
             if (kind == 0) hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 2, PRO_NORM, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
             else if (kind == 1) hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 4, PRO_PLAIN, EPI_RESIDUAL>), dim3(grid), dim3(256), shm, st, g);
             else if (kind == 2) hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 2, PRO_NORM, EPI_SWIGLU>), dim3(grid), dim3(256), shm, st, g);
             else if (kind == 3) hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 6, PRO_PLAIN, EPI_RESIDUAL>), dim3(grid), dim3(256), shm, st, g);
-            else if (kind == 4) hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 4, PRO_COMBINE, EPI_RESIDUAL>), dim3(grid), dim3(256), shm, st, g);
             else hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 2, PRO_NORM, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
         };
-        auto run_m = [&](int kind, int i, int B, void* y) {      // matrix-core batch kernel
+        auto run_m = [&](int kind, int i, int B, void* y) {      // matrix-core batch kernels
             BatchGemvArgs g = bargs(kind, i, B, y);
             const int grid = (g.N + 15) / 16; const int NRr = kind == 2 ? 2 : 1;
             const size_t shm = (((size_t)kMaxLanes * (g.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NRr * 256 * 4;
-            if (kind == 0) hipLaunchKernelGGL((gemv_batch_mfma_kernel<8, PRO_NORM, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
-            else if (kind == 1) hipLaunchKernelGGL((gemv_batch_mfma_kernel<16, PRO_PLAIN, EPI_RESIDUAL>), dim3(grid), dim3(256), shm, st, g);
-            else if (kind == 2) hipLaunchKernelGGL((gemv_batch_mfma_kernel<8, PRO_NORM, EPI_SWIGLU>), dim3(grid), dim3(256), shm, st, g);
-            else if (kind == 3) { auto kern = gemv_batch_mfma_kernel<24, PRO_PLAIN, EPI_RESIDUAL>;
-                CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, st, g); }
-            else if (kind == 4) hipLaunchKernelGGL((gemv_batch_mfma_kernel<16, PRO_COMBINE, EPI_RESIDUAL>), dim3(grid), dim3(256), shm, st, g);
-            else hipLaunchKernelGGL((gemv_batch_mfma_kernel<8, PRO_NORM, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
+            if (kind == 0) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
+            else if (kind == 1) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, EPI_RESIDUAL>), dim3(grid), dim3(512), 0, st, g);
+            else if (kind == 2) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_SWIGLU>), dim3(grid), dim3(256), shm, st, g);
+            else if (kind == 3) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<12, 8, EPI_RESIDUAL>), dim3(grid), dim3(512), 0, st, g);
+            else hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
         };
         auto run_1 = [&](int kind, int i, int m) {                // product single-token kernels, token m of the same buffers
             GemvArgs g{}; g.eps = 1e-6f; g.norm_w = norm_w;
@@ -330,16 +327,17 @@ int main(int argc, char** argv) {
             else if (kind == 4) { g.W = Wo[i % NL]; g.N = H; g.K = QD; g.part = part8 + (size_t)m * pstride; g.n_part = 8; g.rep = 2; gemv<4, PRO_COMBINE, EPI_RESIDUAL, false>(g, 1); }
             else { g.W = Whead[i % NL]; g.N = Vp; g.K = H; g.bias = bias; gemv<2, PRO_NORM, EPI_STORE, false>(g, 2); }
         };
-        const char* kn[6] = {"qkv NORM/STORE", "o PLAIN/RESID", "gate_up NORM/SWIGLU", "down PLAIN/RESID", "o COMBINE(8 parts)/RESID", "head NORM/STORE+bias+xn_out"};
+        const char* kn[6] = {"qkv NORM/STORE", "o PLAIN/RESID", "gate_up NORM/SWIGLU", "down PLAIN/RESID", "", "head NORM/STORE+bias+xn_out"};
         const int outn[6] = {NQKV, H, I, H, H, Vp};
-        for (int B : {8, 3}) for (int kind = 0; kind < 6; ++kind) {
-            CHK(hipMemset(yb, 0, (size_t)8 * 8192 * 2)); CHK(hipMemset(ym, 0, (size_t)8 * 8192 * 2)); CHK(hipMemset(y1, 0, (size_t)8 * 8192 * 2));
+        for (int B : {16, 11, 8, 3}) for (int kind = 0; kind < 6; ++kind) {
+            if (kind == 4) continue;
+            CHK(hipMemset(yb, 0, (size_t)MB * 8192 * 2)); CHK(hipMemset(ym, 0, (size_t)MB * 8192 * 2)); CHK(hipMemset(y1, 0, (size_t)MB * 8192 * 2));
             run_v(kind, 0, B, yb); run_m(kind, 0, B, ym);
             for (int m = 0; m < B; ++m) run_1(kind, 0, m);
             CHK(hipStreamSynchronize(st));
-            auto av = fetch_bf16(yb, (size_t)8 * 8192), am = fetch_bf16(ym, (size_t)8 * 8192), a1 = fetch_bf16(y1, (size_t)8 * 8192);
+            auto av = fetch_bf16(yb, (size_t)MB * 8192), am = fetch_bf16(ym, (size_t)MB * 8192), a1 = fetch_bf16(y1, (size_t)MB * 8192);
             int bad = 0; double e = 0;
-            for (int m = 0; m < 8; ++m) for (int r = 0; r < outn[kind]; ++r) {
+            for (int m = 0; m < MB; ++m) for (int r = 0; r < outn[kind]; ++r) {
                 const size_t ix = (size_t)m * 8192 + r;
                 bad += av[ix] != a1[ix];                          // rows of lanes >= B must stay untouched (0) in all three
                 e = fmax(e, fabs(am[ix] - a1[ix]) / (1.0 + fabs(a1[ix])));
@@ -347,22 +345,28 @@ int main(int argc, char** argv) {
             char nm[112]; snprintf(nm, sizeof nm, "batch VALU B=%d %s == single-token", B, kn[kind]); report(nm, bad, 0.5);
             snprintf(nm, sizeof nm, "batch MFMA B=%d %s ~ single-token", B, kn[kind]); report(nm, e, 1e-2);
         }
+        {   // merge kernel + PLAIN o_proj (the batch chain's pair) must equal the single-stream COMBINE o_proj bit for bit (VALU kernel)
+            void* merged = dev_bf16((size_t)MB * 8192, 0.f);
+            const int B = 16;
+            CHK(hipMemset(yb, 0, (size_t)MB * 8192 * 2)); CHK(hipMemset(y1, 0, (size_t)MB * 8192 * 2));
+            hipLaunchKernelGGL((combine_batch_kernel<bf16_t>), dim3((QD / 8 + 255) / 256, B), dim3(256), 0, st, (const float*)part8, pstride, 8, 2, QD, (bf16_t*)merged, 8192);
+            { BatchGemvArgs g = bargs(1, 0, B, yb); g.x = merged; g.x_stride = 8192; g.group = kGroupLanes;
+              hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 4, PRO_PLAIN, EPI_RESIDUAL>), dim3((g.N + 3) / 4), dim3(256), (size_t)g.group * g.K * 2, st, g); }
+            for (int m = 0; m < B; ++m) run_1(4, 0, m);
+            CHK(hipStreamSynchronize(st));
+            auto a0 = fetch_bf16(yb, (size_t)MB * 8192), a2 = fetch_bf16(y1, (size_t)MB * 8192);
+            int bad = 0; for (int m = 0; m < B; ++m) for (int r = 0; r < H; ++r) bad += a0[(size_t)m * 8192 + r] != a2[(size_t)m * 8192 + r];
+            report("merge kernel + PLAIN o_proj == single-stream COMBINE o_proj (B=16)", bad, 0.5);
+        }
         chain("batch  B=1 (single-token product kernels): qkv, o, gate_up, down x80", N, [&](int j) { run_1(j % 4, j / 4, 0); });
-        chain("batch  B=8 VALU kernel: qkv, o, gate_up, down x80", N, [&](int j) { run_v(j % 4, j / 4, 8, yb); });
-        chain("batch  B=8 MFMA kernel: qkv, o, gate_up, down x80", N, [&](int j) { run_m(j % 4, j / 4, 8, ym); });
-        chain("batch  B=8 MFMA kernel: talker o_proj with 8-part merge", N, [&](int j) { run_m(4, j, 8, ym); });
-        chain("batch  B=8 VALU kernel: talker o_proj with 8-part merge", N, [&](int j) { run_v(4, j, 8, yb); });
-        {   // candidate: merge kernel + PLAIN o_proj must equal the COMBINE o_proj bit for bit
-            void* merged = dev_bf16((size_t)8 * 8192, 0.f);
-            auto run_merge = [&]() { hipLaunchKernelGGL((combine_batch_kernel<bf16_t>), dim3((QD / 8 + 255) / 256, 8), dim3(256), 0, st, (const float*)part8, pstride, 8, 2, QD, (bf16_t*)merged, 8192); };
-            auto run_plain = [&](int i, void* y) { BatchGemvArgs g = bargs(1, i, 8, y); g.x = merged; g.x_stride = 8192;
-                hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 4, PRO_PLAIN, EPI_RESIDUAL>), dim3((g.N + 3) / 4), dim3(256), (size_t)8 * g.K * 2, st, g); };
-            CHK(hipMemset(yb, 0, (size_t)8 * 8192 * 2)); CHK(hipMemset(ym, 0, (size_t)8 * 8192 * 2));
-            run_v(4, 0, 8, yb); run_merge(); run_plain(0, ym); CHK(hipStreamSynchronize(st));
-            auto a0 = fetch_bf16(yb, (size_t)8 * 8192), a2 = fetch_bf16(ym, (size_t)8 * 8192);
-            int bad = 0; for (int m = 0; m < 8; ++m) for (int r = 0; r < H; ++r) bad += a0[(size_t)m * 8192 + r] != a2[(size_t)m * 8192 + r];
-            report("merge kernel + PLAIN o_proj == COMBINE o_proj (B=8)", bad, 0.5);
-            chain("batch  B=8 product: merge kernel, then PLAIN o_proj (2 launches per step)", N, [&](int j) { if (j & 1) run_plain(j / 2, ym); else run_merge(); });
+        for (int B : {8, 16}) {
+            char nm[112];
+            snprintf(nm, sizeof nm, "batch  B=%d VALU kernel: qkv, o, gate_up, down x80", B); chain(nm, N, [&](int j) { run_v(j % 4, j / 4, B, yb); });
+            snprintf(nm, sizeof nm, "batch  B=%d MFMA kernels: qkv, o, gate_up, down x80", B); chain(nm, N, [&](int j) { run_m(j % 4, j / 4, B, ym); });
+            const char* one[4] = {"qkv NORM", "o PLAIN (8 waves)", "gate_up NORM/SWIGLU", "down PLAIN (8 waves)"};
+            for (int kind = 0; kind < 4; ++kind) {
+                snprintf(nm, sizeof nm, "batch  B=%d MFMA %s alone", B, one[kind]); chain(nm, N, [&](int j) { run_m(kind, j, B, ym); });
+            }
         }
     }
     return g_fail ? 1 : 0;
