@@ -19,9 +19,13 @@ The JSON line also carries (all measured in this run unless tagged otherwise):
   roofline_mfma       the matrix-core kernels of the path (codec conv GEMMs, prefill GEMMs): FLOPs / event time vs the
                       2.5 PFLOP/s dense bf16 peak
   parity_bf16_frames  teacher-forced id agreement of this very model (bf16, full depth) with the CPU oracle's golden ids
-  batched_decode_one_gpu   8 lock-step lanes over one weight stream (fq3_batch_*), with its own HBM roofline
-  config3_sharded_batched  BASELINE configs[3] shape: 64 utterances, sharded over the ranks, 8 lanes per GPU
-  model_1p7b          BASELINE configs[2]: the 1.7B shapes, single stream (N = 1 only)
+  parity_pcm          PCM RMS of this model's codec (bf16, and the fp32 high-precision mode with its cost in ms) against the
+                      fp32-arithmetic oracle's golden waveform on the same bf16 checkpoint weights
+  batched_decode_one_gpu   16 lock-step lanes over one weight stream (fq3_batch_*), with its own HBM roofline
+  config3_sharded_batched  BASELINE configs[3]: 1.7B-CustomVoice shapes, 64 utterances through generate_custom_voice_batch,
+                      sharded over the ranks, 16 lanes per GPU (all ranks)
+  model_1p7b          BASELINE configs[2]: the 1.7B shapes, single stream (N = 1 only); config4_voice_design_4k inside it:
+                      BASELINE configs[4], a 4096-row VoiceDesign prompt streamed end to end
   cpu_baseline        the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded
                       sample of the same workload (rank 0, N=1 only)
 
@@ -97,11 +101,16 @@ def prefill_gemm_flops(cfg, L: int) -> float:
 # ------------------------------------------------------------------------------------------------------------------
 # GPU runner
 # ------------------------------------------------------------------------------------------------------------------
-def build_model(device, size="0p6b", frames=FRAMES, max_seq_len=2048):
+SPEAKER = "synthetic"
+
+
+def build_model(device, size="0p6b", frames=FRAMES, max_seq_len=2048, model_type="base"):
     from fq3hip.config import qwen3_tts_0p6b, qwen3_tts_1p7b
     from fq3hip.weights import synth_weights
     from fq3hip.model import FasterQwen3TTS
     cfg = qwen3_tts_0p6b() if size == "0p6b" else qwen3_tts_1p7b()
+    cfg.tts_model_type = model_type                          # Base / CustomVoice / VoiceDesign share one architecture
+    cfg.spk_id = {SPEAKER: cfg.talker.vocab_size - 1024 + 300}
     W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor", "codec", "text"), codec_normalized=True)
     model = FasterQwen3TTS.from_weights(cfg, W, device=device, dtype=torch.bfloat16, max_seq_len=max_seq_len,
                                         codec_max_frames=REF_FRAMES + frames + 16, max_frames=frames + 8)
@@ -405,11 +414,68 @@ def parity_note(cfg, model):
         dec = TF.forced_decisions(eng, cfg, tie, tth, tpe, case["codes"], graph=True)
     finally:
         pg.do_sample, pg.top_k, pg.temperature = saved["do_sample"], saved["top_k"], saved["temperature"]
-    s = TF.score(dec, case, 4.0)
+    s = TF.score(dec, case, 2.0)
     return {"matched_frames": s["matched_frames"], "frames": s["frames"], "matched_decisions": s["matched_decisions"],
             "decisions": s["total"], "worst_mismatch_margin_bf16_ulp": s["worst_mismatch_ulp"], "unexplained": s["unexplained"],
             "method": "teacher-forced vs CPU-oracle golden ids, 28+5 layers, 200-token prompt; a mismatch counts as explained "
-                      "when the oracle's own top-2 margin is <= 4 bf16 ulps (tests/test_gpu_fulldepth.py)"}
+                      "when the oracle's own top-2 margin is <= 2 bf16 ulps (tests/test_gpu_fulldepth.py)"}
+
+
+def parity_pcm(cfg, model, device):
+    """PCM parity of THIS model's codec weights (bf16 checkpoint values) on a bounded sample: the committed golden waveform of
+    the fp32-arithmetic CPU oracle on the same bf16-valued weights (tests/golden/codec_real_q.npz, T = 100 frames > the
+    attention window; oracle/make_golden_codec_real.py) against (a) the bf16 codec the headline runs, (b) the high-precision mode
+    (codec_precision="fp32": same weights, fp32 activations and fp32 MFMA products), with the cost of each for the full
+    370-frame decode.  The north star's 1e-3 is met by (b); (a) sits at the bf16 arithmetic floor of this network (the oracle's
+    own bf16 run is 7.6e-3 from its fp32 run)."""
+    from fq3hip.codec import HipSpeechTokenizer
+    g = np.load(os.path.join(ROOT, "tests", "golden", "codec_real_q.npz"))
+    T = 100
+    codes = torch.from_numpy(g[f"codes_{T}"].astype(np.int64)).to(device)
+    ref = g[f"pcm_f32q_{T}"]
+    W = model._bench_weights
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a.astype(np.float64)))))
+    lo = model.model.model.speech_tokenizer
+    hp = HipSpeechTokenizer(cfg.codec, W, str(device), torch.float32, max_frames=REF_FRAMES + FRAMES + 16)
+    gg = torch.Generator().manual_seed(4)
+    full = torch.randint(0, cfg.codec.codebook_size, (REF_FRAMES + FRAMES, cfg.codec.num_quantizers), generator=gg).to(device)
+
+    def timed(tok, reps=3):
+        tok.decode_tensor(full)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            tok.decode_tensor(full)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def chunk_ms(tok, reps=5):
+        """a streaming phase-2 chunk: 25 context + 8 new frames, only the new samples produced"""
+        w = full[:33].contiguous()
+        first = tok.num_samples_total(33) - 8 * 1920
+        tok.decode_tensor(w, first)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            tok.decode_tensor(w, first)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    out = {"sample": f"T = {T} frames ({ref.size} samples), fp32-arithmetic CPU-oracle golden on the bf16 checkpoint weights", "signal_rms": round(rms(ref), 4),
+           "tolerance_north_star": 1e-3}
+    for name, tok in (("bf16", lo), ("fp32_mode", hp)):
+        wav = tok.decode_tensor(codes).cpu().numpy()
+        out[name] = {"pcm_rms_vs_fp32_oracle": float(f"{rms(wav - ref):.3e}"), "full_decode_370_frames_ms": round(timed(tok), 3),
+                     "streaming_chunk_8_frames_ms": round(chunk_ms(tok), 3)}
+    out["fp32_mode"]["meets_1e-3"] = bool(out["fp32_mode"]["pcm_rms_vs_fp32_oracle"] <= 1e-3)
+    out["note"] = ("bf16 arithmetic of this synthetic vocoder is chaotic at the 7.6e-3 level (the CPU oracle's own bf16 run vs its fp32 run on "
+                   "the same weights); codec_precision='fp32' is the mode that meets the north star's 1e-3")
+    hp.close()
+    return out
 
 
 def cpu_baseline(cfg, frames=6, budget_s=45.0):
@@ -514,10 +580,82 @@ def ref_analysis_block(cfg, device, seconds=10.0, reps=10):
     return out
 
 
-def model_1p7b_block(device):
+def sentences(n: int):
+    """`n` distinct ~110-character lines (the utterances of the configs[3] block)."""
+    words = ("the quick brown fox jumps over the lazy dog and keeps running through the quiet evening fields while "
+             "a small boat drifts along the river past the old stone bridge under a pale and patient moon ").split()
+    out = []
+    for i in range(n):
+        k = (7 * i) % len(words)
+        line = " ".join(words[k:] + words[:k])
+        out.append((f"line {i}: " + line)[:110])
+    return out
+
+
+def custom_voice_batch_run(model, texts, lanes, frames=FRAMES, seed=2000):
+    """BASELINE configs[3] on this rank's share: CustomVoice utterances (speaker-id prompts, model.py:1139-1326) through the
+    public generate_custom_voice_batch -- text in, waveforms on the host out.  Returns (audio_s, wall_s, sample counts)."""
+    torch.manual_seed(seed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = model.generate_custom_voice_batch(texts, SPEAKER, "English", max_new_tokens=frames, min_new_tokens=frames, lanes=lanes)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    lens = [int(len(w[0])) for w, _sr in outs]
+    return sum(lens) / 24000.0, wall, lens
+
+
+def config4_block(cfg, model, device, prompt_rows=4096, runs=2):
+    """BASELINE configs[4]: VoiceDesign long-form -- a `prompt_rows`-row instruct + text prompt (non_streaming_mode = the
+    VoiceDesign default, model.py:1348-1351: the whole text sits in the prompt), max_seq_len >= prompt + frames, streamed in
+    8-frame chunks through the public generate_voice_design_streaming: device prompt build (text projection of ~4k tokens),
+    matrix-core prefill (flash attention + 256-wide GEMM tiles), 200 decode frames at KV 4096..4296, chunked codec decode."""
+    inner = model.model.model
+    saved = inner.tts_model_type
+    inner.tts_model_type = "voice_design"
+    try:
+        text = sentences(1)[0]
+        base = "a calm, low and steady narrator who speaks slowly, with long pauses and a warm tone; "
+        instruct = (base * (prompt_rows // len(base) + 2))[:prompt_rows - 200]
+        for _ in range(4):                      # byte-level stand-in tokenizer: trim / extend the instruct to hit the row count exactly
+            _m, _t, _c, tie, _tam, _tth, _tpe = model._design_prepare(text, instruct, "English", None)
+            d = prompt_rows - int(tie.shape[1])
+            if d == 0:
+                break
+            instruct = instruct + base[:d] if d > 0 else instruct[:d]
+        rows = int(tie.shape[1])
+
+        def one(seed):
+            torch.manual_seed(seed)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ttfa, n, samples = None, 0, 0
+            for audio, _sr, tm in model.generate_voice_design_streaming(text, instruct, "English", chunk_size=CHUNK,
+                                                                        max_new_tokens=FRAMES, min_new_tokens=FRAMES):
+                if ttfa is None:
+                    ttfa = time.perf_counter() - t0
+                n = tm["total_steps_so_far"]
+                samples += len(audio)
+            torch.cuda.synchronize()
+            return ttfa, time.perf_counter() - t0, n, samples
+
+        one(700)
+        res = [one(701 + i) for i in range(runs)]
+        # the decode-frame graph at this context length (KV ~ 4096 + 100)
+        return {"workload": f"configs[4]: Qwen3-TTS-12Hz-1.7B-VoiceDesign shapes, {rows}-row prompt ({len(instruct)} instruct bytes + text, "
+                            f"byte-level stand-in tokenizer), streaming chunk_size={CHUNK}, {FRAMES} frames, max_seq_len {model.max_seq_len}",
+                "prompt_rows": rows, "rtf": round(float(np.mean([n * FRAME_S / w for _t, w, n, _s in res])), 3),
+                "ttfa_ms_p50": round(1000 * float(np.median([t for t, _w, _n, _s in res])), 2),
+                "wall_ms_per_utterance": round(1000 * float(np.mean([w for _t, w, _n, _s in res])), 1),
+                "frames": int(res[0][2]), "samples": int(res[0][3])}
+    finally:
+        inner.tts_model_type = saved
+
+
+def model_1p7b_block(cfg, model, device, lanes=16):
     """BASELINE configs[2]: the 1.7B shapes (talker hidden 2048 / intermediate 6144, predictor with projection), single
-    stream: RTF / TTFA over 2 utterances + the decode-frame roofline; and 8 lock-step lanes (configs[3]'s model)."""
-    cfg, model = build_model(device, "1p7b", max_seq_len=6144)
+    stream: RTF / TTFA over 2 utterances + the decode-frame roofline; the lock-step batch at these shapes; the 4096-token prefill;
+    and BASELINE configs[4] end to end (config4_voice_design_4k)."""
     req = build_request(cfg, device)
     one_utterance(model, req, 900)
     prompt = prepared_prompt(model, req)
@@ -549,15 +687,18 @@ def model_1p7b_block(device):
                                "frac": round((gemm_fl + attn_fl) / (pms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "bound": "mfma"}
     except Exception as e:
         out["prefill_4096"] = {"error": repr(e)}
+    for B in sorted({8, lanes}):
+        try:
+            ms, p = batched_frame_time(model, cfg, prompt, lanes=B)
+            out[f"batched_b{B}"] = {"ms_per_lockstep_frame": round(ms, 3), "value": round(B * 80.0 / ms, 1),
+                                    "unit": f"x real-time aggregate, decode only ({B} lanes, one GPU)",
+                                    "roofline": frame_roofline(cfg, ms, p, lanes=B, what=f"batched decode-frame hipGraph, {B} lanes")}
+        except Exception as e:
+            out[f"batched_b{B}"] = {"error": repr(e)}
     try:
-        ms, p = batched_frame_time(model, cfg, prompt, lanes=8)
-        out["batched_b8"] = {"ms_per_lockstep_frame": round(ms, 3), "value": round(8 * 80.0 / ms, 1),
-                             "unit": "x real-time aggregate, decode only (8 lanes, one GPU)",
-                             "roofline": frame_roofline(cfg, ms, p, lanes=8, what="batched decode-frame hipGraph, 8 lanes")}
+        out["config4_voice_design_4k"] = config4_block(cfg, model, device)
     except Exception as e:
-        out["batched_b8"] = {"error": repr(e)}
-    del model
-    torch.cuda.empty_cache()
+        out["config4_voice_design_4k"] = {"error": repr(e)}
     return out
 
 
@@ -599,7 +740,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
-    ap.add_argument("--batch", type=int, default=8, help="lock-step lanes of the batched figures (0 = skip them)")
+    ap.add_argument("--batch", type=int, default=16, help="lock-step lanes of the batched figures, <= 16 (0 = skip them)")
     ap.add_argument("--batch-groups", type=int, default=1, help="opt-in: concurrent lock-step batches on one GPU, `batched_groups_one_gpu` (1 = skip; measured: two host-threaded groups of 8 give 159x vs 159x for one)")
     ap.add_argument("--config3-utterances", type=int, default=64, help="utterances of the sharded batched run (0 = skip)")
     ap.add_argument("--concurrent", type=int, default=4,
@@ -686,10 +827,11 @@ def main():
     if solo:
         guarded("reference_audio_analysis", lambda: ref_analysis_block(cfg, device))
         guarded("parity_bf16_frames", lambda: parity_note(cfg, model))
+        guarded("parity_pcm", lambda: parity_pcm(cfg, model, device))
         guarded("roofline_mfma", lambda: measure_mfma(cfg, model, prompt))
     if solo and args.batch > 1:
         def _batched():
-            lanes = min(args.batch, 8)
+            lanes = min(args.batch, 16)
             batched_run(model, prompt, lanes, lanes)                                   # warm-up: contexts, graph capture
             audio_s, wall, _ = batched_run(model, prompt, 2 * lanes, lanes)
             ms, p = batched_frame_time(model, cfg, prompt, lanes)
@@ -708,22 +850,32 @@ def main():
                                     "note": "VALU batch GEMVs: lanes bit-identical to single-stream decoding"}
             except Exception as e:
                 out["valu_gemv"] = {"error": repr(e)}
+            if lanes > 8:
+                try:
+                    ms8, p8 = batched_frame_time(model, cfg, prompt, 8)
+                    out["lanes_8"] = {"ms_per_lockstep_frame": round(ms8, 3), "decode_only_value": round(8 * 80.0 / ms8, 1)}
+                except Exception as e:
+                    out["lanes_8"] = {"error": repr(e)}
             return out
         guarded("batched_decode_one_gpu", _batched)
         if args.batch_groups > 1:
             guarded("batched_groups_one_gpu", lambda: batched_groups_run(cfg, model, prompt, device, args.config3_utterances or 64,
-                                                                         groups=args.batch_groups, lanes=min(args.batch, 8)))
+                                                                         groups=args.batch_groups, lanes=min(args.batch, 16)))
 
-    # ---- BASELINE configs[3] shape: 64 utterances sharded over the ranks, 8 lock-step lanes per GPU (all ranks take part) ----
+    # ---- BASELINE configs[3]: 1.7B-CustomVoice shapes, 64 utterances sharded over the ranks, 16 lock-step lanes per GPU (all
+    #      ranks take part), through the public generate_custom_voice_batch ----
     c3 = None
+    cfg17 = model17 = None
     if args.config3_utterances > 0 and args.batch > 1 and not args.no_extras:
         from fq3hip.sharding import shard_indices
         mine = shard_indices(args.config3_utterances, rank, world)
-        lanes = min(args.batch, 8)
+        lanes = min(args.batch, 16)
         err, c3_audio, c3_lens = None, 0.0, []
+        texts = sentences(args.config3_utterances)
         try:
             if not stub:
-                batched_run(model, prompt, min(lanes, len(mine)), lanes)               # warm-up
+                cfg17, model17 = build_model(device, "1p7b", max_seq_len=6144 if world == 1 else 2048, model_type="custom_voice")
+                custom_voice_batch_run(model17, [texts[i] for i in mine[:lanes]], lanes, frames=16, seed=1999)     # warm-up: contexts, graph
         except Exception as e:
             err = repr(e)
         barrier()
@@ -734,7 +886,7 @@ def main():
                     time.sleep(0.005 * len(mine))
                     c3_audio, c3_lens = len(mine) * FRAMES * FRAME_S, [1000 + i for i in mine]
                 else:
-                    c3_audio, _w, c3_lens = batched_run(model, prompt, len(mine), lanes, seed0=2000 + rank)
+                    c3_audio, _w, c3_lens = custom_voice_batch_run(model17, [texts[i] for i in mine], lanes, seed=2000 + rank)
             except Exception as e:
                 err = repr(e)
         barrier()
@@ -800,16 +952,19 @@ def main():
                 out["config3_sharded_batched"] = {"error": c3["error"]}
             else:
                 out["config3_sharded_batched"] = {
-                    "workload": f"configs[3] shape on the 0.6B shapes: {args.config3_utterances} utterances x {FRAMES} frames, round-robin over "
+                    "workload": f"configs[3]: Qwen3-TTS-12Hz-1.7B-CustomVoice shapes, {args.config3_utterances} utterances x {FRAMES} frames through "
+                                f"generate_custom_voice_batch (speaker-id prompts, text in -> waveforms on the host), round-robin over "
                                 f"{world} GPU(s), {c3['lanes']} lock-step lanes per GPU, non-streaming vocoder, result gather only",
                     "value": round(c3["audio_s"] / c3["wall"], 3) if c3["wall"] > 0 else None,
                     "unit": "x real-time (aggregate audio s / max wall s)", "utterances": len(c3["lens"]), "wall_s": round(c3["wall"], 3)}
         out.update(extras)
         if solo and not args.no_1p7b:
             try:
-                del model
-                torch.cuda.empty_cache()
-                out["model_1p7b"] = model_1p7b_block(device)
+                if model17 is None:
+                    cfg17, model17 = build_model(device, "1p7b", max_seq_len=6144, model_type="custom_voice")
+                inner17 = model17.model.model
+                inner17.tts_model_type = "base"                # configs[2] is the Base model: same weights, voice-clone entry points
+                out["model_1p7b"] = model_1p7b_block(cfg17, model17, device, lanes=min(max(args.batch, 8), 16))
             except Exception as e:
                 out["model_1p7b"] = {"error": repr(e)}
         if world == 1 and not stub and not args.no_cpu_baseline:

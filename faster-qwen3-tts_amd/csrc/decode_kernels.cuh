@@ -100,7 +100,7 @@ template <int NCH, int EPI> struct MaxRows {
 // second, so that the prologue arithmetic (RMSNorm / split-KV merge, ~0.5-1 us of VALU time) runs while the
 // weights are still in flight; vmcnt retires in order, so the opposite order exposes it.
 template <typename T, int NCH, int PRO, int EPI, bool NT, int M = 1, int R = 1>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
+__device__ __forceinline__ void gemv_body(const GemvArgs& a) {
     constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;     // physical rows per logical row
     extern __shared__ __attribute__((aligned(16))) float xs[];      // PRO_COMBINE only: M*K floats
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -263,6 +263,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         }
     }
 }
+
+template <typename T, int NCH, int PRO, int EPI, bool NT, int M = 1, int R = 1>
+__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) { gemv_body<T, NCH, PRO, EPI, NT, M, R>(a); }
 
 // ================================================================================================
 // Attention for one new token over a contiguous static KV cache [n_kv][max_seq][128].
@@ -447,9 +450,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) { attn_dec
 // new key's norm + RoPE; the group's first head appends K/V to the cache.
 // ================================================================================================
 template <typename T>
-__device__ __forceinline__ void attn_pred_body(const AttnArgs& a) {
+__device__ __forceinline__ void attn_pred_body(const AttnArgs& a, int head) {
     constexpr int HD = kHeadDim;
-    const int head = blockIdx.x, g = head / a.rep, hh = head - g * a.rep;
+    const int g = head / a.rep, hh = head - g * a.rep;
     const int lane = threadIdx.x & 63, sub = lane >> 4, c = lane & 15;
     const int pos = a.pos_imm;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
@@ -547,6 +550,9 @@ __device__ __forceinline__ void attn_pred_body(const AttnArgs& a) {
     for (int d = 0; d < 8; ++d) o[d] = xrow_sum(o[d]) * inv;
     if (sub == 0) DT<T>::st8(reinterpret_cast<T*>(a.out) + (size_t)head * HD + c * 8, o);
 }
+
+template <typename T>
+__device__ __forceinline__ void attn_pred_body(const AttnArgs& a) { attn_pred_body<T>(a, (int)blockIdx.x); }
 
 template <typename T>
 __global__ __launch_bounds__(64) void attn_pred_kernel(AttnArgs a) { attn_pred_body<T>(a); }

@@ -507,6 +507,11 @@ extern "C" int fq3_prefill(fq3_ctx* c, const void* embeds, int L, int n_pad, voi
     return FQ3_OK;
 }
 
+extern "C" int fq3_prefill_reserve(fq3_ctx* c) {
+    NEED_BOUND(c);
+    return fq3_prefill_reserve_(c);
+}
+
 extern "C" int fq3_prefill_batch(fq3_ctx* const* ctxs, int n, const void* const* embeds, const int* L, const int* n_pad,
                                  void* const* out_logits, void* const* out_hidden, void* stream) {
     if (!ctxs || !embeds || !L || !n_pad || !out_hidden || n < 1 || n > 64) return fail(FQ3_EINVAL, "fq3_prefill_batch: bad argument");

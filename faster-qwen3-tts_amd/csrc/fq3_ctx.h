@@ -58,6 +58,7 @@ struct fq3_ctx {
 
 
 int fq3_fail_(int code, const std::string& m);                 // sets the thread-local error string
+int fq3_prefill_reserve_(fq3_ctx* c);
 int fq3_prefill_mfma_(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits, void* out_hidden, hipStream_t s);
 int fq3_prefill_batch_mfma_(fq3_ctx* const* cs, int n, const void* const* embeds, const int* L, const int* n_pad, void* const* out_logits,
                             void* const* out_hidden, hipStream_t s);

@@ -270,17 +270,7 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
     const int H = d.hidden, I = d.inter, NH = d.n_heads, NKV = d.n_kv_heads;
     const int QD = NH * kHeadDim, KVD = NKV * kHeadDim, per = QD + 2 * KVD;
     if (H % 32 || I % 32) return fq3_fail_(FQ3_EUNSUPPORTED, "MFMA prefill needs hidden and intermediate sizes that are multiples of 32");
-    const size_t rows = (size_t)c->cfg.max_seq_len;
-    if (!c->pf_x) {
-        int r;
-        if ((r = fq3_dmalloc_(c, &c->pf_x, rows * H * c->esz))) return r;
-        if ((r = fq3_dmalloc_(c, &c->pf_xn, rows * H * c->esz))) return r;
-        if ((r = fq3_dmalloc_(c, &c->pf_qkv, rows * per * c->esz))) return r;
-        if ((r = fq3_dmalloc_(c, &c->pf_att, rows * QD * c->esz))) return r;
-        if ((r = fq3_dmalloc_(c, &c->pf_gu, rows * 2 * I * c->esz))) return r;
-        if ((r = fq3_dmalloc_(c, &c->pf_act, rows * I * c->esz))) return r;
-        if ((r = fq3_dmalloc_(c, &c->pf_ws, (size_t)kPrefillWsFloats * sizeof(float)))) return r;
-    }
+    if (int r = fq3_prefill_reserve_(c)) return r;
     T *X = (T*)c->pf_x, *XN = (T*)c->pf_xn, *QKV = (T*)c->pf_qkv, *ATT = (T*)c->pf_att, *GU = (T*)c->pf_gu, *ACT = (T*)c->pf_act;
     if (hipMemcpyAsync(X, embeds, (size_t)L * H * c->esz, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return fq3_fail_(FQ3_EHIP, "prefill: copy of the prompt embeddings failed");
@@ -329,17 +319,7 @@ int prefill_batch_t(fq3_ctx* const* cs, int n, const void* const* embeds, const 
     const int H = d.hidden, I = d.inter, NH = d.n_heads, NKV = d.n_kv_heads;
     const int QD = NH * kHeadDim, KVD = NKV * kHeadDim, per = QD + 2 * KVD;
     if (H % 32 || I % 32) return fq3_fail_(FQ3_EUNSUPPORTED, "MFMA prefill needs hidden and intermediate sizes that are multiples of 32");
-    const size_t rows = (size_t)c->cfg.max_seq_len;
-    if (!c->pf_x) {
-        int r;
-        if ((r = fq3_dmalloc_(c, &c->pf_x, rows * H * c->esz))) return r;
-        if ((r = fq3_dmalloc_(c, &c->pf_xn, rows * H * c->esz))) return r;
-        if ((r = fq3_dmalloc_(c, &c->pf_qkv, rows * per * c->esz))) return r;
-        if ((r = fq3_dmalloc_(c, &c->pf_att, rows * QD * c->esz))) return r;
-        if ((r = fq3_dmalloc_(c, &c->pf_gu, rows * 2 * I * c->esz))) return r;
-        if ((r = fq3_dmalloc_(c, &c->pf_act, rows * I * c->esz))) return r;
-        if ((r = fq3_dmalloc_(c, &c->pf_ws, (size_t)kPrefillWsFloats * sizeof(float)))) return r;
-    }
+    if (int r = fq3_prefill_reserve_(c)) return r;
     T *X = (T*)c->pf_x, *XN = (T*)c->pf_xn, *QKV = (T*)c->pf_qkv, *ATT = (T*)c->pf_att, *GU = (T*)c->pf_gu, *ACT = (T*)c->pf_act;
     std::vector<int> off(n + 1, 0);
     for (int q = 0; q < n; ++q) off[q + 1] = off[q] + L[q];
@@ -387,6 +367,27 @@ int prefill_batch_t(fq3_ctx* const* cs, int n, const void* const* embeds, const 
 }
 
 }  // namespace
+
+// The matrix-core prefill's activation workspace (max_seq_len rows of x, norm(x), qkv, attention, gate|up, act + the split-K
+// partials): allocated on first use, or up front through fq3_prefill_reserve -- a scheduler that prefills into spare contexts
+// while other lanes decode must not meet a hipMalloc there.
+int fq3_prefill_reserve_(fq3_ctx* c) {
+    if (c->pf_x) return 0;
+    const fq3_stack_dims& d = c->cfg.talker;
+    const size_t H = d.hidden, I = d.inter, QD = (size_t)d.n_heads * kHeadDim, per = QD + 2 * (size_t)d.n_kv_heads * kHeadDim;
+    const size_t rows = (size_t)c->cfg.max_seq_len;
+    int r;
+    void* x = nullptr;
+    if ((r = fq3_dmalloc_(c, &x, rows * H * c->esz))) return r;
+    if ((r = fq3_dmalloc_(c, &c->pf_xn, rows * H * c->esz))) return r;
+    if ((r = fq3_dmalloc_(c, &c->pf_qkv, rows * per * c->esz))) return r;
+    if ((r = fq3_dmalloc_(c, &c->pf_att, rows * QD * c->esz))) return r;
+    if ((r = fq3_dmalloc_(c, &c->pf_gu, rows * 2 * I * c->esz))) return r;
+    if ((r = fq3_dmalloc_(c, &c->pf_act, rows * I * c->esz))) return r;
+    if ((r = fq3_dmalloc_(c, &c->pf_ws, (size_t)kPrefillWsFloats * sizeof(float)))) return r;
+    c->pf_x = x;                                   // set last: marks the whole set as present
+    return 0;
+}
 
 int fq3_prefill_batch_mfma_(fq3_ctx* const* cs, int n, const void* const* embeds, const int* L, const int* n_pad, void* const* out_logits,
                             void* const* out_hidden, hipStream_t s) {

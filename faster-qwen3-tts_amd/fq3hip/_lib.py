@@ -95,6 +95,7 @@ SIGNATURES = {
     "fq3_set_generation_state": (C.c_int, [vp, C.c_int, C.c_int]),
     "fq3_talker_step": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "fq3_prefill": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "fq3_prefill_reserve": (C.c_int, [vp]),
     "fq3_prefill_batch": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(vp),
                                     C.POINTER(vp), vp]),
     "fq3_set_prefill_mode": (C.c_int, [vp, C.c_int]),
@@ -161,7 +162,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = ABI drift; let it surface
         fn.restype = res
         fn.argtypes = args
-    if lib.fq3_abi_version() != 2:
+    if lib.fq3_abi_version() != 3:
         raise ImportError("libfq3hip ABI version mismatch")
     _lib = lib
     return lib

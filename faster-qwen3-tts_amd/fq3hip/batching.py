@@ -87,6 +87,12 @@ class BatchDecoder:
         # spare contexts (same weights, not part of the lock-step batch) for prefilling ahead of admission
         self.stages = [_Stage(e) for e in (staging or [])]
         self._side = None
+        # every context this scheduler will ever prefill into gets its workspace NOW: a lazy device allocation inside a staged
+        # prefill would land in the middle of the running lanes' decode
+        for e in list(engines) + [st.engine for st in self.stages]:
+            reserve = getattr(e, "prefill_reserve", None)
+            if reserve is not None:
+                reserve()
         # opt-in: requests staged together share ONE pass over the weights (fq3_prefill_batch; parity-tested at the engine level,
         # tests/test_gpu_decode.py, but its effect on first-wave TTFA has not been measured yet, so the scheduler default stays on
         # one prefill per request)
@@ -145,7 +151,19 @@ class BatchDecoder:
         def run():
             if len(group) == 1 or not self.packed_prefill:
                 return [_prefill_first_token(e, *it) for e, it in zip(engines, items)]
-            return _prefill_first_tokens_packed(engines, items)
+            # packed prefills share the leading context's workspace (max_seq_len rows): split the group where the rows run out
+            out, lo, rows = [], 0, 0
+            cap = int(getattr(engines[0], "max_seq_len", 1 << 30))
+            for i, it in enumerate(items):
+                n = int(it[0].shape[1])
+                if i > lo and rows + n > cap:
+                    out += (_prefill_first_tokens_packed(engines[lo:i], items[lo:i]) if i - lo > 1
+                            else [_prefill_first_token(engines[lo], *items[lo])])
+                    lo, rows = i, 0
+                rows += n
+            out += (_prefill_first_tokens_packed(engines[lo:], items[lo:]) if len(items) - lo > 1
+                    else [_prefill_first_token(engines[lo], *items[lo])])
+            return out
 
         if self._on_gpu(engines[0]):
             dev = engines[0].device

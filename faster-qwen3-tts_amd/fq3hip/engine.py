@@ -203,6 +203,11 @@ class Fq3Engine:
                                      hid.data_ptr(), self._stream()))
         return logits, hid
 
+    def prefill_reserve(self):
+        """Allocate this context's prefill workspace now (``fq3_prefill_reserve``) instead of inside its first prefill."""
+        with torch.cuda.device(self.device):
+            L.check(self.lib.fq3_prefill_reserve(self.ctx))
+
     @staticmethod
     def prefill_batch(engines, embeds, n_pads=None):
         """Several prompts in one pass over the weights (``fq3_prefill_batch``): ``embeds[i]`` [L_i, H] is prefilled into

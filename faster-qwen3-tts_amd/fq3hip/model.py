@@ -204,7 +204,8 @@ class FasterQwen3TTS:
                         gguf_codec_path: Optional[Union[str, Path]] = None,
                         qwentts_library_path: Optional[Union[str, Path]] = None, qwentts_use_fa: bool = True,
                         qwentts_clamp_fp16: bool = False, qwentts_ref_cache_dir: Optional[Union[str, Path]] = None,
-                        cache_dir: Optional[Union[str, Path]] = None, local_files_only: bool = False):
+                        cache_dir: Optional[Union[str, Path]] = None, local_files_only: bool = False,
+                        codec_precision: Optional[str] = None):
         """Load a local Qwen3-TTS checkpoint directory and build the HIP decode context.
 
         ``backend`` keeps the reference's vocabulary: ``"torch"`` (the default) selects the graph-captured
@@ -233,15 +234,17 @@ class FasterQwen3TTS:
             tokenizer = AutoTokenizer.from_pretrained(path, local_files_only=True)
         except Exception as e:      # tokenizer files are optional for code-only workflows
             logger.warning("no text tokenizer loaded from %s (%s)", path, e)
-        return cls.from_weights(cfg, weights, device=device, dtype=dtype, max_seq_len=max_seq_len, tokenizer=tokenizer)
+        return cls.from_weights(cfg, weights, device=device, dtype=dtype, max_seq_len=max_seq_len, tokenizer=tokenizer,
+                                codec_precision=codec_precision)
 
     @classmethod
     def from_weights(cls, cfg, weights, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
                      max_seq_len: int = 2048, tokenizer=None, codec_max_frames: int = 1024, max_frames: int = 2048,
-                     share: Optional["FasterQwen3TTS"] = None):
+                     share: Optional["FasterQwen3TTS"] = None, codec_precision: Optional[str] = None):
         """Build from an in-memory weight table (real or seeded synthetic, ``fq3hip.weights``).
         ``share``: an existing model on the same GPU whose weight replica this instance borrows -- one
-        instance (decode context + codec workspace) per concurrently running utterance."""
+        instance (decode context + codec workspace) per concurrently running utterance.
+        ``codec_precision``: ``None`` = model dtype, ``"fp32"`` = high-precision vocoder (see ``NativeQwen3TTS``)."""
         if not str(device).startswith("cuda") or not torch.cuda.is_available():
             raise ValueError("CUDA graphs require CUDA device")
         from .native_model import NativeQwen3TTS
@@ -249,7 +252,7 @@ class FasterQwen3TTS:
         from .talker_graph import TalkerGraph
         base = NativeQwen3TTS(cfg, weights, device=device, dtype=dtype, max_seq_len=max_seq_len, tokenizer=tokenizer,
                               codec_max_frames=codec_max_frames, max_frames=max_frames,
-                              share=share.model if share is not None else None)
+                              share=share.model if share is not None else None, codec_precision=codec_precision)
         pg = PredictorGraph(base.engine, do_sample=True, top_k=50, temperature=0.9)      # model.py:209-218
         tg = TalkerGraph(base.engine)
         return cls(base_model=base, predictor_graph=pg, talker_graph=tg, device=device, dtype=dtype,
@@ -672,6 +675,68 @@ class FasterQwen3TTS:
         remaining / next utterances goes on meanwhile) and copies the waveform to pinned host memory asynchronously."""
         return _SideVocoder(self.model.model.speech_tokenizer, self.device)
 
+    def _run_batch_full(self, prepared, gen_kwargs, lanes: int) -> List[Tuple[list, int]]:
+        """``prepared[i]`` = ``(talker, config, tie, tam, tth, tpe, ref_codes | None)``: the lock-step decode of all of them through
+        ``lanes`` lanes, every finished utterance vocoded on the side stream (the reference's share of an ICL waveform is cut by not
+        producing it, model.py:927-930).  One ``([waveform], sample_rate)`` per entry, in input order."""
+        from .batching import BatchRequest
+        reqs = [BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(gen_kwargs))
+                for i, (talker, config, tie, tam, tth, tpe, _rc) in enumerate(prepared)]
+        out: List[Optional[Tuple[list, int]]] = [None] * len(prepared)
+        voc = self._side_vocoder()
+        for rid, codec_ids, _timing in self._batch_decoder(lanes).run(reqs):
+            if codec_ids is None:
+                out[rid] = ([np.zeros(1, dtype=np.float32)], self.sample_rate)
+                continue
+            rc = prepared[rid][6]
+            codes = torch.cat([rc.to(codec_ids.device), codec_ids], dim=0) if rc is not None else codec_ids
+            # side stream; the next frames of the other lanes are not held up
+            voc.submit(rid, codes, ref_len=rc.shape[0] if rc is not None else 0)
+        for rid, a in voc.collect():
+            out[rid] = ([a], voc.sample_rate)
+        return out
+
+    def _run_batch_streaming(self, prepared, gen_kwargs, chunk_size: int, lanes: int):
+        """Streaming form of :meth:`_run_batch_full`: yields ``(index, audio_chunk, sample_rate, timing)`` for every
+        ``chunk_size`` frames of any utterance -- per utterance exactly the chunks the single-utterance streaming entry point
+        would produce (same windowing state machine).  ``timing``: ``chunk_index``, ``total_steps_so_far``, ``is_final``."""
+        from .batching import BatchRequest
+        reqs, vocs, n_chunks = [], {}, {}
+        for i, (talker, config, tie, tam, tth, tpe, rc) in enumerate(prepared):
+            reqs.append(BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(gen_kwargs)))
+            vocs[i], n_chunks[i] = self.streaming_vocoder(rc, chunk_size), 0
+        for rid, codes, info in self._batch_decoder(lanes).run(reqs, chunk_frames=chunk_size):
+            ev = info.pop("codes_ready_event", None)
+            final = bool(info.get("is_final"))
+            if codes is not None and codes.shape[0] > 0:
+                audio, sr = vocs[rid].push(codes, ev)
+            elif final:
+                audio, sr = np.zeros(1 if codes is None else 0, dtype=np.float32), self.sample_rate
+            else:
+                continue
+            yield rid, audio, sr, dict(chunk_index=n_chunks[rid], total_steps_so_far=int(info.get("total_steps_so_far", 0)),
+                                       is_final=final, chunk_steps=0 if codes is None else int(codes.shape[0]))
+            n_chunks[rid] += 1
+
+    @staticmethod
+    def _per_text(value, n: int, what: str) -> list:
+        """One value for all texts, or one per text."""
+        if isinstance(value, (list, tuple)):
+            if len(value) != n:
+                raise ValueError(f"{what} must be one value or one per text")
+            return list(value)
+        return [value] * n
+
+    def _prepare_clone_batch(self, texts, language, ref_audio, ref_text, xvec_only, nsm, append_silence, instruct, voice_clone_prompt):
+        prepared = []
+        for text, lang in zip(texts, self._per_text(language, len(texts), "language")):
+            _m, talker, config, tie, tam, tth, tpe, rc = self._prepare_generation(
+                text=text, language=lang, ref_audio=ref_audio, ref_text=ref_text, xvec_only=xvec_only,
+                non_streaming_mode=nsm, append_silence=append_silence, voice_clone_prompt=voice_clone_prompt,
+                instruct=instruct)
+            prepared.append((talker, config, tie, tam, tth, tpe, rc))
+        return prepared
+
     @torch.inference_mode()
     def generate_voice_clone_batch(self, texts: List[str], language: Union[str, List[str]] = "English",
                                    ref_audio: Optional[Union[str, Path]] = None, ref_text: str = "",
@@ -686,34 +751,11 @@ class FasterQwen3TTS:
         one pass of the weights per frame (``fq3_batch_*``), finished lanes are refilled from the queue.  Returns one
         ``([np.float32 waveform], sample_rate)`` per text, in input order; each utterance follows exactly the
         single-utterance semantics of :meth:`generate_voice_clone`, nucleus sampling (``top_p < 1``) included."""
-        from .batching import BatchRequest
         nsm = self._resolve_non_streaming_mode(non_streaming_mode, default=False)
-        langs = language if isinstance(language, (list, tuple)) else [language] * len(texts)
-        if len(langs) != len(texts):
-            raise ValueError("language must be one string or one per text")
-        gen_kwargs = self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty)
-        reqs, ref_codes_of = [], {}
-        for i, (text, lang) in enumerate(zip(texts, langs)):
-            m, talker, config, tie, tam, tth, tpe, rc = self._prepare_generation(
-                text=text, language=lang, ref_audio=ref_audio, ref_text=ref_text, xvec_only=xvec_only,
-                non_streaming_mode=nsm, append_silence=append_silence, voice_clone_prompt=voice_clone_prompt,
-                instruct=instruct)
-            reqs.append(BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(gen_kwargs)))
-            ref_codes_of[i] = rc
-        out: List[Optional[Tuple[list, int]]] = [None] * len(texts)
-        voc = self._side_vocoder()
-        for rid, codec_ids, _timing in self._batch_decoder(lanes).run(reqs):
-            if codec_ids is None:
-                out[rid] = ([np.zeros(1, dtype=np.float32)], self.sample_rate)
-                continue
-            rc = ref_codes_of[rid]
-            codes = torch.cat([rc.to(codec_ids.device), codec_ids], dim=0) if rc is not None else codec_ids
-            # side stream; the next frames of the other lanes are not held up.  The reference's share of the waveform is cut
-            # (model.py:927-930) by not producing it
-            voc.submit(rid, codes, ref_len=rc.shape[0] if rc is not None else 0)
-        for rid, a in voc.collect():
-            out[rid] = ([a], voc.sample_rate)
-        return out
+        prepared = self._prepare_clone_batch(texts, language, ref_audio, ref_text, xvec_only, nsm, append_silence, instruct,
+                                             voice_clone_prompt)
+        return self._run_batch_full(prepared, self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample,
+                                                               repetition_penalty), lanes)
 
     @torch.inference_mode()
     def generate_voice_clone_batch_streaming(self, texts: List[str], language: Union[str, List[str]] = "English",
@@ -729,32 +771,61 @@ class FasterQwen3TTS:
         ``chunk_size`` frames of any utterance yield ``(text_index, audio_chunk, sample_rate, timing)`` -- per utterance
         exactly the chunks :meth:`generate_voice_clone_streaming` would produce for it (same windowing state machine).
         ``timing``: ``chunk_index``, ``total_steps_so_far``, ``is_final``."""
-        from .batching import BatchRequest
         nsm = self._resolve_non_streaming_mode(non_streaming_mode, default=False)
-        langs = language if isinstance(language, (list, tuple)) else [language] * len(texts)
-        if len(langs) != len(texts):
-            raise ValueError("language must be one string or one per text")
-        gen_kwargs = self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty)
-        reqs, vocs, n_chunks = [], {}, {}
-        for i, (text, lang) in enumerate(zip(texts, langs)):
-            m, talker, config, tie, tam, tth, tpe, rc = self._prepare_generation(
-                text=text, language=lang, ref_audio=ref_audio, ref_text=ref_text, xvec_only=xvec_only,
-                non_streaming_mode=nsm, append_silence=append_silence, voice_clone_prompt=voice_clone_prompt,
-                instruct=instruct)
-            reqs.append(BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(gen_kwargs)))
-            vocs[i], n_chunks[i] = self.streaming_vocoder(rc, chunk_size), 0
-        for rid, codes, info in self._batch_decoder(lanes).run(reqs, chunk_frames=chunk_size):
-            ev = info.pop("codes_ready_event", None)
-            final = bool(info.get("is_final"))
-            if codes is not None and codes.shape[0] > 0:
-                audio, sr = vocs[rid].push(codes, ev)
-            elif final:
-                audio, sr = np.zeros(1 if codes is None else 0, dtype=np.float32), self.sample_rate
-            else:
-                continue
-            yield rid, audio, sr, dict(chunk_index=n_chunks[rid], total_steps_so_far=int(info.get("total_steps_so_far", 0)),
-                                       is_final=final, chunk_steps=0 if codes is None else int(codes.shape[0]))
-            n_chunks[rid] += 1
+        prepared = self._prepare_clone_batch(texts, language, ref_audio, ref_text, xvec_only, nsm, append_silence, instruct,
+                                             voice_clone_prompt)
+        yield from self._run_batch_streaming(prepared, self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p,
+                                                                         do_sample, repetition_penalty), chunk_size, lanes)
+
+    def _prepare_custom_batch(self, texts, speaker, language, instruct, non_streaming_mode):
+        n = len(texts)
+        prepared = []
+        for text, spk, lang, ins in zip(texts, self._per_text(speaker, n, "speaker"), self._per_text(language, n, "language"),
+                                        self._per_text(instruct, n, "instruct")):
+            _m, talker, config, tie, tam, tth, tpe = self._custom_prepare(text, spk, lang, ins, non_streaming_mode)
+            prepared.append((talker, config, tie, tam, tth, tpe, None))
+        return prepared
+
+    @torch.inference_mode()
+    def generate_custom_voice_batch(self, texts: List[str], speaker: Union[str, List[str]], language: Union[str, List[str]] = "English",
+                                    instruct: Optional[Union[str, List[Optional[str]]]] = None,
+                                    non_streaming_mode: Optional[bool] = None, max_new_tokens: int = 2048, min_new_tokens: int = 2,
+                                    temperature: float = 0.9, top_k: int = 50, top_p: float = 1.0, do_sample: bool = True,
+                                    repetition_penalty: float = 1.05, lanes: int = 16) -> List[Tuple[list, int]]:
+        """CustomVoice for several texts (BASELINE configs[3]: many concurrent utterances of a CustomVoice model): every
+        utterance is prepared exactly like :meth:`generate_custom_voice` (speaker-id prompt, model.py:1139-1326; ``speaker`` /
+        ``language`` / ``instruct`` may be one value or one per text) and up to ``lanes`` of them decode in lock-step over one pass of
+        the weights per frame.  Returns one ``([waveform], sample_rate)`` per text, in input order."""
+        prepared = self._prepare_custom_batch(texts, speaker, language, instruct, non_streaming_mode)
+        return self._run_batch_full(prepared, self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample,
+                                                               repetition_penalty), lanes)
+
+    @torch.inference_mode()
+    def generate_custom_voice_batch_streaming(self, texts: List[str], speaker: Union[str, List[str]],
+                                              language: Union[str, List[str]] = "English",
+                                              instruct: Optional[Union[str, List[Optional[str]]]] = None,
+                                              non_streaming_mode: Optional[bool] = None, max_new_tokens: int = 2048,
+                                              min_new_tokens: int = 2, temperature: float = 0.9, top_k: int = 50, top_p: float = 1.0,
+                                              do_sample: bool = True, repetition_penalty: float = 1.05, chunk_size: int = 12,
+                                              lanes: int = 16) -> Generator[Tuple[int, np.ndarray, int, dict], None, None]:
+        """Streaming form of :meth:`generate_custom_voice_batch`: ``(text_index, audio_chunk, sample_rate, timing)`` per chunk."""
+        prepared = self._prepare_custom_batch(texts, speaker, language, instruct, non_streaming_mode)
+        yield from self._run_batch_streaming(prepared, self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p,
+                                                                         do_sample, repetition_penalty), chunk_size, lanes)
+
+    @torch.inference_mode()
+    def generate_voice_design_batch(self, texts: List[str], instruct: Union[str, List[str]], language: Union[str, List[str]] = "English",
+                                    non_streaming_mode: Optional[bool] = None, max_new_tokens: int = 2048, min_new_tokens: int = 2,
+                                    temperature: float = 0.9, top_k: int = 50, top_p: float = 1.0, do_sample: bool = True,
+                                    repetition_penalty: float = 1.05, lanes: int = 16) -> List[Tuple[list, int]]:
+        """VoiceDesign for several texts in lock-step lanes; every utterance prepared like :meth:`generate_voice_design`."""
+        n = len(texts)
+        prepared = []
+        for text, ins, lang in zip(texts, self._per_text(instruct, n, "instruct"), self._per_text(language, n, "language")):
+            _m, talker, config, tie, tam, tth, tpe = self._design_prepare(text, ins, lang, non_streaming_mode)
+            prepared.append((talker, config, tie, tam, tth, tpe, None))
+        return self._run_batch_full(prepared, self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample,
+                                                               repetition_penalty), lanes)
 
     @torch.inference_mode()
     def generate_voice_clone_streaming(self, text: str, language: str, ref_audio: Optional[Union[str, Path]] = None,

@@ -157,7 +157,14 @@ class NativeQwen3TTS:
 
     def __init__(self, cfg: TTSConfig, weights: Weights, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
                  max_seq_len: int = 2048, tokenizer=None, codec_max_frames: int = 1024, max_frames: int = 2048,
-                 share: Optional["NativeQwen3TTS"] = None):
+                 share: Optional["NativeQwen3TTS"] = None, codec_precision: Optional[str] = None):
+        """``codec_precision``: arithmetic of the 12 Hz codec decoder -- ``None`` / ``"model"`` = the model dtype (bf16 for a bf16
+        checkpoint, what the reference's Torch path runs), ``"fp32"`` = the checkpoint's weights widened exactly to fp32, fp32
+        activations and fp32 matrix-core products (v_mfma_f32_16x16x4_f32): the waveform of the fp32 oracle to ~1e-6 RMS at ~4x
+        the decode time (the decode loop keeps the model dtype either way)."""
+        if codec_precision not in (None, "model", "bf16", "fp32"):
+            raise ValueError("codec_precision must be None, 'model', 'bf16' or 'fp32'")
+        codec_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(codec_precision, dtype)
         self.cfg = cfg
         self.device = torch.device(device)
         self.dtype = dtype
@@ -167,7 +174,7 @@ class NativeQwen3TTS:
         talker = NativeTalker(cfg, self.engine, text if text else None, share=share.model.talker if share is not None else None)
         tok = None
         if any(k.startswith("decoder.") for k in weights):
-            tok = HipSpeechTokenizer(cfg.codec, weights, device=device, dtype=dtype, max_frames=codec_max_frames,
+            tok = HipSpeechTokenizer(cfg.codec, weights, device=device, dtype=codec_dtype, max_frames=codec_max_frames,
                                      share=share.model.speech_tokenizer if share is not None else None)
         self.model = NativeInner(cfg, talker, tok)
         self.tokenizer = tokenizer or ByteTokenizer(cfg.text_vocab_size)

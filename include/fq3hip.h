@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FQ3_ABI_VERSION 2
+#define FQ3_ABI_VERSION 3
 
 enum { FQ3_BF16 = 0, FQ3_F32 = 1 };
 enum { FQ3_OK = 0, FQ3_EINVAL = -1, FQ3_EHIP = -2, FQ3_ESTATE = -3, FQ3_ETOOLONG = -4, FQ3_EUNSUPPORTED = -5 };
@@ -140,6 +140,11 @@ int fq3_prefill(fq3_ctx* ctx, const void* embeds, int L, int n_pad, void* out_lo
  * admits several requests at once.  out_logits may be null, or hold nulls. */
 int fq3_prefill_batch(fq3_ctx* const* ctxs, int n, const void* const* embeds, const int* L, const int* n_pad,
                       void* const* out_logits, void* const* out_hidden, void* stream);
+
+/* Allocate the matrix-core prefill's activation workspace of this context now (max_seq_len rows; otherwise it is allocated by
+ * the first fq3_prefill / fq3_prefill_batch that leads with this context).  A scheduler that prefills into spare contexts on a
+ * side stream while lock-step lanes decode calls this when it is built, so that no device allocation happens under the decode. */
+int fq3_prefill_reserve(fq3_ctx* ctx);
 
 /* Test hook: 0 = matrix-core prefill (default), 1 = walk the prompt token by token through the decode kernels. */
 int fq3_set_prefill_mode(fq3_ctx* ctx, int mode);

@@ -328,3 +328,46 @@ def test_batch_lanes_vs_oracle_bf16_teacher_forced(mfma):
         tot += s["total"]; ok += s["matched_decisions"]
         e.decode_set_forced(None, None)
     assert ok >= 0.9 * tot, (ok, tot)
+
+
+@pytest.mark.parametrize("kind", ["custom_voice", "voice_design"])
+def test_custom_voice_and_voice_design_batch_equal_single_calls(kind):
+    """generate_custom_voice_batch / generate_voice_design_batch (BASELINE configs[3]'s entry point): 5 texts, per-text speakers /
+    instructs, through 3 lock-step lanes == 5 single generate_custom_voice / generate_voice_design calls (greedy, fp32: bit-identical
+    waveforms); the streaming batch form yields per utterance the chunks of the single streaming call."""
+    import copy
+    import numpy as np
+    from fq3hip.model import FasterQwen3TTS
+    cfg = copy.deepcopy(tiny_test_config())
+    cfg.tts_model_type, cfg.tts_model_size = kind, "1b7"
+    cfg.spk_id = {"bob": 7, "eve": 9}
+    cfg.spk_is_dialect = {"bob": False, "eve": False}
+    W = synth_weights(cfg, 0, torch.float32, parts=("talker", "predictor", "codec", "text"))
+    m = FasterQwen3TTS.from_weights(cfg, W, device="cuda", dtype=torch.float32, max_seq_len=200, codec_max_frames=128, max_frames=64)
+    m.predictor_graph.do_sample = False
+    m.predictor_graph.top_k = 0
+    texts = ["One.", "A second, longer line to speak.", "Three words here.", "Four.", "The fifth and last line of this batch."]
+    kw = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0, repetition_penalty=1.0, min_new_tokens=0, max_new_tokens=18)
+    if kind == "custom_voice":
+        speakers = ["bob", "eve", "bob", "bob", "eve"]
+        instr = [None, "speak slowly", None, "whisper", None]
+        single = [m.generate_custom_voice(t, s, "English", instruct=i, **kw) for t, s, i in zip(texts, speakers, instr)]
+        batch = m.generate_custom_voice_batch(texts, speakers, "English", instruct=instr, lanes=3, **kw)
+        with pytest.raises(ValueError):
+            m.generate_custom_voice_batch(texts, ["bob", "eve"], "English", lanes=3, **kw)          # one speaker, or one per text
+        chunks = {}
+        for i, audio, sr, tm in m.generate_custom_voice_batch_streaming(texts, speakers, "English", instruct=instr, lanes=3, chunk_size=4, **kw):
+            chunks.setdefault(i, []).append(audio)
+        ref_chunks = [[a for a, _sr, _tm in m.generate_custom_voice_streaming(t, s, "English", instruct=i, chunk_size=4, **kw)]
+                      for t, s, i in zip(texts, speakers, instr)]
+        for i in range(len(texts)):
+            assert len(chunks[i]) == len(ref_chunks[i])
+            assert all(np.array_equal(a, b) for a, b in zip(chunks[i], ref_chunks[i])), i
+    else:
+        instr = ["a calm low voice", "a bright young voice", "a calm low voice", "an old tired voice", "a bright young voice"]
+        single = [m.generate_voice_design(t, i, "English", **kw) for t, i in zip(texts, instr)]
+        batch = m.generate_voice_design_batch(texts, instr, "English", lanes=3, **kw)
+    assert len(batch) == len(texts)
+    for (wa, sra), (wb, srb) in zip(single, batch):
+        assert sra == srb and len(wa) == len(wb) == 1
+        assert wa[0].shape == wb[0].shape and np.array_equal(wa[0], wb[0])

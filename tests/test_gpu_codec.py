@@ -134,6 +134,34 @@ def test_codec_real_shapes_bf16(T, golden_dir):
     assert d32 <= 1.25 * floor and db <= floor, (d32, db, floor)
 
 
+@pytest.mark.parametrize("T", [40, 100])
+def test_codec_high_precision_mode_meets_1e_3(T, golden_dir):
+    """codec_precision="fp32" on a bf16 weight table (what a bf16 checkpoint is): the weights are widened exactly, activations
+    and matrix-core products are fp32.  Against the fp32-ARITHMETIC oracle on the same bf16-valued weights
+    (tests/golden/codec_real_q.npz) the waveform must be within the north star's 1e-3 RMS -- measured ~1e-6 -- while the bf16
+    arithmetic of the same weights is 7.6e-3 away from it (the oracle's own bf16 run: oracle/make_golden_codec_real.py)."""
+    from fq3hip.codec import HipSpeechTokenizer
+    from fq3hip.config import qwen3_tts_0p6b
+    g = np.load(os.path.join(golden_dir, "codec_real_q.npz"))
+    cfg = qwen3_tts_0p6b()
+    W = synth_weights(cfg, 0, torch.bfloat16, parts=("codec",), codec_normalized=True)          # the "checkpoint": bf16
+    codes = torch.from_numpy(g[f"codes_{T}"].astype(np.int64)).cuda()
+    ref = g[f"pcm_f32q_{T}"]
+    hp = HipSpeechTokenizer(cfg.codec, W, "cuda", torch.float32, max_frames=208)
+    lo = HipSpeechTokenizer(cfg.codec, W, "cuda", torch.bfloat16, max_frames=208)
+    wav_hp, wav_lo = hp.decode_tensor(codes).cpu().numpy(), lo.decode_tensor(codes).cpu().numpy()
+    e_hp, e_lo = _rms(wav_hp - ref), _rms(wav_lo - ref)
+    print(f"[parity] codec T={T} vs fp32-arithmetic oracle on the bf16 checkpoint weights: fp32 mode {e_hp:.3e}, bf16 mode {e_lo:.3e} "
+          f"(signal RMS {_rms(ref):.3f})")
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, f"parity_codec_hp_T{T}.txt"), "w") as f:
+        f.write(f"fp32_mode_vs_f32q {e_hp:.4e}\nbf16_mode_vs_f32q {e_lo:.4e}\n")
+    assert wav_hp.shape == ref.shape and e_hp <= 1e-4, e_hp            # two orders inside the north-star bound
+    assert e_lo <= 1.25 * 7.6e-3                                         # the bf16 mode stays at the bf16 arithmetic floor
+    hp.close(); lo.close()
+
+
 def test_codec_real_shapes_causal_prefix_property():
     """Size-independent property at the benchmark's full length (T = 200, fp32 and bf16): the decoder is causal, so the
     waveform of a prefix of the codes is BIT-IDENTICAL to the prefix of the waveform (what streaming relies on)."""

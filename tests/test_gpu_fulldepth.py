@@ -6,12 +6,13 @@ golden ids produced by the CPU oracle (oracle/make_golden_fulldepth.py -> tests/
 Tolerances (north star: "bit-identical in RVQ token indices"):
   fp32 : every decision identical (the oracle's smallest top-2 margin in these vectors is > 1e-3, far above fp32
          summation-order noise).
-  bf16 : every decision identical, except where the ORACLE's own top-2 margin is at most K_ULP = 4 bf16 ulps of the
-         winning logit (bf16 logits are multiples of the ulp, so margins are 0, 1, 2, ... ulps) -- there the id is decided by summation order inside a dot product (HIP: fixed 8-wide fma
-         chains + DPP tree; CPU oracle: oneDNN blocking), not by the algorithm.  The matched fraction is printed and
-         written to gpurun_out/parity_fulldepth.json (and carried into the bench line).  Measured (round 2, MI355X):
-         0.6B 373/384 decisions identical, 1.7B 370/384, every mismatch at an oracle margin of <= 4 ulps; with these
-         random-weight logits (top-1 ~ 3-5, 2048-3072 candidates) 18 % of all decisions have a margin <= 4 ulps.
+  bf16 : every decision identical, except where the ORACLE's own top-2 margin is at most K_ULP = 2 bf16 ulps of the
+         winning logit (bf16 logits are multiples of the ulp, so margins are 0, 1, 2, ... ulps) -- there the id is decided by
+         summation order inside a dot product (HIP: fixed 8-wide fma chains + DPP tree; CPU oracle: oneDNN blocking), not by
+         the algorithm.  K_ULP and the minimum matched fraction are set to what this path has been measured at (rounds 2-3,
+         MI355X, deterministic kernels: 0.6B 373-376 / 384 decisions identical, 1.7B 367-370 / 384, the worst mismatch at an
+         oracle margin of exactly 2 ulps), so a regression of either figure fails the test.  The figures are printed, written
+         to gpurun_out/parity_fulldepth.json and carried into the bench line.
 """
 import json
 import os
@@ -22,7 +23,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-K_ULP = 4.0
+K_ULP = 2.0
+MIN_MATCH = {"0p6b": 0.97, "1p7b": 0.95}
 
 from fq3hip.config import qwen3_tts_0p6b, qwen3_tts_1p7b
 from fq3hip.weights import synth_weights, synth_prompt
@@ -67,7 +69,7 @@ def test_full_depth_teacher_forced(size, tag, golden_dir):
             assert s["matched_decisions"] == s["total"], s
         else:
             assert s["unexplained"] == 0, s
-            assert s["matched_decisions"] >= 0.9 * s["total"], s
+            assert s["matched_decisions"] >= MIN_MATCH[size] * s["total"], s
     assert res["graph"]["matched_decisions"] == res["direct"]["matched_decisions"]
     _note(f"{size}_{tag}", res["graph"])
     eng.close()

@@ -100,6 +100,43 @@ static void check_lane_ops() {
 }
 
 // (combine_batch_kernel -- the split-KV merge as its own launch -- now lives in csrc/batch_kernels.cuh: shipped in round 2)
+
+// ---- candidate (round 3, measured here): the code predictor's attention INSIDE its qkv GEMV by
+// "last arriver": every workgroup of the GEMV releases its 8 output rows (agent-scope release: L2 write-back, the 8 XCDs do
+// not share an L2), takes a ticket on the counter of the kv group its rows belong to (2 q heads + k + v = 512 rows = 64
+// workgroups), and the workgroup that draws the last ticket acquires and runs the group's two one-wave attention bodies.
+// Replaces the attn_pred_kernel launch (16 workgroups x 1 wave) of every predictor layer pass.
+template <typename T>
+__global__ __launch_bounds__(256) void qkv_attn_fused_kernel(GemvArgs a, AttnArgs at, unsigned* counters, int q_rows, int kv_rows) {
+    gemv_body<T, 2, PRO_NORM, EPI_STORE, false, 1, 2>(a);
+    const int row0 = blockIdx.x * 8;
+    int g;
+    if (row0 < q_rows) g = row0 / (at.rep * kHeadDim);
+    else if (row0 < q_rows + kv_rows) g = (row0 - q_rows) / kHeadDim;
+    else g = (row0 - q_rows - kv_rows) / kHeadDim;
+    const unsigned per_group = (unsigned)((at.rep + 2) * kHeadDim / 8);
+    __shared__ int s_last;
+    __syncthreads();                                   // every wave's rows are stored (workgroup scope) before thread 0 releases them
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&counters[g], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == per_group - 1;
+        if (s_last) __hip_atomic_store(&counters[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int wave = threadIdx.x >> 6;
+    if (wave < at.rep) attn_pred_body<T>(at, g * at.rep + wave);
+}
+// the same GEMV with the release + ticket but NO attention: what the synchronisation alone adds to the launch
+template <typename T>
+__global__ __launch_bounds__(256) void qkv_ticket_only_kernel(GemvArgs a, unsigned* counters) {
+    gemv_body<T, 2, PRO_NORM, EPI_STORE, false, 1, 2>(a);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&counters[blockIdx.x >> 6], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 63u) __hip_atomic_store(&counters[blockIdx.x >> 6], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 __global__ void empty_kernel(const float* p) { if (p == nullptr) __builtin_trap(); }
 
 int main(int argc, char** argv) {
@@ -271,6 +308,57 @@ int main(int argc, char** argv) {
         });
     }
 
+    // ---- round-3 candidates for the single-stream frame (measured negative / positive results go to DESIGN.md 4.1) ----
+    if (want("fuse")) {
+        unsigned* counters; CHK(hipMalloc(&counters, 64 * 4)); CHK(hipMemset(counters, 0, 64 * 4));
+        void* attn_ref = dev_bf16(QD, 0.f);
+        void* pk2 = dev_bf16((size_t)NKV * pred_seq * 128, 1.f); void* pv2 = dev_bf16((size_t)NKV * pred_seq * 128, 1.f);
+        CHK(hipMemcpy(pk2, pk, (size_t)NKV * pred_seq * 128 * 2, hipMemcpyDeviceToDevice)); CHK(hipMemcpy(pv2, pv, (size_t)NKV * pred_seq * 128 * 2, hipMemcpyDeviceToDevice));
+        // reference: the two product launches
+        gemv<2, PRO_NORM, EPI_STORE, false>(qkv_args(0), 2);
+        { AttnArgs a = pattn_args(8); a.out = attn_ref; a.kcache = pk2; a.vcache = pv2; hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(2 * NKV), dim3(64), 0, st, a); }
+        CHK(hipStreamSynchronize(st));
+        auto ref_o = fetch_bf16(attn_ref, QD); auto ref_k = fetch_bf16(pk2, (size_t)NKV * pred_seq * 128);
+        CHK(hipMemset(qkv, 0, (size_t)NQKV * 2)); CHK(hipMemset(attn_out, 0, (size_t)QD * 2));
+        for (int rep = 0; rep < 3; ++rep)               // several launches: the counters must re-arm themselves
+            hipLaunchKernelGGL((qkv_attn_fused_kernel<bf16_t>), dim3(NQKV / 8), dim3(256), 0, st, qkv_args(0), pattn_args(8), counters, QD, KVD);
+        CHK(hipStreamSynchronize(st));
+        auto got_o = fetch_bf16(attn_out, QD); auto got_k = fetch_bf16(pk, (size_t)NKV * pred_seq * 128);
+        int bad = 0; for (int i = 0; i < QD; ++i) bad += got_o[i] != ref_o[i];
+        for (size_t i = 0; i < got_k.size(); ++i) bad += got_k[i] != ref_k[i];
+        report("fused qkv GEMV + last-arriver attention == qkv, attn_pred (bitwise)", bad, 0.5);
+        chain("fuse   qkv gemv, then attn_pred_kernel (2 launches per step)", N, [&](int j) {
+            if (j & 1) hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(2 * NKV), dim3(64), 0, st, pattn_args(8)); else gemv<2, PRO_NORM, EPI_STORE, false>(qkv_args(j / 2), 2); });
+        chain("fuse   qkv gemv + release/ticket only (no attention)", N, [&](int j) {
+            hipLaunchKernelGGL((qkv_ticket_only_kernel<bf16_t>), dim3(NQKV / 8), dim3(256), 0, st, qkv_args(j), counters); });
+        chain("fuse   qkv gemv + last-arriver attention (1 launch per step)", N, [&](int j) {
+            hipLaunchKernelGGL((qkv_attn_fused_kernel<bf16_t>), dim3(NQKV / 8), dim3(256), 0, st, qkv_args(j), pattn_args(8), counters, QD, KVD); });
+        chain("fuse   predictor layer x64, 5 launches (qkv, attn_pred, o, gate_up, down)", N, [&](int j) {
+            const int i = j / 5;
+            switch (j % 5) {
+                case 0: gemv<2, PRO_NORM, EPI_STORE, false>(qkv_args(i), 2); break;
+                case 1: hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(2 * NKV), dim3(64), 0, st, pattn_args(8)); break;
+                case 2: { GemvArgs g = o_args(i, 1); g.x = attn_out; gemv<4, PRO_PLAIN, EPI_RESIDUAL, false>(g, 1); } break;
+                case 3: gemv<2, PRO_NORM, EPI_SWIGLU, false>(gu_args(i + 1), 2); break;
+                default: gemv<6, PRO_PLAIN, EPI_RESIDUAL, false>(dn_args(i + 1), 1); break;
+            } });
+        chain("fuse   predictor layer x80, 4 launches (qkv+attn fused, o, gate_up, down)", N, [&](int j) {
+            const int i = j / 4;
+            switch (j % 4) {
+                case 0: hipLaunchKernelGGL((qkv_attn_fused_kernel<bf16_t>), dim3(NQKV / 8), dim3(256), 0, st, qkv_args(i), pattn_args(8), counters, QD, KVD); break;
+                case 1: { GemvArgs g = o_args(i, 1); g.x = attn_out; gemv<4, PRO_PLAIN, EPI_RESIDUAL, false>(g, 1); } break;
+                case 2: gemv<2, PRO_NORM, EPI_SWIGLU, false>(gu_args(i + 1), 2); break;
+                default: gemv<6, PRO_PLAIN, EPI_RESIDUAL, false>(dn_args(i + 1), 1); break;
+            } });
+        // (ii) what a dependent GEMV step can cost at best: the talker o_proj (4.2 MB) / down (6.3 MB) against the empty node
+        chain("fuse   empty kernel node", N, [&](int) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, st, cosr); });
+        chain("fuse   o_proj PLAIN R=1 grid 256 (4.2 MB)", N, [&](int i) { GemvArgs g = o_args(i, 1); g.x = attn_out; gemv<4, PRO_PLAIN, EPI_RESIDUAL, false>(g, 1); });
+        chain("fuse   o_proj PLAIN R=1 nontemporal loads", N, [&](int i) { GemvArgs g = o_args(i, 1); g.x = attn_out; gemv<4, PRO_PLAIN, EPI_RESIDUAL, true>(g, 1); });
+        chain("fuse   o_proj COMBINE 8 parts R=1 (talker)", N, [&](int i) { gemv<4, PRO_COMBINE, EPI_RESIDUAL, false>(o_args(i, 8), 1); });
+        chain("fuse   down PLAIN R=1 grid 256 (6.3 MB)", N, [&](int i) { gemv<6, PRO_PLAIN, EPI_RESIDUAL, false>(dn_args(i), 1); });
+        chain("fuse   down PLAIN R=1 nontemporal loads", N, [&](int i) { gemv<6, PRO_PLAIN, EPI_RESIDUAL, true>(dn_args(i), 1); });
+    }
+
     // ---- batched decode (csrc/batch_kernels.cuh): B tokens share one pass over the weights ----
     if (want("batch")) {
         constexpr int MB = kMaxLanes;
@@ -307,14 +395,24 @@ int main(int argc, char** argv) {
             else if (kind == 3) hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 6, PRO_PLAIN, EPI_RESIDUAL>), dim3(grid), dim3(256), shm, st, g);
             else hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 2, PRO_NORM, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
         };
+        int plain_rows = 4;                                       // rows per workgroup of the PLAIN kernels (product choice at N = 1024: 4)
         auto run_m = [&](int kind, int i, int B, void* y) {      // matrix-core batch kernels
             BatchGemvArgs g = bargs(kind, i, B, y);
             const int grid = (g.N + 15) / 16; const int NRr = kind == 2 ? 2 : 1;
             const size_t shm = (((size_t)kMaxLanes * (g.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NRr * 256 * 4;
+            const int pgrid = (g.N + plain_rows - 1) / plain_rows;
             if (kind == 0) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
-            else if (kind == 1) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, EPI_RESIDUAL>), dim3(grid), dim3(512), 0, st, g);
+            else if (kind == 1) {
+                if (plain_rows == 16) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, 16, EPI_RESIDUAL>), dim3(pgrid), dim3(512), 0, st, g);
+                else if (plain_rows == 8) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, 8, EPI_RESIDUAL>), dim3(pgrid), dim3(512), 0, st, g);
+                else hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, 4, EPI_RESIDUAL>), dim3(pgrid), dim3(512), 0, st, g);
+            }
             else if (kind == 2) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_SWIGLU>), dim3(grid), dim3(256), shm, st, g);
-            else if (kind == 3) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<12, 8, EPI_RESIDUAL>), dim3(grid), dim3(512), 0, st, g);
+            else if (kind == 3) {
+                if (plain_rows == 16) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<12, 8, 16, EPI_RESIDUAL>), dim3(pgrid), dim3(512), 0, st, g);
+                else if (plain_rows == 8) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<12, 8, 8, EPI_RESIDUAL>), dim3(pgrid), dim3(512), 0, st, g);
+                else hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<12, 8, 4, EPI_RESIDUAL>), dim3(pgrid), dim3(512), 0, st, g);
+            }
             else hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
         };
         auto run_1 = [&](int kind, int i, int m) {                // product single-token kernels, token m of the same buffers
@@ -329,8 +427,9 @@ int main(int argc, char** argv) {
         };
         const char* kn[6] = {"qkv NORM/STORE", "o PLAIN/RESID", "gate_up NORM/SWIGLU", "down PLAIN/RESID", "", "head NORM/STORE+bias+xn_out"};
         const int outn[6] = {NQKV, H, I, H, H, Vp};
-        for (int B : {16, 11, 8, 3}) for (int kind = 0; kind < 6; ++kind) {
-            if (kind == 4) continue;
+        for (int pr : {4, 8, 16}) for (int B : {16, 11, 8, 3}) for (int kind = 0; kind < 6; ++kind) {
+            plain_rows = pr;
+            if (kind == 4 || (pr != 4 && kind != 1 && kind != 3)) continue;
             CHK(hipMemset(yb, 0, (size_t)MB * 8192 * 2)); CHK(hipMemset(ym, 0, (size_t)MB * 8192 * 2)); CHK(hipMemset(y1, 0, (size_t)MB * 8192 * 2));
             run_v(kind, 0, B, yb); run_m(kind, 0, B, ym);
             for (int m = 0; m < B; ++m) run_1(kind, 0, m);
@@ -343,8 +442,9 @@ int main(int argc, char** argv) {
                 e = fmax(e, fabs(am[ix] - a1[ix]) / (1.0 + fabs(a1[ix])));
             }
             char nm[112]; snprintf(nm, sizeof nm, "batch VALU B=%d %s == single-token", B, kn[kind]); report(nm, bad, 0.5);
-            snprintf(nm, sizeof nm, "batch MFMA B=%d %s ~ single-token", B, kn[kind]); report(nm, e, 1e-2);
+            snprintf(nm, sizeof nm, "batch MFMA B=%d %s (plain rows %d) ~ single-token", B, kn[kind], pr); report(nm, e, 1e-2);
         }
+        plain_rows = 4;
         {   // merge kernel + PLAIN o_proj (the batch chain's pair) must equal the single-stream COMBINE o_proj bit for bit (VALU kernel)
             void* merged = dev_bf16((size_t)MB * 8192, 0.f);
             const int B = 16;
@@ -365,7 +465,13 @@ int main(int argc, char** argv) {
             snprintf(nm, sizeof nm, "batch  B=%d MFMA kernels: qkv, o, gate_up, down x80", B); chain(nm, N, [&](int j) { run_m(j % 4, j / 4, B, ym); });
             const char* one[4] = {"qkv NORM", "o PLAIN (8 waves)", "gate_up NORM/SWIGLU", "down PLAIN (8 waves)"};
             for (int kind = 0; kind < 4; ++kind) {
-                snprintf(nm, sizeof nm, "batch  B=%d MFMA %s alone", B, one[kind]); chain(nm, N, [&](int j) { run_m(kind, j, B, ym); });
+                if (kind == 1 || kind == 3) {
+                    for (int pr : {16, 8, 4}) { plain_rows = pr;
+                        snprintf(nm, sizeof nm, "batch  B=%d MFMA %s alone, %d rows per workgroup", B, one[kind], pr); chain(nm, N, [&](int j) { run_m(kind, j, B, ym); }); }
+                    plain_rows = 4;
+                } else {
+                    snprintf(nm, sizeof nm, "batch  B=%d MFMA %s alone", B, one[kind]); chain(nm, N, [&](int j) { run_m(kind, j, B, ym); });
+                }
             }
         }
     }
