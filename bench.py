@@ -478,6 +478,45 @@ def parity_pcm(cfg, model, device):
     return out
 
 
+def measure_frame_traffic(timeout_s=300):
+    """HBM-side traffic of one decode frame, measured in THIS run: a separate `rocprofv3 --pmc FETCH_SIZE` pass (counters only,
+    no trace domains: MI355X_MICROARCH.md, HBM section) over tools/pmc_workload.py (the same model, direct launches of the frame's
+    kernels), summed over the frame's kernels and divided by the number of frames that ran (one frame_begin_kernel dispatch each).
+    FETCH_SIZE is reported in KB and counts 64 B per 128-B fabric request on gfx950: x2.  Returns bytes per frame, or None."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="fq3_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = [exe, "--pmc", "FETCH_SIZE", "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), "frames"]
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+        dbs = [os.path.join(dp, f) for dp, _dn, fs in os.walk(out) for f in fs if f.endswith(".db")]
+        if not dbs:
+            return None, "the counter pass produced no database"
+        cur = sqlite3.connect(dbs[0]).cursor()
+        rows = cur.execute("""select s.kernel_name, count(*), sum(e.value) from rocpd_pmc_event e
+                              join rocpd_info_pmc p on e.pmc_id = p.id
+                              join rocpd_kernel_dispatch d on e.event_id = d.event_id
+                              join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+                              where p.name = 'FETCH_SIZE' group by s.kernel_name""").fetchall()
+        frame_kernels = ("gemv_kernel", "attn_pred_kernel", "attn_decode_kernel", "sample_pred", "sample_talker", "frame_begin_kernel",
+                         "embed_sum_kernel")
+        kb = sum(v for name, _n, v in rows if any(k in name for k in frame_kernels))
+        frames = sum(n for name, n, _v in rows if "frame_begin_kernel" in name)
+        if frames <= 0 or kb <= 0:
+            return None, "no decode-frame dispatches in the counter pass"
+        return 2.0 * 1024.0 * kb / frames, f"{int(frames)} profiled frames"
+    except Exception as e:
+        return None, repr(e)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def cpu_baseline(cfg, frames=6, budget_s=45.0):
     """CPU oracle ("port") on the host cores: same shapes, fp32 (bf16 matmuls are not accelerated on every host),
     same prompt; a BOUNDED sample: 200-token prefill + up to `frames` generated frames + their vocoding, cut short when
@@ -746,6 +785,7 @@ def main():
     ap.add_argument("--concurrent", type=int, default=4,
                     help="extra figure (N=1 only, after the timed region): utterances in flight on one GPU (0 = skip)")
     ap.add_argument("--no-1p7b", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc FETCH_SIZE pass (roofline.traffic)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:
@@ -942,10 +982,17 @@ def main():
             out["decode_ms_per_frame"] = round(frame_ms, 4)
             rl = frame_roofline(cfg, frame_ms, p_mid, what="decode-frame hipGraph (554 launches: predictor M=2 prefill pass + 14 token "
                                                            "passes, talker 28 layers, heads, samplers)")
-            # HBM-side traffic of one frame: separate `rocprofv3 --pmc FETCH_SIZE` pass (x2 gfx950 correction), not collected in
-            # this run: the 15 predictor weight passes re-read their 157 MB through the fabric every pass
-            rl["traffic"] = 3.455e9
-            rl["traffic_source"] = "measured_offline: profiles/r02_pmc_fetch_size.txt (rocprofv3 --pmc FETCH_SIZE, own pass, x2 gfx950 correction, 24 profiled frames)"
+            # HBM-side traffic of one frame: a separate `rocprofv3 --pmc FETCH_SIZE` pass (x2 gfx950 correction) run from here after
+            # the timed region (N = 1 only); the 15 predictor weight passes re-read their 157 MB through the fabric every pass
+            traffic, how = (None, "not collected (N > 1, stub, or --no-pmc)")
+            if solo and not args.no_pmc:
+                traffic, how = measure_frame_traffic()
+            if traffic is not None:
+                rl["traffic"] = float(round(traffic))
+                rl["traffic_source"] = f"measured in this run: rocprofv3 --pmc FETCH_SIZE over tools/pmc_workload.py frames (own pass, x2 gfx950 correction, {how})"
+            else:
+                rl["traffic"] = 3.455e9
+                rl["traffic_source"] = f"measured_offline: profiles/r02_pmc_fetch_size.txt (rocprofv3 --pmc FETCH_SIZE, own pass, x2 gfx950 correction, 24 profiled frames); in-run pass: {how}"
             out["roofline"] = rl
         if c3 is not None:
             if "error" in c3:

@@ -420,21 +420,20 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
     }
 }
 
-// ROWS (16, 8 or 4): weight rows per workgroup.  The MFMA tile always has 16 A rows; with ROWS < 16 the upper rows repeat the
-// lower ones (same addresses: no extra traffic) and are dropped, which buys 2x / 4x the workgroups for the narrow outputs
-// (o_proj / down: N = 1024 gives 64 tiles of 16 rows on 256 CUs; every CU then pulls 98 KB of weights AND its own copy of
-// the 16-token panel through one L1).
-template <int KSTEPS, int NW, int ROWS, int EPI>  // K = KSTEPS * 32 * NW; NW waves split K
+// Rows per workgroup: the full 16-row tile.  Tiles of 8 or 4 real rows (the rest of the MFMA tile repeating them), which give the
+// narrow outputs (N = 1024: 64 tiles on 256 CUs) 2x / 4x the workgroups, were measured SLOWER at every shape (B = 16, chain of
+// 320: o_proj 5.66 / 5.81 / 6.21 us and down 7.49 / 7.59 / 7.93 us for 16 / 8 / 4 rows, profiles/r03_kernel_chain_batch.txt):
+// every extra workgroup pulls its own copy of the 16-token panel (98 KB at K = 3072) through its L1.
+template <int KSTEPS, int NW, int EPI>            // K = KSTEPS * 32 * NW; NW waves split K
 __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGemvArgs a) {
     typedef bf16_t T;
     static_assert(EPI == EPI_STORE || EPI == EPI_RESIDUAL, "SwiGLU always follows an RMSNorm prologue");
-    static_assert(ROWS == 16 || ROWS == 8 || ROWS == 4, "rows per workgroup");
     constexpr int K = KSTEPS * 32 * NW;
     __shared__ __attribute__((aligned(16))) float red[NW * 64 * 4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int fr = lane & 15, fq = lane >> 4, B = a.B;
     const T* W = reinterpret_cast<const T*>(a.W);
-    const int row0 = blockIdx.x * ROWS;
+    const int row0 = blockIdx.x * 16;
     // ---- 1. token fragments (small, L2-resident) first, then the weight fragments: vmcnt retires in order, so the wait before
     //         MFMA step s (its weight fragment) also covers every token fragment ----
     const int tokc = fr < B ? fr : B - 1;
@@ -443,15 +442,14 @@ __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGem
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) ldraw<false>(breg[s], xp + s * 32);
     __builtin_amdgcn_sched_barrier(0);
-    const int rowc = row0 + (fr & (ROWS - 1)) < a.N ? row0 + (fr & (ROWS - 1)) : a.N - 1;
+    const int rowc = row0 + fr < a.N ? row0 + fr : a.N - 1;
     const T* wp = W + (size_t)rowc * K + wave * (K / NW) + fq * 8;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) ldraw<false>(wreg[s], wp + s * 32);
     float resv[4], biasv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int rr = (fq * 4 + i) & (ROWS - 1);
-        const int r = row0 + rr < a.N ? row0 + rr : a.N - 1;
+        const int r = row0 + fq * 4 + i < a.N ? row0 + fq * 4 + i : a.N - 1;
         resv[i] = 0.f;
         if constexpr (EPI == EPI_RESIDUAL) resv[i] = DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)tokc * a.res_stride + r);
         const T* bp = a.bias ? reinterpret_cast<const T*>(a.bias) + r : W;
@@ -471,7 +469,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGem
     f32x4 t = *reinterpret_cast<const f32x4*>(red + (size_t)lane * 4);
 #pragma unroll
     for (int w = 1; w < NW; ++w) t += *reinterpret_cast<const f32x4*>(red + ((size_t)w * 64 + lane) * 4);
-    if (fr >= B || fq * 4 >= ROWS) return;                      // C rows fq * 4 + i; rows >= ROWS are the repeats
+    if (fr >= B) return;
     const float tot[4] = {t.x, t.y, t.z, t.w};
     T* yp = reinterpret_cast<T*>(a.y) + (size_t)fr * a.y_stride + row0 + fq * 4;
 #pragma unroll

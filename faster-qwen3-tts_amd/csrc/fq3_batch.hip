@@ -173,14 +173,10 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
 }
 template <int EPI>
 static int launch_gemv_batch_mfma_plain(const BatchGemvArgs& a, hipStream_t s) {
-    // rows per workgroup: 16-row tiles when they already fill the chip, otherwise 8 or 4 (see the kernel)
-    const int rows = a.N >= 4096 ? 16 : (a.N >= 2048 ? 8 : 4);
-    const int grid = (a.N + rows - 1) / rows;
+    const int grid = (a.N + 15) / 16;
     auto go = [&](auto ks, auto nw) -> int {
         constexpr int KS = decltype(ks)::value, NW = decltype(nw)::value;
-        if (rows == 16) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, 16, EPI>), dim3(grid), dim3(64 * NW), 0, s, a);
-        else if (rows == 8) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, 8, EPI>), dim3(grid), dim3(64 * NW), 0, s, a);
-        else hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, 4, EPI>), dim3(grid), dim3(64 * NW), 0, s, a);
+        hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI>), dim3(grid), dim3(64 * NW), 0, s, a);
         return 0;
     };
 #define FQ3_PLAIN(KS, NW) return go(std::integral_constant<int, KS>{}, std::integral_constant<int, NW>{})

@@ -75,7 +75,7 @@ class BatchDecoder:
     (``Fq3Engine(..., share=engines[0])``)."""
 
     def __init__(self, engines: List[Any], predictor_policy: Optional[Dict[str, Any]] = None, poll_every: int = 8,
-                 use_graph: bool = True, batch_factory=None, staging: Optional[List[Any]] = None, packed_prefill: bool = False):
+                 use_graph: bool = True, batch_factory=None, staging: Optional[List[Any]] = None, packed_prefill: bool = True):
         if batch_factory is None:
             from .engine import Fq3Batch as batch_factory
         policy = predictor_policy or dict(do_sample=True, top_k=50, top_p=1.0, temperature=0.9)
@@ -93,9 +93,9 @@ class BatchDecoder:
             reserve = getattr(e, "prefill_reserve", None)
             if reserve is not None:
                 reserve()
-        # opt-in: requests staged together share ONE pass over the weights (fq3_prefill_batch; parity-tested at the engine level,
-        # tests/test_gpu_decode.py, but its effect on first-wave TTFA has not been measured yet, so the scheduler default stays on
-        # one prefill per request)
+        # requests staged together share ONE pass over the weights (fq3_prefill_batch; parity-tested at the engine level,
+        # tests/test_gpu_decode.py).  Measured with the workspaces reserved up front (profiles/r03_packed_prefill.txt, 0.6B shapes,
+        # 200-row prompts): first-wave TTFA 82.5 -> 63.6 ms at 8 lanes and 125 -> 89 ms at 16, aggregate 153.5 -> 156x / 229 -> 234x.
         self.packed_prefill = bool(packed_prefill)
 
     def set_predictor_policy(self, **policy):
@@ -270,11 +270,15 @@ class BatchDecoder:
         now: List[Tuple[Any, Any, Dict[str, Any]]] = []
 
         def pull():
-            while source is not None and len(pending) < len(self.lanes) + len(self.stages):
+            # while lanes decode, at most two new requests per frame boundary: whatever the source does to produce one (a
+            # model's prompt build, say) runs on the host between two batches of queued frames
+            budget = len(self.lanes) + len(self.stages) if not active else 2
+            while source is not None and budget > 0 and len(pending) < len(self.lanes) + len(self.stages):
                 r = source()
                 if r is None:
                     break
                 pending.append(stamped(r))
+                budget -= 1
 
         def stage_ahead(limit: int = 1 << 30):
             # while lanes decode, only a couple of prefills per batch of queued frames: the host waits for the staged requests'

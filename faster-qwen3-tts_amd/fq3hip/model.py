@@ -675,20 +675,44 @@ class FasterQwen3TTS:
         remaining / next utterances goes on meanwhile) and copies the waveform to pinned host memory asynchronously."""
         return _SideVocoder(self.model.model.speech_tokenizer, self.device)
 
-    def _run_batch_full(self, prepared, gen_kwargs, lanes: int) -> List[Tuple[list, int]]:
-        """``prepared[i]`` = ``(talker, config, tie, tam, tth, tpe, ref_codes | None)``: the lock-step decode of all of them through
-        ``lanes`` lanes, every finished utterance vocoded on the side stream (the reference's share of an ICL waveform is cut by not
-        producing it, model.py:927-930).  One ``([waveform], sample_rate)`` per entry, in input order."""
+    def _batch_feed(self, prepared, gen_kwargs, lanes: int, meta: dict):
+        """``prepared``: an iterable (usually a generator: the prompt of utterance i is built when the scheduler asks for it) of
+        ``(talker, config, tie, tam, tth, tpe, ref_codes | None)``.  Returns ``(head, source)`` for ``BatchDecoder.run``: the first
+        ``lanes`` requests up front -- the first wave starts decoding before the later prompts exist -- and a ``source`` callback
+        that prepares the rest one at a time at frame boundaries.  ``meta[i]`` receives the entry's ``ref_codes``."""
         from .batching import BatchRequest
-        reqs = [BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(gen_kwargs))
-                for i, (talker, config, tie, tam, tth, tpe, _rc) in enumerate(prepared)]
-        out: List[Optional[Tuple[list, int]]] = [None] * len(prepared)
+        it = enumerate(prepared)
+
+        def pull():
+            nxt = next(it, None)
+            if nxt is None:
+                return None
+            i, (talker, config, tie, tam, tth, tpe, rc) = nxt
+            meta[i] = rc
+            return BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(gen_kwargs))
+
+        head = []
+        for _ in range(max(1, int(lanes))):
+            r = pull()
+            if r is None:
+                break
+            head.append(r)
+        return head, pull
+
+    def _run_batch_full(self, prepared, gen_kwargs, lanes: int, count: int) -> List[Tuple[list, int]]:
+        """The lock-step decode of ``count`` prepared utterances (see :meth:`_batch_feed`) through ``lanes`` lanes, every finished
+        utterance vocoded on the side stream (the reference's share of an ICL waveform is cut by not producing it,
+        model.py:927-930).  One ``([waveform], sample_rate)`` per entry, in input order."""
+        meta: dict = {}
+        dec = self._batch_decoder(lanes)
+        head, source = self._batch_feed(prepared, gen_kwargs, len(dec.lanes), meta)
+        out: List[Optional[Tuple[list, int]]] = [None] * count
         voc = self._side_vocoder()
-        for rid, codec_ids, _timing in self._batch_decoder(lanes).run(reqs):
+        for rid, codec_ids, _timing in dec.run(head, source=source):
             if codec_ids is None:
                 out[rid] = ([np.zeros(1, dtype=np.float32)], self.sample_rate)
                 continue
-            rc = prepared[rid][6]
+            rc = meta[rid]
             codes = torch.cat([rc.to(codec_ids.device), codec_ids], dim=0) if rc is not None else codec_ids
             # side stream; the next frames of the other lanes are not held up
             voc.submit(rid, codes, ref_len=rc.shape[0] if rc is not None else 0)
@@ -700,12 +724,13 @@ class FasterQwen3TTS:
         """Streaming form of :meth:`_run_batch_full`: yields ``(index, audio_chunk, sample_rate, timing)`` for every
         ``chunk_size`` frames of any utterance -- per utterance exactly the chunks the single-utterance streaming entry point
         would produce (same windowing state machine).  ``timing``: ``chunk_index``, ``total_steps_so_far``, ``is_final``."""
-        from .batching import BatchRequest
-        reqs, vocs, n_chunks = [], {}, {}
-        for i, (talker, config, tie, tam, tth, tpe, rc) in enumerate(prepared):
-            reqs.append(BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(gen_kwargs)))
-            vocs[i], n_chunks[i] = self.streaming_vocoder(rc, chunk_size), 0
-        for rid, codes, info in self._batch_decoder(lanes).run(reqs, chunk_frames=chunk_size):
+        meta: dict = {}
+        vocs, n_chunks = {}, {}
+        dec = self._batch_decoder(lanes)
+        head, source = self._batch_feed(prepared, gen_kwargs, len(dec.lanes), meta)
+        for rid, codes, info in dec.run(head, source=source, chunk_frames=chunk_size):
+            if rid not in vocs:
+                vocs[rid], n_chunks[rid] = self.streaming_vocoder(meta[rid], chunk_size), 0
             ev = info.pop("codes_ready_event", None)
             final = bool(info.get("is_final"))
             if codes is not None and codes.shape[0] > 0:
@@ -728,14 +753,16 @@ class FasterQwen3TTS:
         return [value] * n
 
     def _prepare_clone_batch(self, texts, language, ref_audio, ref_text, xvec_only, nsm, append_silence, instruct, voice_clone_prompt):
-        prepared = []
-        for text, lang in zip(texts, self._per_text(language, len(texts), "language")):
-            _m, talker, config, tie, tam, tth, tpe, rc = self._prepare_generation(
-                text=text, language=lang, ref_audio=ref_audio, ref_text=ref_text, xvec_only=xvec_only,
-                non_streaming_mode=nsm, append_silence=append_silence, voice_clone_prompt=voice_clone_prompt,
-                instruct=instruct)
-            prepared.append((talker, config, tie, tam, tth, tpe, rc))
-        return prepared
+        langs = self._per_text(language, len(texts), "language")            # argument errors surface before anything is decoded
+
+        def gen():
+            for text, lang in zip(texts, langs):
+                _m, talker, config, tie, tam, tth, tpe, rc = self._prepare_generation(
+                    text=text, language=lang, ref_audio=ref_audio, ref_text=ref_text, xvec_only=xvec_only,
+                    non_streaming_mode=nsm, append_silence=append_silence, voice_clone_prompt=voice_clone_prompt,
+                    instruct=instruct)
+                yield talker, config, tie, tam, tth, tpe, rc
+        return gen()
 
     @torch.inference_mode()
     def generate_voice_clone_batch(self, texts: List[str], language: Union[str, List[str]] = "English",
@@ -755,7 +782,7 @@ class FasterQwen3TTS:
         prepared = self._prepare_clone_batch(texts, language, ref_audio, ref_text, xvec_only, nsm, append_silence, instruct,
                                              voice_clone_prompt)
         return self._run_batch_full(prepared, self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample,
-                                                               repetition_penalty), lanes)
+                                                               repetition_penalty), lanes, len(texts))
 
     @torch.inference_mode()
     def generate_voice_clone_batch_streaming(self, texts: List[str], language: Union[str, List[str]] = "English",
@@ -779,12 +806,17 @@ class FasterQwen3TTS:
 
     def _prepare_custom_batch(self, texts, speaker, language, instruct, non_streaming_mode):
         n = len(texts)
-        prepared = []
-        for text, spk, lang, ins in zip(texts, self._per_text(speaker, n, "speaker"), self._per_text(language, n, "language"),
-                                        self._per_text(instruct, n, "instruct")):
-            _m, talker, config, tie, tam, tth, tpe = self._custom_prepare(text, spk, lang, ins, non_streaming_mode)
-            prepared.append((talker, config, tie, tam, tth, tpe, None))
-        return prepared
+        spks, langs, inss = self._per_text(speaker, n, "speaker"), self._per_text(language, n, "language"), self._per_text(instruct, n, "instruct")
+        if self.model.model.tts_model_type != "custom_voice":
+            raise ValueError("Loaded model does not support custom voice generation")
+        self.model._validate_languages(langs)                                # every argument error before anything is decoded
+        self.model._validate_speakers(spks)
+
+        def gen():
+            for text, spk, lang, ins in zip(texts, spks, langs, inss):
+                _m, talker, config, tie, tam, tth, tpe = self._custom_prepare(text, spk, lang, ins, non_streaming_mode)
+                yield talker, config, tie, tam, tth, tpe, None
+        return gen()
 
     @torch.inference_mode()
     def generate_custom_voice_batch(self, texts: List[str], speaker: Union[str, List[str]], language: Union[str, List[str]] = "English",
@@ -798,7 +830,7 @@ class FasterQwen3TTS:
         the weights per frame.  Returns one ``([waveform], sample_rate)`` per text, in input order."""
         prepared = self._prepare_custom_batch(texts, speaker, language, instruct, non_streaming_mode)
         return self._run_batch_full(prepared, self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample,
-                                                               repetition_penalty), lanes)
+                                                               repetition_penalty), lanes, len(texts))
 
     @torch.inference_mode()
     def generate_custom_voice_batch_streaming(self, texts: List[str], speaker: Union[str, List[str]],
@@ -820,12 +852,17 @@ class FasterQwen3TTS:
                                     repetition_penalty: float = 1.05, lanes: int = 16) -> List[Tuple[list, int]]:
         """VoiceDesign for several texts in lock-step lanes; every utterance prepared like :meth:`generate_voice_design`."""
         n = len(texts)
-        prepared = []
-        for text, ins, lang in zip(texts, self._per_text(instruct, n, "instruct"), self._per_text(language, n, "language")):
-            _m, talker, config, tie, tam, tth, tpe = self._design_prepare(text, ins, lang, non_streaming_mode)
-            prepared.append((talker, config, tie, tam, tth, tpe, None))
-        return self._run_batch_full(prepared, self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample,
-                                                               repetition_penalty), lanes)
+        inss, langs = self._per_text(instruct, n, "instruct"), self._per_text(language, n, "language")
+        if self.model.model.tts_model_type != "voice_design":
+            raise ValueError("Loaded model does not support voice design generation")
+        self.model._validate_languages(langs)
+
+        def gen():
+            for text, ins, lang in zip(texts, inss, langs):
+                _m, talker, config, tie, tam, tth, tpe = self._design_prepare(text, ins, lang, non_streaming_mode)
+                yield talker, config, tie, tam, tth, tpe, None
+        return self._run_batch_full(gen(), self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample,
+                                                            repetition_penalty), lanes, n)
 
     @torch.inference_mode()
     def generate_voice_clone_streaming(self, text: str, language: str, ref_audio: Optional[Union[str, Path]] = None,

@@ -395,24 +395,14 @@ int main(int argc, char** argv) {
             else if (kind == 3) hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 6, PRO_PLAIN, EPI_RESIDUAL>), dim3(grid), dim3(256), shm, st, g);
             else hipLaunchKernelGGL((gemv_batch_kernel<bf16_t, 2, PRO_NORM, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
         };
-        int plain_rows = 4;                                       // rows per workgroup of the PLAIN kernels (product choice at N = 1024: 4)
         auto run_m = [&](int kind, int i, int B, void* y) {      // matrix-core batch kernels
             BatchGemvArgs g = bargs(kind, i, B, y);
             const int grid = (g.N + 15) / 16; const int NRr = kind == 2 ? 2 : 1;
             const size_t shm = (((size_t)kMaxLanes * (g.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NRr * 256 * 4;
-            const int pgrid = (g.N + plain_rows - 1) / plain_rows;
             if (kind == 0) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
-            else if (kind == 1) {
-                if (plain_rows == 16) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, 16, EPI_RESIDUAL>), dim3(pgrid), dim3(512), 0, st, g);
-                else if (plain_rows == 8) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, 8, EPI_RESIDUAL>), dim3(pgrid), dim3(512), 0, st, g);
-                else hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, 4, EPI_RESIDUAL>), dim3(pgrid), dim3(512), 0, st, g);
-            }
+            else if (kind == 1) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, EPI_RESIDUAL>), dim3(grid), dim3(512), 0, st, g);
             else if (kind == 2) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_SWIGLU>), dim3(grid), dim3(256), shm, st, g);
-            else if (kind == 3) {
-                if (plain_rows == 16) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<12, 8, 16, EPI_RESIDUAL>), dim3(pgrid), dim3(512), 0, st, g);
-                else if (plain_rows == 8) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<12, 8, 8, EPI_RESIDUAL>), dim3(pgrid), dim3(512), 0, st, g);
-                else hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<12, 8, 4, EPI_RESIDUAL>), dim3(pgrid), dim3(512), 0, st, g);
-            }
+            else if (kind == 3) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<12, 8, EPI_RESIDUAL>), dim3(grid), dim3(512), 0, st, g);
             else hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
         };
         auto run_1 = [&](int kind, int i, int m) {                // product single-token kernels, token m of the same buffers
@@ -427,9 +417,8 @@ int main(int argc, char** argv) {
         };
         const char* kn[6] = {"qkv NORM/STORE", "o PLAIN/RESID", "gate_up NORM/SWIGLU", "down PLAIN/RESID", "", "head NORM/STORE+bias+xn_out"};
         const int outn[6] = {NQKV, H, I, H, H, Vp};
-        for (int pr : {4, 8, 16}) for (int B : {16, 11, 8, 3}) for (int kind = 0; kind < 6; ++kind) {
-            plain_rows = pr;
-            if (kind == 4 || (pr != 4 && kind != 1 && kind != 3)) continue;
+        for (int B : {16, 11, 8, 3}) for (int kind = 0; kind < 6; ++kind) {
+            if (kind == 4) continue;
             CHK(hipMemset(yb, 0, (size_t)MB * 8192 * 2)); CHK(hipMemset(ym, 0, (size_t)MB * 8192 * 2)); CHK(hipMemset(y1, 0, (size_t)MB * 8192 * 2));
             run_v(kind, 0, B, yb); run_m(kind, 0, B, ym);
             for (int m = 0; m < B; ++m) run_1(kind, 0, m);
@@ -442,9 +431,8 @@ int main(int argc, char** argv) {
                 e = fmax(e, fabs(am[ix] - a1[ix]) / (1.0 + fabs(a1[ix])));
             }
             char nm[112]; snprintf(nm, sizeof nm, "batch VALU B=%d %s == single-token", B, kn[kind]); report(nm, bad, 0.5);
-            snprintf(nm, sizeof nm, "batch MFMA B=%d %s (plain rows %d) ~ single-token", B, kn[kind], pr); report(nm, e, 1e-2);
+            snprintf(nm, sizeof nm, "batch MFMA B=%d %s ~ single-token", B, kn[kind]); report(nm, e, 1e-2);
         }
-        plain_rows = 4;
         {   // merge kernel + PLAIN o_proj (the batch chain's pair) must equal the single-stream COMBINE o_proj bit for bit (VALU kernel)
             void* merged = dev_bf16((size_t)MB * 8192, 0.f);
             const int B = 16;
@@ -465,13 +453,7 @@ int main(int argc, char** argv) {
             snprintf(nm, sizeof nm, "batch  B=%d MFMA kernels: qkv, o, gate_up, down x80", B); chain(nm, N, [&](int j) { run_m(j % 4, j / 4, B, ym); });
             const char* one[4] = {"qkv NORM", "o PLAIN (8 waves)", "gate_up NORM/SWIGLU", "down PLAIN (8 waves)"};
             for (int kind = 0; kind < 4; ++kind) {
-                if (kind == 1 || kind == 3) {
-                    for (int pr : {16, 8, 4}) { plain_rows = pr;
-                        snprintf(nm, sizeof nm, "batch  B=%d MFMA %s alone, %d rows per workgroup", B, one[kind], pr); chain(nm, N, [&](int j) { run_m(kind, j, B, ym); }); }
-                    plain_rows = 4;
-                } else {
-                    snprintf(nm, sizeof nm, "batch  B=%d MFMA %s alone", B, one[kind]); chain(nm, N, [&](int j) { run_m(kind, j, B, ym); });
-                }
+                snprintf(nm, sizeof nm, "batch  B=%d MFMA %s alone", B, one[kind]); chain(nm, N, [&](int j) { run_m(kind, j, B, ym); });
             }
         }
     }
