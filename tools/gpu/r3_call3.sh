@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 (timeout 300 rocprofv3 --kernel-trace -d /tmp/kt_codec -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py codec > /tmp/kt_codec.log 2>&1
  DB=$(find /tmp/kt_codec -name "*.db" | head -1)
  python $GRAFT_REPO_ROOT/tools/prof_summary.py $DB > $O/trace_codec370.txt 2>&1
- python $GRAFT_REPO_ROOT/tools/prof_dispatches.py $DB > $O/dispatches_codec370.txt 2>&1)
+ python $GRAFT_REPO_ROOT/tools/prof_timeline.py $DB 215 > $O/dispatches_codec370.txt 2>&1)
 head -25 $O/trace_codec370.txt
 (timeout 300 rocprofv3 --kernel-trace -d /tmp/kt_p4k -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py prefill4k > /tmp/kt_p4k.log 2>&1
  DB=$(find /tmp/kt_p4k -name "*.db" | head -1)
