@@ -42,6 +42,8 @@ struct GemmArgs {
     // split-K (single-tap GEMMs with few rows, e.g. the 200-token prefill's o_proj / down): workgroup z multiplies channel
     // slice z and stores fp32 partials to ws[z][m - m_lo][n]; splitk_reduce_kernel sums them in order and runs the epilogue
     float* ws; long ws_floats; int ksplit;
+    int epi_legacy;                                   // measurement switch: 1 = the register-layout epilogue (32-byte runs per row) instead of the
+                                                      // LDS-parked one (whole tile rows per store instruction); 0 in the product
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -100,7 +102,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; j += 2) {
+                for (int j = 0; j + 1 < TN; j += 2) {       // (an odd TN -- the 96-wide tile -- never runs SwiGLU; never index acc[i][TN])
                     const int np = n0 + wc * (BN / 2) + j * 16;             // physical column of the gate tile
                     if (np >= a.N) continue;
                     const int no = np / 2 + (lane & 15);                    // logical output column
@@ -165,51 +167,96 @@ __device__ __forceinline__ void epilogue_elem(const GemmArgs& a, float accv, int
     }
 }
 
-// Four consecutive columns of one output row (what a lane holds when the MFMA is issued with its operands swapped): the
-// general epilogue, out of line so that a kernel can call it from a fully unrolled loop over 32 accumulator tiles.
-struct EpiArgs {
-    const bf16_t* bias; int bias_mod; const bf16_t* scale; const bf16_t* res; int ldr; bf16_t* Y; int ldy; bf16_t* Y2;
-    const bf16_t* sn_a; const bf16_t* sn_ib; int act, act2, M, N;
+// Four consecutive columns (n .. n + 3, n % 4 == 0) of output row m: the same per-element arithmetic as gemm_epilogue, with
+// 8-byte (bf16) / 16-byte (fp32) accesses.  Caller guarantees m < M, n + 3 < N and 4-element alignment of ldy / ldr / bias_mod.
+struct EpiQ {
+    const void* bias; int bias_mod; const void* scale; const void* res; int ldr; void* Y; int ldy; void* Y2;
+    const void* sn_a; const void* sn_ib; int act, act2;
 };
-__device__ __noinline__ void epi_store4(EpiArgs e, f32x4_t acc, int m, int n) {
-    typedef bf16_t T;
-    if (m >= e.M || n >= e.N) return;
-    if (n + 3 < e.N && (e.ldy & 3) == 0 && (!e.res || (e.ldr & 3) == 0) && (e.bias_mod & 3) == 0) {
-        const int ch = n % e.bias_mod;
-        float rv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (e.res) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(e.res + (size_t)m * e.ldr + n);
+__device__ __forceinline__ EpiQ epiq_of(const GemmArgs& a) {
+    return EpiQ{a.bias, a.bias_mod, a.scale, a.res, a.ldr, a.Y, a.ldy, a.Y2, a.sn_a, a.sn_ib, a.act, a.act2};
+}
+template <typename T>
+__device__ __forceinline__ void epi_quad(const EpiQ& a, f32x4_t acc, int m, int n) {
+    const int ch = n % a.bias_mod;
+    float rv[4] = {0.f, 0.f, 0.f, 0.f}, v[4], v2[4];
+    if (a.res) {
+        const T* rp = reinterpret_cast<const T*>(a.res) + (size_t)m * a.ldr + n;
+        if constexpr (sizeof(T) == 2) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(rp);
             rv[0] = __uint_as_float(rr.x << 16); rv[1] = __uint_as_float(rr.x & 0xFFFF0000u);
             rv[2] = __uint_as_float(rr.y << 16); rv[3] = __uint_as_float(rr.y & 0xFFFF0000u);
+        } else {
+            const f32x4_t rr = *reinterpret_cast<const f32x4_t*>(rp);
+            rv[0] = rr[0]; rv[1] = rr[1]; rv[2] = rr[2]; rv[3] = rr[3];
         }
-        float v[4], v2[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float x = DT<T>::rnd(acc[c] + (e.bias ? DT<T>::ld(e.bias + ch + c) : 0.f));
-            if (e.act == 1) x = DT<T>::rnd(gelu_exact(x));
-            if (e.act == 3) x = DT<T>::rnd(x / (1.0f + expf(-x)));
-            if (e.act >= 4) x = DT<T>::rnd(act_extra(e.act, x));
-            if (e.scale) x = DT<T>::rnd(DT<T>::ld(e.scale + n + c) * x);
-            if (e.res) x = x + rv[c];
-            v[c] = DT<T>::rnd(x);
-            v2[c] = 0.f;
-            if (e.Y2) v2[c] = e.act2 ? DT<T>::rnd(elu1(v[c])) : snake_apply<T>(v[c], DT<T>::ld(e.sn_a + ch + c), DT<T>::ld(e.sn_ib + ch + c));
-        }
-        if (e.Y) *reinterpret_cast<uint2*>(e.Y + (size_t)m * e.ldy + n) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        if (e.Y2) *reinterpret_cast<uint2*>(e.Y2 + (size_t)m * e.ldy + n) = uint2{pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3])};
-        return;
     }
-    for (int c = 0; c < 4 && n + c < e.N; ++c) {            // ragged right edge / unaligned leading dimensions
-        const int nn = n + c, ch = nn % e.bias_mod;
-        float x = DT<T>::rnd(acc[c] + (e.bias ? DT<T>::ld(e.bias + ch) : 0.f));
-        if (e.act == 1) x = DT<T>::rnd(gelu_exact(x));
-        if (e.act == 3) x = DT<T>::rnd(x / (1.0f + expf(-x)));
-        if (e.act >= 4) x = DT<T>::rnd(act_extra(e.act, x));
-        if (e.scale) x = DT<T>::rnd(DT<T>::ld(e.scale + nn) * x);
-        if (e.res) x = x + DT<T>::ld(e.res + (size_t)m * e.ldr + nn);
-        x = DT<T>::rnd(x);
-        if (e.Y) DT<T>::st(e.Y + (size_t)m * e.ldy + nn, x);
-        if (e.Y2) DT<T>::st(e.Y2 + (size_t)m * e.ldy + nn, e.act2 ? DT<T>::rnd(elu1(x)) : snake_apply<T>(x, DT<T>::ld(e.sn_a + ch), DT<T>::ld(e.sn_ib + ch)));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float x = DT<T>::rnd(acc[c] + (a.bias ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + ch + c) : 0.f));
+        if (a.act == 1) x = DT<T>::rnd(gelu_exact(x));
+        if (a.act == 3) x = DT<T>::rnd(x / (1.0f + expf(-x)));
+        if (a.act >= 4) x = DT<T>::rnd(act_extra(a.act, x));
+        if (a.scale) x = DT<T>::rnd(DT<T>::ld(reinterpret_cast<const T*>(a.scale) + n + c) * x);
+        if (a.res) x = x + rv[c];
+        v[c] = DT<T>::rnd(x);
+        v2[c] = 0.f;
+        if (a.Y2) v2[c] = a.act2 ? DT<T>::rnd(elu1(v[c]))
+                                 : snake_apply<T>(v[c], DT<T>::ld(reinterpret_cast<const T*>(a.sn_a) + ch + c), DT<T>::ld(reinterpret_cast<const T*>(a.sn_ib) + ch + c));
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (a.Y) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + n) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        if (a.Y2) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(a.Y2) + (size_t)m * a.ldy + n) = uint2{pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3])};
+    } else {
+        if (a.Y) *reinterpret_cast<f32x4_t*>(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + n) = f32x4_t{v[0], v[1], v[2], v[3]};
+        if (a.Y2) *reinterpret_cast<f32x4_t*>(reinterpret_cast<T*>(a.Y2) + (size_t)m * a.ldy + n) = f32x4_t{v2[0], v2[1], v2[2], v2[3]};
+    }
+}
+// may the LDS-parked epilogue serve this GEMM?  (no split-K partials, no SwiGLU column pairing)
+__device__ __forceinline__ bool epi_can_park(const GemmArgs& a) { return !a.epi_legacy && a.ksplit <= 1 && a.act != 2; }
+// are 4-column accesses legal for this GEMM's outputs?
+__device__ __forceinline__ bool epi_quads_ok(const GemmArgs& a) {
+    return (a.N & 3) == 0 && (a.ldy & 3) == 0 && (a.bias_mod & 3) == 0 && (!a.res || (a.ldr & 3) == 0);
+}
+// Row-contiguous epilogue of the 4-wave (2 x 2) GEMM kernels: the accumulators -- in the MFMA C layout a lane holds one COLUMN of
+// four rows, so a store instruction of the register-layout epilogue touches 32 bytes of each of 64 rows -- are parked in LDS
+// (the operand stages are dead by now) and walked with four consecutive columns per lane: one instruction stores whole rows
+// of the tile (128 B for BN = 64), the residual is read the same way.  PARK_FLOATS = floats of LDS available; when the tile
+// does not fit it goes in two halves (the rows of wave row 0, then of wave row 1).  Padded row of BN + 4 floats: the four
+// 16-lane groups of a C-layout write are 4 rows apart, 4 x (BN + 4) = 16 mod 64 banks, so the 64 lanes hit 64 distinct banks.
+// Same arithmetic per element as gemm_epilogue: bit-identical.
+// WCOLS = waves across the tile's columns (2 for the 4-wave kernels, 4 for the 8-wave 256-row tile), NTHREADS = workgroup size.
+template <typename T, int BM, int BN, int TM, int TN, int PARK_FLOATS, int WCOLS = 2, int NTHREADS = 256>
+__device__ __forceinline__ void gemm_epilogue_parked(const GemmArgs& a, f32x4_t (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane, float* park) {
+    constexpr int LDP = BN + 4;
+    constexpr int HALVES = (BM * LDP <= PARK_FLOATS) ? 1 : 2;
+    static_assert((BM / HALVES) * LDP <= PARK_FLOATS, "LDS too small to park half a tile");
+    constexpr int ROWS = BM / HALVES, QPR = BN / 4;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int half = 0; half < HALVES; ++half) {
+        if (HALVES == 1 || wr == half) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = (HALVES == 1 ? wr * (BM / 2) : 0) + i * 16 + fq * 4 + r;
+                        park[row * LDP + wc * (BN / WCOLS) + j * 16 + fr] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        const EpiQ e = epiq_of(a);
+        const bool quads = epi_quads_ok(a);
+        for (int q = threadIdx.x; q < ROWS * QPR; q += NTHREADS) {
+            const int row = q / QPR, c4 = (q - row * QPR) * 4;
+            const int m = m0 + half * ROWS + row, n = n0 + c4;
+            if (m >= a.M || n >= a.N) continue;
+            if (quads) epi_quad<T>(e, *reinterpret_cast<const f32x4_t*>(park + row * LDP + c4), m, n);
+            else for (int c = 0; c < 4 && n + c < a.N; ++c) epilogue_elem<T>(a, park[row * LDP + c4 + c], m, n + c);      // unaligned leading dimensions
+        }
+        if (half + 1 < HALVES) __syncthreads();
     }
 }
 
@@ -227,8 +274,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 4);          // padded LDS row (elements): breaks the 64/128-byte stride
     constexpr int TM = BM / 32, TN = BN / 32;
     static_assert(TM >= 1 && TN >= 1, "tile too small");
-    __shared__ __attribute__((aligned(16))) T As[2][BM * LD];
-    __shared__ __attribute__((aligned(16))) T Bs[2][BN * LD];
+    __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LD];          // operand stages; the epilogue parks the tile here
+    T (*As)[BM * LD] = reinterpret_cast<T (*)[BM * LD]>(smem);
+    T (*Bs)[BN * LD] = reinterpret_cast<T (*)[BN * LD]>(smem + 2 * BM * LD);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m0 = a.m_lo + blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wr = wave >> 1, wc = wave & 1;
@@ -333,7 +381,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
             __syncthreads();
         }
     }
-    gemm_epilogue<T, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
+    constexpr int kParkFloats = (int)(sizeof(T) * 2 * (BM + BN) * LD / sizeof(float));
+    if constexpr (BN % 64 != 0 && BN != 32) {
+        // the 96-wide tile never serves split-K or SwiGLU GEMMs (gemm_launch), and a third register-layout epilogue copy for
+        // its 12 accumulator tiles is more than the unroller takes (the accumulators would move to scratch)
+        gemm_epilogue_parked<T, BM, BN, TM, TN, kParkFloats>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(smem));
+    } else {
+        if (epi_can_park(a)) gemm_epilogue_parked<T, BM, BN, TM, TN, kParkFloats>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(smem));
+        else gemm_epilogue<T, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
+    }
 }
 
 // Large-M variant (bf16): 128 x 64 tile, K step 64, operands copied global -> LDS by the DMA path (global_load_lds, 16 bytes
@@ -433,7 +489,11 @@ __global__ __launch_bounds__(256) void glds_gemm_kernel(GemmArgs a) {
         }
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
-    gemm_epilogue<T, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
+    constexpr int kParkFloats = STAGES * (BM + BN) * BK * 2 / 4;
+    if (epi_can_park(a)) {
+        __syncthreads();                                 // everybody is done reading the last stage
+        gemm_epilogue_parked<T, BM, BN, TM, TN, kParkFloats>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(glds_smem));
+    } else gemm_epilogue<T, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
 }
 
 template <int BN, int STAGES>
@@ -462,7 +522,7 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
     // tiles): wave block 128 x 32 (8 x 2 tiles), 3 copies per thread and step.
     constexpr int BM = kBigBM, BK = kBigBK, TM = 8, TN = BN / 64, WN = BN / 4, NPB = BN / 128, CP = 2 + NPB;
     static_assert(ST == 4, "ring of four stages");
-    static_assert(BN == 256 || (BN == 128 && TR), "256-wide tiles, or 128-wide with the register epilogue");
+    static_assert(BN == 256 || BN == 128, "256- or 128-wide tiles");
     extern __shared__ __attribute__((aligned(128))) unsigned char big_smem[];
     T* As = reinterpret_cast<T*>(big_smem);                                   // [ST][BM * BK]
     T* Bs = As + ST * BM * BK;                                                // [ST][BN * BK]
@@ -566,32 +626,27 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);                  // the tail's redundant copies must not outlive the workgroup's LDS
     if constexpr (TR) {
-    // Variant TR (wide, plain outputs: the prefill's qkv / gate_up): the MFMAs ran with swapped operands, so each accumulator
-    // tile is the TRANSPOSE of the usual layout: a lane holds 4 consecutive output COLUMNS (n = j * 16 + fq * 4 + r) of one
-    // row (m = i * 16 + fr) -> 8-byte stores straight from the registers.  Plain outputs are stored inline; anything else
-    // goes through one out-of-line call per tile, which keeps the 32-tile loop small enough to unroll (a loop over `acc`
-    // that is not unrolled sends the accumulators to scratch).
-    const bool plain = a.act == 0 && !a.scale && !a.res && !a.Y2 && a.Y && (a.ldy & 3) == 0 && (a.bias_mod & 3) == 0;
-    const EpiArgs e{reinterpret_cast<const T*>(a.bias), a.bias_mod, reinterpret_cast<const T*>(a.scale), reinterpret_cast<const T*>(a.res), a.ldr,
-                    reinterpret_cast<T*>(a.Y), a.ldy, reinterpret_cast<T*>(a.Y2), reinterpret_cast<const T*>(a.sn_a),
-                    reinterpret_cast<const T*>(a.sn_ib), a.act, a.act2, a.M, a.N};
+    // Variant TR (wide, PLAIN outputs only -- bias at most; the prefill's qkv / gate_up / o / down: gemm_launch never sends anything
+    // else here): the MFMAs ran with swapped operands, so each accumulator tile is the TRANSPOSE of the usual layout: a lane holds 4
+    // consecutive output COLUMNS (n = j * 16 + fq * 4 + r) of one row (m = i * 16 + fr) -> 8-byte stores straight from the registers.
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int m = m0 + wr * 128 + i * 16 + fr, n = n0 + wc * WN + j * 16 + fq * 4;
-            if (plain && n + 3 < a.N) {
-                if (m < a.M) {
-                    f32x4_t t = acc[i][j];
-                    if (a.bias) {
-                        const int ch = n % a.bias_mod;
+            if (m >= a.M || n >= a.N) continue;
+            f32x4_t t = acc[i][j];
+            const int ch = n % a.bias_mod;
+            if (n + 3 < a.N && (a.ldy & 3) == 0 && (a.bias_mod & 3) == 0) {
+                if (a.bias) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) t[c] += DT<T>::ld(reinterpret_cast<const T*>(a.bias) + ch + c);
-                    }
-                    *reinterpret_cast<uint2*>(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + n) = uint2{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
+                    for (int c = 0; c < 4; ++c) t[c] += DT<T>::ld(reinterpret_cast<const T*>(a.bias) + ch + c);
                 }
+                *reinterpret_cast<uint2*>(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + n) = uint2{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
             } else {
-                epi_store4(e, acc[i][j], m, n);
+                for (int c = 0; c < 4 && n + c < a.N; ++c)          // ragged right edge / unaligned leading dimension
+                    DT<T>::st(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + n + c,
+                              t[c] + (a.bias ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + (n + c) % a.bias_mod) : 0.f));
             }
         }
     } else if constexpr (BN == 256) {
@@ -661,6 +716,13 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
         }
         __builtin_amdgcn_wave_barrier();                 // before the second half overwrites the region
     }
+    } else {
+    // Variant !TR, BN = 128 (the codec's N = 384 / 768 convs with bias / residual / SnakeBeta second output): the whole 256 x 128
+    // tile is parked in the (dead) operand ring in two halves of 128 rows and walked by all 512 threads, 256 contiguous bytes per
+    // output row (the register epilogue of the TR variant touches 32-byte runs and calls out of line per 4 columns).
+    __syncthreads();
+    constexpr int kParkFloats = ST * (BM + BN) * BK * 2 / 4;
+    gemm_epilogue_parked<T, BM, BN, TM, TN, kParkFloats, 4, 512>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(big_smem));
     }
 }
 
@@ -750,11 +812,16 @@ inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
         if (a.act != 2 && a.Cin % 32 == 0) {
             if (big_tiling_pays(rows, a.N, kBigBN)) { big_go(a, s); return; }
             // 256 x 128 tiles where the 256-wide ones would leave half the CUs idle (N = 2048 at M = 4096: o_proj / down at 1.7B)
-            if (rows >= 1024 && a.N % 128 == 0 && big_tiling_pays(rows, a.N, 128)) { big_go_t<true, 128>(a, s); return; }
+            if (rows >= 1024 && a.N % 128 == 0 && big_tiling_pays(rows, a.N, 128)) {
+                const bool plain = a.act == 0 && !a.scale && !a.res && !a.Y2;
+                if (plain) big_go_t<true, 128>(a, s); else big_go_t<false, 128>(a, s);      // full epilogue: LDS-parked, whole rows per store
+                return;
+            }
         }
         if (a.N % 64 == 0 && a.Cin % 64 == 0 && wgs(128, 64) >= 512) {
             glds_go<64, 2>(a, s);
         } else if (n64 && wgs(128, 64) >= 512) gemm_go<T, 128, 64>(a, s);
+        else if (a.act != 2 && !n64 && a.N % 96 == 0 && wgs(128, 96) >= 256) gemm_go<T, 128, 96>(a, s);      // N = 96 / 288 (codec block 4): 3x fewer reads of the A tile than 32-wide tiles
         else if (a.act != 2 && !n64 && wgs(128, 32) >= 256) gemm_go<T, 128, 32>(a, s);
         else if (n64 && (wgs(64, 64) >= 256 || a.act == 2)) gemm_go<T, 64, 64>(a, s);
         else if (a.act == 2) gemm_go<T, 64, 64>(a, s);

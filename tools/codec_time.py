@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Codec decoder timing (development aid): full decode of 370 frames (two pieces: 300 + 95 with context), one 300-frame piece,
+a streaming phase-2 chunk (25 context + 8 new frames, tail decode) and the first streaming chunk (178 frames in, 8 out), bf16.
+usage: codec_time.py [fp32]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "faster-qwen3-tts_amd"))
+import torch
+from fq3hip.config import qwen3_tts_0p6b
+from fq3hip.weights import synth_weights
+from fq3hip.codec import HipSpeechTokenizer
+
+
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    dt = torch.float32 if len(sys.argv) > 1 and sys.argv[1] == "fp32" else torch.bfloat16
+    cfg = qwen3_tts_0p6b()
+    W = synth_weights(cfg, 0, torch.bfloat16, parts=("codec",), codec_normalized=True)
+    tok = HipSpeechTokenizer(cfg.codec, W, "cuda", dt, max_frames=400)
+    g = torch.Generator().manual_seed(4)
+    codes = torch.randint(0, cfg.codec.codebook_size, (370, 16), generator=g).cuda()
+    n33 = tok.num_samples_total(33); n178 = tok.num_samples_total(178)
+    print(f"dtype {dt}: full 370 frames {timed(lambda: tok.decode_tensor(codes)):.3f} ms | one piece of 300 frames {timed(lambda: tok.decode_tensor(codes[:300].contiguous())):.3f} ms | "
+          f"chunk 25+8 frames (tail of 8) {timed(lambda: tok.decode_tensor(codes[:33].contiguous(), n33 - 8 * 1920), 10):.3f} ms | "
+          f"first chunk 170+8 frames (tail of 8) {timed(lambda: tok.decode_tensor(codes[:178].contiguous(), n178 - 8 * 1920), 10):.3f} ms")
+
+
+if __name__ == "__main__":
+    main()

@@ -39,8 +39,72 @@ int main(int argc, char** argv) {
         {"chunk13 b1 conv1 k7", 416, 768, 768, 7, 1},
         {"chunk13 b4 conv1 k7", 24960, 96, 96, 7, 1},
     };
-    hipStream_t s; hipStreamCreate(&s);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipStream_t s; (void)hipStreamCreate(&s);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    if (argc > 2 && !strcmp(argv[2], "codec")) {
+        // The codec's decoder convs of one 300-frame piece WITH their real epilogues (bias, residual, SnakeBeta second output),
+        // through the product's own tile choice: LDS-parked row-contiguous epilogue (product) vs the register-layout one
+        // (epi_legacy = 1), outputs compared bit for bit.  kind: T = transposed conv (2 taps, Y + Y2), 1 = conv1 (k7, Y2 only),
+        // 2 = conv2 (1x1, residual + Y + Y2).
+        struct CS { const char* name; char kind; int M, Cin, N, co, dil; };
+        const std::vector<CS> cs = {
+            {"b1 convT  1536 -> 8 x 768", 'T', 1199, 1536, 6144, 768, 1}, {"b1 conv1 k7  768", '1', 9592, 768, 768, 768, 1}, {"b1 conv2 1x1 768", '2', 9592, 768, 768, 768, 1},
+            {"b2 convT   768 -> 5 x 384", 'T', 9591, 768, 1920, 384, 1}, {"b2 conv1 k7  384 d3", '1', 47955, 384, 384, 384, 3}, {"b2 conv2 1x1 384", '2', 47955, 384, 384, 384, 1},
+            {"b3 convT   384 -> 4 x 192", 'T', 47954, 384, 768, 192, 1}, {"b3 conv1 k7  192 d9", '1', 191816, 192, 192, 192, 9}, {"b3 conv2 1x1 192", '2', 191816, 192, 192, 192, 1},
+            {"b4 convT   192 -> 3 x 96", 'T', 191815, 192, 288, 96, 1}, {"b4 conv1 k7   96", '1', 575445, 96, 96, 96, 1}, {"b4 conv2 1x1  96", '2', 575445, 96, 96, 96, 1},
+            {"chunk b1 conv2 1x1 768", '2', 416, 768, 768, 768, 1}, {"chunk b4 conv1 k7 96", '1', 24960, 96, 96, 96, 1}, {"chunk b4 conv2 1x1 96", '2', 24960, 96, 96, 96, 1},
+        };
+        double tot_new = 0, tot_old = 0;
+        for (auto& c : cs) {
+            const int taps = c.kind == 'T' ? 2 : (c.kind == '1' ? 7 : 1);
+            const size_t K = (size_t)taps * c.Cin, arows = (size_t)c.M + (c.kind == 'T' ? 1 : 0);
+            const size_t na = arows * c.Cin, nw = (size_t)c.N * K, ny = (size_t)c.M * c.N;
+            std::vector<uint16_t> ha(na), hw(nw), hr(ny), hc(4 * (size_t)c.co);
+            uint32_t x = 4242;
+            auto rnd = [&]() { x = x * 1664525u + 1013904223u; return x >> 16; };
+            for (auto& v : ha) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 128.f);
+            for (auto& v : hw) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 1024.f);
+            for (auto& v : hr) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 128.f);
+            for (size_t i = 0; i < hc.size(); ++i) hc[i] = f_to_bf16_host(i < (size_t)c.co ? (float)((int)(rnd() & 0xff) - 128) / 512.f : 0.75f + (float)(rnd() & 0xff) / 512.f);
+            void *A, *W, *R, *C, *Y[2], *Y2[2];
+            (void)hipMalloc(&A, na * 2); (void)hipMalloc(&W, nw * 2); (void)hipMalloc(&R, ny * 2); (void)hipMalloc(&C, hc.size() * 2);
+            for (int v = 0; v < 2; ++v) { (void)hipMalloc(&Y[v], ny * 2); (void)hipMalloc(&Y2[v], ny * 2); (void)hipMemset(Y[v], 0, ny * 2); (void)hipMemset(Y2[v], 0, ny * 2); }
+            (void)hipMemcpy(A, ha.data(), na * 2, hipMemcpyHostToDevice); (void)hipMemcpy(W, hw.data(), nw * 2, hipMemcpyHostToDevice);
+            (void)hipMemcpy(R, hr.data(), ny * 2, hipMemcpyHostToDevice); (void)hipMemcpy(C, hc.data(), hc.size() * 2, hipMemcpyHostToDevice);
+            GemmArgs a{};
+            a.A = A; a.lda = c.Cin; a.M = c.M; a.a_rows = (int)arows; a.n_taps = taps; a.Cin = c.Cin; a.W = W; a.N = c.N;
+            if (c.kind == 'T') { a.tap_off[0] = 1; a.tap_off[1] = 0; } else for (int i = 0; i < taps; ++i) a.tap_off[i] = -(taps - 1 - i) * c.dil;
+            a.bias = C; a.bias_mod = c.co; a.ldy = c.N;
+            a.sn_a = (const uint16_t*)C + 2 * c.co; a.sn_ib = (const uint16_t*)C + 3 * c.co;
+            if (c.kind == '2') { a.res = R; a.ldr = c.N; }
+            float ms[2];
+            for (int v = 0; v < 2; ++v) {
+                GemmArgs b = a; b.epi_legacy = v; b.Y = c.kind == '1' ? nullptr : Y[v]; b.Y2 = Y2[v];
+                gemm_launch<bf16_t>(b, s); (void)hipStreamSynchronize(s);
+                (void)hipEventRecord(e0, s);
+                for (int r = 0; r < reps; ++r) gemm_launch<bf16_t>(b, s);
+                (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+                (void)hipEventElapsedTime(&ms[v], e0, e1); ms[v] /= reps;
+            }
+            std::vector<uint16_t> y0(ny), y1(ny);
+            size_t bad = 0;
+            (void)hipMemcpy(y0.data(), Y2[0], ny * 2, hipMemcpyDeviceToHost); (void)hipMemcpy(y1.data(), Y2[1], ny * 2, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < ny; ++i) bad += y0[i] != y1[i];
+            if (c.kind != '1') {
+                (void)hipMemcpy(y0.data(), Y[0], ny * 2, hipMemcpyDeviceToHost); (void)hipMemcpy(y1.data(), Y[1], ny * 2, hipMemcpyDeviceToHost);
+                for (size_t i = 0; i < ny; ++i) bad += y0[i] != y1[i];
+            }
+            const double fl = 2.0 * c.M * c.N * K;
+            const double bytes = 2.0 * ((double)na + (c.kind == '2' ? 3.0 : (c.kind == 'T' ? 2.0 : 1.0)) * ny);      // A + [residual] + outputs
+            printf("%-28s M=%7d N=%5d K=%5zu  parked %8.2f us (%6.1f TFLOP/s, %5.2f TB/s)   register-layout %8.2f us   outputs %s\n", c.name, c.M, c.N, K,
+                   ms[0] * 1e3, fl / (ms[0] * 1e-3) / 1e12, bytes / (ms[0] * 1e-3) / 1e12, ms[1] * 1e3, bad ? "DIFFER  <-- MISMATCH" : "bit-identical");
+            if (c.name[0] == 'b') { tot_new += ms[0]; tot_old += ms[1]; }
+            (void)hipFree(A); (void)hipFree(W); (void)hipFree(R); (void)hipFree(C);
+            for (int v = 0; v < 2; ++v) { (void)hipFree(Y[v]); (void)hipFree(Y2[v]); }
+        }
+        printf("one pass over the 12 decoder-block convs of a 300-frame piece (x1; each residual unit runs 3x): parked %.3f ms, register-layout %.3f ms\n", tot_new, tot_old);
+        return 0;
+    }
     if (argc > 2) {        // variant sweep on 4096 x 4096 x 4096: tile shape x prefetch depth
         const int M = 4096, N = 4096, K = 4096;
         void *A, *W, *Y;
