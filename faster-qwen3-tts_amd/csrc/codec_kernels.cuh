@@ -61,9 +61,19 @@ __device__ __forceinline__ float act_extra(int act, float v) {
 
 // SnakeBeta on an already T-rounded value, each Torch op rounded to T (modeling :3566-3580):
 // x + (1 / (exp(beta) + 1e-9)) * sin(x * exp(alpha))^2; a = rnd(exp(alpha)), ib = rnd(1 / rnd(rnd(exp(beta)) + 1e-9))
+// The sine: fp32 contexts use the accurate sinf (the fp32 waveform is compared with the oracle at 1e-6); in bf16 the value is rounded
+// to 8 mantissa bits straight away, so the hardware sine (v_sin_f32 on x / 2 pi, absolute error ~1e-6 at the arguments of a
+// vocoder, |x a| up to a few hundred) gives the same bf16 value except within ~1e-6 of a rounding boundary (about one element in
+// 3000, one bf16 ulp of the sine) -- at ~40 fewer VALU instructions per element.  The SnakeBeta epilogues evaluate it for
+// 8 x 10^8 elements per 300 decoded frames: it was a quarter of the decoder's time.
+template <typename T>
+__device__ __forceinline__ float snake_sin(float x) {
+    if constexpr (sizeof(T) == 2) return __sinf(x);
+    else return sinf(x);
+}
 template <typename T>
 __device__ __forceinline__ float snake_apply(float v, float a, float ib) {
-    const float s = DT<T>::rnd(sinf(DT<T>::rnd(v * a)));
+    const float s = DT<T>::rnd(snake_sin<T>(DT<T>::rnd(v * a)));
     return v + DT<T>::rnd(ib * DT<T>::rnd(s * s));
 }
 template <typename T>
@@ -179,30 +189,34 @@ __device__ __forceinline__ EpiQ epiq_of(const GemmArgs& a) {
 template <typename T>
 __device__ __forceinline__ void epi_quad(const EpiQ& a, f32x4_t acc, int m, int n) {
     const int ch = n % a.bias_mod;
-    float rv[4] = {0.f, 0.f, 0.f, 0.f}, v[4], v2[4];
-    if (a.res) {
-        const T* rp = reinterpret_cast<const T*>(a.res) + (size_t)m * a.ldr + n;
+    // four consecutive values of a per-column vector / of a row, one 8-byte (bf16) or 16-byte (fp32) load each
+    auto ld4 = [](const void* base, size_t off, float (&f)[4]) {
+        const T* p = reinterpret_cast<const T*>(base) + off;
         if constexpr (sizeof(T) == 2) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(rp);
-            rv[0] = __uint_as_float(rr.x << 16); rv[1] = __uint_as_float(rr.x & 0xFFFF0000u);
-            rv[2] = __uint_as_float(rr.y << 16); rv[3] = __uint_as_float(rr.y & 0xFFFF0000u);
+            const uint2 rr = *reinterpret_cast<const uint2*>(p);
+            f[0] = __uint_as_float(rr.x << 16); f[1] = __uint_as_float(rr.x & 0xFFFF0000u);
+            f[2] = __uint_as_float(rr.y << 16); f[3] = __uint_as_float(rr.y & 0xFFFF0000u);
         } else {
-            const f32x4_t rr = *reinterpret_cast<const f32x4_t*>(rp);
-            rv[0] = rr[0]; rv[1] = rr[1]; rv[2] = rr[2]; rv[3] = rr[3];
+            const f32x4_t rr = *reinterpret_cast<const f32x4_t*>(p);
+            f[0] = rr[0]; f[1] = rr[1]; f[2] = rr[2]; f[3] = rr[3];
         }
-    }
+    };
+    float rv[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f}, sa[4] = {0.f, 0.f, 0.f, 0.f}, sib[4] = {0.f, 0.f, 0.f, 0.f}, v[4], v2[4];
+    if (a.res) ld4(a.res, (size_t)m * a.ldr + n, rv);
+    if (a.bias) ld4(a.bias, ch, bv);
+    if (a.scale) ld4(a.scale, n, sv);
+    if (a.Y2 && !a.act2) { ld4(a.sn_a, ch, sa); ld4(a.sn_ib, ch, sib); }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        float x = DT<T>::rnd(acc[c] + (a.bias ? DT<T>::ld(reinterpret_cast<const T*>(a.bias) + ch + c) : 0.f));
+        float x = DT<T>::rnd(acc[c] + bv[c]);
         if (a.act == 1) x = DT<T>::rnd(gelu_exact(x));
         if (a.act == 3) x = DT<T>::rnd(x / (1.0f + expf(-x)));
         if (a.act >= 4) x = DT<T>::rnd(act_extra(a.act, x));
-        if (a.scale) x = DT<T>::rnd(DT<T>::ld(reinterpret_cast<const T*>(a.scale) + n + c) * x);
+        if (a.scale) x = DT<T>::rnd(sv[c] * x);
         if (a.res) x = x + rv[c];
         v[c] = DT<T>::rnd(x);
         v2[c] = 0.f;
-        if (a.Y2) v2[c] = a.act2 ? DT<T>::rnd(elu1(v[c]))
-                                 : snake_apply<T>(v[c], DT<T>::ld(reinterpret_cast<const T*>(a.sn_a) + ch + c), DT<T>::ld(reinterpret_cast<const T*>(a.sn_ib) + ch + c));
+        if (a.Y2) v2[c] = a.act2 ? DT<T>::rnd(elu1(v[c])) : snake_apply<T>(v[c], sa[c], sib[c]);
     }
     if constexpr (sizeof(T) == 2) {
         if (a.Y) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + n) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
