@@ -983,37 +983,62 @@ __global__ __launch_bounds__(256) void swa_attn_kernel(const T* qkv, T* out, int
 }
 
 // Output conv k=7, C -> 1, + clamp to [-1, 1]; fp32 PCM out for samples [t_lo, rows), written to pcm[t - t_lo].
-// One workgroup per 128 samples: the 134 x C input window and the 7 x C weights are staged in LDS once (rows padded to
-// an odd number of words: conflict-free), two threads per sample split the channels.
-constexpr int kFinalSpw = 128;
+// One workgroup per `spw` consecutive samples (a multiple of 64, <= 256; one thread per sample): the (spw + 6) x C input window is
+// copied to LDS as it is (16-byte chunks, no conversion; rows padded by 16 bytes so that consecutive samples' 16-byte reads fall
+// into distinct bank quads), the 7 x C weights as fp32.  A thread walks its 7 rows with 16-byte LDS reads (the weights are
+// broadcast reads: every lane the same address) and one fp32 fma chain in (tap, channel) order.  The input is read from HBM once:
+// 110 MB for 300 decoded frames (the round-2 kernel staged fp32 element by element and took 331 us for them).
+constexpr int kFinalSpwMax = 256;
 template <typename T>
-__global__ __launch_bounds__(256) void final_conv_kernel(const T* x, const T* w /*[7][C]*/, const T* b, float* pcm, int t_lo, int rows, int C) {
-    extern __shared__ __attribute__((aligned(16))) float fsm[];
-    const int pitch = C | 1;                                  // floats per staged row (odd)
-    float* xs = fsm;                                          // [kFinalSpw + 6][pitch]
-    float* ws = fsm + (kFinalSpw + 6) * pitch;                // [7][C]
-    const int t0 = t_lo + blockIdx.x * kFinalSpw;
-    for (int e = threadIdx.x; e < (kFinalSpw + 6) * C; e += 256) {
-        const int r = e / C, c = e - r * C, tt = t0 - 6 + r;
-        xs[r * pitch + c] = (tt >= 0 && tt < rows) ? DT<T>::ld(x + (size_t)tt * C + c) : 0.f;
+__global__ __launch_bounds__(256) void final_conv_kernel(const T* x, const T* w /*[7][C]*/, const T* b, float* pcm, int t_lo, int rows, int C, int spw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm_raw[];
+    constexpr int EPC = 16 / sizeof(T);                       // elements per 16-byte chunk
+    const int pitch = C + EPC;                                // elements per staged row
+    T* xs = reinterpret_cast<T*>(fsm_raw);                    // [spw + 6][pitch]
+    float* ws = reinterpret_cast<float*>(fsm_raw + (((size_t)(spw + 6) * pitch * sizeof(T) + 15) & ~(size_t)15));       // [7][C]
+    const int t0 = t_lo + blockIdx.x * spw;
+    const int cpr = C / EPC;                                  // chunks per row
+    for (int e = threadIdx.x; e < (spw + 6) * cpr; e += 256) {
+        const int r = e / cpr, c = (e - r * cpr) * EPC, tt = t0 - 6 + r;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (tt >= 0 && tt < rows) v = *reinterpret_cast<const u32x4*>(x + (size_t)tt * C + c);
+        *reinterpret_cast<u32x4*>(xs + (size_t)r * pitch + c) = v;
     }
     for (int e = threadIdx.x; e < 7 * C; e += 256) ws[e] = DT<T>::ld(w + e);
     __syncthreads();
-    const int s = threadIdx.x >> 1, half = threadIdx.x & 1;
-    const int c0 = half * (C / 2), c1 = half ? C : C / 2;
+    const int s = threadIdx.x, t = t0 + s;
+    if (s >= spw || t >= rows) return;
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
-        const float* xr = xs + (s + k) * pitch;
+        const T* xr = xs + (size_t)(s + k) * pitch;
         const float* wr = ws + k * C;
-        for (int c = c0; c < c1; ++c) acc = fmaf(wr[c], xr[c], acc);
+        for (int c = 0; c < C; c += 8) {
+            float xf[8];
+            if constexpr (sizeof(T) == 2) {
+                Raw8<T> q;
+                q.v = *reinterpret_cast<const u32x4*>(xr + c);
+                unpack(q, xf);
+            } else {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(xr + c), hi = *reinterpret_cast<const f32x4*>(xr + c + 4);
+                xf[0] = lo.x; xf[1] = lo.y; xf[2] = lo.z; xf[3] = lo.w; xf[4] = hi.x; xf[5] = hi.y; xf[6] = hi.z; xf[7] = hi.w;
+            }
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + c), w1 = *reinterpret_cast<const f32x4*>(wr + c + 4);
+            acc = fmaf(w0.x, xf[0], acc); acc = fmaf(w0.y, xf[1], acc); acc = fmaf(w0.z, xf[2], acc); acc = fmaf(w0.w, xf[3], acc);
+            acc = fmaf(w1.x, xf[4], acc); acc = fmaf(w1.y, xf[5], acc); acc = fmaf(w1.z, xf[6], acc); acc = fmaf(w1.w, xf[7], acc);
+        }
     }
-    acc += dpp_move<kDppXor1, 0xF>(0.f, acc);                 // the two halves of a sample sit in adjacent lanes
-    const int t = t0 + s;
-    if (half == 0 && t < rows) {
-        const float v = DT<T>::rnd(acc + DT<T>::ld(b));
-        pcm[t - t_lo] = fminf(1.f, fmaxf(-1.f, v));
+    const float v = DT<T>::rnd(acc + DT<T>::ld(b));
+    pcm[t - t_lo] = fminf(1.f, fmaxf(-1.f, v));
+}
+// samples per workgroup and dynamic LDS bytes of final_conv_kernel for C channels of element size esz (0: C does not fit)
+inline int final_conv_spw(int C, int esz, size_t* shm) {
+    const int pitch = C + 16 / esz;
+    for (int spw = kFinalSpwMax; spw >= 64; spw -= 64) {
+        const size_t bytes = (((size_t)(spw + 6) * pitch * esz + 15) & ~(size_t)15) + (size_t)7 * C * sizeof(float);
+        if (bytes <= 64 * 1024 || (spw == 64 && bytes <= 150 * 1024)) { *shm = bytes; return spw; }
     }
+    return 0;
 }
 
 }  // namespace fq3

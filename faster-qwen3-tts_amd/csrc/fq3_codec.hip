@@ -359,12 +359,14 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, int64_t first_sa
         const int R = rows, C = ch;
         const T* xin = bufS;
         Op o; o.out = t_pcm; o.in = {{t_s, DEP_BACK, 6}};
+        size_t shm = 0;
+        const int spw = final_conv_spw(C, (int)sizeof(T), &shm);
+        if (spw == 0 || C % 8) return cfail(FQ3_EUNSUPPORTED, "output conv: channel count not supported (multiple of 8, window must fit the LDS)");
         o.run = [=](int lo) {
             if (lo >= R) return;
-            const size_t shm = ((size_t)(kFinalSpw + 6) * (C | 1) + 7 * (size_t)C) * sizeof(float);
             auto kern = final_conv_kernel<T>;
             if (shm > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            hipLaunchKernelGGL(kern, dim3((R - lo + kFinalSpw - 1) / kFinalSpw), dim3(256), shm, s, xin, fw, fb, pcm, lo, R, C);
+            hipLaunchKernelGGL(kern, dim3((R - lo + spw - 1) / spw), dim3(256), shm, s, xin, fw, fb, pcm, lo, R, C, spw);
         };
         P.add(std::move(o));
     }

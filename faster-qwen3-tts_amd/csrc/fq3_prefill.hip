@@ -123,18 +123,30 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(const T* qkv, const T
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kFaQ = 64, kFaK = 64, kFaKLd = kHeadDim + 8, kFaVLd = kFaK + 8, kFaPLd = kFaK + 8;
 
-__global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* qkv, const bf16_t* kcache, const bf16_t* vcache, bf16_t* out,
-                                                            int max_seq, int L, int n_pad, int NH, int NKV, float scale) {
-    constexpr int HD = kHeadDim;
+// NW waves = 16 * NW queries per block (4: 64 queries, the short-prompt shape; 8: 128 queries -- a staged K/V tile feeds twice the
+// MFMA work).  PAIRED: the workgroup handles query block bx and then block nqb - 1 - bx, so that under the causal mask every
+// workgroup walks the same number of key tiles (nqb + 1) instead of 1 .. nqb of them: a 4096-token prompt at 128 queries per block
+// is 16 pairs x 16 heads = 256 equal workgroups, one per CU.
+template <int NW, bool PAIRED>
+__global__ __launch_bounds__(64 * NW) void flash_prefill_kernel(const bf16_t* qkv, const bf16_t* kcache, const bf16_t* vcache, bf16_t* out,
+                                                                int max_seq, int L, int n_pad, int NH, int NKV, float scale, int nqb) {
+    constexpr int HD = kHeadDim, Q = 16 * NW, CPT = 16 / NW;             // CPT: 16-byte chunks of a K (and V) row staged per thread
     __shared__ __attribute__((aligned(16))) bf16_t Ks[kFaK * kFaKLd];            // [key][dim]
     __shared__ __attribute__((aligned(16))) bf16_t Vt[HD * kFaVLd];              // [dim][key]
-    __shared__ __attribute__((aligned(16))) bf16_t Ps[4][2][16 * kFaPLd];        // per wave: P high / residual, [query][key]
+    __shared__ __attribute__((aligned(16))) bf16_t Ps[NW][2][16 * kFaPLd];       // per wave: P high / residual, [query][key]
     const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.y, g = h / (NH / NKV), per = NH + 2 * NKV;
-    const int q0 = blockIdx.x * kFaQ;
     const bf16_t* kc = kcache + (size_t)g * max_seq * HD;
     const bf16_t* vc = vcache + (size_t)g * max_seq * HD;
+    const float sl2 = scale * 1.4426950408889634f;                        // softmax in base 2: exp(x) = exp2(x * log2 e)
+    // staging: thread -> key (tid & 63), 16-byte chunks (tid >> 6) + NW j of that key's K and V rows
+    const int skey = tid & 63, sch = tid >> 6;
+    for (int pass = 0; pass < (PAIRED ? 2 : 1); ++pass) {
+    const int qb = pass == 0 ? (int)blockIdx.x : nqb - 1 - (int)blockIdx.x;
+    if (pass == 1 && qb <= (int)blockIdx.x) break;                        // odd block count: the middle block was pass 0
+    const int q0 = qb * Q;
+    if (q0 >= L) continue;
     // Q fragments of this wave's 16 rows (A operand: row = fr, dims fq*8 + 32*ks), kept in registers
     const int qrow = q0 + wave * 16 + fr;
     const int qrc = qrow < L ? qrow : L - 1;
@@ -148,30 +160,35 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* qkv, c
     float m[4], l[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { m[r] = -1e30f; l[r] = 0.f; }
-    const int q_hi = min(q0 + kFaQ, L) - 1;                              // last query of the workgroup
+    const int q_hi = min(q0 + Q, L) - 1;                                  // last query of the block
     const int t_lo = n_pad / kFaK, t_hi = q_hi / kFaK;                    // key tiles [t_lo, t_hi]
-    // staging registers: thread -> key (tid & 63), 16-byte chunks (tid >> 6) + 4 j of that key's K and V rows
-    const int skey = tid & 63, sch = tid >> 6;
-    u32x4 kst[4], vst[4];
+    u32x4 kst[CPT], vst[CPT];
     auto issue = [&](int tile) {
         int key = tile * kFaK + skey;
         key = key < max_seq ? key : max_seq - 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            kst[j] = *reinterpret_cast<const u32x4*>(kc + (size_t)key * HD + (sch + 4 * j) * 8);
-            vst[j] = *reinterpret_cast<const u32x4*>(vc + (size_t)key * HD + (sch + 4 * j) * 8);
+        for (int j = 0; j < CPT; ++j) {
+            kst[j] = *reinterpret_cast<const u32x4*>(kc + (size_t)key * HD + (sch + NW * j) * 8);
+            vst[j] = *reinterpret_cast<const u32x4*>(vc + (size_t)key * HD + (sch + NW * j) * 8);
         }
     };
     issue(t_lo);
-    const float sl2 = scale * 1.4426950408889634f;                        // softmax in base 2: exp(x) = exp2(x * log2 e)
     for (int tile = t_lo; tile <= t_hi; ++tile) {
         __syncthreads();                                                  // everyone is done reading the previous tile
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<u32x4*>(&Ks[skey * kFaKLd + (sch + 4 * j) * 8]) = kst[j];
+        for (int j = 0; j < CPT; ++j) {
+            *reinterpret_cast<u32x4*>(&Ks[skey * kFaKLd + (sch + NW * j) * 8]) = kst[j];
+            // transposed store (dim-major image of V), two keys per 32-bit write: lanes 2i / 2i + 1 hold keys k / k + 1; they swap
+            // words (DPP quad_perm [1,0,3,2]), the even lane writes the even dim of each pair for both keys, the odd lane the odd dim
 #pragma unroll
-            for (int i = 0; i < 8; ++i)                                    // transposed store: dim-major image of V
-                Vt[((sch + 4 * j) * 8 + i) * kFaVLd + skey] = (bf16_t)((vst[j][i >> 1] >> (16 * (i & 1))) & 0xffffu);
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t mine = vst[j][w];
+                const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);
+                const bool odd = skey & 1;
+                const uint32_t word = odd ? ((other >> 16) | (mine & 0xFFFF0000u)) : ((mine & 0xFFFFu) | (other << 16));
+                const int dim = (sch + NW * j) * 8 + 2 * w + (odd ? 1 : 0);
+                *reinterpret_cast<uint32_t*>(&Vt[dim * kFaVLd + (skey & ~1)]) = word;
+            }
         }
         __syncthreads();
         if (tile < t_hi) issue(tile + 1);                                 // next tile's loads fly under the MFMAs
@@ -254,6 +271,23 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* qkv, c
 #pragma unroll
         for (int d = 0; d < 8; ++d) out[((size_t)qi * NH + h) * HD + d * 16 + fr] = f_to_bf16(o[d][r] * inv);
     }
+    }
+}
+
+// shape choice: short prompts keep 64-query blocks, one per workgroup (parallelism first); from 1024 tokens the blocks are paired
+// (equal work per workgroup under the causal mask), from 3072 tokens they hold 128 queries
+static void flash_prefill_launch(const bf16_t* qkv, const bf16_t* k, const bf16_t* v, bf16_t* out, int max_seq, int L, int n_pad, int NH,
+                                 int NKV, float scale, hipStream_t s) {
+    if (L >= 3072) {
+        const int nqb = (L + 127) / 128;
+        hipLaunchKernelGGL((flash_prefill_kernel<8, true>), dim3((nqb + 1) / 2, NH), dim3(512), 0, s, qkv, k, v, out, max_seq, L, n_pad, NH, NKV, scale, nqb);
+    } else if (L >= 1024) {
+        const int nqb = (L + 63) / 64;
+        hipLaunchKernelGGL((flash_prefill_kernel<4, true>), dim3((nqb + 1) / 2, NH), dim3(256), 0, s, qkv, k, v, out, max_seq, L, n_pad, NH, NKV, scale, nqb);
+    } else {
+        const int nqb = (L + 63) / 64;
+        hipLaunchKernelGGL((flash_prefill_kernel<4, false>), dim3(nqb, NH), dim3(256), 0, s, qkv, k, v, out, max_seq, L, n_pad, NH, NKV, scale, nqb);
+    }
 }
 
 template <typename T>
@@ -284,8 +318,8 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
                            (T*)c->tk.k[i], (T*)c->tk.v[i], c->tk.max_seq, L, n_pad, NH, NKV);
         if constexpr (sizeof(T) == 2) {
             if (c->opt_flash_prefill)
-                hipLaunchKernelGGL(flash_prefill_kernel, dim3((L + kFaQ - 1) / kFaQ, NH), dim3(256), 0, s, (const bf16_t*)QKV, (const bf16_t*)c->tk.k[i],
-                                   (const bf16_t*)c->tk.v[i], (bf16_t*)ATT, c->tk.max_seq, L, n_pad, NH, NKV, scale);
+                flash_prefill_launch((const bf16_t*)QKV, (const bf16_t*)c->tk.k[i], (const bf16_t*)c->tk.v[i], (bf16_t*)ATT, c->tk.max_seq, L, n_pad,
+                                     NH, NKV, scale, s);
             else
                 hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((L * NH + 3) / 4), dim3(256), 0, s, (const T*)QKV, (const T*)c->tk.k[i],
                                    (const T*)c->tk.v[i], ATT, c->tk.max_seq, L, n_pad, NH, NKV, scale);
@@ -344,8 +378,8 @@ int prefill_batch_t(fq3_ctx* const* cs, int n, const void* const* embeds, const 
             if constexpr (sizeof(T) == 2) flash = c->opt_flash_prefill != 0;
             if constexpr (sizeof(T) == 2) {
                 if (flash)
-                    hipLaunchKernelGGL(flash_prefill_kernel, dim3((Lq + kFaQ - 1) / kFaQ, NH), dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)cq->tk.k[i],
-                                       (const bf16_t*)cq->tk.v[i], (bf16_t*)att, cq->tk.max_seq, Lq, pq, NH, NKV, scale);
+                    flash_prefill_launch((const bf16_t*)qkv, (const bf16_t*)cq->tk.k[i], (const bf16_t*)cq->tk.v[i], (bf16_t*)att, cq->tk.max_seq, Lq, pq,
+                                         NH, NKV, scale, s);
             }
             if (!flash)
                 hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((Lq * NH + 3) / 4), dim3(256), 0, s, (const T*)qkv, (const T*)cq->tk.k[i],

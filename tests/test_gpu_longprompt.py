@@ -74,3 +74,30 @@ def test_flash_prefill_left_padded_matches_wave_kernel():
         outs.append((logits.float().cpu(), hidden.float().cpu()))
     assert (outs[0][1] - outs[1][1]).abs().max() <= 2.0 ** -7 * max(1.0, float(outs[1][1].abs().max()))
     assert (outs[0][0] - outs[1][0]).abs().max() <= 2.0 ** -6 * max(1.0, float(outs[1][0].abs().max()))
+
+
+@pytest.mark.parametrize("Lp,n_pad", [(1500, 0), (1500, 70), (3200, 70), (3137, 0)])
+def test_flash_prefill_paired_block_variants_match_wave_kernel(Lp, n_pad):
+    """The mid-length (>= 1024 tokens: 64-query blocks handled in pairs bx / nqb-1-bx) and long (>= 3072: 128-query blocks, 8
+    waves, pairs; 3137 tokens = an odd block count with a ragged last block) shapes of the flash kernel against the per-row wave
+    kernel on the same inputs.  Compared on EVERY row: the second layer's K / V cache rows are functions of the first layer's
+    attention output of that row, the last row's hidden / logits of all of them."""
+    from fq3hip.engine import Fq3Engine
+    cfg = config()
+    dtype = torch.bfloat16
+    W = synth_weights(cfg, 0, dtype, parts=("talker", "predictor"))
+    tie, _, _, _, _ = synth_prompt(cfg, Lp, 4, 0, dtype=dtype)
+    x = (tie * 30).to(dtype)[0].cuda().contiguous()
+    eng = Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=Lp + 8, max_frames=8)
+    outs = []
+    for flash in (1, 0):
+        eng.set_option("flash_prefill", flash)
+        logits, hidden = eng.prefill(x, n_pad=n_pad)
+        k, v = eng.kv_export(cfg.talker.num_hidden_layers - 1, Lp)
+        outs.append((logits.float().cpu(), hidden.float().cpu(), k.float().cpu()[:, n_pad:], v.float().cpu()[:, n_pad:]))
+    for i, name in enumerate(("logits", "hidden", "K of the last layer", "V of the last layer")):
+        a, b = outs[0][i], outs[1][i]
+        d = float((a - b).abs().max())
+        assert d <= 2.0 ** -6 * max(1.0, float(b.abs().max())), (name, d)
+    # all rows really differ from zero (a skipped query block would leave stale / zero rows behind)
+    assert float(outs[0][3].abs().amax(dim=(0, 2)).min()) > 0
