@@ -282,17 +282,17 @@ __device__ __forceinline__ void gemm_epilogue_parked(const GemmArgs& a, f32x4_t 
 // Every load is unconditional on a clamped address (out-of-range rows / the padded tail steps are zeroed when the tile
 // is staged) so that the compiler's s_waitcnt vmcnt(N) stays exact and the loads really stay in flight.
 // grid = (ceil(N / BN), ceil((M - m_lo) / BM)).
+// the K loop of conv_gemm_kernel: accumulates the BM x BN tile at (m0, n0) into acc; smem holds 2 * (BM + BN) * LD elements.
+// Ends with a workgroup barrier: the operand stages are dead afterwards.
 template <typename T, int BM, int BN, int PF>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
+__device__ __forceinline__ void conv_gemm_mainloop(const GemmArgs& a, T* smem, f32x4_t (&acc)[BM / 32][BN / 32], int m0, int n0) {
     constexpr int BK = 32;
     constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 4);          // padded LDS row (elements): breaks the 64/128-byte stride
     constexpr int TM = BM / 32, TN = BN / 32;
     static_assert(TM >= 1 && TN >= 1, "tile too small");
-    __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LD];          // operand stages; the epilogue parks the tile here
     T (*As)[BM * LD] = reinterpret_cast<T (*)[BM * LD]>(smem);
     T (*Bs)[BN * LD] = reinterpret_cast<T (*)[BN * LD]>(smem + 2 * BM * LD);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int m0 = a.m_lo + blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wr = wave >> 1, wc = wave & 1;
     const int ldw = a.n_taps * a.Cin;                   // weight row stride
     const T* A = reinterpret_cast<const T*>(a.A);
@@ -305,7 +305,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     constexpr int TPR = BK / EPT;                       // threads per tile row
     constexpr int RPP = 256 / TPR;                      // rows per pass
     constexpr int NPA = (BM + RPP - 1) / RPP, NPB = (BN + RPP - 1) / RPP;
-    f32x4_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -395,6 +394,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
             __syncthreads();
         }
     }
+}
+
+template <typename T, int BM, int BN, int PF>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
+    constexpr int BK = 32;
+    constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 4);
+    constexpr int TM = BM / 32, TN = BN / 32;
+    __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LD];          // operand stages; the epilogue parks the tile here
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m0 = a.m_lo + blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x4_t acc[TM][TN];
+    conv_gemm_mainloop<T, BM, BN, PF>(a, smem, acc, m0, n0);
     constexpr int kParkFloats = (int)(sizeof(T) * 2 * (BM + BN) * LD / sizeof(float));
     if constexpr (BN % 64 != 0 && BN != 32) {
         // the 96-wide tile never serves split-K or SwiGLU GEMMs (gemm_launch), and a third register-layout epilogue copy for
@@ -403,6 +415,108 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     } else {
         if (epi_can_park(a)) gemm_epilogue_parked<T, BM, BN, TM, TN, kParkFloats>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(smem));
         else gemm_epilogue<T, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused residual unit of the decoder blocks with C = 96 / 192 channels (blocks 4 and 3: 0.7M / 0.24M rows for 370 frames):
+//   mid = SnakeBeta_act2(conv1_k7(S) + b1);   h' = (conv2_1x1(mid) + b2) + h;   S' = SnakeBeta_next(h')
+// in ONE kernel per 128-row tile: conv1 is conv_gemm_kernel's K loop over a 128 x C tile (BN = C: the whole channel width, so the
+// tile holds complete rows of `mid`), its SnakeBeta image goes to LDS as bf16 [128][C + 8] -- exactly the A operand of the 1x1
+// conv -- and the second GEMM (K = C: 3 or 6 MFMA steps) reads its weight fragments straight from global memory in operand layout
+// (double-buffered per K step).  The `mid` tensor never goes to HBM (one write + one read of rows x C less per unit) and the unit
+// is one launch instead of two.  Every value follows the same chain as the two-kernel path (same MFMA step order, same roundings,
+// mid rounded to T exactly where it was stored before): bit-identical (tools/microbench/gemm_bench.hip codec).
+// c1: the conv1 GemmArgs (A = S, 7 taps, W1, bias b1, sn_a / sn_ib of act2; Y / Y2 unused); c2: the conv2 GemmArgs (W = W2 [C][C],
+// bias b2, res = h, Y = h' (may be null), Y2 = S', sn_a / sn_ib of the next activation; A unused).
+// ---------------------------------------------------------------------------------------------------------------------
+struct ResUnitArgs { GemmArgs c1, c2; };
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void resunit_kernel(ResUnitArgs u) {
+    static_assert(sizeof(T) == 2 && (C == 96 || C == 192), "bf16, 96 or 192 channels");
+    constexpr int BM = 128, BN = C, BK = 32, LD = BK + 8, TM = BM / 32, TN = BN / 32, KS = C / 32;
+    constexpr int MLD = C + 8;                                            // mid tile row (elements): 16-byte rows, bank-spread
+    constexpr int kOperandElems = 2 * (BM + BN) * LD, kMidElems = BM * MLD;
+    constexpr int kSmemElems = kOperandElems > kMidElems ? kOperandElems : kMidElems;
+    __shared__ __attribute__((aligned(16))) T smem[kSmemElems];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = u.c1.m_lo + blockIdx.x * BM;
+    f32x4_t acc[TM][TN];
+    conv_gemm_mainloop<T, BM, BN, 2>(u.c1, smem, acc, m0, 0);             // ends with a barrier: the operand stages are dead
+    // ---- mid = SnakeBeta(rnd(acc + b1)) -> LDS, row-major (the C layout holds column fr of rows fq * 4 + r) ----
+    {
+        const T* b1 = reinterpret_cast<const T*>(u.c1.bias);
+        const T* sa = reinterpret_cast<const T*>(u.c1.sn_a);
+        const T* sib = reinterpret_cast<const T*>(u.c1.sn_ib);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = wc * (BN / 2) + j * 16 + fr;
+            const float bv = b1 ? DT<T>::ld(b1 + n) : 0.f, av = DT<T>::ld(sa + n), iv = DT<T>::ld(sib + n);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wr * (BM / 2) + i * 16 + fq * 4 + r;
+                    const float v = DT<T>::rnd(DT<T>::rnd(acc[i][j][r] + bv));          // the unfused epilogue rounds twice (idempotent)
+                    DT<T>::st(smem + row * MLD + n, snake_apply<T>(v, av, iv));
+                }
+        }
+    }
+    __syncthreads();
+    // ---- conv2: acc2 = mid (LDS, A operand) x W2^T (B operand from global: row n = fr, k = ks * 32 + fq * 8) ----
+    const T* W2 = reinterpret_cast<const T*>(u.c2.W);
+    const T* wp = W2 + (size_t)(wc * (BN / 2) + fr) * C + fq * 8;
+    bf16x8_t bfr[2][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)j * 16 * C);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)j * 16 * C + (ks + 1) * 32);
+        }
+        bf16x8_t af[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(smem + (wr * (BM / 2) + i * 16 + fr) * MLD + ks * 32 + fq * 8);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                                                      // everybody is done reading mid: the epilogue parks there
+    constexpr int kParkFloats = (int)(sizeof(T) * kSmemElems / sizeof(float));
+    gemm_epilogue_parked<T, BM, BN, TM, TN, kParkFloats>(u.c2, acc, m0, 0, wr, wc, lane, reinterpret_cast<float*>(smem));
+}
+
+// can this (conv1, conv2) pair run as one resunit_kernel launch?
+template <typename T>
+inline bool resunit_ok(const GemmArgs& c1, const GemmArgs& c2) {
+    const int C = c1.N;
+    return sizeof(T) == 2 && (C == 96 || C == 192) && c1.n_taps == 7 && c1.Cin == C && c2.N == C && c2.Cin == C && c2.n_taps == 1 && c1.sn_a &&
+           c1.sn_ib && c2.Y2 && c2.sn_a && !c2.act2 && !c1.act && !c2.act && !c1.scale && !c2.scale && !c1.res && c2.res && c2.ldr == C &&
+           c2.ldy == C && c2.bias_mod == C && c1.bias_mod == C && c1.lda == C;
+}
+template <typename T>
+inline bool resunit_launch(const GemmArgs& c1, const GemmArgs& c2, hipStream_t s) {
+    if constexpr (sizeof(T) != 2) return false;
+    else {
+        const int rows = c1.M - c1.m_lo, C = c1.N;
+        if (!resunit_ok<T>(c1, c2)) return false;
+        if (rows <= 0) return true;
+        ResUnitArgs u{c1, c2};
+        u.c2.M = c1.M; u.c2.m_lo = c1.m_lo;
+        const dim3 grid((rows + 127) / 128);
+        if (C == 96) hipLaunchKernelGGL((resunit_kernel<T, 96>), grid, dim3(256), 0, s, u);
+        else if (C == 192) hipLaunchKernelGGL((resunit_kernel<T, 192>), grid, dim3(256), 0, s, u);
+        else return false;
+        return true;
     }
 }
 

@@ -45,6 +45,7 @@ struct fq3_codec {
     void* snake_consts = nullptr;                 // per-channel SnakeBeta constants (a, ib), built at finalize
     std::map<std::string, std::pair<const void*, const void*>> snake;     // "<prefix>" -> (a, ib)
     bool ready = false;
+    int fuse_units = 1;                           // residual units of the 96 / 192-channel blocks as one launch each (resunit_kernel)
 };
 
 static int64_t samples_for(const fq3_codec_config& c, int64_t T) {
@@ -94,6 +95,13 @@ extern "C" int fq3_codec_destroy(fq3_codec* c) {
     for (int i = 0; i < 4; ++i) if (c->buf[i]) (void)hipFree(c->buf[i]);
     if (c->snake_consts) (void)hipFree(c->snake_consts);
     delete c;
+    return FQ3_OK;
+}
+
+extern "C" int fq3_codec_set_option(fq3_codec* c, const char* key, int value) {
+    if (!c || !key) return cfail(FQ3_EINVAL, "null argument");
+    if (std::string(key) == "fuse_units") c->fuse_units = value;      // 1 (default): residual units of the 96 / 192-channel blocks as one launch
+    else return cfail(FQ3_EINVAL, std::string("unknown codec option: ") + key);
     return FQ3_OK;
 }
 
@@ -330,14 +338,11 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, int64_t first_sa
         for (int j = 0; j < 3 && !err; ++j) {
             const std::string Un = Bk + std::to_string(j + 2) + ".";
             const int dil = j == 0 ? 1 : (j == 1 ? 3 : 9);
-            const int t_mid = P.tensor();
-            {   // conv1 (k7, dilated): only snake_act2(conv1) is consumed
-                auto sn = SN(Un + "act2.");
-                GemmArgs a = conv(bufS, rows, ch, W(Un + "conv1.conv.weight"), ch, W(Un + "conv1.conv.bias"), nullptr, 7, dil);
-                a.sn_a = sn.first; a.sn_ib = sn.second; a.Y2 = bufM;
-                gemm_op(a, -1, t_mid, {{t_s, DEP_BACK, 6 * dil}});
-            }
-            // conv2 (1x1) + residual -> next raw h (unless nothing reads it) and the next activation's image of it
+            // conv1 (k7, dilated): only snake_act2(conv1) is consumed; conv2 (1x1) + residual -> next raw h (unless nothing reads it)
+            // and the next activation's image of it
+            auto sn1 = SN(Un + "act2.");
+            GemmArgs a1 = conv(bufS, rows, ch, W(Un + "conv1.conv.weight"), ch, W(Un + "conv1.conv.bias"), nullptr, 7, dil);
+            a1.sn_a = sn1.first; a1.sn_ib = sn1.second; a1.Y2 = bufM;
             const bool last_unit = j == 2, last_block = i == g.n_rates - 1;
             const std::string next_sn = !last_unit ? Bk + std::to_string(j + 3) + ".act1."
                                         : (!last_block ? DD + std::to_string(i + 2) + ".block.0." : DD + std::to_string(g.n_rates + 1) + ".");
@@ -345,7 +350,19 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, int64_t first_sa
             GemmArgs a = conv(bufM, rows, ch, W(Un + "conv2.conv.weight"), ch, W(Un + "conv2.conv.bias"), last_unit ? nullptr : (void*)bufN, 1, 1);
             a.res = bufH; a.ldr = ch; a.sn_a = sn.first; a.sn_ib = sn.second; a.Y2 = bufS;      // bufS (conv1's input) is dead by now
             const int t_hn = last_unit ? -1 : P.tensor(), t_sn = P.tensor();
-            gemm_op(a, t_hn, t_sn, {{t_mid, DEP_SAME, 0}, {t_hraw, DEP_SAME, 0}});
+            GemmArgs af = a; af.Y2 = bufM;
+            if (c->fuse_units && resunit_ok<T>(a1, af)) {
+                // the two narrowest blocks: the whole unit in one launch (resunit_kernel), `mid` stays in LDS.  The new activation goes
+                // to bufM (free now): other workgroups still read their halo rows of bufS while this one stores
+                Op o; o.out = t_hn; o.out2 = t_sn; o.in = {{t_s, DEP_BACK, 6 * dil}, {t_hraw, DEP_SAME, 0}};
+                o.run = [a1, af, s](int lo) mutable { a1.m_lo = lo; (void)resunit_launch<T>(a1, af, s); };
+                P.add(std::move(o));
+                std::swap(bufS, bufM);
+            } else {
+                const int t_mid = P.tensor();
+                gemm_op(a1, -1, t_mid, {{t_s, DEP_BACK, 6 * dil}});
+                gemm_op(a, t_hn, t_sn, {{t_mid, DEP_SAME, 0}, {t_hraw, DEP_SAME, 0}});
+            }
             if (!last_unit) { std::swap(bufH, bufN); t_hraw = t_hn; }
             t_s = t_sn;
         }

@@ -113,6 +113,9 @@ __device__ int sample_wave_core(Raw8<T> (&xraw)[NC], int V, const SampleCfg& c, 
             __syncthreads();
             const int tot = (slot[0] + slot[1]) + (slot[2] + slot[3]);
             if (tot >= kk) prefix = cand;
+            // exactly k keys at or above the candidate: they ARE the top k (the k-th largest is >= cand, the next one below it), and
+            // the filter `key >= prefix` keeps the same set as the fully resolved threshold would -- the remaining bits need no rounds
+            if (tot == kk) break;
         }
 #pragma unroll
         for (int j = 0; j < NC; ++j)

@@ -124,6 +124,7 @@ SIGNATURES = {
     "fq3_batch_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "fq3_codec_create": (C.c_int, [C.POINTER(CodecConfig), C.POINTER(vp)]),
     "fq3_codec_destroy": (C.c_int, [vp]),
+    "fq3_codec_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "fq3_codec_bind": (C.c_int, [vp, C.c_char_p, vp, C.c_int64]),
     "fq3_codec_finalize": (C.c_int, [vp, vp]),
     "fq3_codec_num_samples": (C.c_int64, [vp, C.c_int]),

@@ -126,6 +126,10 @@ class HipSpeechTokenizer:
             out.append(an.encode(resample(a, int(sr or self.sample_rate), self.sample_rate)))
         return SimpleNamespace(audio_codes=out)
 
+    def set_option(self, key: str, value: int):
+        """``fq3_codec_set_option``: "fuse_units" 0|1 (fused residual units of the narrow decoder blocks; bit-identical either way)."""
+        L.check(self.lib.fq3_codec_set_option(self.h, key.encode(), int(value)))
+
     def num_samples(self, n_frames: int) -> int:
         return int(self.lib.fq3_codec_num_samples(self.h, int(n_frames)))
 

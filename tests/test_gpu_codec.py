@@ -162,6 +162,27 @@ def test_codec_high_precision_mode_meets_1e_3(T, golden_dir):
     hp.close(); lo.close()
 
 
+def test_codec_fused_residual_units_are_bit_identical():
+    """resunit_kernel (blocks with 192 / 96 channels: conv1 k7 -> SnakeBeta -> 1x1 conv -> + skip -> SnakeBeta in one launch, the middle
+    tensor in LDS) against the two-GEMM path: the waveform is identical bit for bit, for a full decode (T = 40 and T = 100 > window)
+    and for tail decodes (the row ranges of the fused op follow the conv1 halo)."""
+    cfg, tok = _real_codec(torch.bfloat16)
+    g = torch.Generator().manual_seed(11)
+    for T in (40, 100):
+        codes = torch.randint(0, cfg.codec.codebook_size, (T, cfg.codec.num_quantizers), generator=g).cuda()
+        tok.set_option("fuse_units", 1)
+        fused = tok.decode_tensor(codes)
+        n = fused.numel()
+        tails = [tok.decode_tensor(codes, first) for first in (n - 8 * 1920, n // 2 + 7)]
+        tok.set_option("fuse_units", 0)
+        plain = tok.decode_tensor(codes)
+        assert torch.equal(fused, plain), T
+        for first, tail in zip((n - 8 * 1920, n // 2 + 7), tails):
+            assert torch.equal(tail, plain[first:]), (T, first)
+    tok.set_option("fuse_units", 1)
+    tok.close()
+
+
 def test_codec_real_shapes_causal_prefix_property():
     """Size-independent property at the benchmark's full length (T = 200, fp32 and bf16): the decoder is causal, so the
     waveform of a prefix of the codes is BIT-IDENTICAL to the prefix of the waveform (what streaming relies on)."""

@@ -29,7 +29,10 @@ def main():
     g = torch.Generator().manual_seed(4)
     codes = torch.randint(0, cfg.codec.codebook_size, (370, 16), generator=g).cuda()
     n33 = tok.num_samples_total(33); n178 = tok.num_samples_total(178)
-    print(f"dtype {dt}: full 370 frames {timed(lambda: tok.decode_tensor(codes)):.3f} ms | one piece of 300 frames {timed(lambda: tok.decode_tensor(codes[:300].contiguous())):.3f} ms | "
+    for fuse in ((1, 0) if dt == torch.bfloat16 else (1,)):
+      tok.set_option("fuse_units", fuse)
+      print(f"fused residual units = {fuse}: ", end="")
+      print(f"dtype {dt}: full 370 frames {timed(lambda: tok.decode_tensor(codes)):.3f} ms | one piece of 300 frames {timed(lambda: tok.decode_tensor(codes[:300].contiguous())):.3f} ms | "
           f"chunk 25+8 frames (tail of 8) {timed(lambda: tok.decode_tensor(codes[:33].contiguous(), n33 - 8 * 1920), 10):.3f} ms | "
           f"first chunk 170+8 frames (tail of 8) {timed(lambda: tok.decode_tensor(codes[:178].contiguous(), n178 - 8 * 1920), 10):.3f} ms")
 
