@@ -45,7 +45,10 @@ struct fq3_codec {
     void* snake_consts = nullptr;                 // per-channel SnakeBeta constants (a, ib), built at finalize
     std::map<std::string, std::pair<const void*, const void*>> snake;     // "<prefix>" -> (a, ib)
     bool ready = false;
-    int fuse_units = 1;                           // residual units of the 96 / 192-channel blocks as one launch each (resunit_kernel)
+    int fuse_units = 0;                           // 1: residual units of the 96-channel block as one launch each (resunit_kernel), 2: the 192-channel
+                                                  // block too.  Bit-identical either way; measured SLOWER than the two-GEMM path on MI355X (8.02 vs
+                                                  // 7.84 ms per 370-frame decode with both fused: the 128 x C tile runs at lower occupancy than the
+                                                  // 256 x 256 ring tile the k7 conv otherwise gets), so the default is off
 };
 
 static int64_t samples_for(const fq3_codec_config& c, int64_t T) {
@@ -100,7 +103,7 @@ extern "C" int fq3_codec_destroy(fq3_codec* c) {
 
 extern "C" int fq3_codec_set_option(fq3_codec* c, const char* key, int value) {
     if (!c || !key) return cfail(FQ3_EINVAL, "null argument");
-    if (std::string(key) == "fuse_units") c->fuse_units = value;      // 1 (default): residual units of the 96 / 192-channel blocks as one launch
+    if (std::string(key) == "fuse_units") c->fuse_units = value;      // 0 (default) two GEMMs per residual unit; 1: 96-channel units fused; 2: 192 too
     else return cfail(FQ3_EINVAL, std::string("unknown codec option: ") + key);
     return FQ3_OK;
 }
@@ -351,7 +354,7 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, int64_t first_sa
             a.res = bufH; a.ldr = ch; a.sn_a = sn.first; a.sn_ib = sn.second; a.Y2 = bufS;      // bufS (conv1's input) is dead by now
             const int t_hn = last_unit ? -1 : P.tensor(), t_sn = P.tensor();
             GemmArgs af = a; af.Y2 = bufM;
-            if (c->fuse_units && resunit_ok<T>(a1, af)) {
+            if (c->fuse_units && (ch == 96 || c->fuse_units >= 2) && resunit_ok<T>(a1, af)) {
                 // the two narrowest blocks: the whole unit in one launch (resunit_kernel), `mid` stays in LDS.  The new activation goes
                 // to bufM (free now): other workgroups still read their halo rows of bufS while this one stores
                 Op o; o.out = t_hn; o.out2 = t_sn; o.in = {{t_s, DEP_BACK, 6 * dil}, {t_hraw, DEP_SAME, 0}};

@@ -127,7 +127,7 @@ class HipSpeechTokenizer:
         return SimpleNamespace(audio_codes=out)
 
     def set_option(self, key: str, value: int):
-        """``fq3_codec_set_option``: "fuse_units" 0|1 (fused residual units of the narrow decoder blocks; bit-identical either way)."""
+        """``fq3_codec_set_option``: "fuse_units" 0|1|2 (fused residual units of the 96- / 96- and 192-channel decoder blocks; bit-identical, default 0)."""
         L.check(self.lib.fq3_codec_set_option(self.h, key.encode(), int(value)))
 
     def num_samples(self, n_frames: int) -> int:

@@ -170,16 +170,15 @@ def test_codec_fused_residual_units_are_bit_identical():
     g = torch.Generator().manual_seed(11)
     for T in (40, 100):
         codes = torch.randint(0, cfg.codec.codebook_size, (T, cfg.codec.num_quantizers), generator=g).cuda()
-        tok.set_option("fuse_units", 1)
-        fused = tok.decode_tensor(codes)
-        n = fused.numel()
-        tails = [tok.decode_tensor(codes, first) for first in (n - 8 * 1920, n // 2 + 7)]
         tok.set_option("fuse_units", 0)
         plain = tok.decode_tensor(codes)
-        assert torch.equal(fused, plain), T
-        for first, tail in zip((n - 8 * 1920, n // 2 + 7), tails):
-            assert torch.equal(tail, plain[first:]), (T, first)
-    tok.set_option("fuse_units", 1)
+        n = plain.numel()
+        for mode in (1, 2):                                  # 1: the 96-channel block, 2: the 192-channel block too
+            tok.set_option("fuse_units", mode)
+            assert torch.equal(tok.decode_tensor(codes), plain), (T, mode)
+            for first in (n - 8 * 1920, n // 2 + 7):
+                assert torch.equal(tok.decode_tensor(codes, first), plain[first:]), (T, mode, first)
+    tok.set_option("fuse_units", 0)
     tok.close()
 
 

@@ -29,7 +29,7 @@ def main():
     g = torch.Generator().manual_seed(4)
     codes = torch.randint(0, cfg.codec.codebook_size, (370, 16), generator=g).cuda()
     n33 = tok.num_samples_total(33); n178 = tok.num_samples_total(178)
-    for fuse in ((1, 0) if dt == torch.bfloat16 else (1,)):
+    for fuse in ((0, 1, 2) if dt == torch.bfloat16 else (0,)):
       tok.set_option("fuse_units", fuse)
       print(f"fused residual units = {fuse}: ", end="")
       print(f"dtype {dt}: full 370 frames {timed(lambda: tok.decode_tensor(codes)):.3f} ms | one piece of 300 frames {timed(lambda: tok.decode_tensor(codes[:300].contiguous())):.3f} ms | "
