@@ -726,7 +726,7 @@ def model_1p7b_block(cfg, model, device, lanes=16):
                                "frac": round((gemm_fl + attn_fl) / (pms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "bound": "mfma"}
     except Exception as e:
         out["prefill_4096"] = {"error": repr(e)}
-    for B in sorted({8, lanes}):
+    for B in sorted({8, lanes, 32}):
         try:
             ms, p = batched_frame_time(model, cfg, prompt, lanes=B)
             out[f"batched_b{B}"] = {"ms_per_lockstep_frame": round(ms, 3), "value": round(B * 80.0 / ms, 1),
@@ -779,7 +779,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
-    ap.add_argument("--batch", type=int, default=16, help="lock-step lanes of the batched figures, <= 16 (0 = skip them)")
+    ap.add_argument("--batch", type=int, default=16, help="lock-step lanes of the batched figures, <= 32 (0 = skip them)")
     ap.add_argument("--batch-groups", type=int, default=1, help="opt-in: concurrent lock-step batches on one GPU, `batched_groups_one_gpu` (1 = skip; measured: two host-threaded groups of 8 give 159x vs 159x for one)")
     ap.add_argument("--config3-utterances", type=int, default=64, help="utterances of the sharded batched run (0 = skip)")
     ap.add_argument("--concurrent", type=int, default=4,
@@ -871,7 +871,7 @@ def main():
         guarded("roofline_mfma", lambda: measure_mfma(cfg, model, prompt))
     if solo and args.batch > 1:
         def _batched():
-            lanes = min(args.batch, 16)
+            lanes = min(args.batch, 32)
             batched_run(model, prompt, lanes, lanes)                                   # warm-up: contexts, graph capture
             audio_s, wall, _ = batched_run(model, prompt, 2 * lanes, lanes)
             ms, p = batched_frame_time(model, cfg, prompt, lanes)
@@ -890,17 +890,19 @@ def main():
                                     "note": "VALU batch GEMVs: lanes bit-identical to single-stream decoding"}
             except Exception as e:
                 out["valu_gemv"] = {"error": repr(e)}
-            if lanes > 8:
+            for other in (8, 32):
+                if other == lanes:
+                    continue
                 try:
-                    ms8, p8 = batched_frame_time(model, cfg, prompt, 8)
-                    out["lanes_8"] = {"ms_per_lockstep_frame": round(ms8, 3), "decode_only_value": round(8 * 80.0 / ms8, 1)}
+                    mso, _po = batched_frame_time(model, cfg, prompt, other)
+                    out[f"lanes_{other}"] = {"ms_per_lockstep_frame": round(mso, 3), "decode_only_value": round(other * 80.0 / mso, 1)}
                 except Exception as e:
-                    out["lanes_8"] = {"error": repr(e)}
+                    out[f"lanes_{other}"] = {"error": repr(e)}
             return out
         guarded("batched_decode_one_gpu", _batched)
         if args.batch_groups > 1:
             guarded("batched_groups_one_gpu", lambda: batched_groups_run(cfg, model, prompt, device, args.config3_utterances or 64,
-                                                                         groups=args.batch_groups, lanes=min(args.batch, 16)))
+                                                                         groups=args.batch_groups, lanes=min(args.batch, 32)))
 
     # ---- BASELINE configs[3]: 1.7B-CustomVoice shapes, 64 utterances sharded over the ranks, 16 lock-step lanes per GPU (all
     #      ranks take part), through the public generate_custom_voice_batch ----
@@ -909,7 +911,7 @@ def main():
     if args.config3_utterances > 0 and args.batch > 1 and not args.no_extras:
         from fq3hip.sharding import shard_indices
         mine = shard_indices(args.config3_utterances, rank, world)
-        lanes = min(args.batch, 16)
+        lanes = min(args.batch, 32)
         err, c3_audio, c3_lens = None, 0.0, []
         texts = sentences(args.config3_utterances)
         try:
@@ -1011,7 +1013,7 @@ def main():
                     cfg17, model17 = build_model(device, "1p7b", max_seq_len=6144, model_type="custom_voice")
                 inner17 = model17.model.model
                 inner17.tts_model_type = "base"                # configs[2] is the Base model: same weights, voice-clone entry points
-                out["model_1p7b"] = model_1p7b_block(cfg17, model17, device, lanes=min(max(args.batch, 8), 16))
+                out["model_1p7b"] = model_1p7b_block(cfg17, model17, device, lanes=min(max(args.batch, 8), 32))
             except Exception as e:
                 out["model_1p7b"] = {"error": repr(e)}
         if world == 1 and not stub and not args.no_cpu_baseline:

@@ -15,7 +15,9 @@
 
 namespace fq3 {
 
-constexpr int kMaxLanes = 16;        // one v_mfma_f32_16x16x32_bf16 token tile
+constexpr int kMaxLanes = 32;        // two token tiles
+constexpr int kTokTile = 16;         // token columns of one v_mfma_f32_16x16x32_bf16 tile: lanes 0..15 / 16..31 of a batch are passes of the
+                                     // same launch over register-resident weight fragments
 constexpr int kGroupLanes = 8;       // VALU batch GEMV: tokens staged in LDS per pass over the register-resident weight rows
 
 struct LaneTab {
@@ -294,29 +296,36 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
     constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr int K = KSTEPS * 128, KP = K + 8;                 // padded LDS row: 16 tokens x same k would share a bank
     constexpr int NCH = (K + 511) / 512;
-    constexpr int TPW = kMaxLanes / 4;
+    constexpr int TPW = kTokTile / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* xs = reinterpret_cast<T*>(smem_raw);                     // [16][KP]
-    float* red = reinterpret_cast<float*>(smem_raw + (((size_t)kMaxLanes * KP * sizeof(T) + 15) & ~(size_t)15));   // [4][NR][64][4]
+    float* red = reinterpret_cast<float*>(smem_raw + (((size_t)kTokTile * KP * sizeof(T) + 15) & ~(size_t)15));   // [4][NR][64][4]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int fr = lane & 15, fq = lane >> 4, B = a.B;
     const T* W = reinterpret_cast<const T*>(a.W);
     const int row0 = blockIdx.x * 16;
 
-    // ---- 1. token loads ----
+    // ---- 1. token loads of the first token tile (lanes 0..15 of the batch) ----
     Raw8<T> xraw[TPW][NCH], nraw[NCH];
+    auto issue_tokens = [&](int t0, int nb) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int off = j * 512 + lane * 8, offc = off < K ? off : 0;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int m = t0 + (wave + 4 * t < nb ? wave + 4 * t : nb - 1);
+                ldraw<false>(xraw[t][j], reinterpret_cast<const T*>(a.x) + (size_t)m * a.x_stride + offc);
+            }
+        }
+    };
+    issue_tokens(0, B < kTokTile ? B : kTokTile);
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-        const int off = j * 512 + lane * 8, offc = off < K ? off : 0;
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            const int m = wave + 4 * t < B ? wave + 4 * t : B - 1;
-            ldraw<false>(xraw[t][j], reinterpret_cast<const T*>(a.x) + (size_t)m * a.x_stride + offc);
-        }
-        ldraw<false>(nraw[j], reinterpret_cast<const T*>(a.norm_w) + offc);
+        const int off = j * 512 + lane * 8;
+        ldraw<false>(nraw[j], reinterpret_cast<const T*>(a.norm_w) + (off < K ? off : 0));
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- 2. this wave's K quarter of the 16 (x NR) weight rows, in A-operand layout ----
+    // ---- 2. this wave's K quarter of the 16 (x NR) weight rows, in A-operand layout: loaded ONCE, kept for every token tile ----
     Raw8<T> wreg[NR][KSTEPS];
     const int rowc = row0 + fr < a.N ? row0 + fr : a.N - 1;
 #pragma unroll
@@ -334,96 +343,98 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
         biasv[i] = a.bias ? bv : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- 3. prepare tokens while the weights fly ----
+#pragma unroll 1
+    for (int t0 = 0; t0 < B; t0 += kTokTile) {                  // one pass per token tile (a second one only above 16 lanes)
+        const int nb = B - t0 < kTokTile ? B - t0 : kTokTile;
+        if (t0 > 0) issue_tokens(t0, nb);                       // later tiles pay one exposed round trip; the weights are already here
+        // ---- 3. prepare the tile's tokens (the first tile: while the weights fly) ----
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int m = wave + 4 * t;
-        float xr[NCH][8];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            if (j * 512 + lane * 8 >= K) zero(xraw[t][j]);
-            unpack(xraw[t][j], xr[j]);
-        }
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
-        ss = wave_sum(ss);
-        const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            float nw[8];
-            unpack(nraw[j], nw);
-#pragma unroll
-            for (int i = 0; i < 8; i += 2) {
-                float u = xr[j][i] * rs, v = xr[j][i + 1] * rs;
-                DT<T>::rnd2(u, v);
-                u *= nw[i]; v *= nw[i + 1];
-                DT<T>::rnd2(u, v);
-                xr[j][i] = u; xr[j][i + 1] = v;
-            }
-        }
-        if (m < B) {
-            T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[m]) : nullptr;
+        for (int t = 0; t < TPW; ++t) {
+            const int m = wave + 4 * t;
+            float xr[NCH][8];
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
-                const int off = j * 512 + lane * 8;
-                if (off < K) {
-                    DT<T>::st8(xs + (size_t)m * KP + off, xr[j]);
-                    if (xo) DT<T>::st8(xo + off, xr[j]);
+                if (j * 512 + lane * 8 >= K) zero(xraw[t][j]);
+                unpack(xraw[t][j], xr[j]);
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
+            ss = wave_sum(ss);
+            const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                float nw[8];
+                unpack(nraw[j], nw);
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    float u = xr[j][i] * rs, v = xr[j][i + 1] * rs;
+                    DT<T>::rnd2(u, v);
+                    u *= nw[i]; v *= nw[i + 1];
+                    DT<T>::rnd2(u, v);
+                    xr[j][i] = u; xr[j][i + 1] = v;
+                }
+            }
+            if (m < nb) {
+                T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[t0 + m]) : nullptr;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const int off = j * 512 + lane * 8;
+                    if (off < K) {
+                        DT<T>::st8(xs + (size_t)m * KP + off, xr[j]);
+                        if (xo) DT<T>::st8(xo + off, xr[j]);
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
-    // ---- 4. MFMA over this wave's K quarter ----
-    f32x4 acc[NR];
+        __syncthreads();
+        // ---- 4. MFMA over this wave's K quarter ----
+        f32x4 acc[NR];
 #pragma unroll
-    for (int h = 0; h < NR; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int tokc = fr < B ? fr : B - 1;
+        for (int h = 0; h < NR; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int tokc = fr < nb ? fr : nb - 1;
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-        const u32x4 bq = *reinterpret_cast<const u32x4*>(xs + (size_t)tokc * KP + wave * (K / 4) + s * 32 + fq * 8);
-        const mfma_bf16x8 bfrag = __builtin_bit_cast(mfma_bf16x8, bq);
+        for (int s = 0; s < KSTEPS; ++s) {
+            const u32x4 bq = *reinterpret_cast<const u32x4*>(xs + (size_t)tokc * KP + wave * (K / 4) + s * 32 + fq * 8);
+            const mfma_bf16x8 bfrag = __builtin_bit_cast(mfma_bf16x8, bq);
 #pragma unroll
-        for (int h = 0; h < NR; ++h)
-            acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wreg[h][s].v), bfrag, acc[h], 0, 0, 0);
-    }
-    // ---- 5. sum the four K quarters (fixed order), epilogue on wave 0 ----
-#pragma unroll
-    for (int h = 0; h < NR; ++h) *reinterpret_cast<f32x4*>(red + ((size_t)(wave * NR + h) * 64 + lane) * 4) = acc[h];
-    __syncthreads();
-    if (wave != 0) return;
-    float tot[NR][4];
-#pragma unroll
-    for (int h = 0; h < NR; ++h) {
-        f32x4 t = *reinterpret_cast<const f32x4*>(red + ((size_t)(0 * NR + h) * 64 + lane) * 4);
-#pragma unroll
-        for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + ((size_t)(w * NR + h) * 64 + lane) * 4);
-        tot[h][0] = t.x; tot[h][1] = t.y; tot[h][2] = t.z; tot[h][3] = t.w;
-    }
-    if (fr >= B) return;
-    T* yp = reinterpret_cast<T*>(a.y) + (size_t)fr * a.y_stride + row0 + fq * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float v;
-        if constexpr (EPI == EPI_SWIGLU) {
-            const float g = DT<T>::rnd(tot[0][i]);
-            const float u = DT<T>::rnd(tot[NR - 1][i]);
-            const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
-            v = sg * u;
-        } else {
-            v = DT<T>::rnd(tot[0][i] + biasv[i]);
+            for (int h = 0; h < NR; ++h)
+                acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wreg[h][s].v), bfrag, acc[h], 0, 0, 0);
         }
-        if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
+        // ---- 5. sum the four K quarters (fixed order), epilogue on wave 0 ----
+#pragma unroll
+        for (int h = 0; h < NR; ++h) *reinterpret_cast<f32x4*>(red + ((size_t)(wave * NR + h) * 64 + lane) * 4) = acc[h];
+        __syncthreads();
+        if (wave == 0 && fr < nb) {
+            float tot[NR][4];
+#pragma unroll
+            for (int h = 0; h < NR; ++h) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(red + ((size_t)(0 * NR + h) * 64 + lane) * 4);
+#pragma unroll
+                for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + ((size_t)(w * NR + h) * 64 + lane) * 4);
+                tot[h][0] = t.x; tot[h][1] = t.y; tot[h][2] = t.z; tot[h][3] = t.w;
+            }
+            T* yp = reinterpret_cast<T*>(a.y) + (size_t)(t0 + fr) * a.y_stride + row0 + fq * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v;
+                if constexpr (EPI == EPI_SWIGLU) {
+                    const float g = DT<T>::rnd(tot[0][i]);
+                    const float u = DT<T>::rnd(tot[NR - 1][i]);
+                    const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
+                    v = sg * u;
+                } else {
+                    v = DT<T>::rnd(tot[0][i] + biasv[i]);
+                }
+                if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
+            }
+        }
+        if (t0 + kTokTile < B) __syncthreads();                 // the next tile overwrites the token panel and the partial sums
     }
 }
 
-// Rows per workgroup: the full 16-row tile.  Tiles of 8 or 4 real rows (the rest of the MFMA tile repeating them), which give the
-// narrow outputs (N = 1024: 64 tiles on 256 CUs) 2x / 4x the workgroups, were measured SLOWER at every shape (B = 16, chain of
-// 320: o_proj 5.66 / 5.81 / 6.21 us and down 7.49 / 7.59 / 7.93 us for 16 / 8 / 4 rows, profiles/r03_kernel_chain_batch.txt):
-// every extra workgroup pulls its own copy of the 16-token panel (98 KB at K = 3072) through its L1.
 template <int KSTEPS, int NW, int EPI>            // K = KSTEPS * 32 * NW; NW waves split K
 __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGemvArgs a) {
     typedef bf16_t T;
@@ -434,49 +445,73 @@ __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGem
     const int fr = lane & 15, fq = lane >> 4, B = a.B;
     const T* W = reinterpret_cast<const T*>(a.W);
     const int row0 = blockIdx.x * 16;
-    // ---- 1. token fragments (small, L2-resident) first, then the weight fragments: vmcnt retires in order, so the wait before
-    //         MFMA step s (its weight fragment) also covers every token fragment ----
-    const int tokc = fr < B ? fr : B - 1;
-    const T* xp = reinterpret_cast<const T*>(a.x) + (size_t)tokc * a.x_stride + wave * (K / NW) + fq * 8;
-    Raw8<T> breg[KSTEPS], wreg[KSTEPS];
+    // ---- 1. token fragments (small, L2-resident) of the first token tile first, then the weight fragments: vmcnt retires in
+    //         order, so the wait before MFMA step s (its weight fragment) also covers every token fragment ----
+    // token fragments held at once: all of a tile's K share, except in the longest variant (K = 6144: 24 steps per wave), where two
+    // halves take turns in the same registers (96 weight + 96 token registers plus the rest would not fit 256 VGPRs)
+    constexpr int BCH = KSTEPS > 16 ? KSTEPS / 2 : KSTEPS, NBCH = KSTEPS / BCH;
+    Raw8<T> breg[BCH], wreg[KSTEPS];
+    auto issue_tokens = [&](int t0, int nb, int chunk) {
+        const int tokc = t0 + (fr < nb ? fr : nb - 1);
+        const T* xp = reinterpret_cast<const T*>(a.x) + (size_t)tokc * a.x_stride + wave * (K / NW) + fq * 8 + chunk * BCH * 32;
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) ldraw<false>(breg[s], xp + s * 32);
+        for (int s = 0; s < BCH; ++s) ldraw<false>(breg[s], xp + s * 32);
+    };
+    issue_tokens(0, B < kTokTile ? B : kTokTile, 0);
     __builtin_amdgcn_sched_barrier(0);
     const int rowc = row0 + fr < a.N ? row0 + fr : a.N - 1;
     const T* wp = W + (size_t)rowc * K + wave * (K / NW) + fq * 8;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) ldraw<false>(wreg[s], wp + s * 32);
-    float resv[4], biasv[4];
+    // epilogue operands (bias, residual): issued up front so that they fly with the weights -- except in the longest variant
+    // (K = 6144: 48 operand registers per K step pair already fill the 256-VGPR budget), where wave 0 fetches them at the end
+    constexpr bool kHoist = KSTEPS <= 16;
+    auto load_epi = [&](int tokc, float (&biasv)[4], float (&resv)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = row0 + fq * 4 + i < a.N ? row0 + fq * 4 + i : a.N - 1;
-        resv[i] = 0.f;
-        if constexpr (EPI == EPI_RESIDUAL) resv[i] = DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)tokc * a.res_stride + r);
-        const T* bp = a.bias ? reinterpret_cast<const T*>(a.bias) + r : W;
-        const float bv = DT<T>::ld(bp);
-        biasv[i] = a.bias ? bv : 0.f;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int r = row0 + fq * 4 + i < a.N ? row0 + fq * 4 + i : a.N - 1;
+            const T* bp = a.bias ? reinterpret_cast<const T*>(a.bias) + r : W;
+            const float bv = DT<T>::ld(bp);
+            biasv[i] = a.bias ? bv : 0.f;
+            resv[i] = 0.f;
+            if constexpr (EPI == EPI_RESIDUAL) resv[i] = DT<T>::ld(reinterpret_cast<const T*>(a.res) + (size_t)tokc * a.res_stride + r);
+        }
+    };
     __builtin_amdgcn_sched_barrier(0);
-    // ---- 2. MFMA over this wave's K share ----
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int t0 = 0; t0 < B; t0 += kTokTile) {                  // one pass per token tile; the weight fragments stay in registers
+        const int nb = B - t0 < kTokTile ? B - t0 : kTokTile;
+        if (t0 > 0) issue_tokens(t0, nb, 0);
+        const int tokc = t0 + (fr < nb ? fr : nb - 1);
+        float biasv[4], resv[4];
+        if constexpr (kHoist) load_epi(tokc, biasv, resv);
+        // ---- 2. MFMA over this wave's K share ----
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wreg[s].v), __builtin_bit_cast(mfma_bf16x8, breg[s].v), acc, 0, 0, 0);
-    // ---- 3. sum the NW shares (fixed order), epilogue on wave 0 ----
-    *reinterpret_cast<f32x4*>(red + ((size_t)wave * 64 + lane) * 4) = acc;
-    __syncthreads();
-    if (wave != 0) return;
-    f32x4 t = *reinterpret_cast<const f32x4*>(red + (size_t)lane * 4);
+        for (int ch = 0; ch < NBCH; ++ch) {
+            if (ch > 0) issue_tokens(t0, nb, ch);
 #pragma unroll
-    for (int w = 1; w < NW; ++w) t += *reinterpret_cast<const f32x4*>(red + ((size_t)w * 64 + lane) * 4);
-    if (fr >= B) return;
-    const float tot[4] = {t.x, t.y, t.z, t.w};
-    T* yp = reinterpret_cast<T*>(a.y) + (size_t)fr * a.y_stride + row0 + fq * 4;
+            for (int s = 0; s < BCH; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wreg[ch * BCH + s].v), __builtin_bit_cast(mfma_bf16x8, breg[s].v), acc, 0, 0, 0);
+        }
+        // ---- 3. sum the NW shares (fixed order), epilogue on wave 0 ----
+        *reinterpret_cast<f32x4*>(red + ((size_t)wave * 64 + lane) * 4) = acc;
+        __syncthreads();
+        if (wave == 0 && fr < nb) {
+            if constexpr (!kHoist) load_epi(tokc, biasv, resv);
+            f32x4 t = *reinterpret_cast<const f32x4*>(red + (size_t)lane * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float v = DT<T>::rnd(tot[i] + biasv[i]);
-        if constexpr (EPI == EPI_RESIDUAL) v = v + resv[i];
-        if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
+            for (int w = 1; w < NW; ++w) t += *reinterpret_cast<const f32x4*>(red + ((size_t)w * 64 + lane) * 4);
+            const float tot[4] = {t.x, t.y, t.z, t.w};
+            T* yp = reinterpret_cast<T*>(a.y) + (size_t)(t0 + fr) * a.y_stride + row0 + fq * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = DT<T>::rnd(tot[i] + biasv[i]);
+                if constexpr (EPI == EPI_RESIDUAL) v = v + resv[i];
+                if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
+            }
+        }
+        if (t0 + kTokTile < B) __syncthreads();                 // the next tile's partial sums reuse `red`
     }
 }
 

@@ -60,7 +60,7 @@ extern "C" int fq3_batch_destroy(fq3_batch* b) {
 
 extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out) {
     if (!lanes || !out) return fq3_fail_(FQ3_EINVAL, "null argument");
-    if (n_lanes < 1 || n_lanes > kMaxLanes) return fq3_fail_(FQ3_EINVAL, "n_lanes must be 1..16");
+    if (n_lanes < 1 || n_lanes > kMaxLanes) return fq3_fail_(FQ3_EINVAL, "n_lanes must be 1..32");
     for (int i = 0; i < n_lanes; ++i) {
         if (!lanes[i] || !lanes[i]->bound) return fq3_fail_(FQ3_ESTATE, "every lane needs a context with bound weights");
         for (int j = 0; j < i; ++j) if (lanes[i] == lanes[j]) return fq3_fail_(FQ3_EINVAL, "a context can fill only one lane");
@@ -155,7 +155,7 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
     if (a.K % 128) return -1000;
     const int grid = (a.N + 15) / 16;
     constexpr int NR = EPI == EPI_SWIGLU ? 2 : 1;
-    const size_t shm = (((size_t)kMaxLanes * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NR * 256 * sizeof(float);
+    const size_t shm = (((size_t)kTokTile * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NR * 256 * sizeof(float);
     auto go = [&](auto ks) -> int {
         constexpr int KS = decltype(ks)::value;
         auto kern = gemv_batch_mfma_norm_kernel<KS, EPI>;

@@ -396,8 +396,8 @@ class Fq3Batch:
 
     def __init__(self, lanes):
         lanes = list(lanes)
-        if not 1 <= len(lanes) <= 16:
-            raise ValueError("a batch holds 1..16 lanes")
+        if not 1 <= len(lanes) <= 32:
+            raise ValueError("a batch holds 1..32 lanes")
         self.lanes = lanes
         self.lib = lanes[0].lib
         self.device = lanes[0].device

@@ -89,17 +89,19 @@ def test_lanes_equal_single_stream(dtype, graph):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_sixteen_lanes_equal_single_stream(dtype):
+@pytest.mark.parametrize("n_lanes,n_armed", [(16, 13), (32, 27)])
+def test_sixteen_lanes_equal_single_stream(dtype, n_lanes, n_armed):
     """More than 8 lanes: the VALU batch GEMV walks the tokens in LDS groups of 8 over register-resident weight rows -- 13 armed
-    lanes of a 16-lane batch (sampled and greedy, padded, short budgets, > 64 keys) are still bit-identical to single-stream runs,
-    and the matrix-core kernels (one 16-column token tile) run the same 13 lanes to the same frame counts in bf16."""
+    lanes of a 16-lane batch / 27 of a 32-lane batch (sampled and greedy, padded, short budgets, > 64 keys) are still bit-identical
+    to single-stream runs, and the matrix-core kernels (one 16-column token tile per pass, two passes above 16 lanes) run the same
+    lanes to the same frame counts in bf16."""
     from fq3hip.engine import Fq3Batch
     cfg = tiny_test_config()
     W = synth_weights(cfg, 0, dtype)
-    utts = [_utterance(cfg, dtype, 100 + i, 18 + 5 * i, (i % 3) * 2, 6 + (i * 5) % 9, 6 + (i * 5) % 9, i % 4 != 3) for i in range(13)]
+    utts = [_utterance(cfg, dtype, 100 + i, 18 + (5 * i) % 61, (i % 3) * 2, 6 + (i * 5) % 9, 6 + (i * 5) % 9, i % 4 != 3) for i in range(n_armed)]
     solo = _engines(cfg, W, dtype, 1)[0]
     ref = [_alone(solo, cfg, u, 16) for u in utts]
-    lanes = _engines(cfg, W, dtype, 16)
+    lanes = _engines(cfg, W, dtype, n_lanes)
     batch = Fq3Batch(lanes)
     batch.set_option("mfma", 0)
     for e, u in zip(lanes, utts):
@@ -110,7 +112,7 @@ def test_sixteen_lanes_equal_single_stream(dtype):
         n, d = e.decode_poll()
         assert n == codes.shape[0] and d == done, f"lane {i}: {n} frames (done={d}) vs {codes.shape[0]} alone (done={done})"
         assert torch.equal(e.decode_codes(0, n).cpu(), codes), f"lane {i} ids differ from the single-stream run"
-    for e in lanes[13:]:
+    for e in lanes[n_armed:]:
         n, d = e.decode_poll()
         assert n == 0 and d
     if dtype == torch.bfloat16:

@@ -1,5 +1,5 @@
 """Parity of the LOCK-STEP BATCH at the benchmarked configurations: full-depth 0.6B / 1.7B (28 talker + 5 predictor layers at
-the real shapes), 8 AND 16 lanes, the matrix-core batch GEMVs the bench line uses (the template instantiations selected by
+the real shapes), 8, 16 AND 32 lanes, the matrix-core batch GEMVs the bench line uses (the template instantiations selected by
 H = 1024 / 2048, I = 3072 / 6144: gemv_batch_mfma_norm_kernel<8|16, *>, gemv_batch_mfma_plain_kernel<8|12|24, 8, *>), every lane
 teacher-forced with golden oracle ids and every one of its 16 x frames decisions scored (oracle/teacher_forced.py).
 
@@ -115,10 +115,10 @@ def test_batch_full_depth_bf16_mfma_lanes_vs_oracle(size, golden_dir):
     frames = max(c[0]["codes"].shape[0] for c in cases) + 8
     first = Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames)
     del W
-    engines = [first] + [Fq3Engine(cfg, first.weights, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames, share=first) for _ in range(15)]
+    engines = [first] + [Fq3Engine(cfg, first.weights, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames, share=first) for _ in range(31)]
     for e in engines:
         e.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
-    for B in (8, 16):
+    for B in (8, 16, 32):
         scores = _run_batch(engines, cfg, cases, B, mfma=1)
         tot = sum(s["total"] for s in scores); ok = sum(s["matched_decisions"] for s in scores)
         worst = max(s["worst_mismatch_ulp"] for s in scores)
@@ -137,8 +137,8 @@ def test_batch_full_depth_bf16_mfma_lanes_vs_oracle(size, golden_dir):
     first.close()
 
 
-def test_batch_full_depth_fp32_16_lanes_exact(golden_dir):
-    """fp32 (VALU batch GEMVs, two LDS passes of 8 tokens each at 16 lanes): every decision of every lane identical to the oracle."""
+def test_batch_full_depth_fp32_32_lanes_exact(golden_dir):
+    """fp32 (VALU batch GEMVs, four LDS passes of 8 tokens each at 32 lanes): every decision of every lane identical to the oracle."""
     from fq3hip.engine import Fq3Engine
     cfg = qwen3_tts_0p6b()
     dtype = torch.float32
@@ -148,12 +148,12 @@ def test_batch_full_depth_fp32_16_lanes_exact(golden_dir):
     frames = max(c[0]["codes"].shape[0] for c in cases) + 8
     first = Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames)
     del W
-    engines = [first] + [Fq3Engine(cfg, first.weights, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames, share=first) for _ in range(15)]
+    engines = [first] + [Fq3Engine(cfg, first.weights, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames, share=first) for _ in range(31)]
     for e in engines:
         e.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
-    scores = _run_batch(engines, cfg, cases, 16, mfma=0)
-    print(f"[parity] batch 0p6b f32 B=16: per lane {[s['matched_decisions'] for s in scores]} of {[s['total'] for s in scores]}")
-    _note("0p6b_f32_valu_B16", dict(matched=sum(s["matched_decisions"] for s in scores), total=sum(s["total"] for s in scores)))
+    scores = _run_batch(engines, cfg, cases, 32, mfma=0)
+    print(f"[parity] batch 0p6b f32 B=32: per lane {[s['matched_decisions'] for s in scores]} of {[s['total'] for s in scores]}")
+    _note("0p6b_f32_valu_B32", dict(matched=sum(s["matched_decisions"] for s in scores), total=sum(s["total"] for s in scores)))
     for s in scores:
         assert s["matched_decisions"] == s["total"], s
     for e in engines[1:]:

@@ -398,7 +398,7 @@ int main(int argc, char** argv) {
         auto run_m = [&](int kind, int i, int B, void* y) {      // matrix-core batch kernels
             BatchGemvArgs g = bargs(kind, i, B, y);
             const int grid = (g.N + 15) / 16; const int NRr = kind == 2 ? 2 : 1;
-            const size_t shm = (((size_t)kMaxLanes * (g.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NRr * 256 * 4;
+            const size_t shm = (((size_t)kTokTile * (g.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NRr * 256 * 4;
             if (kind == 0) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
             else if (kind == 1) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, EPI_RESIDUAL>), dim3(grid), dim3(512), 0, st, g);
             else if (kind == 2) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_SWIGLU>), dim3(grid), dim3(256), shm, st, g);
@@ -417,7 +417,7 @@ int main(int argc, char** argv) {
         };
         const char* kn[6] = {"qkv NORM/STORE", "o PLAIN/RESID", "gate_up NORM/SWIGLU", "down PLAIN/RESID", "", "head NORM/STORE+bias+xn_out"};
         const int outn[6] = {NQKV, H, I, H, H, Vp};
-        for (int B : {16, 11, 8, 3}) for (int kind = 0; kind < 6; ++kind) {
+        for (int B : {32, 27, 16, 11, 8, 3}) for (int kind = 0; kind < 6; ++kind) {
             if (kind == 4) continue;
             CHK(hipMemset(yb, 0, (size_t)MB * 8192 * 2)); CHK(hipMemset(ym, 0, (size_t)MB * 8192 * 2)); CHK(hipMemset(y1, 0, (size_t)MB * 8192 * 2));
             run_v(kind, 0, B, yb); run_m(kind, 0, B, ym);
@@ -435,7 +435,7 @@ int main(int argc, char** argv) {
         }
         {   // merge kernel + PLAIN o_proj (the batch chain's pair) must equal the single-stream COMBINE o_proj bit for bit (VALU kernel)
             void* merged = dev_bf16((size_t)MB * 8192, 0.f);
-            const int B = 16;
+            const int B = 32;
             CHK(hipMemset(yb, 0, (size_t)MB * 8192 * 2)); CHK(hipMemset(y1, 0, (size_t)MB * 8192 * 2));
             hipLaunchKernelGGL((combine_batch_kernel<bf16_t>), dim3((QD / 8 + 255) / 256, B), dim3(256), 0, st, (const float*)part8, pstride, 8, 2, QD, (bf16_t*)merged, 8192);
             { BatchGemvArgs g = bargs(1, 0, B, yb); g.x = merged; g.x_stride = 8192; g.group = kGroupLanes;
@@ -444,10 +444,10 @@ int main(int argc, char** argv) {
             CHK(hipStreamSynchronize(st));
             auto a0 = fetch_bf16(yb, (size_t)MB * 8192), a2 = fetch_bf16(y1, (size_t)MB * 8192);
             int bad = 0; for (int m = 0; m < B; ++m) for (int r = 0; r < H; ++r) bad += a0[(size_t)m * 8192 + r] != a2[(size_t)m * 8192 + r];
-            report("merge kernel + PLAIN o_proj == single-stream COMBINE o_proj (B=16)", bad, 0.5);
+            report("merge kernel + PLAIN o_proj == single-stream COMBINE o_proj (B=32)", bad, 0.5);
         }
         chain("batch  B=1 (single-token product kernels): qkv, o, gate_up, down x80", N, [&](int j) { run_1(j % 4, j / 4, 0); });
-        for (int B : {8, 16}) {
+        for (int B : {8, 16, 32}) {
             char nm[112];
             snprintf(nm, sizeof nm, "batch  B=%d VALU kernel: qkv, o, gate_up, down x80", B); chain(nm, N, [&](int j) { run_v(j % 4, j / 4, B, yb); });
             snprintf(nm, sizeof nm, "batch  B=%d MFMA kernels: qkv, o, gate_up, down x80", B); chain(nm, N, [&](int j) { run_m(j % 4, j / 4, B, ym); });
