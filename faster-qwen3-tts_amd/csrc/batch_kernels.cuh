@@ -290,10 +290,15 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(BatchGemvArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int KSTEPS, int EPI>                    // K = KSTEPS * 128
+// NT = token tiles of 16 lanes the launch walks (1: B <= 16, 2: 17..32).  The weight fragments are loaded once and stay in
+// registers; with NT = 2 the second tile's raw tokens are loaded up front as well when they fit (PRE2: K <= 1024), otherwise after
+// the first tile has been multiplied (one exposed L2 round trip).
+template <int KSTEPS, int EPI, int NT>            // K = KSTEPS * 128
 __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs a) {
     typedef bf16_t T;
     constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr bool PRE2 = NT == 2 && KSTEPS <= 8;
+    constexpr int NXR = PRE2 ? 2 : 1;
     constexpr int K = KSTEPS * 128, KP = K + 8;                 // padded LDS row: 16 tokens x same k would share a bank
     constexpr int NCH = (K + 511) / 512;
     constexpr int TPW = kTokTile / 4;
@@ -305,20 +310,21 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
     const T* W = reinterpret_cast<const T*>(a.W);
     const int row0 = blockIdx.x * 16;
 
-    // ---- 1. token loads of the first token tile (lanes 0..15 of the batch) ----
-    Raw8<T> xraw[TPW][NCH], nraw[NCH];
-    auto issue_tokens = [&](int t0, int nb) {
+    // ---- 1. token loads of the first token tile (lanes 0..15 of the batch), and of the second when it fits ----
+    Raw8<T> xraw[NXR][TPW][NCH], nraw[NCH];
+    auto issue_tokens = [&](int slot, int t0, int nb) {
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int off = j * 512 + lane * 8, offc = off < K ? off : 0;
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int m = t0 + (wave + 4 * t < nb ? wave + 4 * t : nb - 1);
-                ldraw<false>(xraw[t][j], reinterpret_cast<const T*>(a.x) + (size_t)m * a.x_stride + offc);
+                ldraw<false>(xraw[slot][t][j], reinterpret_cast<const T*>(a.x) + (size_t)m * a.x_stride + offc);
             }
         }
     };
-    issue_tokens(0, B < kTokTile ? B : kTokTile);
+    issue_tokens(0, 0, B < kTokTile ? B : kTokTile);
+    if constexpr (PRE2) issue_tokens(1, kTokTile, B - kTokTile);
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int off = j * 512 + lane * 8;
@@ -343,10 +349,13 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
         biasv[i] = a.bias ? bv : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-    for (int t0 = 0; t0 < B; t0 += kTokTile) {                  // one pass per token tile (a second one only above 16 lanes)
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {                           // one pass per token tile (a second one only above 16 lanes)
+        const int t0 = tt * kTokTile;
         const int nb = B - t0 < kTokTile ? B - t0 : kTokTile;
-        if (t0 > 0) issue_tokens(t0, nb);                       // later tiles pay one exposed round trip; the weights are already here
+        constexpr int kNoSlot = 0;
+        const int slot = PRE2 ? tt : kNoSlot;
+        if (tt > 0 && !PRE2) issue_tokens(0, t0, nb);           // one exposed round trip; the weights are already here
         // ---- 3. prepare the tile's tokens (the first tile: while the weights fly) ----
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
@@ -354,8 +363,8 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
             float xr[NCH][8];
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
-                if (j * 512 + lane * 8 >= K) zero(xraw[t][j]);
-                unpack(xraw[t][j], xr[j]);
+                if (j * 512 + lane * 8 >= K) zero(xraw[slot][t][j]);
+                unpack(xraw[slot][t][j], xr[j]);
             }
             float ss = 0.f;
 #pragma unroll
@@ -431,15 +440,17 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                 if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
             }
         }
-        if (t0 + kTokTile < B) __syncthreads();                 // the next tile overwrites the token panel and the partial sums
+        if (tt + 1 < NT) __syncthreads();                       // the next tile overwrites the token panel and the partial sums
     }
 }
 
-template <int KSTEPS, int NW, int EPI>            // K = KSTEPS * 32 * NW; NW waves split K
+template <int KSTEPS, int NW, int EPI, int NT>    // K = KSTEPS * 32 * NW; NW waves split K; NT token tiles (see the NORM kernel)
 __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGemvArgs a) {
     typedef bf16_t T;
     static_assert(EPI == EPI_STORE || EPI == EPI_RESIDUAL, "SwiGLU always follows an RMSNorm prologue");
     constexpr int K = KSTEPS * 32 * NW;
+    constexpr bool PRE2 = NT == 2 && KSTEPS <= 12;              // both tiles' token fragments in registers from the start
+    constexpr int NBR = PRE2 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float red[NW * 64 * 4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int fr = lane & 15, fq = lane >> 4, B = a.B;
@@ -450,14 +461,15 @@ __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGem
     // token fragments held at once: all of a tile's K share, except in the longest variant (K = 6144: 24 steps per wave), where two
     // halves take turns in the same registers (96 weight + 96 token registers plus the rest would not fit 256 VGPRs)
     constexpr int BCH = KSTEPS > 16 ? KSTEPS / 2 : KSTEPS, NBCH = KSTEPS / BCH;
-    Raw8<T> breg[BCH], wreg[KSTEPS];
-    auto issue_tokens = [&](int t0, int nb, int chunk) {
+    Raw8<T> breg[NBR][BCH], wreg[KSTEPS];
+    auto issue_tokens = [&](int slot, int t0, int nb, int chunk) {
         const int tokc = t0 + (fr < nb ? fr : nb - 1);
         const T* xp = reinterpret_cast<const T*>(a.x) + (size_t)tokc * a.x_stride + wave * (K / NW) + fq * 8 + chunk * BCH * 32;
 #pragma unroll
-        for (int s = 0; s < BCH; ++s) ldraw<false>(breg[s], xp + s * 32);
+        for (int s = 0; s < BCH; ++s) ldraw<false>(breg[slot][s], xp + s * 32);
     };
-    issue_tokens(0, B < kTokTile ? B : kTokTile, 0);
+    issue_tokens(0, 0, B < kTokTile ? B : kTokTile, 0);
+    if constexpr (PRE2) issue_tokens(1, kTokTile, B - kTokTile, 0);
     __builtin_amdgcn_sched_barrier(0);
     const int rowc = row0 + fr < a.N ? row0 + fr : a.N - 1;
     const T* wp = W + (size_t)rowc * K + wave * (K / NW) + fq * 8;
@@ -478,10 +490,12 @@ __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGem
         }
     };
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-    for (int t0 = 0; t0 < B; t0 += kTokTile) {                  // one pass per token tile; the weight fragments stay in registers
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {                           // one pass per token tile; the weight fragments stay in registers
+        const int t0 = tt * kTokTile;
         const int nb = B - t0 < kTokTile ? B - t0 : kTokTile;
-        if (t0 > 0) issue_tokens(t0, nb, 0);
+        const int slot = PRE2 ? tt : 0;
+        if (tt > 0 && !PRE2) issue_tokens(0, t0, nb, 0);
         const int tokc = t0 + (fr < nb ? fr : nb - 1);
         float biasv[4], resv[4];
         if constexpr (kHoist) load_epi(tokc, biasv, resv);
@@ -489,10 +503,10 @@ __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGem
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ch = 0; ch < NBCH; ++ch) {
-            if (ch > 0) issue_tokens(t0, nb, ch);
+            if (ch > 0) issue_tokens(slot, t0, nb, ch);
 #pragma unroll
             for (int s = 0; s < BCH; ++s)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wreg[ch * BCH + s].v), __builtin_bit_cast(mfma_bf16x8, breg[s].v), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wreg[ch * BCH + s].v), __builtin_bit_cast(mfma_bf16x8, breg[slot][s].v), acc, 0, 0, 0);
         }
         // ---- 3. sum the NW shares (fixed order), epilogue on wave 0 ----
         *reinterpret_cast<f32x4*>(red + ((size_t)wave * 64 + lane) * 4) = acc;
@@ -511,7 +525,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGem
                 if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
             }
         }
-        if (t0 + kTokTile < B) __syncthreads();                 // the next tile's partial sums reuse `red`
+        if (tt + 1 < NT) __syncthreads();                       // the next tile's partial sums reuse `red`
     }
 }
 

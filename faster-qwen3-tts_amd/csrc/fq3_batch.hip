@@ -158,9 +158,15 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
     const size_t shm = (((size_t)kTokTile * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NR * 256 * sizeof(float);
     auto go = [&](auto ks) -> int {
         constexpr int KS = decltype(ks)::value;
-        auto kern = gemv_batch_mfma_norm_kernel<KS, EPI>;
-        if (shm > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, a);
+        if (a.B <= kTokTile) {
+            auto kern = gemv_batch_mfma_norm_kernel<KS, EPI, 1>;
+            if (shm > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, a);
+        } else {
+            auto kern = gemv_batch_mfma_norm_kernel<KS, EPI, 2>;
+            if (shm > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, a);
+        }
         return 0;
     };
     switch (a.K / 128) {                      // hidden sizes: 256 (tests), 512, 1024 (0.6B, predictor), 2048 (1.7B)
@@ -176,7 +182,8 @@ static int launch_gemv_batch_mfma_plain(const BatchGemvArgs& a, hipStream_t s) {
     const int grid = (a.N + 15) / 16;
     auto go = [&](auto ks, auto nw) -> int {
         constexpr int KS = decltype(ks)::value, NW = decltype(nw)::value;
-        hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI>), dim3(grid), dim3(64 * NW), 0, s, a);
+        if (a.B <= kTokTile) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 1>), dim3(grid), dim3(64 * NW), 0, s, a);
+        else hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 2>), dim3(grid), dim3(64 * NW), 0, s, a);
         return 0;
     };
 #define FQ3_PLAIN(KS, NW) return go(std::integral_constant<int, KS>{}, std::integral_constant<int, NW>{})

@@ -45,10 +45,10 @@ struct fq3_codec {
     void* snake_consts = nullptr;                 // per-channel SnakeBeta constants (a, ib), built at finalize
     std::map<std::string, std::pair<const void*, const void*>> snake;     // "<prefix>" -> (a, ib)
     bool ready = false;
-    int fuse_units = 0;                           // 1: residual units of the 96-channel block as one launch each (resunit_kernel), 2: the 192-channel
-                                                  // block too.  Bit-identical either way; measured SLOWER than the two-GEMM path on MI355X (8.02 vs
-                                                  // 7.84 ms per 370-frame decode with both fused: the 128 x C tile runs at lower occupancy than the
-                                                  // 256 x 256 ring tile the k7 conv otherwise gets), so the default is off
+    int fuse_units = 1;                           // 1 (default): residual units of the 96-channel block as one launch each (resunit_kernel), 2: the
+                                                  // 192-channel block too, 0: two GEMMs per unit.  Bit-identical; measured per 370-frame decode on
+                                                  // MI355X: 7.92 (0) / 7.45 (1) / 7.93 ms (2) -- at 192 channels the 128 x C tile loses more against the
+                                                  // 256 x 256 ring tile the k7 conv otherwise gets than the saved `mid` round trip brings
 };
 
 static int64_t samples_for(const fq3_codec_config& c, int64_t T) {
@@ -103,7 +103,7 @@ extern "C" int fq3_codec_destroy(fq3_codec* c) {
 
 extern "C" int fq3_codec_set_option(fq3_codec* c, const char* key, int value) {
     if (!c || !key) return cfail(FQ3_EINVAL, "null argument");
-    if (std::string(key) == "fuse_units") c->fuse_units = value;      // 0 (default) two GEMMs per residual unit; 1: 96-channel units fused; 2: 192 too
+    if (std::string(key) == "fuse_units") c->fuse_units = value;      // 0: two GEMMs per residual unit; 1 (default): 96-channel units fused; 2: 192 too
     else return cfail(FQ3_EINVAL, std::string("unknown codec option: ") + key);
     return FQ3_OK;
 }

@@ -399,11 +399,19 @@ int main(int argc, char** argv) {
             BatchGemvArgs g = bargs(kind, i, B, y);
             const int grid = (g.N + 15) / 16; const int NRr = kind == 2 ? 2 : 1;
             const size_t shm = (((size_t)kTokTile * (g.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NRr * 256 * 4;
-            if (kind == 0) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
-            else if (kind == 1) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, EPI_RESIDUAL>), dim3(grid), dim3(512), 0, st, g);
-            else if (kind == 2) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_SWIGLU>), dim3(grid), dim3(256), shm, st, g);
-            else if (kind == 3) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<12, 8, EPI_RESIDUAL>), dim3(grid), dim3(512), 0, st, g);
-            else hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE>), dim3(grid), dim3(256), shm, st, g);
+            if (B <= kTokTile) {
+                if (kind == 0) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE, 1>), dim3(grid), dim3(256), shm, st, g);
+                else if (kind == 1) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, EPI_RESIDUAL, 1>), dim3(grid), dim3(512), 0, st, g);
+                else if (kind == 2) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_SWIGLU, 1>), dim3(grid), dim3(256), shm, st, g);
+                else if (kind == 3) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<12, 8, EPI_RESIDUAL, 1>), dim3(grid), dim3(512), 0, st, g);
+                else hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE, 1>), dim3(grid), dim3(256), shm, st, g);
+            } else {
+                if (kind == 0) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE, 2>), dim3(grid), dim3(256), shm, st, g);
+                else if (kind == 1) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<8, 8, EPI_RESIDUAL, 2>), dim3(grid), dim3(512), 0, st, g);
+                else if (kind == 2) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_SWIGLU, 2>), dim3(grid), dim3(256), shm, st, g);
+                else if (kind == 3) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<12, 8, EPI_RESIDUAL, 2>), dim3(grid), dim3(512), 0, st, g);
+                else hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<8, EPI_STORE, 2>), dim3(grid), dim3(256), shm, st, g);
+            }
         };
         auto run_1 = [&](int kind, int i, int m) {                // product single-token kernels, token m of the same buffers
             GemvArgs g{}; g.eps = 1e-6f; g.norm_w = norm_w;
