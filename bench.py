@@ -21,9 +21,9 @@ The JSON line also carries (all measured in this run unless tagged otherwise):
   parity_bf16_frames  teacher-forced id agreement of this very model (bf16, full depth) with the CPU oracle's golden ids
   parity_pcm          PCM RMS of this model's codec (bf16, and the fp32 high-precision mode with its cost in ms) against the
                       fp32-arithmetic oracle's golden waveform on the same bf16 checkpoint weights
-  batched_decode_one_gpu   16 lock-step lanes over one weight stream (fq3_batch_*), with its own HBM roofline
+  batched_decode_one_gpu   32 lock-step lanes over one weight stream (fq3_batch_*; frame times at 8 / 16 lanes beside it), with its own HBM roofline
   config3_sharded_batched  BASELINE configs[3]: 1.7B-CustomVoice shapes, 64 utterances through generate_custom_voice_batch,
-                      sharded over the ranks, 16 lanes per GPU (all ranks)
+                      sharded over the ranks, up to 32 lanes per GPU (all ranks)
   model_1p7b          BASELINE configs[2]: the 1.7B shapes, single stream (N = 1 only); config4_voice_design_4k inside it:
                       BASELINE configs[4], a 4096-row VoiceDesign prompt streamed end to end
   cpu_baseline        the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded
@@ -726,7 +726,7 @@ def model_1p7b_block(cfg, model, device, lanes=16):
                                "frac": round((gemm_fl + attn_fl) / (pms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "bound": "mfma"}
     except Exception as e:
         out["prefill_4096"] = {"error": repr(e)}
-    for B in sorted({8, lanes, 32}):
+    for B in sorted({8, 16, lanes}):
         try:
             ms, p = batched_frame_time(model, cfg, prompt, lanes=B)
             out[f"batched_b{B}"] = {"ms_per_lockstep_frame": round(ms, 3), "value": round(B * 80.0 / ms, 1),
@@ -779,7 +779,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
-    ap.add_argument("--batch", type=int, default=16, help="lock-step lanes of the batched figures, <= 32 (0 = skip them)")
+    ap.add_argument("--batch", type=int, default=32, help="lock-step lanes of the batched figures, <= 32 (0 = skip them)")
     ap.add_argument("--batch-groups", type=int, default=1, help="opt-in: concurrent lock-step batches on one GPU, `batched_groups_one_gpu` (1 = skip; measured: two host-threaded groups of 8 give 159x vs 159x for one)")
     ap.add_argument("--config3-utterances", type=int, default=64, help="utterances of the sharded batched run (0 = skip)")
     ap.add_argument("--concurrent", type=int, default=4,
@@ -890,7 +890,7 @@ def main():
                                     "note": "VALU batch GEMVs: lanes bit-identical to single-stream decoding"}
             except Exception as e:
                 out["valu_gemv"] = {"error": repr(e)}
-            for other in (8, 32):
+            for other in (8, 16, 32):
                 if other == lanes:
                     continue
                 try:
