@@ -19,6 +19,7 @@
 // (transformers modeling_qwen3_omni_moe.py:3180-3263, :3542-3696): one rounding to T per op output.
 #pragma once
 #include "fq3_common.cuh"
+#include "skinny_gemm.cuh"
 
 namespace fq3 {
 
@@ -42,6 +43,7 @@ struct GemmArgs {
     // split-K (single-tap GEMMs with few rows, e.g. the 200-token prefill's o_proj / down): workgroup z multiplies channel
     // slice z and stores fp32 partials to ws[z][m - m_lo][n]; splitk_reduce_kernel sums them in order and runs the epilogue
     float* ws; long ws_floats; int ksplit;
+    int no_skinny;                                    // measurement switch: 1 = keep the tiled / split-K kernels where skinny_gemm.cuh would serve
     int epi_legacy;                                   // measurement switch: 1 = the register-layout epilogue (32-byte runs per row) instead of the
                                                       // LDS-parked one (whole tile rows per store instruction); 0 in the product
 };
@@ -908,6 +910,10 @@ inline void gemm_go(const GemmArgs& a, hipStream_t s) {
     dim3 grid((a.N + BN - 1) / BN, (a.M - a.m_lo + BM - 1) / BM);
     hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, PF>), grid, dim3(256), 0, s, a);
 }
+inline bool skinny_ok(const GemmArgs& a) {
+    return a.ws && !a.no_skinny && a.n_taps == 1 && a.tap_off[0] == 0 && a.m_lo == 0 && a.M <= kSkinnyMaxRows && a.a_rows >= a.M && a.act == 0 &&
+           !a.bias && !a.scale && !a.Y2 && a.Y && skinny_k_ok(a.Cin) && a.N % 32 == 0 && a.lda % 8 == 0 && a.ldy % 4 == 0 && (!a.res || a.ldr % 4 == 0);
+}
 template <typename T>
 inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
     const int rows = a.M - a.m_lo;
@@ -915,6 +921,15 @@ inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
     if constexpr (sizeof(T) == 4) { gemm_go<T, 64, 64>(a, s); return; }      // fp32 = parity mode, one shape
     else {
         auto wgs = [&](int bm, int bn) { return (long)((rows + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+        // few rows against a whole weight matrix (the short-prompt prefill): weight-stationary kernel (skinny_gemm.cuh).  Its
+        // accumulation order is its own, so -- like split-K below -- only for callers that lend a workspace.
+        if (skinny_ok(a)) {
+            SkinnyArgs k{};
+            k.X = reinterpret_cast<const bf16_t*>(a.A); k.ldx = a.lda; k.M = a.M; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = a.N;
+            k.res = reinterpret_cast<const bf16_t*>(a.res); k.ldr = a.ldr; k.Y = reinterpret_cast<bf16_t*>(a.Y); k.ldy = a.ldy;
+            if (a.res) skinny_launch<SK_RESIDUAL>(k, a.Cin, s); else skinny_launch<SK_STORE>(k, a.Cin, s);
+            return;
+        }
         // few rows, one tap, long K, narrow N (the 200-token prefill's o_proj / down): split K over workgroups, two passes.
         // Only where the caller lends a workspace: the codec does not (a tail decode must stay bit-identical to a full one).
         if (a.ws && a.n_taps == 1 && a.act != 2 && wgs(64, 32) < 384 && a.Cin >= 1536) {
@@ -955,6 +970,27 @@ inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
         else if (a.act == 2) gemm_go<T, 64, 64>(a, s);
         else gemm_go<T, 64, 32>(a, s);
     }
+}
+
+// forward declaration target of gemm_swiglu_halves
+template <typename T> __global__ void silu_mul_kernel(const T* gu, T* y, int rows, int I);
+
+// y[M][I] = silu(x W_gate^T) * (x W_up^T) for a weight of two halves [gate | up] (N = 2 I): one weight-stationary launch where
+// skinny_gemm.cuh serves the shape (the [M][2I] image is never written), else the GEMM into `gu` and the elementwise pass.
+template <typename T>
+inline void gemm_swiglu_halves(const GemmArgs& a, void* y, hipStream_t s) {
+    const int I = a.N / 2;
+    if constexpr (sizeof(T) == 2) {
+        if (skinny_ok(a) && !a.res && I % 8 == 0) {
+            SkinnyArgs k{};
+            k.X = reinterpret_cast<const bf16_t*>(a.A); k.ldx = a.lda; k.M = a.M; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = a.N;
+            k.Y = reinterpret_cast<bf16_t*>(y); k.ldy = I;
+            skinny_launch<SK_SWIGLU>(k, a.Cin, s);
+            return;
+        }
+    }
+    gemm_launch<T>(a, s);
+    hipLaunchKernelGGL((silu_mul_kernel<T>), dim3((unsigned)(((size_t)a.M * I + 255) / 256)), dim3(256), 0, s, (const T*)a.Y, (T*)y, a.M, I);
 }
 
 // ---- RVQ: sequential (rounded) sum of codebook rows; one block per frame ------------------------------

@@ -290,12 +290,53 @@ static void flash_prefill_launch(const bf16_t* qkv, const bf16_t* k, const bf16_
     }
 }
 
-template <typename T>
-GemmArgs lin(const void* A, int M, int K, const void* W, int N, void* Y) {
-    GemmArgs a{}; a.A = A; a.lda = K; a.M = M; a.a_rows = M; a.n_taps = 1; a.tap_off[0] = 0; a.Cin = K; a.W = W; a.N = N;
-    a.bias_mod = N; a.Y = Y; a.ldy = N; return a;
+// RMSNorm of prompt rows, one wave per row, the whole row in registers: 16-byte loads, one reduction, 16-byte stores (the row-loop
+// kernel the codec uses takes 10 us on 200 rows of 1024: 32 dependent 2-byte accesses per lane).  Per element the arithmetic is
+// the same -- w * rnd(x * rs), rounded on store; only the order of the sum of squares differs.  C = NCH * 512.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_rows_vec_kernel(const T* x, const T* w, T* y, int rows, float eps) {
+    constexpr int C = NCH * 512;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    Raw8<T> xr[NCH], wr[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        ldraw<false>(xr[j], x + (size_t)row * C + j * 512 + lane * 8);
+        ldraw<false>(wr[j], w + j * 512 + lane * 8);
+    }
+    float xv[NCH][8], ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        unpack(xr[j], xv[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss = fmaf(xv[j][i], xv[j][i], ss);
+    }
+    ss = wave_sum(ss);
+    const float rs = 1.0f / sqrtf(ss / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        float wv[8];
+        unpack(wr[j], wv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[j][i] = wv[i] * DT<T>::rnd(xv[j][i] * rs);
+        DT<T>::st8(y + (size_t)row * C + j * 512 + lane * 8, xv[j]);
+    }
 }
+template <typename T>
+void rmsnorm_rows(const T* x, const T* w, T* y, int rows, int C, float eps, hipStream_t s) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (C == 1024) hipLaunchKernelGGL((rmsnorm_rows_vec_kernel<T, 2>), grid, block, 0, s, x, w, y, rows, eps);
+    else if (C == 2048) hipLaunchKernelGGL((rmsnorm_rows_vec_kernel<T, 4>), grid, block, 0, s, x, w, y, rows, eps);
+    else hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), grid, block, 0, s, x, w, y, 0, rows, C, eps);
+}
+
 constexpr long kPrefillWsFloats = 8L << 20;       // split-K partials of the short-prompt GEMMs (32 MB)
+// every prefill GEMM lends the split-K workspace: that also marks it free to take the weight-stationary kernel (skinny_gemm.cuh)
+template <typename T>
+GemmArgs lin(fq3_ctx* c, const void* A, int M, int K, const void* W, int N, void* Y) {
+    GemmArgs a{}; a.A = A; a.lda = K; a.M = M; a.a_rows = M; a.n_taps = 1; a.tap_off[0] = 0; a.Cin = K; a.W = W; a.N = N;
+    a.bias_mod = N; a.Y = Y; a.ldy = N; a.ws = (float*)c->pf_ws; a.ws_floats = kPrefillWsFloats; a.no_skinny = c->opt_no_skinny; return a;
+}
 template <typename T> void gemm(const GemmArgs& a, hipStream_t s) { gemm_launch<T>(a, s); }
 
 template <typename T>
@@ -311,8 +352,8 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
     const float scale = 1.0f / sqrtf((float)kHeadDim);
     for (int i = 0; i < d.n_layers; ++i) {
         const fq3_layer_weights& w = c->tl[i];
-        hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((L + 3) / 4), dim3(256), 0, s, (const T*)X, (const T*)w.input_norm, XN, 0, L, H, d.rms_eps);
-        gemm<T>(lin<T>(XN, L, H, w.qkv, per, QKV), s);
+        rmsnorm_rows<T>((const T*)X, (const T*)w.input_norm, XN, L, H, d.rms_eps, s);
+        gemm<T>(lin<T>(c, XN, L, H, w.qkv, per, QKV), s);
         hipLaunchKernelGGL((qk_norm_rope_kv_kernel<T>), dim3((L * (NH + 2 * NKV) + 3) / 4), dim3(256), 0, s, QKV, (const T*)w.q_norm,
                            (const T*)w.k_norm, d.rms_eps, c->wt.talker_cos, c->wt.talker_sin, c->wt.talker_rope_len, c->rope_delta,
                            (T*)c->tk.k[i], (T*)c->tk.v[i], c->tk.max_seq, L, n_pad, NH, NKV);
@@ -327,11 +368,10 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
             hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((L * NH + 3) / 4), dim3(256), 0, s, (const T*)QKV, (const T*)c->tk.k[i],
                                (const T*)c->tk.v[i], ATT, c->tk.max_seq, L, n_pad, NH, NKV, scale);
         }
-        { GemmArgs a = lin<T>(ATT, L, QD, w.o, H, X); a.res = X; a.ldr = H; a.ws = (float*)c->pf_ws; a.ws_floats = kPrefillWsFloats; gemm<T>(a, s); }
-        hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((L + 3) / 4), dim3(256), 0, s, (const T*)X, (const T*)w.post_norm, XN, 0, L, H, d.rms_eps);
-        gemm<T>(lin<T>(XN, L, H, w.gate_up, 2 * I, GU), s);
-        hipLaunchKernelGGL((silu_mul_kernel<T>), dim3((unsigned)(((size_t)L * I + 255) / 256)), dim3(256), 0, s, (const T*)GU, ACT, L, I);
-        { GemmArgs a = lin<T>(ACT, L, I, w.down, H, X); a.res = X; a.ldr = H; a.ws = (float*)c->pf_ws; a.ws_floats = kPrefillWsFloats; gemm<T>(a, s); }
+        { GemmArgs a = lin<T>(c, ATT, L, QD, w.o, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
+        rmsnorm_rows<T>((const T*)X, (const T*)w.post_norm, XN, L, H, d.rms_eps, s);
+        gemm_swiglu_halves<T>(lin<T>(c, XN, L, H, w.gate_up, 2 * I, GU), ACT, s);
+        { GemmArgs a = lin<T>(c, ACT, L, I, w.down, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
     }
     // final norm of the last row only -> past_hidden; logits through the decode-path head GEMV
     hipLaunchKernelGGL((rmsnorm_kernel<T>), dim3(1), dim3(256), 0, s, (const T*)X + (size_t)(L - 1) * H, (const T*)c->wt.talker_final_norm,
@@ -364,8 +404,8 @@ int prefill_batch_t(fq3_ctx* const* cs, int n, const void* const* embeds, const 
     const float scale = 1.0f / sqrtf((float)kHeadDim);
     for (int i = 0; i < d.n_layers; ++i) {
         const fq3_layer_weights& w = c->tl[i];
-        hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Lt + 3) / 4), dim3(256), 0, s, (const T*)X, (const T*)w.input_norm, XN, 0, Lt, H, d.rms_eps);
-        gemm<T>(lin<T>(XN, Lt, H, w.qkv, per, QKV), s);
+        rmsnorm_rows<T>((const T*)X, (const T*)w.input_norm, XN, Lt, H, d.rms_eps, s);
+        gemm<T>(lin<T>(c, XN, Lt, H, w.qkv, per, QKV), s);
         for (int q = 0; q < n; ++q) {
             fq3_ctx* cq = cs[q];
             T* qkv = QKV + (size_t)off[q] * per;
@@ -385,11 +425,10 @@ int prefill_batch_t(fq3_ctx* const* cs, int n, const void* const* embeds, const 
                 hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((Lq * NH + 3) / 4), dim3(256), 0, s, (const T*)qkv, (const T*)cq->tk.k[i],
                                    (const T*)cq->tk.v[i], att, cq->tk.max_seq, Lq, pq, NH, NKV, scale);
         }
-        { GemmArgs a = lin<T>(ATT, Lt, QD, w.o, H, X); a.res = X; a.ldr = H; a.ws = (float*)c->pf_ws; a.ws_floats = kPrefillWsFloats; gemm<T>(a, s); }
-        hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Lt + 3) / 4), dim3(256), 0, s, (const T*)X, (const T*)w.post_norm, XN, 0, Lt, H, d.rms_eps);
-        gemm<T>(lin<T>(XN, Lt, H, w.gate_up, 2 * I, GU), s);
-        hipLaunchKernelGGL((silu_mul_kernel<T>), dim3((unsigned)(((size_t)Lt * I + 255) / 256)), dim3(256), 0, s, (const T*)GU, ACT, Lt, I);
-        { GemmArgs a = lin<T>(ACT, Lt, I, w.down, H, X); a.res = X; a.ldr = H; a.ws = (float*)c->pf_ws; a.ws_floats = kPrefillWsFloats; gemm<T>(a, s); }
+        { GemmArgs a = lin<T>(c, ATT, Lt, QD, w.o, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
+        rmsnorm_rows<T>((const T*)X, (const T*)w.post_norm, XN, Lt, H, d.rms_eps, s);
+        gemm_swiglu_halves<T>(lin<T>(c, XN, Lt, H, w.gate_up, 2 * I, GU), ACT, s);
+        { GemmArgs a = lin<T>(c, ACT, Lt, I, w.down, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
     }
     for (int q = 0; q < n; ++q) {
         hipLaunchKernelGGL((rmsnorm_kernel<T>), dim3(1), dim3(256), 0, s, (const T*)X + (size_t)(off[q + 1] - 1) * H, (const T*)c->wt.talker_final_norm,

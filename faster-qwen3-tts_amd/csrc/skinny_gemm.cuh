@@ -1,0 +1,279 @@
+// Weight-stationary GEMM for FEW rows (the short-prompt prefill: M <= kSkinnyMaxRows tokens against a [N][K] weight), bf16.
+//
+// The tiled kernels of codec_kernels.cuh need M x N / (64 x 64) workgroups to fill the chip and walk K behind one barrier per
+// 32-wide step; at M = 200 that is a latency-bound K loop on a quarter of the matrix cores' issue slots (16-33 us per GEMM,
+// profiles/r03_gemm_bench.txt).  Here the roles are those of the batch-decode GEMV (batch_kernels.cuh): one workgroup owns
+// 16 * RB WEIGHT rows, its 8 waves split K, and every wave keeps its K share of those rows in registers for the whole launch
+// (v_mfma_f32_16x16x32_bf16: A = weights, lane (row = lane & 15, k group = lane >> 4) -- a 16-byte global load per lane IS the
+// operand layout).  The tokens stream past in units of 16 rows x 1024 columns; a wave handles ITS 128 columns of a unit alone:
+// coalesced 16-byte loads (a quarter-wave reads 256 contiguous bytes of one token row) into staging registers, a unit later a
+// swizzled ds_write into the wave's own 4 KB LDS slot, a unit later b128 reads in B-operand layout, a unit later the MFMAs -- no
+// barrier anywhere on that path, the compiler's vmcnt / lgkmcnt bookkeeping is exact (straight-line, branch-free loads).
+// Only the K split meets across waves: per group of two token tiles the 8 partial 16 x 16 products per row block go through LDS
+// (double-buffered: one barrier per group) and each (tile, row block) epilogue runs on a different wave while the others go on.
+// Each weight byte is fetched from HBM once (mt = 1); the token matrix is re-read from L2 by every workgroup, N / (16 RB) times
+// in all -- that L2 -> CU stream (~30 B/clk per CU measured) is what bounds a unit, hence RB up to 3 where registers allow.
+// What did NOT work, measured (profiles/r03_skinny_gemm.txt): B fragments loaded straight from global memory in operand layout
+// (64 separate 16-byte requests per instruction: 14 B/clk per CU); the LDS-DMA path (global_load_lds) in a shared or per-wave
+// ring (same ~25 B/clk, SQ_LDS_DATA_FIFO_FULL 11 % of the time, profiles/r03_pmc_skinny_dma_*.txt); one epilogue wave per tile
+// (the others wait for it at the next barrier: +40 % on the SwiGLU variant).
+//
+//   SK_STORE      y = rnd(acc)                                   (qkv)
+//   SK_RESIDUAL   y = rnd(rnd(acc) + res)                        (o_proj, down: the epilogue order of the tiled kernels)
+//   SK_SWIGLU     [gate | up] weight halves: a row block is gate rows j0 .. j0+7 and up rows I+j0 .. I+j0+7, so both factors of
+//                 an output sit in the same 16 x 16 tile: y = rnd(rnd(silu(rnd(g))) * rnd(u)) -- the values the two-launch form
+//                 (GEMM, then silu_mul_kernel on the stored bf16 halves) produces -- and the [M][2I] image is never written.
+// The accumulation order differs from the tiled kernels (8 partial sums per element, two chains each), so this path is for
+// callers that lend a workspace (GemmArgs::ws != null marks "order-free"): the prefill.  The codec never takes it (a tail decode
+// must stay bit-identical to a full decode, which runs on the tiled kernels).
+#pragma once
+#include "fq3_common.cuh"
+
+namespace fq3 {
+
+enum { SK_STORE = 0, SK_RESIDUAL = 1, SK_SWIGLU = 2 };
+constexpr int kSkinnyMaxRows = 416;
+
+struct SkinnyArgs {
+    const bf16_t* X; int ldx; int M;        // tokens [M][K]
+    const bf16_t* W; int N;                 // weight [N][K]; SK_SWIGLU: N = 2 I
+    const bf16_t* res; int ldr;             // SK_RESIDUAL
+    bf16_t* Y; int ldy;                     // [M][N] (SK_SWIGLU: [M][I])
+    int nrb;                                // weight-row groups: N / (16 RB)
+    int mt;                                 // workgroups per row group; workgroup (rb, j) takes token tiles j, j + mt, ...
+    int no_stagger;                         // measurement switch: 1 = every workgroup walks the token tiles from tile 0 (see `rot` below)
+};
+
+typedef __bf16 sk_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kSkKC = 1024;                 // columns of one unit (all 8 waves); a wave's share: 128 columns = 256 B per token row
+constexpr int kSkNW = 8;
+constexpr int kSkSlotB = 16 * 256;          // one wave's slot: 16 token rows x 256 B
+constexpr int kSkT = 2;                     // token tiles per reduction group
+constexpr size_t skinny_lds_bytes(int RB) { return (size_t)kSkNW * 2 * kSkSlotB + (size_t)2 * kSkT * kSkNW * RB * 1024; }
+
+template <int K, int RB, int EPI>
+__global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
+    typedef bf16_t T_;
+    constexpr int NW = kSkNW, KC = kSkKC, NCH = K / KC, KS = KC / NW / 32, T = kSkT;   // KS = 4 MFMA steps per wave and unit
+    static_assert(K % KC == 0 && (T * NCH) % 2 == 0, "shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    unsigned char* ring = sk_smem + (size_t)wave * (2 * kSkSlotB);              // this wave's [2][16 rows][256 B]
+    float* red = reinterpret_cast<float*>(sk_smem + (size_t)NW * 2 * kSkSlotB); // [2][T][NW][RB][64 lanes][4]
+    constexpr int kRedTile = NW * RB * 256, kRedBuf = T * kRedTile;             // floats
+    // workgroups that share a row group (mt > 1) sit on the same XCD (consecutive workgroup ids go round the 8 XCDs), so the group's
+    // weight rows cross the fabric once per XCD L2
+    int rb, mj;
+    {
+        const int b = blockIdx.x;
+        if (a.nrb % 8 == 0) { const int q = b >> 3; mj = q % a.mt; rb = (q / a.mt) * 8 + (b & 7); }
+        else { rb = b / a.mt; mj = b % a.mt; }
+    }
+    const int ntiles = (a.M + 15) >> 4;
+    const int nmine = mj < ntiles ? (ntiles - mj + a.mt - 1) / a.mt : 0;
+    if (nmine == 0) return;
+    const int ngroups = (nmine + T - 1) / T;
+    const int nunits = nmine * NCH;
+    // every workgroup reads the same token matrix: workgroup q of an XCD starts its walk q tiles further on (no measurable effect,
+    // kept: it costs nothing)
+    const int rot = a.no_stagger ? 0 : (int)((blockIdx.x >> 3) % (unsigned)nmine);
+    auto tile_t0 = [&](int i) { int j = i + rot; j = j >= nmine ? j - nmine : j; return (mj + j * a.mt) << 4; };
+
+    // Unit v = (this workgroup's tile v / NCH, column chunk v % NCH): this wave's share is 16 token rows x 256 B.  Load p of a unit
+    // moves rows 4p .. 4p+3 (lane: row 4p + lane / 16, 16-byte chunk lane % 16: every quarter-wave reads 256 contiguous bytes) into
+    // staging registers; a unit later they go to the wave's LDS slot v % 2 with the chunk index XORed by the row (row stride 256 B =
+    // all 64 banks; the swizzle spreads the 16 rows of a fragment read over the banks), and come back as B-operand fragments.
+    // Units past the end repeat the last one (uniform control flow; nobody uses them).
+    const int ld_r = lane >> 4, ld_c = lane & 15;
+    // byte offsets in 32 bits off the uniform base (no 64-bit multiplies in the loop): rows past M clamp to row M - 1 by a min on the
+    // offset (offsets grow with the row)
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.X);
+    const uint32_t rowb = (uint32_t)a.ldx * 2u;
+    const uint32_t lane_off = (uint32_t)ld_r * rowb + (uint32_t)wave * (KC / NW * 2) + (uint32_t)ld_c * 16u;
+    const uint32_t max_off = (uint32_t)(a.M - 1) * rowb + (uint32_t)wave * (KC / NW * 2) + (uint32_t)ld_c * 16u;
+    auto load_unit = [&](u32x4 (&st)[4], int v) {
+        v = v < nunits - 1 ? v : nunits - 1;
+        const int i = v / NCH, kc = v - i * NCH;
+        const uint32_t tile_off = (uint32_t)tile_t0(i) * rowb, kc_off = (uint32_t)kc * (KC * 2);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint32_t off = tile_off + (uint32_t)(4 * p) * rowb + lane_off;
+            off = off < max_off ? off : max_off;
+            st[p] = *reinterpret_cast<const u32x4*>(xb + (size_t)(off + kc_off));
+        }
+    };
+    const int wr_off = ld_r * 256 + ((ld_c ^ ld_r) & 15) * 16;                  // + p * 1024 + ((4p) swizzle): row 4p + ld_r, chunk c ^ row
+    auto write_unit = [&](const u32x4 (&st)[4], int v) {
+        unsigned char* slot = ring + (v & 1) * kSkSlotB;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)             // row = 4p + ld_r: chunk ^ row = (ld_c ^ ld_r) ^ 4p
+            *reinterpret_cast<u32x4*>(slot + p * 1024 + (wr_off ^ ((4 * p) << 4))) = st[p];
+    };
+    const int fro = fr * 256;
+    auto read_frags = [&](sk_bf16x8 (&f)[KS], int v) {
+        const unsigned char* slot = ring + (v & 1) * kSkSlotB + fro;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) f[s] = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const u32x4*>(slot + (((s * 4 + fq) ^ fr) & 15) * 16));
+    };
+
+    u32x4 stg[2][4];
+    load_unit(stg[0], 0);
+    load_unit(stg[1], 1);
+    // this wave's K share (KS steps in every 1024-column chunk) of the 16 RB weight rows, in A-operand layout
+    Raw8<T_> wreg[RB][NCH * KS];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        int wrow;
+        if constexpr (EPI == SK_SWIGLU) { const int j0 = (rb * RB + b) * 8; wrow = fr < 8 ? j0 + fr : (a.N >> 1) + j0 + (fr - 8); }
+        else wrow = (rb * RB + b) * 16 + fr;
+        const T_* wp = a.W + (size_t)wrow * K + wave * (KC / NW) + fq * 8;
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) ldraw<false>(wreg[b][kc * KS + s], wp + kc * KC + s * 32);
+    }
+
+    // epilogue of row block b of one token tile by the calling wave: the 8 partial products at `rd`, summed in wave order
+    auto epilogue = [&](const float* rd, int t0, int b) {
+        const int nb = a.M - t0 < 16 ? a.M - t0 : 16;
+        const int yc = (EPI == SK_SWIGLU ? (rb * RB + b) * 8 : (rb * RB + b) * 16) + fq * 4;
+        uint2 rv{0u, 0u};
+        if constexpr (EPI == SK_RESIDUAL) {
+            const int row = t0 + (fr < nb ? fr : nb - 1);
+            rv = *reinterpret_cast<const uint2*>(a.res + (size_t)row * a.ldr + yc);
+        }
+        const float* rp = rd + b * 256 + lane * 4;
+        f32x4 t = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) t += *reinterpret_cast<const f32x4*>(rp + w * RB * 256);
+        float v[4] = {t.x, t.y, t.z, t.w};
+        bool live = fr < nb;
+        if constexpr (EPI == SK_SWIGLU) {
+            const float* up = rd + b * 256 + ((lane & 31) + 32) * 4;            // the up rows of gate rows fq * 4 + e sit two k groups further
+            f32x4 u = *reinterpret_cast<const f32x4*>(up);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) u += *reinterpret_cast<const f32x4*>(up + w * RB * 256);
+            const float uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = DT<T_>::rnd(v[e]);
+                v[e] = DT<T_>::rnd(g / (1.0f + expf(-g))) * DT<T_>::rnd(uu[e]);
+            }
+            live = live && fq < 2;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = DT<T_>::rnd(v[e]);
+            if constexpr (EPI == SK_RESIDUAL) {
+                v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+                v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+            }
+        }
+        if (live) {
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(a.Y + (size_t)(t0 + fr) * a.ldy + yc) = o;
+        }
+    };
+
+    // Groups of T tiles: every wave walks the token units on its own (no barrier between a load and its MFMAs), leaves its partial
+    // 16 x 16 products of the group's tiles in LDS, ONE barrier per group, then T waves (a different set each group) run one
+    // tile's epilogue each while the others start the next group into the other partial-sum buffer.  Tiles past the end of the last
+    // group recompute the last tile and are not stored.
+    // The wave's pipeline, unit u multiplying: fragments of u in registers (read a unit ago), fragments of u + 1 being read from LDS,
+    // unit u + 2 going from staging registers to LDS, units u + 3 and u + 4 in flight from L2; the K steps of a unit alternate
+    // between two accumulators per row block (two independent MFMA chains).
+    sk_bf16x8 fcur[KS], fnext[KS];
+    write_unit(stg[0], 0);
+    load_unit(stg[0], 2);
+    write_unit(stg[1], 1);
+    load_unit(stg[1], 3);
+    read_frags(fcur, 0);
+    for (int g = 0; g < ngroups; ++g) {
+        float* rbuf = red + (g & 1) * kRedBuf;
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+            const int i = g * T + tt;
+            f32x4 acc[RB][2];
+#pragma unroll
+            for (int b = 0; b < RB; ++b) acc[b][0] = acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < NCH; ++kc) {
+                const int par = (tt * NCH + kc) & 1;                 // = u & 1 (a group has an even number of units): static after unrolling
+                const int u = i * NCH + kc;
+                read_frags(fnext, u + 1);                            // written a unit ago
+                __builtin_amdgcn_sched_barrier(0);                   // the reads go out BEFORE this unit's MFMAs
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int b = 0; b < RB; ++b)
+                        acc[b][s & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sk_bf16x8, wreg[b][kc * KS + s].v), fcur[s], acc[b][s & 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // unit u + 2 into the slot of unit u (its fragments are in registers, the MFMAs above have read them), then its
+                // staging registers take unit u + 4
+                if (par == 0) { write_unit(stg[0], u + 2); load_unit(stg[0], u + 4); }
+                else { write_unit(stg[1], u + 2); load_unit(stg[1], u + 4); }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) fcur[s] = fnext[s];
+            }
+            float* rd = rbuf + tt * kRedTile + wave * RB * 256 + lane * 4;
+#pragma unroll
+            for (int b = 0; b < RB; ++b) *reinterpret_cast<f32x4*>(rd + b * 256) = acc[b][0] + acc[b][1];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): my partial sums are written
+        __builtin_amdgcn_s_barrier();
+        // the group's T x RB (tile, row block) epilogues go to T x RB different waves (rotating with the group)
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const int i = g * T + tt;
+                if (i < nmine && wave == ((g * (T * RB) + tt * RB + b) % NW)) epilogue(rbuf + tt * kRedTile, tile_t0(i), b);
+            }
+    }
+}
+
+// K values served (the talker's hidden / q / intermediate widths at 0.6B and 1.7B)
+inline bool skinny_k_ok(int K) { return K == 1024 || K == 2048 || K == 3072 || K == 6144; }
+
+template <int K, int RB, int EPI>
+inline void skinny_go(const SkinnyArgs& a, hipStream_t s) {
+    constexpr size_t shm = skinny_lds_bytes(RB);
+    static_assert(shm <= 160 * 1024, "LDS");
+    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<K, RB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess; }();
+    (void)once;
+    hipLaunchKernelGGL((skinny_gemm_kernel<K, RB, EPI>), dim3(a.nrb * a.mt), dim3(512), shm, s, a);
+}
+
+// rb_force / a0.mt: 0 = pick (measurement hooks of tools/microbench/gemm_bench.hip)
+template <int EPI>
+inline void skinny_launch(const SkinnyArgs& a0, int K, hipStream_t s, int rb_force = 0) {
+    SkinnyArgs a = a0;
+    const int ntiles = (a.M + 15) / 16;
+    const int groups1 = a.N / 16;                    // SK_SWIGLU: I / 8 pairs of 8 gate + 8 up rows = the same count
+    // row blocks per wave: more of them = fewer re-reads of the token matrix; as many as still leave one full round of workgroups
+    int RB = 1;
+    if (rb_force) RB = rb_force;
+    else if (groups1 % 3 == 0 && groups1 / 3 >= 128 && K <= 2048) RB = 3;
+    else if (groups1 % 2 == 0 && groups1 / 2 >= 128 && K <= 3072) RB = 2;
+    if (K > 3072 || groups1 % RB || (RB == 3 && K > 2048)) RB = 1;           // register budget: 4 K / 1024 weight fragments per row block
+    a.nrb = groups1 / RB;
+    if (a.mt <= 0) {
+        a.mt = 1;
+        while (a.nrb * a.mt * 2 <= 256 && a.mt * 2 <= ntiles) a.mt *= 2;      // fill the CUs before deepening the per-workgroup tile walk
+    }
+    if (a.mt > ntiles) a.mt = ntiles;
+#define FQ3_SK(KK) do { if constexpr (KK <= 2048) { if (RB == 3) { skinny_go<KK, 3, EPI>(a, s); break; } } \
+                        if constexpr (KK <= 3072) { if (RB == 2) { skinny_go<KK, 2, EPI>(a, s); break; } } \
+                        skinny_go<KK, 1, EPI>(a, s); } while (0)
+    switch (K) {
+        case 1024: FQ3_SK(1024); break;
+        case 2048: FQ3_SK(2048); break;
+        case 3072: FQ3_SK(3072); break;
+        default:   FQ3_SK(6144); break;
+    }
+#undef FQ3_SK
+}
+
+}  // namespace fq3

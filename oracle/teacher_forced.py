@@ -59,6 +59,14 @@ def forced_decisions(eng, cfg, tie, tth, tpe, codes: np.ndarray, graph: bool = T
     return out
 
 
+def near_ties(case: dict, k_ulp: float) -> int:
+    """Number of the oracle's decisions whose top-2 margin is at most k_ulp bf16 ulps of the winning logit."""
+    N = case["codes"].shape[0]
+    margin = np.concatenate([case["t_margin"][:N, None], case["p_margin"]], axis=1)
+    top1 = np.concatenate([case["t_top1"][:N, None], case["p_top1"]], axis=1)
+    return int((margin / bf16_ulp(top1) <= k_ulp).sum())
+
+
 def score(decisions: np.ndarray, case: dict, k_ulp: float):
     """-> dict(matched_decisions, total, matched_frames, frames, worst_mismatch_ulp, unexplained)"""
     codes = case["codes"].astype(np.int64)

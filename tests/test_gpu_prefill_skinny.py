@@ -1,0 +1,108 @@
+"""GPU: the weight-stationary GEMMs of the short-prompt prefill (csrc/skinny_gemm.cuh: prompts of <= 416 rows at the real
+talker widths, K in {1024, 2048, 3072, 6144}) -- qkv, the fused [gate | up] + SwiGLU launch, o_proj / down with the residual.
+
+Two talker layers at the 0.6B and at the 1.7B dims.  Checked against (a) the CPU oracle run here on the same bf16-valued
+weights with fp32 arithmetic (0.025 x scale: the bound of the other bf16 prefill tests) and (b) the tiled / split-K kernels the
+same library runs with `fq3_set_option("skinny_gemm", 0)` -- same inputs, only the fp32 summation order differs, so a few
+bf16 ulps after two layers (2^-6 x scale) -- on the last row's hidden state and logits AND on every row of the last layer's
+K / V cache (a skipped token tile or weight-row block would leave a stale row or column behind).  Prompt lengths: 200 (the
+benchmarked one: 13 token tiles, the last one ragged), 37 (three tiles: fewer tiles than ring stages), 416 (the largest
+served), 16 (one tile); a left-padded prompt; and a packed prefill of two prompts (350 packed rows) against the two single
+prefills."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fq3hip.config import qwen3_tts_0p6b, qwen3_tts_1p7b
+from fq3hip.weights import synth_weights, synth_prompt
+from oracle import qwen3tts_oracle as O
+
+
+def _cfg(size):
+    cfg = qwen3_tts_0p6b() if size == "0p6b" else qwen3_tts_1p7b()
+    cfg.talker.num_hidden_layers = 2
+    cfg.predictor.num_hidden_layers = 1
+    return cfg
+
+
+def _setup(size, L, max_seq=None):
+    from fq3hip.engine import Fq3Engine
+    cfg = _cfg(size)
+    W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor"))
+    tie, tam, _, _, _ = synth_prompt(cfg, L, 4, 0, dtype=torch.bfloat16)
+    tie = (tie * 30).to(torch.bfloat16)                          # O(1) activations
+    eng = Fq3Engine(cfg, W, device="cuda", dtype=torch.bfloat16, max_seq_len=max_seq or L + 8, max_frames=8)
+    return cfg, W, tie, tam, eng
+
+
+def _run(eng, cfg, x, L, n_pad=0):
+    logits, hidden = eng.prefill(x, n_pad=n_pad)
+    k, v = eng.kv_export(cfg.talker.num_hidden_layers - 1, L)
+    return logits.float().cpu(), hidden.float().cpu(), k.float().cpu()[:, n_pad:], v.float().cpu()[:, n_pad:]
+
+
+@pytest.mark.parametrize("size", ["0p6b", "1p7b"])
+@pytest.mark.parametrize("L", [200, 37, 416, 16])
+def test_skinny_prefill_matches_oracle_and_tiled_kernels(size, L):
+    cfg, W, tie, tam, eng = _setup(size, L)
+    x = tie[0].cuda().contiguous()
+    eng.set_option("skinny_gemm", 1)
+    got = _run(eng, cfg, x, L)
+    eng.set_option("skinny_gemm", 0)
+    ref = _run(eng, cfg, x, L)
+    for i, name in enumerate(("logits", "hidden", "K of the last layer", "V of the last layer")):
+        d = float((got[i] - ref[i]).abs().max())
+        assert d <= 2.0 ** -6 * max(1.0, float(ref[i].abs().max())), (name, d)
+    assert float(got[3].abs().amax(dim=(0, 2)).min()) > 0                  # every cache row written
+    # the oracle: fp32 arithmetic on the same bf16-valued weights
+    Wq = {k: v.float() for k, v in W.items()}
+    orc = O.OracleTTS(cfg, Wq, max_seq_len=L + 8)
+    with torch.inference_mode():
+        lo, ho, _, _ = orc.prefill(tie.float(), tam)
+    lo, ho = lo.float(), ho.float().view(-1)
+    assert float((got[1] - ho).abs().max()) <= 0.025 * max(1.0, float(ho.abs().max()))
+    assert float((got[0] - lo).abs().max()) <= 0.025 * max(1.0, float(lo.abs().max()))
+    print(f"[skinny prefill] {size} L={L}: max |hidden - oracle| {float((got[1] - ho).abs().max()):.4f} (tiled kernels: "
+          f"{float((ref[1] - ho).abs().max()):.4f}), skinny vs tiled {float((got[1] - ref[1]).abs().max()):.4f}")
+
+
+def test_skinny_prefill_left_padded():
+    L, n_pad = 200, 5
+    cfg, W, tie, tam, eng = _setup("0p6b", L)
+    x = tie[0].cuda().contiguous()
+    outs = []
+    for v in (1, 0):
+        eng.set_option("skinny_gemm", v)
+        outs.append(_run(eng, cfg, x, L, n_pad=n_pad))
+    for i in range(4):
+        d = float((outs[0][i] - outs[1][i]).abs().max())
+        assert d <= 2.0 ** -6 * max(1.0, float(outs[1][i].abs().max())), (i, d)
+
+
+def test_packed_prefill_of_two_short_prompts_through_the_skinny_kernels():
+    """150 + 200 packed rows (<= 416: every row-wise GEMM of the packed pass is a weight-stationary launch) against the two
+    single prefills: the rows of a prompt see the same arithmetic either way except for which token tile they sit in."""
+    from fq3hip.engine import Fq3Engine
+    cfg = _cfg("0p6b")
+    W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor"))
+    engs = [Fq3Engine(cfg, W, device="cuda", dtype=torch.bfloat16, max_seq_len=512, max_frames=8)]
+    engs.append(Fq3Engine(cfg, W, device="cuda", dtype=torch.bfloat16, max_seq_len=512, max_frames=8, share=engs[0]))
+    xs = []
+    for L, seed in ((150, 1), (200, 2)):
+        tie, _, _, _, _ = synth_prompt(cfg, L, 4, seed, dtype=torch.bfloat16)
+        xs.append((tie * 30).to(torch.bfloat16)[0].cuda().contiguous())
+    single = []
+    for e, x in zip(engs, xs):
+        lg, hd = e.prefill(x)
+        k, v = e.kv_export(1, x.shape[0])
+        single.append((lg.float().cpu(), hd.float().cpu(), k.float().cpu(), v.float().cpu()))
+    packed = Fq3Engine.prefill_batch(engs, xs)
+    for q, (e, x) in enumerate(zip(engs, xs)):
+        lg, hd = packed[q]
+        k, v = e.kv_export(1, x.shape[0])
+        got = (lg.float().cpu(), hd.float().cpu(), k.float().cpu(), v.float().cpu())
+        for i in range(4):
+            d = float((got[i] - single[q][i]).abs().max())
+            assert d <= 2.0 ** -6 * max(1.0, float(single[q][i].abs().max())), (q, i, d)

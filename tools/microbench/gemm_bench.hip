@@ -41,6 +41,110 @@ int main(int argc, char** argv) {
     };
     hipStream_t s; (void)hipStreamCreate(&s);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    if (argc > 2 && !strcmp(argv[2], "skinny1")) {
+        // one shape of the weight-stationary kernel, a few launches: the workload of the rocprofv3 --pmc passes
+        // usage: gemm_bench <reps> skinny1 <M> <N> <K> [RB] [mt]
+        const int M = atoi(argv[3]), N = atoi(argv[4]), K = atoi(argv[5]), rbf = argc > 6 ? atoi(argv[6]) : 0, mt = argc > 7 ? atoi(argv[7]) : 0;
+        void *X, *W, *Y;
+        (void)hipMalloc(&X, (size_t)M * K * 2); (void)hipMalloc(&W, (size_t)N * K * 2); (void)hipMalloc(&Y, (size_t)M * N * 2);
+        (void)hipMemset(X, 0x3c, (size_t)M * K * 2); (void)hipMemset(W, 0x3c, (size_t)N * K * 2);
+        SkinnyArgs q{}; q.X = (const bf16_t*)X; q.ldx = K; q.M = M; q.W = (const bf16_t*)W; q.N = N; q.Y = (bf16_t*)Y; q.ldy = N; q.mt = mt;
+        for (int r = 0; r < reps; ++r) skinny_launch<SK_STORE>(q, K, s, rbf);
+        (void)hipStreamSynchronize(s);
+        return 0;
+    }
+    if (argc > 2 && !strcmp(argv[2], "skinny")) {
+        // The short-prompt prefill's four GEMMs: the tiled / split-K kernels (what gemm_launch picked before) against the
+        // weight-stationary kernel of skinny_gemm.cuh, over a ROTATION of weight copies larger than the Infinity Cache (as in the real
+        // prefill, where every layer's weights come from HBM).  Outputs compared element by element (the accumulation order differs:
+        // a few bf16 ulps at most) and against a host double dot product on a sample.
+        struct SS { const char* name; int M, N, K; int epi; };        // epi: 0 store, 1 residual, 2 [gate|up] + SwiGLU
+        std::vector<SS> ss;
+        for (int M : {200, 52, 416}) {
+            ss.push_back({"0.6B qkv", M, 4096, 1024, 0}); ss.push_back({"0.6B gate_up+silu", M, 6144, 1024, 2});
+            ss.push_back({"0.6B o_proj", M, 1024, 2048, 1}); ss.push_back({"0.6B down", M, 1024, 3072, 1});
+            if (M == 200) {
+                ss.push_back({"1.7B qkv", M, 4096, 2048, 0}); ss.push_back({"1.7B gate_up+silu", M, 12288, 2048, 2});
+                ss.push_back({"1.7B o_proj", M, 2048, 2048, 1}); ss.push_back({"1.7B down", M, 2048, 6144, 1});
+            }
+        }
+        void* ws; (void)hipMalloc(&ws, (size_t)(8 << 20) * 4);
+        for (auto& c : ss) {
+            const size_t nx = (size_t)c.M * c.K, nw = (size_t)c.N * c.K, nyf = (size_t)c.M * c.N, ny = c.epi == 2 ? nyf / 2 : nyf;
+            const int copies = (int)((320ull << 20) / (nw * 2)) + 1;
+            std::vector<uint16_t> hx(nx), hw(nw), hr(ny);
+            uint32_t x = 99 + c.K;
+            auto rnd = [&]() { x = x * 1664525u + 1013904223u; return x >> 16; };
+            for (auto& v : hx) v = f_to_bf16_host((float)((int)(rnd() & 0xfff) - 2048) / 1931.f);
+            for (auto& v : hw) v = f_to_bf16_host((float)((int)(rnd() & 0xfff) - 2048) / 16411.f);
+            for (auto& v : hr) v = f_to_bf16_host((float)((int)(rnd() & 0xfff) - 2048) / 1931.f);
+            void *X, *W, *R, *GU, *Y[2];
+            (void)hipMalloc(&X, nx * 2); (void)hipMalloc(&W, nw * 2 * copies); (void)hipMalloc(&R, ny * 2); (void)hipMalloc(&GU, nyf * 2);
+            for (int v = 0; v < 2; ++v) { (void)hipMalloc(&Y[v], ny * 2); (void)hipMemset(Y[v], 0, ny * 2); }
+            (void)hipMemcpy(X, hx.data(), nx * 2, hipMemcpyHostToDevice); (void)hipMemcpy(R, hr.data(), ny * 2, hipMemcpyHostToDevice);
+            for (int k = 0; k < copies; ++k) (void)hipMemcpy((char*)W + (size_t)k * nw * 2, hw.data(), nw * 2, hipMemcpyHostToDevice);
+            auto args = [&](int k, int v) {
+                GemmArgs a{};
+                a.A = X; a.lda = c.K; a.M = c.M; a.a_rows = c.M; a.n_taps = 1; a.Cin = c.K; a.W = (char*)W + (size_t)k * nw * 2; a.N = c.N; a.bias_mod = c.N;
+                a.Y = c.epi == 2 ? GU : Y[v]; a.ldy = c.N; a.ws = (float*)ws; a.ws_floats = 8 << 20; a.no_skinny = v == 0;
+                if (c.epi == 1) { a.res = R; a.ldr = c.N; }
+                return a;
+            };
+            auto go = [&](int k, int v) { GemmArgs a = args(k, v); if (c.epi == 2) gemm_swiglu_halves<bf16_t>(a, Y[v], s); else gemm_launch<bf16_t>(a, s); };
+            float ms[2];
+            for (int v = 0; v < 2; ++v) {
+                if (getenv("SK_TRACE")) { printf("  M=%d %s: %s ...\n", c.M, c.name, v ? "skinny" : "tiled"); fflush(stdout); }
+                go(0, v); (void)hipStreamSynchronize(s);
+                (void)hipEventRecord(e0, s);
+                for (int r = 0; r < reps; ++r) go(r % copies, v);
+                (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+                (void)hipEventElapsedTime(&ms[v], e0, e1); ms[v] /= reps;
+            }
+            std::vector<uint16_t> y0(ny), y1(ny);
+            (void)hipMemcpy(y0.data(), Y[0], ny * 2, hipMemcpyDeviceToHost); (void)hipMemcpy(y1.data(), Y[1], ny * 2, hipMemcpyDeviceToHost);
+            size_t differ = 0; double maxd = 0, maxref = 0;
+            for (size_t i = 0; i < ny; ++i) {
+                const double a0 = bf16_to_f_host(y0[i]), a1 = bf16_to_f_host(y1[i]);
+                differ += y0[i] != y1[i];
+                maxd = fmax(maxd, fabs(a0 - a1)); maxref = fmax(maxref, fabs(a0));
+            }
+            double maxerr = 0;                      // host double reference on a sample (residual / SwiGLU applied as the kernels do)
+            const int ycols = c.epi == 2 ? c.N / 2 : c.N;
+            for (int t = 0; t < 24; ++t) {
+                const int m = (int)(((uint64_t)t * 7919 + 13) % c.M), n = t < 2 ? ycols - 1 - t : (int)(((uint64_t)t * 104729 + 7) % ycols);
+                auto dot = [&](int wr) { double acc = 0; for (int k = 0; k < c.K; ++k) acc += (double)bf16_to_f_host(hx[(size_t)m * c.K + k]) * bf16_to_f_host(hw[(size_t)wr * c.K + k]); return acc; };
+                double want;
+                if (c.epi == 2) { const double g = dot(n), u = dot(c.N / 2 + n); want = g / (1.0 + exp(-g)) * u; }
+                else want = dot(n) + (c.epi == 1 ? bf16_to_f_host(hr[(size_t)m * c.N + n]) : 0.0);
+                const double got = bf16_to_f_host(y1[(size_t)m * ycols + n]);
+                maxerr = fmax(maxerr, fabs(got - want) / (fabs(want) + 1.0));
+            }
+            // (row blocks per wave, workgroups per row group) sweep of the weight-stationary kernel
+            char sweep[512]; int sp = 0;
+            for (int rbf : {1, 2, 3, -1}) for (int mt : {1, 2, 4}) {
+                if (rbf > 0 && ((c.N / 16) % rbf || (c.K > 3072 && rbf > 1) || (c.K > 2048 && rbf > 2))) continue;
+                if (rbf < 0 && mt > 1) continue;           // -1: the launcher's own choice WITHOUT the staggered tile walk
+                auto gs = [&](int k) {
+                    SkinnyArgs q{}; q.X = (const bf16_t*)X; q.ldx = c.K; q.M = c.M; q.W = (const bf16_t*)((char*)W + (size_t)k * nw * 2); q.N = c.N;
+                    q.res = (const bf16_t*)R; q.ldr = c.N; q.Y = (bf16_t*)Y[1]; q.ldy = c.epi == 2 ? c.N / 2 : c.N; q.mt = rbf < 0 ? 0 : mt; q.no_stagger = rbf < 0; const int rbf_ = rbf < 0 ? 0 : rbf;
+                    if (c.epi == 2) skinny_launch<SK_SWIGLU>(q, c.K, s, rbf_); else if (c.epi == 1) skinny_launch<SK_RESIDUAL>(q, c.K, s, rbf_); else skinny_launch<SK_STORE>(q, c.K, s, rbf_);
+                };
+                if (getenv("SK_TRACE")) { printf("  sweep RB %d mt %d ...\n", rbf, mt); fflush(stdout); }
+                gs(0); (void)hipStreamSynchronize(s);
+                (void)hipEventRecord(e0, s);
+                for (int r = 0; r < reps; ++r) gs(r % copies);
+                (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+                float t; (void)hipEventElapsedTime(&t, e0, e1);
+                if (rbf < 0) sp += snprintf(sweep + sp, sizeof(sweep) - sp, " unstaggered:%.1f", t / reps * 1e3); else sp += snprintf(sweep + sp, sizeof(sweep) - sp, " %dx%d:%.1f", rbf, mt, t / reps * 1e3);
+            }
+            const double wbytes = (double)nw * 2;
+            printf("M=%3d %-20s N=%5d K=%4d  tiled %7.2f us   skinny %7.2f us (%5.2f TB/s of weights)   %zu / %zu outputs differ, max |d| %.3g of %.3g   host check %.2e %s   [RBxmt us:%s]\n",
+                   c.M, c.name, c.N, c.K, ms[0] * 1e3, ms[1] * 1e3, wbytes / (ms[1] * 1e-3) / 1e12, differ, ny, maxd, maxref, maxerr,
+                   maxerr < 2e-2 && maxd <= 0.02 * maxref ? "ok" : "MISMATCH", sweep);
+            (void)hipFree(X); (void)hipFree(W); (void)hipFree(R); (void)hipFree(GU); (void)hipFree(Y[0]); (void)hipFree(Y[1]);
+        }
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "codec")) {
         // The codec's decoder convs of one 300-frame piece WITH their real epilogues (bias, residual, SnakeBeta second output),
         // through the product's own tile choice: LDS-parked row-contiguous epilogue (product) vs the register-layout one
