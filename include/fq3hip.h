@@ -101,7 +101,8 @@ int fq3_ctx_destroy(fq3_ctx* ctx);
 /* Kernel-variant switches, all parity-tested both ways (no reference equivalent; the defaults are the measured-fastest):
  *   "weight_nt" 0|1|2 (non-temporal weight loads: none | talker | all), "pred_m2" 0|1 (predictor two-token prefill as one
  *   M = 2 pass), "pred_attn" 0|1 (one-wave predictor attention), "rows_per_wave_max" 1|2, "prefill_mode" 0|1,
- *   "flash_prefill" 0|1 (bf16 prefill attention as a flash-style matrix-core kernel).
+ *   "flash_prefill" 0|1 (bf16 prefill attention as a flash-style matrix-core kernel), "skinny_gemm" 0|1 (prompts of <= 416 rows:
+ *   weight-stationary GEMMs with the SwiGLU fused into the [gate | up] launch; 0 = the tiled / split-K kernels of longer prompts).
  * Resets a captured graph. */
 int fq3_set_option(fq3_ctx* ctx, const char* key, int value);
 
