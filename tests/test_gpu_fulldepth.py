@@ -16,6 +16,9 @@ Tolerances (north star: "bit-identical in RVQ token indices"):
          at an oracle margin of 3 ulps falls the other way (0.6B), which is the bound the 8..32-lane MFMA batch path has been
          held to all along (tests/test_gpu_batch_fulldepth.py) -- the first-token logits of the two prefill variants differ by
          up to 0.05 = 3 ulps themselves (tools/prefill_time.py).
+         The oracle ITSELF is no more reproducible than that: re-evaluated on one CPU thread, or with fp32 / fp64 operands, or
+         with K summed in 8 slices, it reproduces 365-377 of its own 384 ids, worst flip at 2-3 ulps
+         (oracle/selfcheck_fulldepth.py, tests/test_oracle_selfcheck.py).
          How many near-tie decisions fall the other way is a coin-flip statistic of the summation order, not a quality
          figure: the goldens hold 42 (0.6B) / 52 (1.7B) decisions with a margin <= 2 ulps out of 384 (9 / 13 exact ties).
          Measured (MI355X, deterministic kernels): 0.6B 371-376 identical decisions, 1.7B 367-370.  The second gate bounds
