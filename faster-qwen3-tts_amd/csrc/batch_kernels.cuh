@@ -58,12 +58,27 @@ template <typename T, int REP>
 __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, LaneKV kv, LaneTab t, int qkv_stride,
                                                                 const float* rope_now, size_t part_stride) {
     const int l = blockIdx.z;
+    a.part = a.part + (size_t)l * part_stride;
+    // A worker whose first key tile lies beyond the lane's position has nothing to read and is not the one that appends the new
+    // K / V row.  The single-stream kernel lets it load a (clamped) tile anyway, so that the position need not be known before the
+    // loads go out; across 32 lanes those idle workers were half of the launch's HBM traffic (workers are sized for max_seq_len,
+    // the benchmarked caches hold 4 of 8 tiles: 33 of 66 MB per launch, profiles/r03_pmc_batch32_fetch.txt).  Here it leaves its
+    // empty partial slot -- the very values the walk over no valid key produces: {0, m = -1e30, l = 0} -- and exits.
+    const int pos = t.st[l]->pos;
+    if ((int)blockIdx.y * kKeysPerTile > pos) {
+        for (int e = threadIdx.x; e < REP * kHeadDim; e += 256) {
+            const int h = e / kHeadDim, d = e - h * kHeadDim;
+            float* p = a.part + (((size_t)blockIdx.x * kMaxWorkers + blockIdx.y) * REP + h) * kPartStride;
+            p[d] = 0.f;
+            if (d == 0) { p[kHeadDim] = -1e30f; p[kHeadDim + 1] = 0.f; }
+        }
+        return;
+    }
     a.qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)l * qkv_stride;
     a.kcache = kv.k[l]; a.vcache = kv.v[l];
-    a.pos_ptr = &t.st[l]->pos;
+    a.pos_ptr = nullptr; a.pos_imm = pos;
     a.n_pad = t.st[l]->n_pad;
     a.cos_row = rope_now + (size_t)l * kHeadDim; a.sin_row = a.cos_row + 64;
-    a.part = a.part + (size_t)l * part_stride;
     attn_decode_body<T, REP>(a);
 }
 
