@@ -2,6 +2,7 @@
 // See batch_kernels.cuh for the design; the C ABI is declared in include/fq3hip.h (fq3_batch_*).
 #include "fq3_ctx.h"
 #include "batch_kernels.cuh"
+#include "skinny_gemm.cuh"
 
 #include <algorithm>
 #include <cmath>
@@ -29,6 +30,7 @@ struct fq3_batch {
     hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr;
     std::vector<void*> allocs;
+    int use_skinny = 1;           // above 16 lanes the two residual GEMVs of a layer (o_proj, down) run on the weight-stationary prefill kernel
     int use_mfma = 0;             // bf16 GEMVs on the matrix cores: default ON for bf16 (ids verified against the oracle by teacher forcing
                                   // at full depth, 8 and 16 lanes); fq3_batch_set_option("mfma", 0) selects the VALU kernels, whose
                                   // lanes are bit-identical to the single-stream path
@@ -113,13 +115,17 @@ extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** 
         fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "hipStreamCreateWithFlags");
     }
     b->use_mfma = c0->cfg.dtype == FQ3_BF16 ? 1 : 0;
+    if (c0->cfg.dtype == FQ3_BF16 && !skinny_prepare<SK_RESIDUAL>()) {
+        fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "batch: could not raise the LDS limit of the weight-stationary GEMV kernels");
+    }
     *out = b;
     return FQ3_OK;
 }
 
 extern "C" int fq3_batch_set_option(fq3_batch* b, const char* key, int value) {
     if (!b || !key) return fq3_fail_(FQ3_EINVAL, "null argument");
-    if (std::string(key) == "mfma") b->use_mfma = value;      // bf16 GEMVs on the matrix cores (fp32 summation order differs from the single-stream kernels)
+    if (std::string(key) == "skinny") b->use_skinny = value;  // o_proj / down of 17..32 lanes on skinny_gemm_kernel (default 1); 0: gemv_batch_mfma_plain_kernel
+    else if (std::string(key) == "mfma") b->use_mfma = value;      // bf16 GEMVs on the matrix cores (fp32 summation order differs from the single-stream kernels)
     else return fq3_fail_(FQ3_EINVAL, std::string("unknown batch option: ") + key);
     return fq3_batch_graph_reset(b);
 }
@@ -177,8 +183,22 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
         default: return -1000;
     }
 }
+static thread_local int g_batch_skinny = 1;      // set per enqueue from fq3_batch::use_skinny
 template <int EPI>
 static int launch_gemv_batch_mfma_plain(const BatchGemvArgs& a, hipStream_t s) {
+    // 17..32 lanes, residual epilogue (o_proj, down: N = hidden only -- 64 or 128 workgroups of the one-row-block-per-workgroup GEMV, each
+    // re-reading every lane's K-long token row): the prefill's weight-stationary kernel splits the two token tiles over workgroups and
+    // K over 8 waves with per-wave LDS staging (skinny_gemm.cuh); measured 12.1 -> ~8 us (down) and 9.3 -> ~6.5 us (o_proj) per launch
+    if constexpr (EPI == EPI_RESIDUAL) {
+        if (g_batch_skinny && a.B > kTokTile && !a.bias && skinny_k_ok(a.K) && a.N % 32 == 0 && a.x_stride % 8 == 0 && a.y_stride % 4 == 0 &&
+            a.res_stride % 4 == 0) {
+            SkinnyArgs k{};
+            k.X = reinterpret_cast<const bf16_t*>(a.x); k.ldx = a.x_stride; k.M = a.B; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = a.N;
+            k.res = reinterpret_cast<const bf16_t*>(a.res); k.ldr = a.res_stride; k.Y = reinterpret_cast<bf16_t*>(a.y); k.ldy = a.y_stride;
+            skinny_launch<SK_RESIDUAL>(k, a.K, s);
+            return 0;
+        }
+    }
     const int grid = (a.N + 15) / 16;
     auto go = [&](auto ks, auto nw) -> int {
         constexpr int KS = decltype(ks)::value, NW = decltype(nw)::value;
@@ -327,6 +347,7 @@ static int check_lanes(fq3_batch* b) {
 }
 static int enqueue_batch_frame(fq3_batch* b, hipStream_t s) {
     g_batch_mfma = b->use_mfma;
+    g_batch_skinny = b->use_skinny;
     return b->lanes[0]->cfg.dtype == FQ3_BF16 ? enqueue_batch_frame_t<bf16_t>(b, s) : enqueue_batch_frame_t<float>(b, s);
 }
 

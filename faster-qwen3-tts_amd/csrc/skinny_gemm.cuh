@@ -237,13 +237,29 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
 // K values served (the talker's hidden / q / intermediate widths at 0.6B and 1.7B)
 inline bool skinny_k_ok(int K) { return K == 1024 || K == 2048 || K == 3072 || K == 6144; }
 
+// the kernels need more than the default 64 KB of dynamic LDS: raised once per process and instantiation
 template <int K, int RB, int EPI>
-inline void skinny_go(const SkinnyArgs& a, hipStream_t s) {
+inline bool skinny_attr() {
     constexpr size_t shm = skinny_lds_bytes(RB);
     static_assert(shm <= 160 * 1024, "LDS");
-    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<K, RB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess; }();
-    (void)once;
-    hipLaunchKernelGGL((skinny_gemm_kernel<K, RB, EPI>), dim3(a.nrb * a.mt), dim3(512), shm, s, a);
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<K, RB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess;
+    return ok;
+}
+template <int K, int RB, int EPI>
+inline void skinny_go(const SkinnyArgs& a, hipStream_t s) {
+    (void)skinny_attr<K, RB, EPI>();
+    hipLaunchKernelGGL((skinny_gemm_kernel<K, RB, EPI>), dim3(a.nrb * a.mt), dim3(512), skinny_lds_bytes(RB), s, a);
+}
+// Raise the LDS limit of every instantiation of one epilogue NOW: for callers whose first launch could otherwise happen inside a
+// hipGraph stream capture (the batch decode graph).
+template <int EPI>
+inline bool skinny_prepare() {
+    bool ok = true;
+    ok &= skinny_attr<1024, 1, EPI>() & skinny_attr<1024, 2, EPI>() & skinny_attr<1024, 3, EPI>();
+    ok &= skinny_attr<2048, 1, EPI>() & skinny_attr<2048, 2, EPI>() & skinny_attr<2048, 3, EPI>();
+    ok &= skinny_attr<3072, 1, EPI>() & skinny_attr<3072, 2, EPI>();
+    ok &= skinny_attr<6144, 1, EPI>();
+    return ok;
 }
 
 // rb_force / a0.mt: 0 = pick (measurement hooks of tools/microbench/gemm_bench.hip)

@@ -424,7 +424,8 @@ class Fq3Batch:
         L.check(self.lib.fq3_batch_graph_reset(self.handle))
 
     def set_option(self, key: str, value: int):
-        """``fq3_batch_set_option``: "mfma" 0|1 (matrix-core batch GEMVs, bf16)."""
+        """``fq3_batch_set_option``: "mfma" 0|1 (matrix-core batch GEMVs, bf16), "skinny" 0|1 (o_proj / down of 17..32 lanes on
+        the weight-stationary prefill kernel)."""
         L.check(self.lib.fq3_batch_set_option(self.handle, key.encode(), int(value)))
 
     def close(self):
