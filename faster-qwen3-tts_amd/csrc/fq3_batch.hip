@@ -124,7 +124,8 @@ extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** 
 
 extern "C" int fq3_batch_set_option(fq3_batch* b, const char* key, int value) {
     if (!b || !key) return fq3_fail_(FQ3_EINVAL, "null argument");
-    if (std::string(key) == "skinny") b->use_skinny = value;  // o_proj / down of 17..32 lanes on skinny_gemm_kernel (default 1); 0: gemv_batch_mfma_plain_kernel
+    if (std::string(key) == "skinny") b->use_skinny = value;  // o_proj / down of 17..32 lanes on skinny_gemm_kernel (default 1); 0: gemv_batch_mfma_plain_kernel;
+                                                              // 2: at every lane count (a measurement switch: below 17 lanes the kernel's two-tile group is half empty)
     else if (std::string(key) == "mfma") b->use_mfma = value;      // bf16 GEMVs on the matrix cores (fp32 summation order differs from the single-stream kernels)
     else return fq3_fail_(FQ3_EINVAL, std::string("unknown batch option: ") + key);
     return fq3_batch_graph_reset(b);
@@ -190,7 +191,7 @@ static int launch_gemv_batch_mfma_plain(const BatchGemvArgs& a, hipStream_t s) {
     // re-reading every lane's K-long token row): the prefill's weight-stationary kernel splits the two token tiles over workgroups and
     // K over 8 waves with per-wave LDS staging (skinny_gemm.cuh); measured 12.1 -> ~8 us (down) and 9.3 -> ~6.5 us (o_proj) per launch
     if constexpr (EPI == EPI_RESIDUAL) {
-        if (g_batch_skinny && a.B > kTokTile && !a.bias && skinny_k_ok(a.K) && a.N % 32 == 0 && a.x_stride % 8 == 0 && a.y_stride % 4 == 0 &&
+        if (g_batch_skinny && (a.B > kTokTile || g_batch_skinny >= 2) && !a.bias && skinny_k_ok(a.K) && a.N % 32 == 0 && a.x_stride % 8 == 0 && a.y_stride % 4 == 0 &&
             a.res_stride % 4 == 0) {
             SkinnyArgs k{};
             k.X = reinterpret_cast<const bf16_t*>(a.x); k.ldx = a.x_stride; k.M = a.B; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = a.N;

@@ -262,7 +262,8 @@ int fq3_batch_graph_reset(fq3_batch* b);
 /* "mfma" 0|1: batch GEMVs on the matrix cores (bf16 contexts; default 1: ids checked against the oracle by teacher
  * forcing) or on the VALU kernels (0: every lane bit-identical to the same utterance decoded alone).
  * "skinny" 0|1 (with "mfma" 1, more than 16 lanes): o_proj / down through the weight-stationary kernel of the short-prompt prefill
- * (default 1) or through the one-row-block-per-workgroup batch GEMV (0). */
+ * (default 1) or through the one-row-block-per-workgroup batch GEMV (0); 2 takes the weight-stationary kernel at every lane count
+ * (measurement switch). */
 int fq3_batch_set_option(fq3_batch* b, const char* key, int value);
 
 /* ---- 12 Hz codec decoder (speech_tokenizer.decode, model.py:924) ---------------------------- */
