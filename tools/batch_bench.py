@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Batched decode timing (development aid): B lanes of the 0.6B / 1.7B-shape model in lock-step, one hipGraph per frame.
-usage: batch_bench.py [size=0.6b|1.7b] [B list, e.g. 8,16] [frames=48] [graph=1|0]"""
+usage: batch_bench.py [size=0.6b|1.7b] [B list, e.g. 8,16] [frames=48] [graph=1|0] [skinny=0|1|2 -> fq3_batch_set_option("skinny", v)]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "faster-qwen3-tts_amd"))
@@ -15,6 +15,7 @@ def main():
     Bs = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "8").split(",")]
     frames = int(sys.argv[3]) if len(sys.argv) > 3 else 48
     graph = (sys.argv[4] if len(sys.argv) > 4 else "1") != "0"
+    skinny = int(sys.argv[5]) if len(sys.argv) > 5 else None
     cfg = qwen3_tts_0p6b() if size == "0.6b" else qwen3_tts_1p7b()
     dt = torch.bfloat16
     W = synth_weights(cfg, 0, dt, parts=("talker", "predictor"))
@@ -38,12 +39,14 @@ def main():
                              talker_noise=tn, pred_noise=pn, noise_frames=nf, **kw)
             keep.append((tn, pn))
         batch = Fq3Batch(lanes[:B])
+        if skinny is not None:
+            batch.set_option("skinny", skinny)
         if graph:
             batch.graph_capture()
         batch.frames(8); torch.cuda.synchronize()
         t0 = time.perf_counter(); batch.frames(frames); torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0) / frames
         n = [e.decode_poll()[0] for e in lanes[:B]]
-        print(f"{size} B={B} graph={int(graph)}: {ms:.3f} ms per lock-step frame -> {B * 80.0 / ms:.1f}x real-time aggregate "
+        print(f"{size} B={B} graph={int(graph)}{'' if skinny is None else f' skinny={skinny}'}: {ms:.3f} ms per lock-step frame -> {B * 80.0 / ms:.1f}x real-time aggregate "
               f"({80.0 / ms:.1f}x per lane), frames per lane {sorted(set(n))}", flush=True)
         batch.close()
 
