@@ -104,17 +104,27 @@ def prefill_gemm_flops(cfg, L: int) -> float:
 SPEAKER = "synthetic"
 
 
-def build_model(device, size="0p6b", frames=FRAMES, max_seq_len=2048, model_type="base"):
+HEADLINE_CODEC = "fp32"           # vocoder arithmetic of the single-stream headline / configs[2] / configs[4] runs: the mode that meets the
+                                  # north star's 1e-3 PCM bound (parity_pcm); the bf16-codec figures are reported beside them
+
+
+def build_model(device, size="0p6b", frames=FRAMES, max_seq_len=2048, model_type="base", codec_precision=None, share=None):
+    """`share`: a model built before on this device whose weight replica (and config) the new instance borrows -- e.g. the same
+    decode path with another vocoder precision."""
     from fq3hip.config import qwen3_tts_0p6b, qwen3_tts_1p7b
     from fq3hip.weights import synth_weights
     from fq3hip.model import FasterQwen3TTS
-    cfg = qwen3_tts_0p6b() if size == "0p6b" else qwen3_tts_1p7b()
-    cfg.tts_model_type = model_type                          # Base / CustomVoice / VoiceDesign share one architecture
-    cfg.spk_id = {SPEAKER: cfg.talker.vocab_size - 1024 + 300}
-    W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor", "codec", "text"), codec_normalized=True)
+    if share is not None:
+        cfg, W = share._bench_cfg, share._bench_weights
+    else:
+        cfg = qwen3_tts_0p6b() if size == "0p6b" else qwen3_tts_1p7b()
+        cfg.tts_model_type = model_type                          # Base / CustomVoice / VoiceDesign share one architecture
+        cfg.spk_id = {SPEAKER: cfg.talker.vocab_size - 1024 + 300}
+        W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor", "codec", "text"), codec_normalized=True)
     model = FasterQwen3TTS.from_weights(cfg, W, device=device, dtype=torch.bfloat16, max_seq_len=max_seq_len,
-                                        codec_max_frames=REF_FRAMES + frames + 16, max_frames=frames + 8)
-    model._bench_weights = W
+                                        codec_max_frames=REF_FRAMES + frames + 16, max_frames=frames + 8, share=share,
+                                        codec_precision=codec_precision)
+    model._bench_weights, model._bench_cfg = W, cfg
     return cfg, model
 
 
@@ -190,8 +200,9 @@ def frame_roofline(cfg, frame_ms, p_mid, lanes=1, what="decode-frame hipGraph"):
         # the weights are read ONCE per lock-step frame, so the byte count above barely grows with the lanes; what the
         # batch replaces is `lanes` single-stream frames, each of which would stream the weights itself:
         eq = lanes * algorithmic_bytes_per_frame(cfg, p_mid, 1) / (frame_ms * 1e-3) / 1e9
-        out["equivalent_single_stream"] = {"achieved": round(eq, 1), "unit": "GB/s", "frac": round(eq / HBM_PEAK_GBS, 4),
-                                           "note": f"bandwidth {lanes} independent single-stream decodes would need for the same frame rate"}
+        out["unbatched_equivalent"] = {"bandwidth_needed": round(eq, 1), "unit": "GB/s", "times_hbm_peak": round(eq / HBM_PEAK_GBS, 2),
+                                       "note": f"NOT a roofline fraction: the bandwidth {lanes} independent single-stream decodes would need for the same "
+                                               "frame rate (each streaming the weights itself); above 1.0 x peak means unbatched decoding could not reach it"}
     return out
 
 
@@ -421,22 +432,20 @@ def parity_note(cfg, model):
                       "when the oracle's own top-2 margin is <= 3 bf16 ulps (tests/test_gpu_fulldepth.py)"}
 
 
-def parity_pcm(cfg, model, device):
+def parity_pcm(cfg, model, model_hp, device):
     """PCM parity of THIS model's codec weights (bf16 checkpoint values) on a bounded sample: the committed golden waveform of
     the fp32-arithmetic CPU oracle on the same bf16-valued weights (tests/golden/codec_real_q.npz, T = 100 frames > the
     attention window; oracle/make_golden_codec_real.py) against (a) the bf16 codec the headline runs, (b) the high-precision mode
     (codec_precision="fp32": same weights, fp32 activations and fp32 MFMA products), with the cost of each for the full
     370-frame decode.  The north star's 1e-3 is met by (b); (a) sits at the bf16 arithmetic floor of this network (the oracle's
     own bf16 run is 7.6e-3 from its fp32 run)."""
-    from fq3hip.codec import HipSpeechTokenizer
     g = np.load(os.path.join(ROOT, "tests", "golden", "codec_real_q.npz"))
     T = 100
     codes = torch.from_numpy(g[f"codes_{T}"].astype(np.int64)).to(device)
     ref = g[f"pcm_f32q_{T}"]
-    W = model._bench_weights
     rms = lambda a: float(np.sqrt(np.mean(np.square(a.astype(np.float64)))))
-    lo = model.model.model.speech_tokenizer
-    hp = HipSpeechTokenizer(cfg.codec, W, str(device), torch.float32, max_frames=REF_FRAMES + FRAMES + 16)
+    lo = model.model.model.speech_tokenizer               # bf16 vocoder (the batched figures)
+    hp = model_hp.model.model.speech_tokenizer            # the vocoder the headline ran with
     gg = torch.Generator().manual_seed(4)
     full = torch.randint(0, cfg.codec.codebook_size, (REF_FRAMES + FRAMES, cfg.codec.num_quantizers), generator=gg).to(device)
 
@@ -472,9 +481,9 @@ def parity_pcm(cfg, model, device):
         out[name] = {"pcm_rms_vs_fp32_oracle": float(f"{rms(wav - ref):.3e}"), "full_decode_370_frames_ms": round(timed(tok), 3),
                      "streaming_chunk_8_frames_ms": round(chunk_ms(tok), 3)}
     out["fp32_mode"]["meets_1e-3"] = bool(out["fp32_mode"]["pcm_rms_vs_fp32_oracle"] <= 1e-3)
+    out["headline_vocoder"] = f"codec_precision={HEADLINE_CODEC!r} (the 'fp32_mode' row): value / ttfa_ms_p50 of this line were measured with it"
     out["note"] = ("bf16 arithmetic of this synthetic vocoder is chaotic at the 7.6e-3 level (the CPU oracle's own bf16 run vs its fp32 run on "
                    "the same weights); codec_precision='fp32' is the mode that meets the north star's 1e-3")
-    hp.close()
     return out
 
 
@@ -694,15 +703,24 @@ def config4_block(cfg, model, device, prompt_rows=4096, runs=2):
 def model_1p7b_block(cfg, model, device, lanes=16):
     """BASELINE configs[2]: the 1.7B shapes (talker hidden 2048 / intermediate 6144, predictor with projection), single
     stream: RTF / TTFA over 2 utterances + the decode-frame roofline; the lock-step batch at these shapes; the 4096-token prefill;
-    and BASELINE configs[4] end to end (config4_voice_design_4k)."""
+    and BASELINE configs[4] end to end (config4_voice_design_4k).  The single-stream figures (rtf / ttfa_ms_p50 here and in
+    config4_voice_design_4k) run with the 1e-3-compliant vocoder (HEADLINE_CODEC) on a sibling instance over the same weight
+    replica; `*_bf16_codec` are the same runs with the bf16 vocoder of `model`."""
     req = build_request(cfg, device)
+    _c, model_hp = build_model(device, max_seq_len=model.max_seq_len, share=model, codec_precision=HEADLINE_CODEC)
+    model_hp.model.model.tts_model_type = model.model.model.tts_model_type
     one_utterance(model, req, 900)
+    one_utterance(model_hp, req, 901)
     prompt = prepared_prompt(model, req)
     frame_ms, p_mid = measure_frame_graph(model, prompt)
-    res = [one_utterance(model, req, 910 + i) for i in range(2)]
+    res = [one_utterance(model_hp, req, 910 + i) for i in range(2)]
+    res_lo = [one_utterance(model, req, 910 + i) for i in range(2)]
     out = {"workload": "configs[2]: Qwen3-TTS-12Hz-1.7B-Base shapes, voice-clone streaming chunk_size=8, bf16, synthetic weights",
+           "vocoder": f"codec_precision={HEADLINE_CODEC!r} (meets the 1e-3 PCM bound, parity_pcm); *_bf16_codec: the bf16 vocoder",
            "rtf": round(float(np.mean([n * FRAME_S / w for _, w, n, _ in res])), 3),
            "ttfa_ms_p50": round(1000 * float(np.median([t for t, _, _, _ in res])), 2),
+           "rtf_bf16_codec": round(float(np.mean([n * FRAME_S / w for _, w, n, _ in res_lo])), 3),
+           "ttfa_ms_p50_bf16_codec": round(1000 * float(np.median([t for t, _, _, _ in res_lo])), 2),
            "decode_ms_per_frame": round(frame_ms, 4), "roofline": frame_roofline(cfg, frame_ms, p_mid)}
     try:
         # BASELINE configs[4] shape: a 4096-token prompt (synthetic embeddings) through the matrix-core prefill
@@ -735,10 +753,47 @@ def model_1p7b_block(cfg, model, device, lanes=16):
         except Exception as e:
             out[f"batched_b{B}"] = {"error": repr(e)}
     try:
-        out["config4_voice_design_4k"] = config4_block(cfg, model, device)
+        c4 = config4_block(cfg, model_hp, device)
+        lo = config4_block(cfg, model, device, runs=1)
+        c4["vocoder"] = f"codec_precision={HEADLINE_CODEC!r}; *_bf16_codec: the bf16 vocoder"
+        c4["rtf_bf16_codec"], c4["ttfa_ms_p50_bf16_codec"] = lo["rtf"], lo["ttfa_ms_p50"]
+        c4["parity"] = config4_parity(cfg, model)
+        out["config4_voice_design_4k"] = c4
     except Exception as e:
         out["config4_voice_design_4k"] = {"error": repr(e)}
     return out
+
+
+def config4_parity(cfg, model):
+    """Parity of the configs[4] shape AT FULL DEPTH on this very model (1.7B shapes, bf16, 28 + 5 layers): the 4096-token prefill's
+    last-position hidden state / logits and 8 teacher-forced frames over the > 4096-key cache against the CPU oracle's goldens
+    (tests/golden/longprompt_full.npz, oracle/make_golden_longprompt_full.py; same seeded weights and prompt).  oracle/ is the
+    checker only (tests/test_gpu_longprompt.py holds the gates)."""
+    from oracle import teacher_forced as TF
+    from fq3hip.weights import synth_prompt
+    g = np.load(os.path.join(ROOT, "tests", "golden", "longprompt_full.npz"))
+    frames, plen, tlen = (int(x) for x in g["meta"])
+    case = TF.load_case(g, "1p7b_bf16")
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, plen, tlen, 0, dtype=torch.bfloat16)
+    eng = model.talker_graph.engine
+    if eng.max_seq_len < plen + frames + 1:
+        return {"skipped": f"max_seq_len {eng.max_seq_len} < {plen + frames + 1}"}
+    pg = model.predictor_graph
+    saved = (pg.do_sample, pg.top_k, pg.temperature)
+    pg.do_sample, pg.top_k, pg.temperature = False, 0, 1.0
+    try:
+        logits, hidden = eng.prefill(tie[0].to(eng.device).contiguous())
+        lg, hd = logits.float().cpu().numpy(), hidden.float().cpu().numpy()
+        dec = TF.forced_decisions(eng, cfg, tie, tth, tpe, case["codes"], graph=True)
+    finally:
+        pg.do_sample, pg.top_k, pg.temperature = saved
+    sc = TF.score(dec, case, 3.0)
+    ref_l, ref_h = g["1p7b_bf16_logits"], g["1p7b_bf16_hidden"]
+    return {"prefill_hidden_max_err_over_scale": float(f"{np.abs(hd - ref_h).max() / max(1.0, np.abs(ref_h).max()):.3e}"),
+            "prefill_logits_max_err_over_scale": float(f"{np.abs(lg - ref_l).max() / max(1.0, np.abs(ref_l).max()):.3e}"),
+            "matched_decisions": sc["matched_decisions"], "decisions": sc["total"], "matched_frames": sc["matched_frames"],
+            "frames": sc["frames"], "worst_mismatch_margin_bf16_ulp": sc["worst_mismatch_ulp"], "unexplained": sc["unexplained"],
+            "method": "28 + 5 layers, 4096-token prompt, teacher-forced vs CPU-oracle golden ids (K_ULP = 3 rule of tests/test_gpu_fulldepth.py)"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -832,9 +887,10 @@ def main():
     if stub:
         run_one = lambda seed: _stub_utterance(seed)
     else:
-        cfg, model = build_model(device)
+        cfg, model_hp = build_model(device, codec_precision=HEADLINE_CODEC)      # the headline's model: 1e-3-compliant vocoder
+        _c, model = build_model(device, share=model_hp)                          # same weight replica, bf16 vocoder (batched blocks, MFMA rooflines)
         req = build_request(cfg, device)
-        run_one = lambda seed: one_utterance(model, req, seed)
+        run_one = lambda seed: one_utterance(model_hp, req, seed)
 
     # (a high-priority decode stream was tried: no single-stream gain, and it quarters the throughput of the
     #  concurrent-utterance mode -- profiles/r01_concurrent_streams.txt -- so everything stays on default-priority streams)
@@ -865,9 +921,16 @@ def main():
     if solo and args.concurrent > 1:
         guarded("concurrent_utterances_one_gpu", lambda: concurrent_throughput(cfg, model, req, device, streams=args.concurrent))
     if solo:
+        def _bf16_codec_headline():
+            one_utterance(model, req, 1500)
+            r = [one_utterance(model, req, 1501 + i) for i in range(min(max(args.steps, 1), 5))]
+            return {"vocoder": "bf16 (what the reference's Torch path runs; 7.6e-3 PCM RMS from the fp32 oracle, parity_pcm)",
+                    "value": round(float(np.mean([n * FRAME_S / w for _t, w, n, _p in r])), 3), "unit": "x real-time",
+                    "ttfa_ms_p50": round(1000 * float(np.median([t for t, _w, _n, _p in r])), 2), "utterances": len(r)}
+        guarded("headline_with_bf16_codec", _bf16_codec_headline)
         guarded("reference_audio_analysis", lambda: ref_analysis_block(cfg, device))
-        guarded("parity_bf16_frames", lambda: parity_note(cfg, model))
-        guarded("parity_pcm", lambda: parity_pcm(cfg, model, device))
+        guarded("parity_bf16_frames", lambda: parity_note(cfg, model_hp))
+        guarded("parity_pcm", lambda: parity_pcm(cfg, model, model_hp, device))
         guarded("roofline_mfma", lambda: measure_mfma(cfg, model, prompt))
     if solo and args.batch > 1:
         def _batched():
@@ -967,6 +1030,8 @@ def main():
             "ms_per_step": round(1000 * elapsed / max(args.steps, 1), 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random weights at 0.6B shapes incl. text embedding / projection; 200-row ICL prompt built from text + 170 synthetic reference frames)",
             "config": {"workload": "configs[1]: Qwen3-TTS-12Hz-0.6B-Base voice-clone streaming chunk_size=8, hipGraph decode",
+                       "vocoder": f"codec_precision={HEADLINE_CODEC!r}: the vocoder mode that meets the 1e-3 PCM bound (parity_pcm); the same run with the "
+                                  "bf16 vocoder is in headline_with_bf16_codec",
                        "prompt_tokens": PROMPT_LEN, "ref_frames": REF_FRAMES, "frames_per_utterance": FRAMES,
                        "timed_region": "public generate_voice_clone_streaming(): tokenisation (byte-level stand-in tokenizer: no HF tokenizer "
                                        "offline) + prompt build (HIP) + prefill + decode + streaming vocoder, as the reference times it "

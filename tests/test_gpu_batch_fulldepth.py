@@ -9,8 +9,10 @@ batch sit at different positions and finish at different frames.
 
 Tolerances: bf16 -- a mismatch is accepted only where the ORACLE's own top-2 margin is <= K_ULP = 3 bf16 ulps of the winning
 logit (the largest margin of any mismatch observed on this path: 2 ulps at the 0.6B shapes, 3 at the 1.7B shapes, whose
-dot products are twice as long; the single-stream gate is 2), and the matched fraction over all lanes must be >= 0.95
-(measured: 0.6B 4936 / 5120, 1.7B 2460 / 2560 at 8 lanes); fp32 (VALU batch GEMVs, 16 lanes, 0.6B) -- every decision identical."""
+dot products are twice as long), and every lane must reach a FROZEN floor of identical decisions for its utterance: the
+round-3 measurement per shape (profiles/r03_parity_batch_fulldepth.json) minus one decision per lane -- LANE_FLOOR below; it
+replaces the round-3 "matched fraction >= 0.95", which 1.7B / 32 lanes cleared by a hair (0.9547).  K_ULP and the floors do
+not move again.  fp32 (VALU batch GEMVs, 32 lanes, 0.6B) -- every decision identical."""
 import json
 import os
 
@@ -20,8 +22,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-K_ULP = 3.0
-MIN_MATCH = 0.95
+K_ULP = 3.0                 # frozen (round 3)
+# frozen (round 4): identical decisions per lane for (utterance A: 384 decisions, utterance B: 256), round-3 measurement minus one
+LANE_FLOOR = {("0p6b", 8): (373, 240), ("0p6b", 16): (373, 240), ("0p6b", 32): (374, 245),
+              ("1p7b", 8): (367, 248), ("1p7b", 16): (367, 248), ("1p7b", 32): (363, 246)}
 
 from fq3hip.config import qwen3_tts_0p6b, qwen3_tts_1p7b
 from fq3hip.weights import synth_weights, synth_prompt
@@ -128,7 +132,8 @@ def test_batch_full_depth_bf16_mfma_lanes_vs_oracle(size, golden_dir):
                                               per_lane=[s["matched_decisions"] for s in scores],
                                               unexplained=sum(s["unexplained"] for s in scores)))
         assert all(s["unexplained"] == 0 for s in scores), scores
-        assert ok >= MIN_MATCH * tot, (ok, tot)
+        for i, sc in enumerate(scores):
+            assert sc["matched_decisions"] >= LANE_FLOOR[(size, B)][i % len(cases)], (i, sc)
         # lanes that decode the same utterance must agree with each other exactly (lock-step lanes do not interact)
         for i in range(len(cases), B):
             assert scores[i]["matched_decisions"] == scores[i % len(cases)]["matched_decisions"]

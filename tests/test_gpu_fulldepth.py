@@ -21,9 +21,14 @@ Tolerances (north star: "bit-identical in RVQ token indices"):
          (oracle/selfcheck_fulldepth.py, tests/test_oracle_selfcheck.py).
          How many near-tie decisions fall the other way is a coin-flip statistic of the summation order, not a quality
          figure: the goldens hold 42 (0.6B) / 52 (1.7B) decisions with a margin <= 2 ulps out of 384 (9 / 13 exact ties).
-         Measured (MI355X, deterministic kernels): 0.6B 371-376 identical decisions, 1.7B 367-370.  The second gate bounds
-         the flipped share of the near-tie set (margin <= K_ULP) at MAX_FLIPPED = 0.3, so that a kernel that lost precision --
-         and would flip most of them, or any decision with a wider margin -- fails.  The figures are printed, written to
+         The second gate is a FROZEN floor on the number of identical decisions per shape (round 4; it replaces the
+         round-3 "at most 30 % of the near-tie set flipped", which followed the measurement): the count the round-3 kernels
+         measure on MI355X (deterministic: 0.6B 376, 1.7B 367 of 384) minus ONE decision -- MIN_MATCHED below -- so that a
+         kernel that loses precision, and would flip more near-ties or any decision with a wider margin, fails.  In shares of
+         the near-tie set that is <= 9 / 68 = 13 % (0.6B) and <= 18 / 73 = 25 % (1.7B; the <= 20 % the round-3 review asked for
+         is not reachable there: the round-3 kernels already sit at 17 / 73, and the oracle re-evaluated with exactly rounded
+         dot products flips 17 itself, oracle/selfcheck_fulldepth.py).  K_ULP and MIN_MATCHED do not move again: a kernel
+         change that misses them is a regression of that kernel.  The figures are printed, written to
          gpurun_out/parity_fulldepth.json and carried into the bench line.
 """
 import json
@@ -35,8 +40,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-K_ULP = 3.0
-MAX_FLIPPED = 0.3          # of the oracle's near-tie decisions (margin <= K_ULP ulps)
+K_ULP = 3.0                                     # frozen (round 3)
+MIN_MATCHED = {"0p6b": 375, "1p7b": 366}        # frozen (round 4): identical decisions of 384, round-3 measurement minus one
 
 from fq3hip.config import qwen3_tts_0p6b, qwen3_tts_1p7b
 from fq3hip.weights import synth_weights, synth_prompt
@@ -81,8 +86,7 @@ def test_full_depth_teacher_forced(size, tag, golden_dir):
             assert s["matched_decisions"] == s["total"], s
         else:
             assert s["unexplained"] == 0, s
-            near = TF.near_ties(case, K_ULP)
-            assert s["total"] - s["matched_decisions"] <= MAX_FLIPPED * near, (s, near)
+            assert s["matched_decisions"] >= MIN_MATCHED[size], (s, TF.near_ties(case, K_ULP))
     assert res["graph"]["matched_decisions"] == res["direct"]["matched_decisions"]
     _note(f"{size}_{tag}", res["graph"])
     eng.close()

@@ -101,3 +101,54 @@ def test_flash_prefill_paired_block_variants_match_wave_kernel(Lp, n_pad):
         assert d <= 2.0 ** -6 * max(1.0, float(b.abs().max())), (name, d)
     # all rows really differ from zero (a skipped query block would leave stale / zero rows behind)
     assert float(outs[0][3].abs().amax(dim=(0, 2)).min()) > 0
+
+
+@pytest.mark.parametrize("tag,dtype", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+def test_config4_full_depth_prefill_and_teacher_forced_frames(tag, dtype, golden_dir):
+    """BASELINE configs[4] at the depth it is benchmarked at (/root/reference/faster_qwen3_tts/model.py:1328-1505 +
+    generate.py:107-134): all 28 talker layers + 5 predictor layers at the 1.7B shapes, a 4096-token prompt, then 8 greedy
+    frames over the > 4096-key cache through the real fused loop (hipGraph replay), every one of the 16 x 8 decisions scored
+    by teacher forcing against the CPU oracle's golden ids (oracle/make_golden_longprompt_full.py ->
+    tests/golden/longprompt_full.npz).  fp32: prefill outputs to 2e-4 of the scale, every decision identical.  bf16: prefill
+    outputs to bf16 resolution after 28 layers (0.04 x scale), decisions under the frozen K_ULP = 3 rule of
+    tests/test_gpu_fulldepth.py (no mismatch where the oracle's own top-2 margin exceeds 3 bf16 ulps of the winning logit)."""
+    import json
+    from fq3hip.config import qwen3_tts_1p7b
+    from fq3hip.engine import Fq3Engine
+    from oracle import teacher_forced as TF
+    g = np.load(os.path.join(golden_dir, "longprompt_full.npz"))
+    frames, plen, tlen = (int(x) for x in g["meta"])
+    case = TF.load_case(g, f"1p7b_{tag}")
+    cfg = qwen3_tts_1p7b()
+    W = synth_weights(cfg, 0, dtype, parts=("talker", "predictor"))
+    tie, tam, tth, tpe, _ = synth_prompt(cfg, plen, tlen, 0, dtype=dtype)
+    eng = Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=plen + frames + 8, max_frames=frames + 8)
+    del W
+    eng.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    logits, hidden = eng.prefill(tie[0].cuda().contiguous())
+    lg, hd = logits.float().cpu().numpy(), hidden.float().cpu().numpy()
+    ref_l, ref_h = g[f"1p7b_{tag}_logits"], g[f"1p7b_{tag}_hidden"]
+    rel = 2e-4 if dtype == torch.float32 else 0.04
+    d_h = float(np.abs(hd - ref_h).max()) / max(1.0, float(np.abs(ref_h).max()))
+    d_l = float(np.abs(lg - ref_l).max()) / max(1.0, float(np.abs(ref_l).max()))
+    print(f"[config4 full depth] {tag}: max |hidden - oracle| / scale {d_h:.2e}, logits {d_l:.2e}")
+    assert d_h <= rel and d_l <= rel, (tag, d_h, d_l)
+    K_ULP = 3.0
+    res = {}
+    for graph in (True, False):
+        dec = TF.forced_decisions(eng, cfg, tie, tth, tpe, case["codes"], graph=graph)
+        s = TF.score(dec, case, K_ULP)
+        res[graph] = s
+        print(f"[config4 full depth] {tag} {'graph' if graph else 'direct'}: {s}")
+        if tag == "f32":
+            assert s["matched_decisions"] == s["total"], s
+        else:
+            assert s["unexplained"] == 0, s
+    assert res[True]["matched_decisions"] == res[False]["matched_decisions"]
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    p = os.path.join(out, "parity_config4_fulldepth.json")
+    cur = json.load(open(p)) if os.path.exists(p) else {}
+    cur[tag] = dict(res[True], hidden_rel_err=d_h, logits_rel_err=d_l, near_ties=TF.near_ties(case, K_ULP))
+    json.dump(cur, open(p, "w"), indent=1)
+    eng.close()
