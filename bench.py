@@ -787,13 +787,14 @@ def config4_parity(cfg, model):
         dec = TF.forced_decisions(eng, cfg, tie, tth, tpe, case["codes"], graph=True)
     finally:
         pg.do_sample, pg.top_k, pg.temperature = saved
-    sc = TF.score(dec, case, 3.0)
+    sc = TF.score(dec, case, 4.0)
     ref_l, ref_h = g["1p7b_bf16_logits"], g["1p7b_bf16_hidden"]
     return {"prefill_hidden_max_err_over_scale": float(f"{np.abs(hd - ref_h).max() / max(1.0, np.abs(ref_h).max()):.3e}"),
             "prefill_logits_max_err_over_scale": float(f"{np.abs(lg - ref_l).max() / max(1.0, np.abs(ref_l).max()):.3e}"),
             "matched_decisions": sc["matched_decisions"], "decisions": sc["total"], "matched_frames": sc["matched_frames"],
             "frames": sc["frames"], "worst_mismatch_margin_bf16_ulp": sc["worst_mismatch_ulp"], "unexplained": sc["unexplained"],
-            "method": "28 + 5 layers, 4096-token prompt, teacher-forced vs CPU-oracle golden ids (K_ULP = 3 rule of tests/test_gpu_fulldepth.py)"}
+            "method": "28 + 5 layers, 4096-token prompt, teacher-forced vs CPU-oracle golden ids; a mismatch counts as explained when the oracle's own top-2 "
+                      "margin is <= 4 bf16 ulps -- the floor the oracle's own re-evaluation shows at this shape (tests/test_gpu_longprompt.py)"}
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -26,7 +26,8 @@ struct LaneTab {
     unsigned char* seen[kMaxLanes];
     void* past_hidden[kMaxLanes];
 };
-struct LaneKV { void* k[kMaxLanes]; void* v[kMaxLanes]; };
+struct LaneKV { void* k[kMaxLanes]; void* v[kMaxLanes]; };       // per lane: the predictor's contiguous cache, or the base of the talker's block pool
+struct LaneTabs { const int* t[kMaxLanes]; int blk_stride; };     // talker: every lane's block table (paged KV, decode_kernels.cuh)
 
 template <typename T>
 __global__ __launch_bounds__(256) void frame_begin_batch_kernel(LaneTab t, const T* codec_emb, T* pred_in, int H, int G) {
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(64) void attn_pred_batch_kernel(AttnArgs a, LaneKV 
 
 // talker attention: grid (n_kv, workers, B); position, pad count and RoPE row are the lane's own
 template <typename T, int REP>
-__global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, LaneKV kv, LaneTab t, int qkv_stride,
+__global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, LaneKV kv, LaneTabs tabs, LaneTab t, int qkv_stride,
                                                                 const float* rope_now, size_t part_stride) {
     const int l = blockIdx.z;
     a.part = a.part + (size_t)l * part_stride;
@@ -64,22 +65,29 @@ __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, Lane
     // loads go out; across 32 lanes those idle workers were half of the launch's HBM traffic (workers are sized for max_seq_len,
     // the benchmarked caches hold 4 of 8 tiles: 33 of 66 MB per launch, profiles/r03_pmc_batch32_fetch.txt).  Here it leaves its
     // empty partial slot -- the very values the walk over no valid key produces: {0, m = -1e30, l = 0} -- and exits.
-    const int pos = t.st[l]->pos;
-    if ((int)blockIdx.y * kKeysPerTile > pos) {
+    // A lane that is DONE (EOS / limits reached, cancelled, or never armed) must not touch the cache at all: its block table may be
+    // stale -- the scheduler returns a finished lane's blocks to the pool, and they may already belong to another context -- so the
+    // append of the single-stream body would land in somebody else's rows.  It leaves neutral partials ({0, m = 0, l = 1}: the merge
+    // yields zeros, not 0 / 0) and exits.
+    const DecodeState* stl = t.st[l];
+    const int pos = stl->pos, lane_done = stl->done;
+    const bool no_keys = (int)blockIdx.y * kKeysPerTile > pos;
+    if (lane_done || no_keys) {
         for (int e = threadIdx.x; e < REP * kHeadDim; e += 256) {
             const int h = e / kHeadDim, d = e - h * kHeadDim;
             float* p = a.part + (((size_t)blockIdx.x * kMaxWorkers + blockIdx.y) * REP + h) * kPartStride;
             p[d] = 0.f;
-            if (d == 0) { p[kHeadDim] = -1e30f; p[kHeadDim + 1] = 0.f; }
+            if (d == 0) { p[kHeadDim] = lane_done ? 0.f : -1e30f; p[kHeadDim + 1] = lane_done ? 1.f : 0.f; }
         }
         return;
     }
     a.qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)l * qkv_stride;
     a.kcache = kv.k[l]; a.vcache = kv.v[l];
+    a.table = tabs.t[l]; a.blk_stride = tabs.blk_stride;
     a.pos_ptr = nullptr; a.pos_imm = pos;
     a.n_pad = t.st[l]->n_pad;
     a.cos_row = rope_now + (size_t)l * kHeadDim; a.sin_row = a.cos_row + 64;
-    attn_decode_body<T, REP>(a);
+    attn_decode_body<T, REP, true>(a);
 }
 
 // Split-KV merge of the talker attention as its own launch (one thread per 8 head dims per lane, all slot loads in flight

@@ -268,24 +268,31 @@ template <typename T, int NCH, int PRO, int EPI, bool NT, int M = 1, int R = 1>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) { gemv_body<T, NCH, PRO, EPI, NT, M, R>(a); }
 
 // ================================================================================================
-// Attention for one new token over a contiguous static KV cache [n_kv][max_seq][128].
+// Attention for one new token over the talker's PAGED KV cache: fixed-size blocks of 64 keys (= one
+// attention tile) [n_kv][64][128] drawn from a pool shared by every context of a scheduler, addressed
+// through the context's block table (table[key / 64] = block id; fq3_ctx.h).  The code predictor's
+// 17-slot cache and the kernel-chain harness keep the contiguous layout [n_kv][max_seq][128]
+// (PAGED = false).
 // grid = (n_kv_heads, n_workers); worker s walks key tiles s, s+S, ... of 64 keys and ALWAYS writes
 // its partial slot (empty = {m=-1e30, l=0}), so the consumer (o_proj prologue) needs no position.
 // Prologue (every block, redundantly): per-head RMSNorm + RoPE of this group's q heads and of the
 // new k; the worker that owns `pos` appends K/V to the cache.  Only live keys are read (the
 // reference reads all max_seq slots under an additive mask, talker_graph.py:71-92).
+// A block-table entry is a wave-uniform scalar load; the first tile's entry is fetched first and the
+// token-side loads go out while it is in flight, a later tile's entry one tile ahead.
 // ================================================================================================
 struct AttnArgs {
     const void* qkv;
     const void* q_norm_w; const void* k_norm_w; float eps;
     const float* cos_row; const float* sin_row;       // [64] each: RoPE row of this token's position
-    void* kcache; void* vcache; int max_seq;
+    void* kcache; void* vcache; int max_seq;          // contiguous: [n_kv][max_seq][128]; paged: the layer's block pool [n_blocks][n_kv][64][128]
+    const int* table; int blk_stride;                 // paged: block table of the context, elements per block (n_kv * 64 * 128)
     const int* pos_ptr; int pos_imm; int n_pad;
     int n_kv; float* part; float scale;
     int rep; void* out;                               // attn_pred_kernel: q heads per kv head, final output T[q_dim]
 };
 
-template <typename T, int REP>
+template <typename T, int REP, bool PAGED>
 __device__ __forceinline__ void attn_decode_body(const AttnArgs& a) {
     constexpr int HD = kHeadDim, KS = kKeysPerTile, NG = KS / 16;
     const int g = blockIdx.x, s = blockIdx.y, S = gridDim.y;
@@ -297,21 +304,30 @@ __device__ __forceinline__ void attn_decode_body(const AttnArgs& a) {
     const int sub = lane >> 4, c = lane & 15;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
     const int q_dim = a.n_kv * REP * HD, kv_dim = a.n_kv * HD;
-    T* kc = reinterpret_cast<T*>(a.kcache) + (size_t)g * a.max_seq * HD;
-    T* vc = reinterpret_cast<T*>(a.vcache) + (size_t)g * a.max_seq * HD;
+    // contiguous: this kv head's rows; paged: this kv head's 64 rows inside block 0 (a block id adds blk_stride elements)
+    T* kc = reinterpret_cast<T*>(a.kcache) + (PAGED ? (size_t)g * KS * HD : (size_t)g * a.max_seq * HD);
+    T* vc = reinterpret_cast<T*>(a.vcache) + (PAGED ? (size_t)g * KS * HD : (size_t)g * a.max_seq * HD);
+    const int n_tiles = (a.max_seq + KS - 1) / KS;
+    auto block_of = [&](int tile) -> int {            // wave-uniform: a scalar load
+        if constexpr (PAGED) return a.table[tile < n_tiles ? tile : n_tiles - 1];
+        else return 0;
+    };
+    int blk = block_of(s), blk_next = block_of(s + S);
 
     // ---- issue: first key tile (unconditionally, clamped), q/k/v rows, gains, rope row, position ------
     Raw8<T> kr[NG], vr[NG];
-    auto issue_tile = [&](int tile) {
+    auto issue_tile = [&](int tile, int b) {
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
-            int key = tile * KS + (i * 4 + wave) * 4 + sub;
-            key = key < a.max_seq ? key : a.max_seq - 1;
-            ldraw<false>(kr[i], kc + (size_t)key * HD + c * 8);
-            ldraw<false>(vr[i], vc + (size_t)key * HD + c * 8);
+            const int kt = (i * 4 + wave) * 4 + sub;              // key inside the tile
+            size_t off;
+            if constexpr (PAGED) off = (size_t)b * a.blk_stride + (size_t)kt * HD;      // (a block is 64 full rows: no clamp)
+            else { int key = tile * KS + kt; key = key < a.max_seq ? key : a.max_seq - 1; off = (size_t)key * HD; }
+            ldraw<false>(kr[i], kc + off + c * 8);
+            ldraw<false>(vr[i], vc + off + c * 8);
         }
     };
-    issue_tile(s);
+    if constexpr (!PAGED) issue_tile(s, 0);
     // prologue vectors: wave w handles vec w (and w+4 when REP == 4): q heads, then k, then v
     constexpr int NV = (REP + 2 + 3) / 4;
     float px0[NV], px1[NV], pw0[NV], pw1[NV];
@@ -328,10 +344,14 @@ __device__ __forceinline__ void attn_decode_body(const AttnArgs& a) {
     }
     const float cs = a.cos_row[lane], sn = a.sin_row[lane];
     const int pos = a.pos_ptr ? *a.pos_ptr : a.pos_imm;
+    if constexpr (PAGED) issue_tile(s, blk);     // after the token-side loads: they flew while the table entry arrived
     __builtin_amdgcn_sched_barrier(0);           // keep every load above the arithmetic (one round trip, not two)
 
     const int t_pos = pos / KS;
     const bool owner = (t_pos % S) == s;
+    // where the new K / V row goes (the owner only): contiguous slot `pos`, or slot pos % 64 of the block of tile t_pos
+    size_t new_off = (size_t)pos * HD;
+    if constexpr (PAGED) new_off = (size_t)block_of(t_pos) * a.blk_stride + (size_t)(pos - t_pos * KS) * HD;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int vec = wave + 4 * i;
@@ -350,7 +370,7 @@ __device__ __forceinline__ void attn_decode_body(const AttnArgs& a) {
             float* dst = vec == REP ? knew : vnew;
             dst[lane] = x0; dst[lane + 64] = x1;
             if (owner) {
-                T* cp = (vec == REP ? kc : vc) + (size_t)pos * HD;
+                T* cp = (vec == REP ? kc : vc) + new_off;
                 DT<T>::st(cp + lane, x0); DT<T>::st(cp + lane + 64, x1);
             }
         }
@@ -388,7 +408,8 @@ __device__ __forceinline__ void attn_decode_body(const AttnArgs& a) {
         }
     };
     for (int tile = s; tile * KS < pos || tile == s; tile += S) {
-        if (tile != s) issue_tile(tile);
+        if (tile != s) { blk = blk_next; issue_tile(tile, blk); }
+        blk_next = block_of(tile + S);           // the next tile's table entry is in flight while this tile is multiplied
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int key = tile * KS + (i * 4 + wave) * 4 + sub;
@@ -438,8 +459,8 @@ __device__ __forceinline__ void attn_decode_body(const AttnArgs& a) {
     }
 }
 
-template <typename T, int REP>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) { attn_decode_body<T, REP>(a); }
+template <typename T, int REP, bool PAGED>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) { attn_decode_body<T, REP, PAGED>(a); }
 
 // ================================================================================================
 // Code-predictor attention (context <= 17 keys): ONE wave per q head, everything in registers, no LDS, no
@@ -569,16 +590,6 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* x, const T* w, T*
     const float rs = 1.0f / sqrtf(ss / (float)K + eps);
     for (int e = threadIdx.x; e < K; e += 256)
         DT<T>::st(y + e, DT<T>::ld(w + e) * DT<T>::rnd(DT<T>::ld(x + e) * rs));
-}
-
-// [n_kv][L][128] <-> cache [n_kv][max_seq][128]
-template <typename T>
-__global__ void kv_copy_kernel(T* dst, const T* src, int L, int dst_stride, int src_stride, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int per = L * kHeadDim;
-    const int h = i / per, r = i - h * per;
-    dst[(size_t)h * dst_stride + r] = src[(size_t)h * src_stride + r];
 }
 
 template <typename T>

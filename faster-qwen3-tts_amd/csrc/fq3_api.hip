@@ -39,22 +39,147 @@ static bool dims_ok(const fq3_stack_dims& d) {
            d.vocab <= kMaxVocab && d.vocab % 8 == 0 && d.hidden <= 8192 && d.inter <= 8192 * 3 && d.n_layers >= 1;
 }
 
-static int ctx_build(fq3_ctx* c, const fq3_config* cfg);
-extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) {
-    if (!cfg || !out) return fail(FQ3_EINVAL, "null argument");
+// -------------------------------------------------------------------------------------------------
+// Paged KV: block pool, block tables
+// -------------------------------------------------------------------------------------------------
+static int cfg_check(const fq3_config* cfg) {
     if (cfg->dtype != FQ3_BF16 && cfg->dtype != FQ3_F32) return fail(FQ3_EINVAL, "dtype must be FQ3_BF16 or FQ3_F32");
     if (!dims_ok(cfg->talker) || !dims_ok(cfg->predictor))
         return fail(FQ3_EUNSUPPORTED, "unsupported dims (need head_dim 128, GQA ratio 1/2/4, vocab <= 4096 and a multiple of 8, "
                                       "hidden / intermediate multiples of 8)");
     if (cfg->num_code_groups < 2 || cfg->num_code_groups > 64) return fail(FQ3_EINVAL, "num_code_groups");
     if (cfg->max_seq_len < 8) return fail(FQ3_EINVAL, "max_seq_len");
-    fq3_ctx* c = new fq3_ctx();
-    if (int r = ctx_build(c, cfg)) { const std::string m = g_err; fq3_ctx_destroy(c); g_err = m; return r; }   // no half-built context leaks
-    *out = c;
+    return 0;
+}
+
+static void pool_free_(fq3_kv_pool* p) {
+    for (void* q : p->k) if (q) (void)hipFree(q);
+    for (void* q : p->v) if (q) (void)hipFree(q);
+    delete p;
+}
+
+static int pool_create_(const fq3_config* cfg, int n_blocks, fq3_kv_pool** out) {
+    if (n_blocks < 1) return fail(FQ3_EINVAL, "fq3_kv_pool_create: n_blocks must be positive");
+    fq3_kv_pool* p = new fq3_kv_pool();
+    p->dtype = cfg->dtype; p->esz = cfg->dtype == FQ3_BF16 ? 2 : 4;
+    p->n_layers = cfg->talker.n_layers; p->n_kv = cfg->talker.n_kv_heads; p->n_blocks = n_blocks;
+    p->blk_elems = (size_t)p->n_kv * kKeysPerTile * kHeadDim;
+    p->k.assign(p->n_layers, nullptr); p->v.assign(p->n_layers, nullptr);
+    const size_t bytes = (size_t)n_blocks * p->blk_elems * p->esz;
+    for (int i = 0; i < p->n_layers; ++i) {
+        // zero-filled: a table entry of a tile the context does not own points at block 0, whose rows are loaded (and masked) only
+        if (hipMalloc(&p->k[i], bytes) != hipSuccess || hipMalloc(&p->v[i], bytes) != hipSuccess ||
+            hipMemset(p->k[i], 0, bytes) != hipSuccess || hipMemset(p->v[i], 0, bytes) != hipSuccess) {
+            pool_free_(p);
+            return fail(FQ3_EHIP, "fq3_kv_pool_create: allocation of " + std::to_string(2 * bytes >> 20) + " MiB per layer failed");
+        }
+    }
+    p->free_list.resize(n_blocks);
+    for (int i = 0; i < n_blocks; ++i) p->free_list[i] = n_blocks - 1 - i;      // block 0 is handed out first
+    *out = p;
     return FQ3_OK;
 }
 
-static int ctx_build(fq3_ctx* c, const fq3_config* cfg) {
+extern "C" int fq3_kv_pool_create(const fq3_config* cfg, int n_blocks, fq3_kv_pool** out) {
+    if (!cfg || !out) return fail(FQ3_EINVAL, "null argument");
+    if (int r = cfg_check(cfg)) return r;
+    return pool_create_(cfg, n_blocks, out);
+}
+
+extern "C" int fq3_kv_pool_destroy(fq3_kv_pool* p) {
+    if (!p) return FQ3_OK;
+    if (p->users > 0) return fail(FQ3_ESTATE, "fq3_kv_pool_destroy: contexts are still attached");
+    (void)hipDeviceSynchronize();
+    pool_free_(p);
+    return FQ3_OK;
+}
+
+extern "C" int fq3_kv_pool_stats(const fq3_kv_pool* p, int* n_blocks, int* n_free, int* high_water, int64_t* bytes_per_block) {
+    if (!p) return fail(FQ3_EINVAL, "null pool");
+    fq3_kv_pool* q = const_cast<fq3_kv_pool*>(p);
+    std::lock_guard<std::mutex> lk(q->mu);
+    if (n_blocks) *n_blocks = p->n_blocks;
+    if (n_free) *n_free = (int)p->free_list.size();
+    if (high_water) *high_water = p->in_use_high;
+    if (bytes_per_block) *bytes_per_block = (int64_t)2 * p->n_layers * p->blk_elems * p->esz;
+    return FQ3_OK;
+}
+
+struct KvTableVals { int v[128]; };
+__global__ void kv_table_write_kernel(int* table, KvTableVals vals, int first, int count) {
+    const int i = threadIdx.x;
+    if (i < count) table[first + i] = vals.v[i];
+}
+// entries [first, first + count) of the device table <- ids (by value in the launch: nothing on the host is read later)
+static void table_write(fq3_ctx* c, const int* ids, int first, int count, hipStream_t s) {
+    for (int o = 0; o < count; o += 128) {
+        KvTableVals t{};
+        const int n = std::min(128, count - o);
+        for (int i = 0; i < n; ++i) t.v[i] = ids[o + i];
+        hipLaunchKernelGGL(kv_table_write_kernel, dim3(1), dim3(128), 0, s, c->tk.d_table, t, first + o, n);
+    }
+}
+
+static int kv_ensure(fq3_ctx* c, int n_pos, hipStream_t s, bool sync_copy);
+int fq3_kv_ensure_(fq3_ctx* c, int n_pos, hipStream_t s) { return kv_ensure(c, n_pos, s, false); }
+static int kv_ensure(fq3_ctx* c, int n_pos, hipStream_t s, bool sync_copy) {
+    StackBufs& b = c->tk;
+    int need = (std::min(n_pos, b.max_seq) + kKeysPerTile - 1) / kKeysPerTile;
+    need = std::min(need, b.max_blocks);
+    const int have = (int)b.blocks.size();
+    if (need <= have) return 0;
+    fq3_kv_pool* p = b.pool;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if ((int)p->free_list.size() < need - have) {
+            char m[200];
+            snprintf(m, sizeof m, "KV pool exhausted: %d more block(s) of 64 keys needed, %d free of %d", need - have, (int)p->free_list.size(), p->n_blocks);
+            return fail(FQ3_ENOMEM, m);
+        }
+        for (int i = have; i < need; ++i) { b.blocks.push_back(p->free_list.back()); p->free_list.pop_back(); }
+        p->in_use_high = std::max(p->in_use_high, p->n_blocks - (int)p->free_list.size());
+    }
+    if (sync_copy) HIPCHK(hipMemcpy(b.d_table + have, b.blocks.data() + have, (size_t)(need - have) * sizeof(int), hipMemcpyHostToDevice));
+    else table_write(c, b.blocks.data() + have, have, need - have, s);
+    return 0;
+}
+
+extern "C" int fq3_kv_release(fq3_ctx* c, int keep_positions) {
+    if (!c) return fail(FQ3_EINVAL, "null ctx");
+    StackBufs& b = c->tk;
+    const int keep = std::max(0, std::min((int)b.blocks.size(), (keep_positions + kKeysPerTile - 1) / kKeysPerTile));
+    if (keep >= (int)b.blocks.size()) return FQ3_OK;
+    std::lock_guard<std::mutex> lk(b.pool->mu);
+    while ((int)b.blocks.size() > keep) { b.pool->free_list.push_back(b.blocks.back()); b.blocks.pop_back(); }
+    return FQ3_OK;                      // (the stale device entries are never attended: keys >= the next sequence's position)
+}
+
+extern "C" int fq3_kv_blocks(const fq3_ctx* c) { return c ? (int)c->tk.blocks.size() : 0; }
+
+extern "C" int fq3_kv_reserve(fq3_ctx* c, int n_positions, void* stream) {
+    if (!c) return fail(FQ3_EINVAL, "null ctx");
+    if (n_positions < 0) return fail(FQ3_EINVAL, "fq3_kv_reserve: negative position count");
+    return fq3_kv_ensure_(c, n_positions, (hipStream_t)stream);
+}
+
+static int ctx_build(fq3_ctx* c, const fq3_config* cfg, fq3_kv_pool* pool);
+static int ctx_create_(const fq3_config* cfg, fq3_kv_pool* pool, fq3_ctx** out) {
+    if (!cfg || !out) return fail(FQ3_EINVAL, "null argument");
+    if (int r = cfg_check(cfg)) return r;
+    if (pool && (pool->dtype != cfg->dtype || pool->n_layers != cfg->talker.n_layers || pool->n_kv != cfg->talker.n_kv_heads))
+        return fail(FQ3_EINVAL, "fq3_ctx_create_pooled: the pool was built for another dtype / layer count / kv head count");
+    fq3_ctx* c = new fq3_ctx();
+    if (int r = ctx_build(c, cfg, pool)) { const std::string m = g_err; fq3_ctx_destroy(c); g_err = m; return r; }   // no half-built context leaks
+    *out = c;
+    return FQ3_OK;
+}
+extern "C" int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out) { return ctx_create_(cfg, nullptr, out); }
+extern "C" int fq3_ctx_create_pooled(const fq3_config* cfg, fq3_kv_pool* pool, fq3_ctx** out) {
+    if (!pool) return fail(FQ3_EINVAL, "null pool");
+    return ctx_create_(cfg, pool, out);
+}
+
+static int ctx_build(fq3_ctx* c, const fq3_config* cfg, fq3_kv_pool* pool) {
     c->cfg = *cfg;
     c->esz = cfg->dtype == FQ3_BF16 ? 2 : 4;
     const fq3_stack_dims &t = cfg->talker, &p = cfg->predictor;
@@ -71,7 +196,21 @@ static int ctx_build(fq3_ctx* c, const fq3_config* cfg) {
         return 0;
     };
     int r;
-    if ((r = alloc_stack(c->tk, t, cfg->max_seq_len))) return r;
+    {   // talker: paged.  Private pool (fq3_ctx_create): every block taken now = a static cache of max_seq_len slots
+        StackBufs& b = c->tk;
+        b.max_seq = cfg->max_seq_len;
+        b.max_blocks = (cfg->max_seq_len + kKeysPerTile - 1) / kKeysPerTile;
+        b.workers = std::min(kMaxWorkers, b.max_blocks);
+        if (!pool) {
+            if ((r = pool_create_(cfg, b.max_blocks, &pool))) return r;
+            pool->is_private = true;
+        }
+        b.pool = pool;
+        { std::lock_guard<std::mutex> lk(pool->mu); ++pool->users; }
+        b.k = pool->k; b.v = pool->v;
+        if ((r = dmalloc(c, (void**)&b.d_table, (size_t)b.max_blocks * sizeof(int)))) return r;
+        if (pool->is_private && (r = kv_ensure(c, cfg->max_seq_len, nullptr, true))) return r;
+    }
     if ((r = alloc_stack(c->pk, p, pred_seq))) return r;
     const int Hm = std::max(t.hidden, p.hidden), Im = std::max(t.inter, p.inter);
     const int qkvm = std::max(t.n_heads + 2 * t.n_kv_heads, p.n_heads + 2 * p.n_kv_heads) * kHeadDim;
@@ -138,6 +277,12 @@ extern "C" int fq3_ctx_destroy(fq3_ctx* c) {
     (void)hipDeviceSynchronize();
     fq3_graph_reset(c);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    if (fq3_kv_pool* p = c->tk.pool) {
+        (void)fq3_kv_release(c, 0);
+        bool last;
+        { std::lock_guard<std::mutex> lk(p->mu); last = --p->users == 0; }
+        if (p->is_private && last) pool_free_(p);
+    }
     for (void* p : c->allocs) (void)hipFree(p);
     delete c;
     return FQ3_OK;
@@ -223,12 +368,16 @@ static int launch_gemv(const fq3_ctx* c, const GemvArgs& a, bool nt, hipStream_t
     return nt ? launch_gemv_t<float, PRO, EPI, true>(a, s) : launch_gemv_t<float, PRO, EPI, false>(a, s);
 }
 
+template <typename T, bool PAGED>
+static void launch_attn_p(const AttnArgs& a, int rep, int workers, hipStream_t s) {
+    dim3 grid(a.n_kv, workers);
+    if (rep == 1) hipLaunchKernelGGL((attn_decode_kernel<T, 1, PAGED>), grid, dim3(256), 0, s, a);
+    else if (rep == 2) hipLaunchKernelGGL((attn_decode_kernel<T, 2, PAGED>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<T, 4, PAGED>), grid, dim3(256), 0, s, a);
+}
 template <typename T>
 static void launch_attn_t(const AttnArgs& a, int rep, int workers, hipStream_t s) {
-    dim3 grid(a.n_kv, workers);
-    if (rep == 1) hipLaunchKernelGGL((attn_decode_kernel<T, 1>), grid, dim3(256), 0, s, a);
-    else if (rep == 2) hipLaunchKernelGGL((attn_decode_kernel<T, 2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_decode_kernel<T, 4>), grid, dim3(256), 0, s, a);
+    if (a.table) launch_attn_p<T, true>(a, rep, workers, s); else launch_attn_p<T, false>(a, rep, workers, s);
 }
 
 // One token through every layer of a stack (no final norm).  Layer 0 reads its input (and its
@@ -274,6 +423,7 @@ static int run_stack(fq3_ctx* c, bool talker, const StepSrc& src, hipStream_t s)
         a.qkv = c->qkv; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm; a.eps = d.rms_eps;
         a.cos_row = cos_row; a.sin_row = sin_row;
         a.kcache = kv.k[i]; a.vcache = kv.v[i]; a.max_seq = kv.max_seq;
+        a.table = kv.d_table; a.blk_stride = kv.pool ? (int)kv.pool->blk_elems : 0;       // talker: paged; predictor: contiguous (null table)
         a.pos_ptr = src.pos_ptr; a.pos_imm = src.pos_imm;
         a.n_pad = talker ? c->n_pad : 0;
         a.n_kv = d.n_kv_heads; a.part = c->part;
@@ -369,11 +519,25 @@ extern "C" int fq3_set_generation_state(fq3_ctx* c, int n_pad, int rope_delta) {
     return FQ3_OK;
 }
 
-template <typename T>
-static void kv_copy(void* dst, const void* src, int n_kv, int L, int dst_stride, int src_stride, hipStream_t s) {
-    const int n = n_kv * L * kHeadDim;
-    hipLaunchKernelGGL((kv_copy_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, (T*)dst, (const T*)src, L,
-                       dst_stride, src_stride, n);
+// rows [0, L) of one layer between the paged cache and a dense [n_kv][L][128] tensor (the HF layout), 16 bytes per thread
+template <typename T, bool TO_CACHE>
+__global__ __launch_bounds__(256) void kv_paged_copy_kernel(T* cache, const int* table, int blk_stride, T* dense, int n_kv, int L) {
+    constexpr int EPC = 16 / (int)sizeof(T), CPR = kHeadDim / EPC;          // 16-byte chunks per row
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_kv * L * CPR) return;
+    const int ch = i % CPR, row = i / CPR, key = row % L, h = row / L;
+    T* cp = cache + (size_t)table[key / kKeysPerTile] * blk_stride + ((size_t)h * kKeysPerTile + key % kKeysPerTile) * kHeadDim + ch * EPC;
+    T* dp = dense + ((size_t)h * L + key) * kHeadDim + ch * EPC;
+    if (TO_CACHE) *reinterpret_cast<u32x4*>(cp) = *reinterpret_cast<const u32x4*>(dp);
+    else *reinterpret_cast<u32x4*>(dp) = *reinterpret_cast<const u32x4*>(cp);
+}
+template <typename T, bool TO_CACHE>
+static void kv_paged_copy(fq3_ctx* c, int layer, void* k, void* v, int L, hipStream_t s) {
+    const int nk = c->cfg.talker.n_kv_heads, n = nk * L * (kHeadDim * (int)sizeof(T) / 16);
+    if (n <= 0) return;
+    const int bs = (int)c->tk.pool->blk_elems;
+    hipLaunchKernelGGL((kv_paged_copy_kernel<T, TO_CACHE>), dim3((n + 255) / 256), dim3(256), 0, s, (T*)c->tk.k[layer], c->tk.d_table, bs, (T*)k, nk, L);
+    hipLaunchKernelGGL((kv_paged_copy_kernel<T, TO_CACHE>), dim3((n + 255) / 256), dim3(256), 0, s, (T*)c->tk.v[layer], c->tk.d_table, bs, (T*)v, nk, L);
 }
 
 extern "C" int fq3_kv_import(fq3_ctx* c, int layer, const void* k, const void* v, int L, void* stream) {
@@ -386,9 +550,9 @@ extern "C" int fq3_kv_import(fq3_ctx* c, int layer, const void* k, const void* v
         return fail(FQ3_ETOOLONG, b);
     }
     hipStream_t s = (hipStream_t)stream;
-    const int nk = c->cfg.talker.n_kv_heads, ms = c->tk.max_seq * kHeadDim, ls = L * kHeadDim;
-    if (c->cfg.dtype == FQ3_BF16) { kv_copy<bf16_t>(c->tk.k[layer], k, nk, L, ms, ls, s); kv_copy<bf16_t>(c->tk.v[layer], v, nk, L, ms, ls, s); }
-    else { kv_copy<float>(c->tk.k[layer], k, nk, L, ms, ls, s); kv_copy<float>(c->tk.v[layer], v, nk, L, ms, ls, s); }
+    if (int r = fq3_kv_ensure_(c, L, s)) return r;
+    if (c->cfg.dtype == FQ3_BF16) kv_paged_copy<bf16_t, true>(c, layer, const_cast<void*>(k), const_cast<void*>(v), L, s);
+    else kv_paged_copy<float, true>(c, layer, const_cast<void*>(k), const_cast<void*>(v), L, s);
     LAUNCH_CHECK();
     return FQ3_OK;
 }
@@ -396,31 +560,33 @@ extern "C" int fq3_kv_import(fq3_ctx* c, int layer, const void* k, const void* v
 extern "C" int fq3_kv_export(fq3_ctx* c, int layer, void* k, void* v, int L, void* stream) {
     if (!c || !k || !v) return fail(FQ3_EINVAL, "null argument");
     if (layer < 0 || layer >= c->cfg.talker.n_layers || L > c->cfg.max_seq_len) return fail(FQ3_EINVAL, "range");
+    if (L > (int)c->tk.blocks.size() * kKeysPerTile) return fail(FQ3_EINVAL, "fq3_kv_export: rows beyond the blocks this context owns");
     hipStream_t s = (hipStream_t)stream;
-    const int nk = c->cfg.talker.n_kv_heads, ms = c->tk.max_seq * kHeadDim, ls = L * kHeadDim;
-    if (c->cfg.dtype == FQ3_BF16) { kv_copy<bf16_t>(k, c->tk.k[layer], nk, L, ls, ms, s); kv_copy<bf16_t>(v, c->tk.v[layer], nk, L, ls, ms, s); }
-    else { kv_copy<float>(k, c->tk.k[layer], nk, L, ls, ms, s); kv_copy<float>(v, c->tk.v[layer], nk, L, ls, ms, s); }
+    if (c->cfg.dtype == FQ3_BF16) kv_paged_copy<bf16_t, false>(c, layer, k, v, L, s);
+    else kv_paged_copy<float, false>(c, layer, k, v, L, s);
     LAUNCH_CHECK();
     return FQ3_OK;
 }
 
-// KV rows [0, L) of every talker layer, context to context, in one launch: grid (2 * layers, kv heads)
+// fq3_kv_adopt between contexts of DIFFERENT pools: whole blocks [0, ceil(L / 64)) of every talker layer, block to block, in one
+// launch: grid (2 * layers, blocks)
 struct KvAdoptTab { void* dst[128]; const void* src[128]; };
 template <typename T>
-__global__ __launch_bounds__(256) void kv_adopt_kernel(KvAdoptTab t, int L, int dst_seq, int src_seq) {
-    const int which = blockIdx.x, h = blockIdx.y;
-    const u32x4* s = reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(t.src[which]) + (size_t)h * src_seq * kHeadDim);
-    u32x4* d = reinterpret_cast<u32x4*>(reinterpret_cast<T*>(t.dst[which]) + (size_t)h * dst_seq * kHeadDim);
-    const int n16 = L * kHeadDim * (int)sizeof(T) / 16;
+__global__ __launch_bounds__(256) void kv_adopt_kernel(KvAdoptTab t, const int* dst_table, const int* src_table, int blk_elems) {
+    const int which = blockIdx.x, b = blockIdx.y;
+    const u32x4* s = reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(t.src[which]) + (size_t)src_table[b] * blk_elems);
+    u32x4* d = reinterpret_cast<u32x4*>(reinterpret_cast<T*>(t.dst[which]) + (size_t)dst_table[b] * blk_elems);
+    const int n16 = blk_elems * (int)sizeof(T) / 16;
     for (int i = threadIdx.x; i < n16; i += 256) d[i] = s[i];
 }
 
-extern "C" int fq3_kv_adopt(fq3_ctx* dst, const fq3_ctx* src, int L, void* stream) {
+extern "C" int fq3_kv_adopt(fq3_ctx* dst, fq3_ctx* src, int L, void* stream) {
     if (!dst || !src) return fail(FQ3_EINVAL, "null ctx");
+    if (dst == src) return fail(FQ3_EINVAL, "fq3_kv_adopt: source and destination are the same context");
     const auto &a = dst->cfg, &b = src->cfg;
     if (a.dtype != b.dtype || a.talker.n_layers != b.talker.n_layers || a.talker.n_kv_heads != b.talker.n_kv_heads)
         return fail(FQ3_EINVAL, "fq3_kv_adopt: contexts of different shape");
-    if (L < 0 || L > src->tk.max_seq) return fail(FQ3_EINVAL, "fq3_kv_adopt: L outside the source cache");
+    if (L < 0 || L > src->tk.max_seq || L > (int)src->tk.blocks.size() * kKeysPerTile) return fail(FQ3_EINVAL, "fq3_kv_adopt: L outside the source cache");
     if (L > dst->tk.max_seq) {
         char m[256];
         snprintf(m, sizeof m, "Input is too long: prefill has %d tokens but max_seq_len=%d. Use shorter text or shorter reference audio.", L, a.max_seq_len);
@@ -429,12 +595,31 @@ extern "C" int fq3_kv_adopt(fq3_ctx* dst, const fq3_ctx* src, int L, void* strea
     const int nl = a.talker.n_layers;
     if (2 * nl > 128) return fail(FQ3_EUNSUPPORTED, "fq3_kv_adopt: more than 64 layers");
     if (L == 0) return FQ3_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (L + kKeysPerTile - 1) / kKeysPerTile;
+    if (dst->tk.pool == src->tk.pool) {
+        // one pool: hand the blocks over.  dst returns what it holds and takes ALL of src's block ids -- the prompt's and whatever
+        // src had reserved beyond it for the frames to come (fq3_kv_reserve) -- up to its own table length; its device table is
+        // rewritten by one tiny launch on `stream`; src keeps nothing.  No KV row moves.
+        (void)fq3_kv_release(dst, 0);
+        const size_t take = std::min(src->tk.blocks.size(), (size_t)dst->tk.max_blocks);
+        dst->tk.blocks.assign(src->tk.blocks.begin(), src->tk.blocks.begin() + take);
+        if (take < src->tk.blocks.size()) {
+            std::lock_guard<std::mutex> lk(src->tk.pool->mu);
+            for (size_t i = take; i < src->tk.blocks.size(); ++i) src->tk.pool->free_list.push_back(src->tk.blocks[i]);
+        }
+        src->tk.blocks.clear();
+        table_write(dst, dst->tk.blocks.data(), 0, (int)take, s);
+        LAUNCH_CHECK();
+        return FQ3_OK;
+    }
+    if (int r = fq3_kv_ensure_(dst, L, s)) return r;
     KvAdoptTab t{};
     for (int l = 0; l < nl; ++l) { t.dst[2 * l] = dst->tk.k[l]; t.src[2 * l] = src->tk.k[l]; t.dst[2 * l + 1] = dst->tk.v[l]; t.src[2 * l + 1] = src->tk.v[l]; }
-    hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(2 * nl, a.talker.n_kv_heads);
-    if (a.dtype == FQ3_BF16) hipLaunchKernelGGL((kv_adopt_kernel<bf16_t>), grid, dim3(256), 0, s, t, L, dst->tk.max_seq, src->tk.max_seq);
-    else hipLaunchKernelGGL((kv_adopt_kernel<float>), grid, dim3(256), 0, s, t, L, dst->tk.max_seq, src->tk.max_seq);
+    const dim3 grid(2 * nl, nb);
+    const int be = (int)dst->tk.pool->blk_elems;
+    if (a.dtype == FQ3_BF16) hipLaunchKernelGGL((kv_adopt_kernel<bf16_t>), grid, dim3(256), 0, s, t, dst->tk.d_table, src->tk.d_table, be);
+    else hipLaunchKernelGGL((kv_adopt_kernel<float>), grid, dim3(256), 0, s, t, dst->tk.d_table, src->tk.d_table, be);
     LAUNCH_CHECK();
     return FQ3_OK;
 }
@@ -454,6 +639,7 @@ extern "C" int fq3_talker_step(fq3_ctx* c, const void* embeds, int position, voi
     if (!embeds || !out_hidden) return fail(FQ3_EINVAL, "null argument");
     if (position < 0 || position >= c->cfg.max_seq_len) return fail(FQ3_EINVAL, "position outside the static cache");
     hipStream_t s = (hipStream_t)stream;
+    if (int r = fq3_kv_ensure_(c, position + 1, s)) return r;
     StepSrc src{embeds, nullptr, position};
     if (int r = run_stack(c, true, src, s)) return r;
     final_norm(c, true, c->h, out_hidden, s);
@@ -486,6 +672,7 @@ extern "C" int fq3_prefill(fq3_ctx* c, const void* embeds, int L, int n_pad, voi
     if (n_pad < 0 || n_pad >= L) return fail(FQ3_EINVAL, "n_pad");
     if (int r = fq3_set_generation_state(c, n_pad, -n_pad)) return r;
     hipStream_t s = (hipStream_t)stream;
+    if (int r = fq3_kv_ensure_(c, L, s)) return r;
     void* hid = out_hidden ? out_hidden : c->tmp_hidden;
     if (c->prefill_mode != 1 && L - n_pad >= 4) {
         // matrix-core prefill: GEMMs over all prompt rows, causal attention, KV written straight to the cache
@@ -544,6 +731,17 @@ extern "C" int fq3_prefill_batch(fq3_ctx* const* ctxs, int n, const void* const*
     }
     for (int q = 0; q < n; ++q)
         if (int r = fq3_set_generation_state(ctxs[q], n_pad[q], -n_pad[q])) return r;
+    {   // the blocks of every prompt, all or nothing: a short pool leaves every context as it was
+        std::vector<int> had(n);
+        for (int q = 0; q < n; ++q) had[q] = (int)ctxs[q]->tk.blocks.size();
+        for (int q = 0; q < n; ++q)
+            if (int r = fq3_kv_ensure_(ctxs[q], L[q], (hipStream_t)stream)) {
+                const std::string m = g_err;
+                for (int p = 0; p < q; ++p) (void)fq3_kv_release(ctxs[p], had[p] * kKeysPerTile);
+                g_err = m;
+                return r;
+            }
+    }
     if (int r = fq3_prefill_batch_mfma_(ctxs, n, embeds, L, n_pad, out_logits, out_hidden, (hipStream_t)stream)) return r;
     LAUNCH_CHECK();
     return FQ3_OK;
@@ -763,6 +961,8 @@ extern "C" int fq3_decode_begin(fq3_ctx* c, const fq3_decode_params* p, void* st
     const bool wave = p->talker.top_p >= 1.0f;
     if (wave != c->talker_wave) { fq3_graph_reset(c); c->talker_wave = wave; }
     hipStream_t s = (hipStream_t)stream;
+    // the blocks the loop can reach: frame f appends slot prefill_len + f, the loop stops at max_new_tokens or at max_seq_len - 1
+    if (int r = fq3_kv_ensure_(c, p->prefill_len + p->max_new_tokens + 1, s)) return r;
     DecodeState h{};
     h.token = p->first_token; h.frame = 0; h.pos = p->prefill_len; h.gen_step = p->gen_step; h.done = 0;
     h.min_new = p->min_new_tokens; h.max_new = p->max_new_tokens; h.trailing_len = p->trailing_len;
@@ -779,6 +979,14 @@ extern "C" int fq3_decode_begin(fq3_ctx* c, const fq3_decode_params* p, void* st
     // is read after the call returns and the host does not wait for the stream
     hipLaunchKernelGGL(decode_arm_kernel, dim3(1), dim3(256), 0, s, c->st, h, c->seen, (int)kMaxVocab,
                        (uint32_t*)c->past_hidden, (const uint32_t*)p->past_hidden, (int)((size_t)c->cfg.talker.hidden * c->esz / 4));
+    LAUNCH_CHECK();
+    return FQ3_OK;
+}
+
+__global__ void decode_cancel_kernel(DecodeState* st) { st->done = 1; }
+extern "C" int fq3_decode_cancel(fq3_ctx* c, void* stream) {
+    if (!c) return fail(FQ3_EINVAL, "null ctx");
+    hipLaunchKernelGGL(decode_cancel_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, c->st);
     LAUNCH_CHECK();
     return FQ3_OK;
 }

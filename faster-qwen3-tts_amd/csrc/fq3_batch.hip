@@ -26,6 +26,7 @@ struct fq3_batch {
     int Hm = 0, Im = 0, qkvm = 0;
     LaneTab tab{};
     std::vector<LaneKV> tkv, pkv;
+    LaneTabs ttab{};              // the lanes' block tables (paged talker KV)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr;
@@ -77,7 +78,7 @@ extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** 
             c->cfg.talker.n_kv_heads == c0->cfg.talker.n_kv_heads && c->cfg.talker.vocab == c0->cfg.talker.vocab &&
             c->cfg.predictor.hidden == c0->cfg.predictor.hidden && c->cfg.predictor.inter == c0->cfg.predictor.inter &&
             c->cfg.predictor.n_layers == c0->cfg.predictor.n_layers && c->cfg.predictor.vocab == c0->cfg.predictor.vocab &&
-            c->tk.max_seq == c0->tk.max_seq && c->tk.workers == c0->tk.workers;
+            c->tk.max_seq == c0->tk.max_seq && c->tk.workers == c0->tk.workers && c->tk.pool->blk_elems == c0->tk.pool->blk_elems;
         // one weight replica: every lane must have been bound to the same table
         const bool same_w = c->wt.codec_head == c0->wt.codec_head && c->wt.codec_embedding == c0->wt.codec_embedding &&
             c->tl[0].qkv == c0->tl[0].qkv && c->pl[0].qkv == c0->pl[0].qkv && c->wt.talker_cos == c0->wt.talker_cos;
@@ -110,6 +111,8 @@ extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** 
     }
     b->tkv.resize(t.n_layers); b->pkv.resize(p.n_layers);
     for (int i = 0; i < t.n_layers; ++i) for (int l = 0; l < B; ++l) { b->tkv[i].k[l] = lanes[l]->tk.k[i]; b->tkv[i].v[l] = lanes[l]->tk.v[i]; }
+    for (int l = 0; l < B; ++l) b->ttab.t[l] = lanes[l]->tk.d_table;
+    b->ttab.blk_stride = (int)c0->tk.pool->blk_elems;
     for (int i = 0; i < p.n_layers; ++i) for (int l = 0; l < B; ++l) { b->pkv[i].k[l] = lanes[l]->pk.k[i]; b->pkv[i].v[l] = lanes[l]->pk.v[i]; }
     if (hipStreamCreateWithFlags(&b->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "hipStreamCreateWithFlags");
@@ -260,9 +263,9 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
         if (talker) {
             a.max_seq = c->tk.max_seq; a.part = b->part;
             const dim3 grid(d.n_kv_heads, c->tk.workers, B);
-            if (rep == 1) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 1>), grid, dim3(256), 0, s, a, b->tkv[i], b->tab, b->qkvm, b->rope_now, b->part_stride);
-            else if (rep == 2) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 2>), grid, dim3(256), 0, s, a, b->tkv[i], b->tab, b->qkvm, b->rope_now, b->part_stride);
-            else hipLaunchKernelGGL((attn_decode_batch_kernel<T, 4>), grid, dim3(256), 0, s, a, b->tkv[i], b->tab, b->qkvm, b->rope_now, b->part_stride);
+            if (rep == 1) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 1>), grid, dim3(256), 0, s, a, b->tkv[i], b->ttab, b->tab, b->qkvm, b->rope_now, b->part_stride);
+            else if (rep == 2) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 2>), grid, dim3(256), 0, s, a, b->tkv[i], b->ttab, b->tab, b->qkvm, b->rope_now, b->part_stride);
+            else hipLaunchKernelGGL((attn_decode_batch_kernel<T, 4>), grid, dim3(256), 0, s, a, b->tkv[i], b->ttab, b->tab, b->qkvm, b->rope_now, b->part_stride);
             hipLaunchKernelGGL((combine_batch_kernel<T>), dim3((q_dim / 8 + 255) / 256, B), dim3(256), 0, s, (const float*)b->part, b->part_stride,
                                c->tk.workers, rep, q_dim, (T*)b->attn_out, b->qkvm);
             o.x = b->attn_out; o.x_stride = b->qkvm;

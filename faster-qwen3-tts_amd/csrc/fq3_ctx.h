@@ -3,12 +3,35 @@
 #include "../../include/fq3hip.h"
 #include "decode_kernels.cuh"
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
+// Talker KV cache: PAGED.  A pool holds, per layer, n_blocks blocks of kKeysPerTile = 64 keys ([n_kv][64][128] elements of K, the
+// same of V); a context owns a list of block ids -- its block table, mirrored on the device for the kernels -- and grows / returns
+// it through kv_ensure_ / fq3_kv_release.  fq3_ctx_create gives a context a private pool of ceil(max_seq_len / 64) blocks, all of
+// them taken at creation (the static cache of the reference, talker_graph.py:43); fq3_ctx_create_pooled draws from a pool shared by
+// the contexts of one scheduler, so that an idle context holds nothing, a prefilled one its prompt's blocks, and a lane takes a
+// staged prompt over by exchanging block ids (fq3_kv_adopt) instead of copying rows.
+struct fq3_kv_pool {
+    int dtype = 0, esz = 2, n_layers = 0, n_kv = 0, n_blocks = 0;
+    size_t blk_elems = 0;             // elements per block per layer and per K | V: n_kv * 64 * 128
+    std::vector<void*> k, v;          // per layer [n_blocks][n_kv][64][128]
+    std::vector<int> free_list;       // LIFO of free block ids
+    std::mutex mu;
+    int in_use_high = 0;              // high-water mark of blocks handed out
+    int users = 0;                    // contexts attached
+    bool is_private = false;          // owned by exactly one context (destroyed with it)
+};
+
 struct StackBufs {
-    std::vector<void*> k, v;          // per layer [n_kv][max_seq][128]
+    std::vector<void*> k, v;          // per layer: predictor [n_kv][max_seq][128] (contiguous); talker: the pool's layer arrays
     int max_seq = 0, workers = 1;
+    // talker only
+    fq3_kv_pool* pool = nullptr;
+    int* d_table = nullptr;           // device int32[max_blocks]: block id of key tile i (unowned entries: 0, never attended)
+    std::vector<int> blocks;          // host mirror: the block ids this context owns, in tile order
+    int max_blocks = 0;
 };
 
 struct fq3_ctx {
@@ -59,6 +82,9 @@ struct fq3_ctx {
 
 
 int fq3_fail_(int code, const std::string& m);                 // sets the thread-local error string
+// make sure the context owns the blocks of key slots [0, n_pos) (capped at max_seq_len); new table entries are written on `s`.
+// FQ3_ENOMEM when the pool has too few free blocks (nothing is taken then).
+int fq3_kv_ensure_(fq3_ctx* c, int n_pos, hipStream_t s);
 int fq3_prefill_reserve_(fq3_ctx* c);
 int fq3_prefill_mfma_(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits, void* out_hidden, hipStream_t s);
 int fq3_prefill_batch_mfma_(fq3_ctx* const* cs, int n, const void* const* embeds, const int* L, const int* n_pad, void* const* out_logits,

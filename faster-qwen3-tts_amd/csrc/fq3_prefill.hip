@@ -12,11 +12,22 @@ using namespace fq3;
 
 namespace {
 
+// One layer of a context's paged talker cache (fq3_ctx.h): pool arrays [n_blocks][n_kv][64][128], the block table, elements per block.
+// Row `key` of kv head g: base + table[key / 64] * blk_stride + (g * 64 + key % 64) * 128.
+template <typename T> struct PagedKV { T* k; T* v; const int* table; int blk_stride; };
+template <typename T> PagedKV<T> paged_kv(const fq3_ctx* c, int layer) {
+    return PagedKV<T>{(T*)c->tk.k[layer], (T*)c->tk.v[layer], c->tk.d_table, (int)c->tk.pool->blk_elems};
+}
+template <typename T>
+__device__ __forceinline__ size_t paged_row(const PagedKV<T>& kv, int g, int key) {
+    return (size_t)kv.table[key / kKeysPerTile] * kv.blk_stride + ((size_t)g * kKeysPerTile + key % kKeysPerTile) * kHeadDim;
+}
+
 // per (token, head): RMSNorm over 128 + RoPE for q (in place) and k (-> cache); v copied to the cache
 template <typename T>
 __global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(T* qkv, const T* qw, const T* kw, float eps, const float* cos_tab,
-                                                              const float* sin_tab, int rope_len, int rope_delta, T* kcache,
-                                                              T* vcache, int max_seq, int L, int n_pad, int NH, int NKV) {
+                                                              const float* sin_tab, int rope_len, int rope_delta, PagedKV<T> kv,
+                                                              int L, int n_pad, int NH, int NKV) {
     constexpr int HD = kHeadDim;
     const int per = NH + 2 * NKV;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -37,8 +48,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(T* qkv, const T* q
         x0 = DT<T>::rnd(DT<T>::rnd(n0 * cs) + DT<T>::rnd(-n1 * sn));
         x1 = DT<T>::rnd(DT<T>::rnd(n1 * cs) + DT<T>::rnd(n0 * sn));
     }
-    T* dst = v < NH ? src : (v < NH + NKV ? kcache + ((size_t)(v - NH) * max_seq + t) * HD
-                                           : vcache + ((size_t)(v - NH - NKV) * max_seq + t) * HD);
+    T* dst = v < NH ? src : (v < NH + NKV ? kv.k + paged_row(kv, v - NH, t) : kv.v + paged_row(kv, v - NH - NKV, t));
     DT<T>::st(dst + lane, x0);
     DT<T>::st(dst + lane + 64, x1);
 }
@@ -46,7 +56,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(T* qkv, const T* q
 // causal attention for the prompt: one wave per (query row, q head); 16 lanes per key (8 dims each),
 // 16 keys in flight per trip; fp32 online softmax, one rounding at the end.
 template <typename T>
-__global__ __launch_bounds__(256) void prefill_attn_kernel(const T* qkv, const T* kcache, const T* vcache, T* out, int max_seq,
+__global__ __launch_bounds__(256) void prefill_attn_kernel(const T* qkv, PagedKV<T> kv, T* out,
                                                            int L, int n_pad, int NH, int NKV, float scale) {
     constexpr int HD = kHeadDim;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -65,8 +75,6 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(const T* qkv, const T
     ldraw<false>(qraw, qkv + (size_t)t * per * HD + (size_t)h * HD + c * 8);
     float q[8];
     unpack(qraw, q);
-    const T* kc = kcache + (size_t)g * max_seq * HD;
-    const T* vc = vcache + (size_t)g * max_seq * HD;
     float m = -1e30f, l = 0.f, o[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = 0.f;
@@ -76,8 +84,9 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(const T* qkv, const T
         for (int i = 0; i < 4; ++i) {
             int key = k0 + i * 4 + sub;
             key = key <= t ? key : t;
-            ldraw<false>(kr[i], kc + (size_t)key * HD + c * 8);
-            ldraw<false>(vr[i], vc + (size_t)key * HD + c * 8);
+            const size_t off = paged_row(kv, g, key) + c * 8;
+            ldraw<false>(kr[i], kv.k + off);
+            ldraw<false>(vr[i], kv.v + off);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -128,8 +137,8 @@ constexpr int kFaQ = 64, kFaK = 64, kFaKLd = kHeadDim + 8, kFaVLd = kFaK + 8, kF
 // workgroup walks the same number of key tiles (nqb + 1) instead of 1 .. nqb of them: a 4096-token prompt at 128 queries per block
 // is 16 pairs x 16 heads = 256 equal workgroups, one per CU.
 template <int NW, bool PAIRED>
-__global__ __launch_bounds__(64 * NW) void flash_prefill_kernel(const bf16_t* qkv, const bf16_t* kcache, const bf16_t* vcache, bf16_t* out,
-                                                                int max_seq, int L, int n_pad, int NH, int NKV, float scale, int nqb) {
+__global__ __launch_bounds__(64 * NW) void flash_prefill_kernel(const bf16_t* qkv, PagedKV<bf16_t> kv, bf16_t* out,
+                                                                int L, int n_pad, int NH, int NKV, float scale, int nqb) {
     constexpr int HD = kHeadDim, Q = 16 * NW, CPT = 16 / NW;             // CPT: 16-byte chunks of a K (and V) row staged per thread
     __shared__ __attribute__((aligned(16))) bf16_t Ks[kFaK * kFaKLd];            // [key][dim]
     __shared__ __attribute__((aligned(16))) bf16_t Vt[HD * kFaVLd];              // [dim][key]
@@ -137,8 +146,9 @@ __global__ __launch_bounds__(64 * NW) void flash_prefill_kernel(const bf16_t* qk
     const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.y, g = h / (NH / NKV), per = NH + 2 * NKV;
-    const bf16_t* kc = kcache + (size_t)g * max_seq * HD;
-    const bf16_t* vc = vcache + (size_t)g * max_seq * HD;
+    // a key tile IS a block of the paged cache: tile t of kv head g = 64 contiguous rows at block table[t]
+    const bf16_t* kc = kv.k + (size_t)g * kFaK * HD;
+    const bf16_t* vc = kv.v + (size_t)g * kFaK * HD;
     const float sl2 = scale * 1.4426950408889634f;                        // softmax in base 2: exp(x) = exp2(x * log2 e)
     // staging: thread -> key (tid & 63), 16-byte chunks (tid >> 6) + NW j of that key's K and V rows
     const int skey = tid & 63, sch = tid >> 6;
@@ -164,12 +174,11 @@ __global__ __launch_bounds__(64 * NW) void flash_prefill_kernel(const bf16_t* qk
     const int t_lo = n_pad / kFaK, t_hi = q_hi / kFaK;                    // key tiles [t_lo, t_hi]
     u32x4 kst[CPT], vst[CPT];
     auto issue = [&](int tile) {
-        int key = tile * kFaK + skey;
-        key = key < max_seq ? key : max_seq - 1;
+        const size_t off = (size_t)kv.table[tile] * kv.blk_stride + (size_t)skey * HD;       // tile <= t_hi: a block this prompt owns
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            kst[j] = *reinterpret_cast<const u32x4*>(kc + (size_t)key * HD + (sch + NW * j) * 8);
-            vst[j] = *reinterpret_cast<const u32x4*>(vc + (size_t)key * HD + (sch + NW * j) * 8);
+            kst[j] = *reinterpret_cast<const u32x4*>(kc + off + (sch + NW * j) * 8);
+            vst[j] = *reinterpret_cast<const u32x4*>(vc + off + (sch + NW * j) * 8);
         }
     };
     issue(t_lo);
@@ -276,17 +285,17 @@ __global__ __launch_bounds__(64 * NW) void flash_prefill_kernel(const bf16_t* qk
 
 // shape choice: short prompts keep 64-query blocks, one per workgroup (parallelism first); from 1024 tokens the blocks are paired
 // (equal work per workgroup under the causal mask), from 3072 tokens they hold 128 queries
-static void flash_prefill_launch(const bf16_t* qkv, const bf16_t* k, const bf16_t* v, bf16_t* out, int max_seq, int L, int n_pad, int NH,
+static void flash_prefill_launch(const bf16_t* qkv, const PagedKV<bf16_t>& kv, bf16_t* out, int L, int n_pad, int NH,
                                  int NKV, float scale, hipStream_t s) {
     if (L >= 3072) {
         const int nqb = (L + 127) / 128;
-        hipLaunchKernelGGL((flash_prefill_kernel<8, true>), dim3((nqb + 1) / 2, NH), dim3(512), 0, s, qkv, k, v, out, max_seq, L, n_pad, NH, NKV, scale, nqb);
+        hipLaunchKernelGGL((flash_prefill_kernel<8, true>), dim3((nqb + 1) / 2, NH), dim3(512), 0, s, qkv, kv, out, L, n_pad, NH, NKV, scale, nqb);
     } else if (L >= 1024) {
         const int nqb = (L + 63) / 64;
-        hipLaunchKernelGGL((flash_prefill_kernel<4, true>), dim3((nqb + 1) / 2, NH), dim3(256), 0, s, qkv, k, v, out, max_seq, L, n_pad, NH, NKV, scale, nqb);
+        hipLaunchKernelGGL((flash_prefill_kernel<4, true>), dim3((nqb + 1) / 2, NH), dim3(256), 0, s, qkv, kv, out, L, n_pad, NH, NKV, scale, nqb);
     } else {
         const int nqb = (L + 63) / 64;
-        hipLaunchKernelGGL((flash_prefill_kernel<4, false>), dim3(nqb, NH), dim3(256), 0, s, qkv, k, v, out, max_seq, L, n_pad, NH, NKV, scale, nqb);
+        hipLaunchKernelGGL((flash_prefill_kernel<4, false>), dim3(nqb, NH), dim3(256), 0, s, qkv, kv, out, L, n_pad, NH, NKV, scale, nqb);
     }
 }
 
@@ -354,19 +363,15 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
         const fq3_layer_weights& w = c->tl[i];
         rmsnorm_rows<T>((const T*)X, (const T*)w.input_norm, XN, L, H, d.rms_eps, s);
         gemm<T>(lin<T>(c, XN, L, H, w.qkv, per, QKV), s);
+        const PagedKV<T> kv = paged_kv<T>(c, i);
         hipLaunchKernelGGL((qk_norm_rope_kv_kernel<T>), dim3((L * (NH + 2 * NKV) + 3) / 4), dim3(256), 0, s, QKV, (const T*)w.q_norm,
                            (const T*)w.k_norm, d.rms_eps, c->wt.talker_cos, c->wt.talker_sin, c->wt.talker_rope_len, c->rope_delta,
-                           (T*)c->tk.k[i], (T*)c->tk.v[i], c->tk.max_seq, L, n_pad, NH, NKV);
+                           kv, L, n_pad, NH, NKV);
         if constexpr (sizeof(T) == 2) {
-            if (c->opt_flash_prefill)
-                flash_prefill_launch((const bf16_t*)QKV, (const bf16_t*)c->tk.k[i], (const bf16_t*)c->tk.v[i], (bf16_t*)ATT, c->tk.max_seq, L, n_pad,
-                                     NH, NKV, scale, s);
-            else
-                hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((L * NH + 3) / 4), dim3(256), 0, s, (const T*)QKV, (const T*)c->tk.k[i],
-                                   (const T*)c->tk.v[i], ATT, c->tk.max_seq, L, n_pad, NH, NKV, scale);
+            if (c->opt_flash_prefill) flash_prefill_launch((const bf16_t*)QKV, kv, (bf16_t*)ATT, L, n_pad, NH, NKV, scale, s);
+            else hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((L * NH + 3) / 4), dim3(256), 0, s, (const T*)QKV, kv, ATT, L, n_pad, NH, NKV, scale);
         } else {
-            hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((L * NH + 3) / 4), dim3(256), 0, s, (const T*)QKV, (const T*)c->tk.k[i],
-                               (const T*)c->tk.v[i], ATT, c->tk.max_seq, L, n_pad, NH, NKV, scale);
+            hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((L * NH + 3) / 4), dim3(256), 0, s, (const T*)QKV, kv, ATT, L, n_pad, NH, NKV, scale);
         }
         { GemmArgs a = lin<T>(c, ATT, L, QD, w.o, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
         rmsnorm_rows<T>((const T*)X, (const T*)w.post_norm, XN, L, H, d.rms_eps, s);
@@ -411,19 +416,17 @@ int prefill_batch_t(fq3_ctx* const* cs, int n, const void* const* embeds, const 
             T* qkv = QKV + (size_t)off[q] * per;
             T* att = ATT + (size_t)off[q] * QD;
             const int Lq = L[q], pq = n_pad[q];
+            const PagedKV<T> kv = paged_kv<T>(cq, i);
             hipLaunchKernelGGL((qk_norm_rope_kv_kernel<T>), dim3((Lq * (NH + 2 * NKV) + 3) / 4), dim3(256), 0, s, qkv, (const T*)w.q_norm,
                                (const T*)w.k_norm, d.rms_eps, c->wt.talker_cos, c->wt.talker_sin, c->wt.talker_rope_len, cq->rope_delta,
-                               (T*)cq->tk.k[i], (T*)cq->tk.v[i], cq->tk.max_seq, Lq, pq, NH, NKV);
+                               kv, Lq, pq, NH, NKV);
             bool flash = false;
             if constexpr (sizeof(T) == 2) flash = c->opt_flash_prefill != 0;
             if constexpr (sizeof(T) == 2) {
-                if (flash)
-                    flash_prefill_launch((const bf16_t*)qkv, (const bf16_t*)cq->tk.k[i], (const bf16_t*)cq->tk.v[i], (bf16_t*)att, cq->tk.max_seq, Lq, pq,
-                                         NH, NKV, scale, s);
+                if (flash) flash_prefill_launch((const bf16_t*)qkv, kv, (bf16_t*)att, Lq, pq, NH, NKV, scale, s);
             }
             if (!flash)
-                hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((Lq * NH + 3) / 4), dim3(256), 0, s, (const T*)qkv, (const T*)cq->tk.k[i],
-                                   (const T*)cq->tk.v[i], att, cq->tk.max_seq, Lq, pq, NH, NKV, scale);
+                hipLaunchKernelGGL((prefill_attn_kernel<T>), dim3((Lq * NH + 3) / 4), dim3(256), 0, s, (const T*)qkv, kv, att, Lq, pq, NH, NKV, scale);
         }
         { GemmArgs a = lin<T>(c, ATT, Lt, QD, w.o, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
         rmsnorm_rows<T>((const T*)X, (const T*)w.post_norm, XN, Lt, H, d.rms_eps, s);

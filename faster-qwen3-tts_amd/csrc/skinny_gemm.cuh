@@ -254,11 +254,12 @@ inline void skinny_go(const SkinnyArgs& a, hipStream_t s) {
 // hipGraph stream capture (the batch decode graph).
 template <int EPI>
 inline bool skinny_prepare() {
+    // (every attribute call is made, whatever the earlier ones returned)
+    const bool r[] = {skinny_attr<1024, 1, EPI>(), skinny_attr<1024, 2, EPI>(), skinny_attr<1024, 3, EPI>(),
+                      skinny_attr<2048, 1, EPI>(), skinny_attr<2048, 2, EPI>(), skinny_attr<2048, 3, EPI>(),
+                      skinny_attr<3072, 1, EPI>(), skinny_attr<3072, 2, EPI>(), skinny_attr<6144, 1, EPI>()};
     bool ok = true;
-    ok &= skinny_attr<1024, 1, EPI>() & skinny_attr<1024, 2, EPI>() & skinny_attr<1024, 3, EPI>();
-    ok &= skinny_attr<2048, 1, EPI>() & skinny_attr<2048, 2, EPI>() & skinny_attr<2048, 3, EPI>();
-    ok &= skinny_attr<3072, 1, EPI>() & skinny_attr<3072, 2, EPI>();
-    ok &= skinny_attr<6144, 1, EPI>();
+    for (bool b : r) ok = ok && b;
     return ok;
 }
 

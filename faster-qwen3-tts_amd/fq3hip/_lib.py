@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfq3hip.so")
 
 FQ3_BF16, FQ3_F32 = 0, 1
-FQ3_OK, FQ3_EINVAL, FQ3_EHIP, FQ3_ESTATE, FQ3_ETOOLONG, FQ3_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+FQ3_OK, FQ3_EINVAL, FQ3_EHIP, FQ3_ESTATE, FQ3_ETOOLONG, FQ3_EUNSUPPORTED, FQ3_ENOMEM = 0, -1, -2, -3, -4, -5, -6
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -87,6 +87,13 @@ SIGNATURES = {
     "fq3_abi_version": (C.c_int, []),
     "fq3_ctx_create": (C.c_int, [C.POINTER(Config), C.POINTER(vp)]),
     "fq3_ctx_destroy": (C.c_int, [vp]),
+    "fq3_kv_pool_create": (C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(vp)]),
+    "fq3_kv_pool_destroy": (C.c_int, [vp]),
+    "fq3_kv_pool_stats": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "fq3_ctx_create_pooled": (C.c_int, [C.POINTER(Config), vp, C.POINTER(vp)]),
+    "fq3_kv_reserve": (C.c_int, [vp, C.c_int, vp]),
+    "fq3_kv_release": (C.c_int, [vp, C.c_int]),
+    "fq3_kv_blocks": (C.c_int, [vp]),
     "fq3_bind_weights": (C.c_int, [vp, C.POINTER(WeightTable)]),
     "fq3_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "fq3_kv_import": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp]),
@@ -106,6 +113,7 @@ SIGNATURES = {
                              C.c_int, vp, vp, vp]),
     "fq3_apply_repetition_penalty": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, vp]),
     "fq3_decode_begin": (C.c_int, [vp, C.POINTER(DecodeParams), vp]),
+    "fq3_decode_cancel": (C.c_int, [vp, vp]),
     "fq3_decode_set_forced": (C.c_int, [vp, vp, vp, vp]),
     "fq3_decode_frames": (C.c_int, [vp, C.c_int, vp]),
     "fq3_decode_poll": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]),
@@ -163,7 +171,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = ABI drift; let it surface
         fn.restype = res
         fn.argtypes = args
-    if lib.fq3_abi_version() != 3:
+    if lib.fq3_abi_version() != 4:
         raise ImportError("libfq3hip ABI version mismatch")
     _lib = lib
     return lib

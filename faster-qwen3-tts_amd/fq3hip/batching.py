@@ -1,7 +1,12 @@
 """Continuous batching over ``Fq3Batch`` (``fq3_batch_*``): several utterances decode in lock-step over one weight
 stream; a finished lane is re-armed with the next request at a frame boundary.  With ``staging`` contexts the next
-requests are prefilled on a side stream WHILE the batch decodes (their KV rows move into the freed lane with one
-``fq3_kv_adopt`` launch), so admission costs the running lanes a few tens of microseconds instead of a prefill.
+requests are prefilled on a side stream WHILE the batch decodes, and a freed lane takes the staged prompt's KV over by a
+block-table hand-over (``fq3_kv_adopt`` between contexts of one ``Fq3KvPool``: no KV row is copied), so admission costs the
+running lanes a few tens of microseconds instead of a prefill.
+
+KV memory follows the work, not the lane count: the contexts draw 64-key blocks from one pool; an idle lane or spare context
+holds none, a staged request the blocks of its prompt + ``max_new_tokens`` (taken BEFORE its prefill is queued: a short pool
+postpones the request instead of failing half-way), and a finished lane returns its blocks at once.
 
 No reference equivalent -- the reference decodes one utterance at a time (``talker_graph.py:46`` /
 ``predictor_graph.py:70`` fix batch = 1 and ``examples/openai_server.py:71`` serialises requests with a lock); the
@@ -18,6 +23,7 @@ from typing import Any, Callable, Dict, Iterable, Iterator, List, Optional, Tupl
 
 import torch
 
+from ._lib import FQ3_ENOMEM
 from .generate import NOISE_RING, _arm_decode, _prefill_and_arm, _prefill_first_token, _prefill_first_tokens_packed, _refill
 from .predictor_graph import PredictorGraph
 from .talker_graph import TalkerGraph
@@ -87,9 +93,10 @@ class BatchDecoder:
         # spare contexts (same weights, not part of the lock-step batch) for prefilling ahead of admission
         self.stages = [_Stage(e) for e in (staging or [])]
         self._side = None
-        # every context this scheduler will ever prefill into gets its workspace NOW: a lazy device allocation inside a staged
-        # prefill would land in the middle of the running lanes' decode
-        for e in list(engines) + [st.engine for st in self.stages]:
+        # every context this scheduler will ever PREFILL into gets its workspace NOW: a lazy device allocation inside a staged
+        # prefill would land in the middle of the running lanes' decode.  With spare contexts the lanes never prefill (they only
+        # adopt), so their workspaces would be dead memory (~100 MB each at 0.6B / 2048 slots, ~380 MB at 1.7B / 6144).
+        for e in ([st.engine for st in self.stages] if self.stages else list(engines)):
             reserve = getattr(e, "prefill_reserve", None)
             if reserve is not None:
                 reserve()
@@ -110,7 +117,8 @@ class BatchDecoder:
                   repetition_penalty=1.05)
         kw.update(req.gen_kwargs)
         # nucleus sampling (top_p < 1, sampling.py:57-65) is a per-lane policy of the loop state: the batch sampler kernels
-        # branch to the LDS sorter for exactly the lanes that ask for it
+        # branch to the LDS sorter for exactly the lanes that ask for it.  (Nothing here can fail: the values are validated by
+        # fq3_decode_begin when the lane is armed.)
         return kw
 
     def _arm(self, ln: _Lane, req: BatchRequest):
@@ -147,6 +155,19 @@ class BatchDecoder:
         items = [(req.talker_input_embeds, req.attention_mask, req.config, kw["min_new_tokens"], kw["temperature"], kw["top_k"],
                   kw["top_p"], kw["do_sample"]) for (_st, req, _ev), kw in zip(group, kws)]
         engines = [st.engine for st, _req, _ev in group]
+        # the KV blocks of every member's whole utterance (prompt + max_new_tokens + 1 slots, capped at max_seq_len) are taken
+        # BEFORE anything is queued: a short pool raises Fq3Error(FQ3_ENOMEM) here with every context as it was
+        taken = []
+        try:
+            for e, it, kw in zip(engines, items, kws):
+                reserve = getattr(e, "kv_reserve", None)
+                if reserve is not None:
+                    reserve(int(it[0].shape[1]) + int(kw["max_new_tokens"]) + 1)
+                    taken.append(e)
+        except Exception:
+            for e in taken:
+                e.kv_release()
+            raise
 
         def run():
             if len(group) == 1 or not self.packed_prefill:
@@ -165,33 +186,39 @@ class BatchDecoder:
                     else [_prefill_first_token(engines[lo], *items[lo])])
             return out
 
-        if self._on_gpu(engines[0]):
-            dev = engines[0].device
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
-            for _st, _req, ev in group:
-                if ev is not None:
-                    self._side.wait_event(ev)                           # the request's tensors were produced on the main stream
-                else:
-                    self._side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(self._side):
+        try:
+            if self._on_gpu(engines[0]):
+                dev = engines[0].device
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                for _st, _req, ev in group:
+                    if ev is not None:
+                        self._side.wait_event(ev)                           # the request's tensors were produced on the main stream
+                    else:
+                        self._side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(self._side):
+                    for st, _req, _ev in group:
+                        if st.released is not None:
+                            self._side.wait_event(st.released)              # the previous tenant's hand-over has been queued
+                    res = run()
+                    done = torch.cuda.Event()
+                    done.record(self._side)
                 for st, _req, _ev in group:
-                    if st.released is not None:
-                        self._side.wait_event(st.released)              # the previous tenant's KV rows have been copied out
+                    st.ready = done
+            else:
                 res = run()
-                done = torch.cuda.Event()
-                done.record(self._side)
-            for st, _req, _ev in group:
-                st.ready = done
-        else:
-            res = run()
+        except Exception:
+            for e in taken:                                                 # a failed prefill keeps no blocks
+                e.kv_release()
+            raise
         ms = (time.time() - t0) * 1000
         for (st, req, _ev), kw, (token, hidden, n_rows, _pad) in zip(group, kws, res):
             st.req, st.kw, st.token, st.hidden, st.n_rows = req, kw, token, hidden, n_rows
             st.t0, st.prefill_ms = t0, ms
 
     def _admit(self, ln: _Lane, st: _Stage):
-        """Hand a staged request to a free lane at a frame boundary: one KV copy launch + the arm kernel."""
+        """Hand a staged request to a free lane at a frame boundary: the block-table hand-over (one tiny launch; a block-wise copy
+        if the two contexts do not share a pool) + the arm kernel."""
         req, kw = st.req, st.kw
         gpu = self._on_gpu(ln.engine)
         if gpu:
@@ -225,6 +252,11 @@ class BatchDecoder:
             timing.update(is_final=True, total_steps_so_far=n)
         rid = ln.req.rid
         ln.req, ln.tn, ln.pn, ln.emitted = None, None, None, 0
+        # the lane's KV blocks go back to the pool now (its queued frames have completed: the poll that found it finished waited for
+        # them; a done lane never touches the cache again, csrc/batch_kernels.cuh)
+        release = getattr(ln.engine, "kv_release", None)
+        if release is not None:
+            release()
         return rid, codes, timing
 
     @torch.inference_mode()
@@ -256,6 +288,20 @@ class BatchDecoder:
 
         # a previous run() may have been abandoned mid-utterance (a streaming consumer that stopped early, an exception in the
         # caller): no lane carries a tenant, a partial-chunk counter or a staged request over into this one
+        abandoned = [ln for ln in self.lanes if ln.req is not None] + [st for st in self.stages if st.req is not None]
+        if abandoned:
+            for x in abandoned:
+                cancel = getattr(x.engine, "decode_cancel", None)
+                if cancel is not None and isinstance(x, _Lane):
+                    cancel()                                  # the device loop state stops at once instead of decoding to its own EOS
+            if gpu:
+                torch.cuda.current_stream(self.lanes[0].engine.device).synchronize()       # its queued frames are over: the blocks may go
+                if self._side is not None:
+                    self._side.synchronize()
+            for x in abandoned:
+                release = getattr(x.engine, "kv_release", None)
+                if release is not None:
+                    release()
         for ln in self.lanes:
             ln.req, ln.tn, ln.pn, ln.issued, ln.emitted = None, None, None, 0, 0
         for st in self.stages:
@@ -271,8 +317,9 @@ class BatchDecoder:
 
         def pull():
             # while lanes decode, at most two new requests per frame boundary: whatever the source does to produce one (a
-            # model's prompt build, say) runs on the host between two batches of queued frames
-            budget = len(self.lanes) + len(self.stages) if not active else 2
+            # model's prompt build, say) runs on the host between two batches of queued frames.  Before anything decodes: only
+            # what the first wave can take (one request per lane) -- every further prompt built now would delay the first frame
+            budget = max(0, len(self.lanes) - len(pending) - len(ready)) if not active else 2
             while source is not None and budget > 0 and len(pending) < len(self.lanes) + len(self.stages):
                 r = source()
                 if r is None:
@@ -287,14 +334,6 @@ class BatchDecoder:
             while pending and idle and limit > 0:
                 limit -= 1
                 st, (req, ev) = idle.popleft(), pending.popleft()
-                try:
-                    self._kwargs(self.lanes[0].predictor_graph, req)                  # malformed sampling arguments fail here, before it joins a group
-                except Exception as exc:
-                    idle.appendleft(st)
-                    if on_error == "raise":
-                        raise
-                    failed.append((req.rid, {"error": repr(exc), "steps": 0}))
-                    continue
                 group.append((st, req, ev))
             if not group:
                 return
@@ -302,7 +341,13 @@ class BatchDecoder:
                 self._stage_many(group)
                 ready.extend(st for st, _r, _e in group)
                 return
-            except Exception:
+            except Exception as exc:
+                if getattr(exc, "code", None) == FQ3_ENOMEM and (active or ready):
+                    # the KV pool is short right now: lanes that finish give blocks back -- keep the requests (in order) for later
+                    for st, req, ev in reversed(group):
+                        idle.appendleft(st)
+                        pending.appendleft((req, ev))
+                    return
                 if len(group) == 1:
                     st, req, _ev = group[0]
                     idle.appendleft(st)
@@ -311,16 +356,26 @@ class BatchDecoder:
                     import sys
                     failed.append((req.rid, {"error": repr(sys.exc_info()[1]), "steps": 0}))
                     return
-            # a packed group failed (one prompt too long, ...): stage its members one by one so that only the culprit fails
+            # a packed group failed (one prompt too long, the pool too short for all of them, ...): stage its members one by one so
+            # that only the culprit fails
+            postponed = []
             for st, req, ev in group:
                 try:
+                    if postponed:
+                        raise postponed[0][3]                         # keep the order: nothing overtakes a postponed request
                     self._stage_many([(st, req, ev)])
                     ready.append(st)
                 except Exception as exc:
+                    if getattr(exc, "code", None) == FQ3_ENOMEM and (active or ready):
+                        postponed.append((st, req, ev, exc))
+                        continue
                     idle.appendleft(st)
                     if on_error == "raise":
                         raise
                     failed.append((req.rid, {"error": repr(exc), "steps": 0}))
+            for st, req, ev, _exc in reversed(postponed):
+                idle.appendleft(st)
+                pending.appendleft((req, ev))
 
         while True:
             pull()

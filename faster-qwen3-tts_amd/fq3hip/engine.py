@@ -31,13 +31,69 @@ def rope_tables(head_dim: int, theta: float, n_pos: int, dtype: torch.dtype):
     return ang.cos().to(dtype).float().contiguous(), ang.sin().to(dtype).float().contiguous()
 
 
+def _fill_config(c, cfg: TTSConfig, dtype: torch.dtype, max_seq_len: int, max_frames: int, has_projection: bool):
+    c.dtype = L.FQ3_BF16 if dtype == torch.bfloat16 else L.FQ3_F32
+    for dst, src in ((c.talker, cfg.talker), (c.predictor, cfg.predictor)):
+        dst.hidden, dst.inter, dst.n_layers = src.hidden_size, src.intermediate_size, src.num_hidden_layers
+        dst.n_heads, dst.n_kv_heads, dst.head_dim = src.num_attention_heads, src.num_key_value_heads, src.head_dim
+        dst.vocab, dst.rms_eps = src.vocab_size, src.rms_norm_eps
+    c.num_code_groups = cfg.num_code_groups
+    c.max_seq_len = int(max_seq_len)
+    c.codec_eos_token_id = cfg.codec_eos_token_id
+    c.has_projection = 1 if has_projection else 0
+    c.max_frames = int(max_frames)
+    return c
+
+
+KV_BLOCK = 64           # keys per block of the paged talker cache (kKeysPerTile of csrc/decode_kernels.cuh)
+
+
+class Fq3KvPool:
+    """A pool of 64-key KV blocks shared by the decode contexts of one scheduler (``fq3_kv_pool_*``): a context built with
+    ``Fq3Engine(..., pool=pool)`` owns nothing while idle, its prompt's blocks after a prefill and those of
+    ``prefill_len + max_new_tokens`` once armed; a lane takes a staged prompt over by exchanging block ids
+    (``Fq3Engine.kv_adopt``) instead of copying rows.  ``Fq3Error`` with code ``FQ3_ENOMEM`` when the pool runs short."""
+
+    def __init__(self, cfg: TTSConfig, n_blocks: int, device: str = "cuda", dtype: torch.dtype = torch.bfloat16):
+        self.lib = L.load()
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.handle = L.vp()
+        c = _fill_config(L.Config(), cfg, dtype, 64, 8, False)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.fq3_kv_pool_create(C.byref(c), int(n_blocks), C.byref(self.handle)))
+
+    def stats(self) -> Dict[str, int]:
+        n, f, h, b = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int64(0)
+        L.check(self.lib.fq3_kv_pool_stats(self.handle, C.byref(n), C.byref(f), C.byref(h), C.byref(b)))
+        return {"blocks": n.value, "free": f.value, "high_water": h.value, "bytes_per_block": b.value}
+
+    @staticmethod
+    def blocks_for(n_positions: int) -> int:
+        return (int(n_positions) + KV_BLOCK - 1) // KV_BLOCK
+
+    def close(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            if self.lib.fq3_kv_pool_destroy(self.handle) == 0:      # refuses (and stays alive) while contexts are attached
+                self.handle = L.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Fq3Engine:
     """One decode context (talker + predictor static state) on one GPU.  Not re-entrant."""
 
     def __init__(self, cfg: TTSConfig, weights: Weights, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
-                 max_seq_len: int = 2048, max_frames: int = 4096, share: Optional["Fq3Engine"] = None):
+                 max_seq_len: int = 2048, max_frames: int = 4096, share: Optional["Fq3Engine"] = None,
+                 pool: Optional[Fq3KvPool] = None):
         """``share``: another engine on the same device/dtype whose packed weight tensors this context borrows
-        (one weight replica per GPU, one context -- KV cache, loop state, graph -- per concurrent utterance)."""
+        (one weight replica per GPU, one context -- KV cache, loop state, graph -- per concurrent utterance).
+        ``pool``: draw the talker's KV blocks from this shared pool (``fq3_ctx_create_pooled``) instead of reserving
+        ``max_seq_len`` slots privately."""
         if dtype not in (torch.bfloat16, torch.float32):
             raise ValueError("fq3hip supports torch.bfloat16 and torch.float32")
         self.lib = L.load()
@@ -48,20 +104,15 @@ class Fq3Engine:
         self.max_frames = int(max_frames)
         self._keep = []          # tensors whose storage the context borrows
         self.ctx = L.vp()
-        c = L.Config()
-        c.dtype = L.FQ3_BF16 if dtype == torch.bfloat16 else L.FQ3_F32
-        for dst, src in ((c.talker, cfg.talker), (c.predictor, cfg.predictor)):
-            dst.hidden, dst.inter, dst.n_layers = src.hidden_size, src.intermediate_size, src.num_hidden_layers
-            dst.n_heads, dst.n_kv_heads, dst.head_dim = src.num_attention_heads, src.num_key_value_heads, src.head_dim
-            dst.vocab, dst.rms_eps = src.vocab_size, src.rms_norm_eps
-        c.num_code_groups = cfg.num_code_groups
-        c.max_seq_len = self.max_seq_len
-        c.codec_eos_token_id = cfg.codec_eos_token_id
-        c.has_projection = 1 if ("talker.code_predictor.small_to_mtp_projection.weight" in weights or
-                                 (share is not None and share._table.proj_w)) else 0
-        c.max_frames = self.max_frames
+        self.pool = pool         # keeps the pool alive as long as this context
+        c = _fill_config(L.Config(), cfg, dtype, self.max_seq_len, self.max_frames,
+                         "talker.code_predictor.small_to_mtp_projection.weight" in weights or
+                         (share is not None and bool(share._table.proj_w)))
         with torch.cuda.device(self.device):
-            L.check(self.lib.fq3_ctx_create(C.byref(c), C.byref(self.ctx)))
+            if pool is not None:
+                L.check(self.lib.fq3_ctx_create_pooled(C.byref(c), pool.handle, C.byref(self.ctx)))
+            else:
+                L.check(self.lib.fq3_ctx_create(C.byref(c), C.byref(self.ctx)))
             if share is not None:
                 if share.dtype != dtype or share.device != self.device or share.max_seq_len < self.max_seq_len:
                     raise ValueError("shared engine must match dtype/device and cover max_seq_len (RoPE tables)")
@@ -184,8 +235,27 @@ class Fq3Engine:
         return k, v
 
     def kv_adopt(self, src: "Fq3Engine", Lk: int):
-        """Take over the first ``Lk`` KV rows of every talker layer from another context (``fq3_kv_adopt``)."""
+        """Take over the first ``Lk`` KV rows of every talker layer from another context (``fq3_kv_adopt``): a block-table
+        hand-over when both draw from one pool (``src`` is left empty), a block-wise copy otherwise."""
         L.check(self.lib.fq3_kv_adopt(self.ctx, src.ctx, int(Lk), self._stream()))
+
+    def kv_reserve(self, n_positions: int):
+        """Take the KV blocks of key slots ``[0, n_positions)`` now (``fq3_kv_reserve``); ``Fq3Error(FQ3_ENOMEM)`` if the pool is
+        short (nothing is taken then)."""
+        L.check(self.lib.fq3_kv_reserve(self.ctx, int(n_positions), self._stream()))
+
+    def kv_release(self, keep_positions: int = 0):
+        """Return the KV blocks beyond ``keep_positions`` key slots to the pool (``fq3_kv_release``).  The caller makes sure this
+        context's queued work has finished."""
+        L.check(self.lib.fq3_kv_release(self.ctx, int(keep_positions)))
+
+    def kv_blocks(self) -> int:
+        """64-key blocks this context owns now."""
+        return int(self.lib.fq3_kv_blocks(self.ctx))
+
+    def decode_cancel(self):
+        """Mark the on-device loop done (``fq3_decode_cancel``): an abandoned utterance stops at the next frame boundary."""
+        L.check(self.lib.fq3_decode_cancel(self.ctx, self._stream()))
 
     def talker_step(self, embeds: torch.Tensor, position: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         H = self.cfg.talker.hidden_size

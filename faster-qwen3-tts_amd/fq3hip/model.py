@@ -646,28 +646,39 @@ class FasterQwen3TTS:
     # ---- batched generation (extension: the reference has no multi-utterance entry point) ---------------------------------
     def _batch_decoder(self, lanes: int, staging: Optional[int] = None):
         """Lazily builds ``lanes`` decode contexts over this model's single weight replica, ``staging`` spare contexts
-        (default: as many as lanes) that the next requests are prefilled into while the batch decodes, and the
-        scheduler on top."""
+        (default: as many as lanes) that the next requests are prefilled into while the batch decodes, the KV block pool they
+        all draw from, and the scheduler on top.
+
+        ``self.batch_kv_blocks`` (attribute, default ``None``): size of that pool in 64-key blocks.  ``None`` = enough for every
+        lane AND every spare context at ``max_seq_len`` (what static caches would reserve; the pool then never runs short).  A
+        server that knows its traffic sets less -- e.g. ``(lanes + staging) * ceil((prompt + max_new_tokens + 1) / 64)`` --
+        and a request the pool cannot hold yet waits until finished lanes give blocks back."""
         from .batching import BatchDecoder
-        from .engine import Fq3Engine
+        from .engine import Fq3Engine, Fq3KvPool
         from .batching import MAX_LANES
         lanes = max(1, min(int(lanes), MAX_LANES))
         staging = lanes if staging is None else max(0, int(staging))
+        first = self.talker_graph.engine
+        full = (lanes + staging) * Fq3KvPool.blocks_for(first.max_seq_len)
+        want = getattr(self, "batch_kv_blocks", None)
+        blocks = full if want is None else max(Fq3KvPool.blocks_for(first.max_seq_len), min(int(want), full))
         cached = getattr(self, "_batch_cache", None)
-        if cached is not None and cached[0] == (lanes, staging):
+        if cached is not None and cached[0] == (lanes, staging, blocks):
             # the lanes follow this model's CURRENT predictor policy (it is copied into the loop state when a lane is armed)
             pg = self.predictor_graph
             cached[1].set_predictor_policy(do_sample=pg.do_sample, top_k=pg.top_k, top_p=pg.top_p, temperature=pg.temperature)
             return cached[1]
-        first = self.talker_graph.engine
+        self._batch_cache = None                    # a differently shaped scheduler: its contexts and pool go first
+        pool = Fq3KvPool(first.cfg, blocks, device=str(first.device), dtype=first.dtype)
         mk = lambda: Fq3Engine(first.cfg, first.weights, device=str(first.device), dtype=first.dtype,
-                               max_seq_len=first.max_seq_len, max_frames=first.max_frames, share=first)
-        engines = [first] + [mk() for _ in range(lanes - 1)]
+                               max_seq_len=first.max_seq_len, max_frames=first.max_frames, share=first, pool=pool)
+        engines = [mk() for _ in range(lanes)]
         pg = self.predictor_graph
         dec = BatchDecoder(engines, predictor_policy=dict(do_sample=pg.do_sample, top_k=pg.top_k, top_p=pg.top_p,
                                                           temperature=pg.temperature),
                            staging=[mk() for _ in range(staging)])
-        self._batch_cache = ((lanes, staging), dec)
+        dec.kv_pool = pool
+        self._batch_cache = ((lanes, staging, blocks), dec)
         return dec
 
     def _side_vocoder(self):

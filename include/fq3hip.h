@@ -28,10 +28,10 @@
 extern "C" {
 #endif
 
-#define FQ3_ABI_VERSION 3
+#define FQ3_ABI_VERSION 4
 
 enum { FQ3_BF16 = 0, FQ3_F32 = 1 };
-enum { FQ3_OK = 0, FQ3_EINVAL = -1, FQ3_EHIP = -2, FQ3_ESTATE = -3, FQ3_ETOOLONG = -4, FQ3_EUNSUPPORTED = -5 };
+enum { FQ3_OK = 0, FQ3_EINVAL = -1, FQ3_EHIP = -2, FQ3_ESTATE = -3, FQ3_ETOOLONG = -4, FQ3_EUNSUPPORTED = -5, FQ3_ENOMEM = -6 };
 
 typedef struct fq3_stack_dims {
     int32_t hidden, inter, n_layers, n_heads, n_kv_heads, head_dim, vocab;
@@ -94,9 +94,34 @@ const char* fq3_last_error(void);
 int fq3_abi_version(void);
 
 /* Replaces TalkerGraph.__init__ + PredictorGraph.__init__ (talker_graph.py:27-58,
- * predictor_graph.py:34-76): allocates static KV caches, I/O buffers and scratch on the current device. */
+ * predictor_graph.py:34-76): allocates the KV cache, I/O buffers and scratch on the current device.  The talker's KV cache is
+ * PAGED: blocks of 64 keys (one attention tile) addressed through a per-context block table; this entry point gives the
+ * context a private pool of ceil(max_seq_len / 64) blocks, all taken at creation -- the static cache of the reference
+ * (talker_graph.py:43,153-170). */
 int fq3_ctx_create(const fq3_config* cfg, fq3_ctx** out);
 int fq3_ctx_destroy(fq3_ctx* ctx);
+
+/* ---- paged KV: a block pool shared by the contexts of one scheduler (no reference equivalent: the reference reserves
+ * max_seq_len slots per graph object, talker_graph.py:43) ------------------------------------------------------------------
+ * A pool holds n_blocks blocks of 64 keys for every talker layer (K and V).  A pooled context owns nothing when idle; prefill
+ * (fq3_prefill / fq3_prefill_batch / fq3_kv_import) takes the blocks of the prompt, fq3_decode_begin those of
+ * prefill_len + max_new_tokens, fq3_talker_step that of its position; FQ3_ENOMEM (and nothing taken) when the pool is short.
+ * fq3_kv_release hands blocks back; the caller makes sure that the context's queued work has finished (the same condition
+ * under which a static cache may be overwritten).  Not thread-safe per context; the pool itself is. */
+typedef struct fq3_kv_pool fq3_kv_pool;
+int fq3_kv_pool_create(const fq3_config* cfg, int n_blocks, fq3_kv_pool** out);
+int fq3_kv_pool_destroy(fq3_kv_pool* pool);            /* FQ3_ESTATE while contexts are attached */
+/* blocks in total / free now / most ever in use at once; bytes of one block over all layers (K + V) */
+int fq3_kv_pool_stats(const fq3_kv_pool* pool, int* n_blocks, int* n_free, int* high_water, int64_t* bytes_per_block);
+int fq3_ctx_create_pooled(const fq3_config* cfg, fq3_kv_pool* pool, fq3_ctx** out);
+/* take the blocks of key slots [0, n_positions) (capped at max_seq_len) now -- what a scheduler does BEFORE it prefills a request
+ * into a spare context (prompt + max_new_tokens + 1), so that a short pool shows up before any work is queued; FQ3_ENOMEM and
+ * nothing taken otherwise.  New table entries are written on `stream`. */
+int fq3_kv_reserve(fq3_ctx* ctx, int n_positions, void* stream);
+/* keep the blocks of key slots [0, keep_positions), return the others to the pool (0: all of them) */
+int fq3_kv_release(fq3_ctx* ctx, int keep_positions);
+/* blocks this context owns now */
+int fq3_kv_blocks(const fq3_ctx* ctx);
 
 /* Kernel-variant switches, all parity-tested both ways (no reference equivalent; the defaults are the measured-fastest):
  *   "weight_nt" 0|1|2 (non-temporal weight loads: none | talker | all), "pred_m2" 0|1 (predictor two-token prefill as one
@@ -117,10 +142,12 @@ int fq3_bind_weights(fq3_ctx* ctx, const fq3_weight_table* table);
 int fq3_kv_import(fq3_ctx* ctx, int layer, const void* k, const void* v, int L, void* stream);
 /* Test hook: copy static KV slots [0, L) of one layer back out in the same layout. */
 int fq3_kv_export(fq3_ctx* ctx, int layer, void* k, void* v, int L, void* stream);
-/* Copies the KV rows [0, L) of every talker layer from `src` to `dst` (same shapes; max_seq_len may differ) in one launch.
- * No reference equivalent: it lets a server prefill the next request into a spare context while the lock-step batch keeps
- * decoding, and hand the result to whichever lane frees up (fq3hip/batching.py).  FQ3_ETOOLONG if L > dst's max_seq_len. */
-int fq3_kv_adopt(fq3_ctx* dst, const fq3_ctx* src, int L, void* stream);
+/* `dst` takes over the KV rows [0, L) of every talker layer from `src`.  Contexts of ONE pool: a block-table hand-over -- dst
+ * returns its own blocks, receives src's block ids (one tiny launch rewrites its device table) and src is left empty; no KV row
+ * moves.  Contexts of different pools (or private ones): the rows are copied block by block in one launch and src keeps its
+ * blocks.  No reference equivalent: it lets a server prefill the next request into a spare context while the lock-step batch
+ * keeps decoding, and hand the result to whichever lane frees up (fq3hip/batching.py).  FQ3_ETOOLONG if L > dst's max_seq_len. */
+int fq3_kv_adopt(fq3_ctx* dst, fq3_ctx* src, int L, void* stream);
 
 /* TalkerGraph.set_generation_state (talker_graph.py:172-196): left-pad count of the prompt mask and
  * the rope delta; replaces the 2048-row additive mask table with two integers. */
@@ -199,6 +226,10 @@ typedef struct fq3_decode_params {
 /* Arms the on-device loop state (token, position, history bitmap, counters).  Asynchronous: `p` is consumed before
  * the call returns, the buffers it points to must stay alive until the loop has finished. */
 int fq3_decode_begin(fq3_ctx* ctx, const fq3_decode_params* p, void* stream);
+/* Stops the loop of this context at the next frame boundary (the device state is marked done: further frames are no-ops, in a
+ * lock-step batch the lane idles).  For a scheduler that abandons an utterance half way (a streaming consumer that went away):
+ * without it the lane would keep decoding to its own EOS / max_new_tokens.  Asynchronous. */
+int fq3_decode_cancel(fq3_ctx* ctx, void* stream);
 /* Parity-test hook (teacher forcing; the shape of the reference's own relation tests, tests/test_e2e_parity.py:414-427,
  * applied decision by decision): after fq3_decode_begin, every sampler of the loop records ITS OWN id in
  * decisions[f][j] and continues with forced_codes[f][j] instead (both device int32[n_frames + 1][16]: [f][0] = the

@@ -2,6 +2,7 @@
 """How reproducible are the ORACLE's own bf16 ids under a change of summation order?
 
     python oracle/selfcheck_fulldepth.py [0p6b|1p7b]      # -> tests/golden/fulldepth_selfcheck.json (minutes on CPU)
+    python oracle/selfcheck_fulldepth.py 1p7b_4096        # the configs[4] goldens (tests/golden/longprompt_full.npz; ~15 minutes)
 
 The teacher-forced GPU parity tests (tests/test_gpu_fulldepth.py) accept a bf16 mismatch only where the oracle's own top-2 margin
 is a few bf16 ulps, arguing that such a decision is made by the summation order inside dot products and not by the algorithm.
@@ -120,9 +121,10 @@ class Fp32Linear:
 
 
 def main():
-    size = sys.argv[1] if len(sys.argv) > 1 else "0p6b"
+    key = sys.argv[1] if len(sys.argv) > 1 else "0p6b"
+    size = key.split("_")[0]
     torch.set_num_threads(os.cpu_count() or 1)
-    g = np.load(os.path.join(ROOT, "tests", "golden", "fulldepth.npz"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "longprompt_full.npz" if key.endswith("_4096") else "fulldepth.npz"))
     frames, plen, tlen = (int(x) for x in g["meta"])
     case = TF.load_case(g, f"{size}_bf16")
     golden = torch.from_numpy(case["codes"].astype(np.int64))
@@ -143,10 +145,10 @@ def main():
         s = TF.score(dec, case, 3.0)
         s["seconds"] = round(time.time() - t0, 1)
         out[name] = s
-        print(size, name, s, flush=True)
+        print(key, name, s, flush=True)
     path = os.path.join(ROOT, "tests", "golden", "fulldepth_selfcheck.json")
     cur = json.load(open(path)) if os.path.exists(path) else {}
-    cur[size] = out
+    cur[key] = out
     json.dump(cur, open(path, "w"), indent=1)
     print("wrote", path)
 

@@ -109,9 +109,16 @@ def test_config4_full_depth_prefill_and_teacher_forced_frames(tag, dtype, golden
     generate.py:107-134): all 28 talker layers + 5 predictor layers at the 1.7B shapes, a 4096-token prompt, then 8 greedy
     frames over the > 4096-key cache through the real fused loop (hipGraph replay), every one of the 16 x 8 decisions scored
     by teacher forcing against the CPU oracle's golden ids (oracle/make_golden_longprompt_full.py ->
-    tests/golden/longprompt_full.npz).  fp32: prefill outputs to 2e-4 of the scale, every decision identical.  bf16: prefill
-    outputs to bf16 resolution after 28 layers (0.04 x scale), decisions under the frozen K_ULP = 3 rule of
-    tests/test_gpu_fulldepth.py (no mismatch where the oracle's own top-2 margin exceeds 3 bf16 ulps of the winning logit)."""
+    tests/golden/longprompt_full.npz).  fp32: prefill outputs to 2e-4 of the scale (measured 5e-6), every decision identical.
+    bf16: prefill outputs to bf16 resolution after 28 layers (0.04 x scale; measured 0.023), decisions under the near-tie rule of
+    tests/test_gpu_fulldepth.py with the floor THIS shape has: no mismatch where the oracle's own top-2 margin exceeds
+    K_ULP_4096 = 4 bf16 ulps of the winning logit, and at least MIN_MATCHED_4096 identical decisions.  Why 4 and not the 3 of the
+    200-token goldens: the oracle re-evaluated on these very goldens with nothing changed but the accumulation inside its dot
+    products (oracle/selfcheck_fulldepth.py 1p7b_4096 -> tests/golden/fulldepth_selfcheck.json, pinned by
+    tests/test_oracle_selfcheck.py) flips 2-6 of its own 128 decisions, and its `fp32_operands_ksplit8` variant -- K summed in 8
+    slices, the shape of the HIP GEMMs' accumulation -- flips one at an oracle margin of exactly 4 ulps; 4096 keys of attention and
+    28 layers sit under every logit.  Both figures were fixed when the test was first measured (round 4: 122 / 128, worst 4 ulps)
+    and do not move."""
     import json
     from fq3hip.config import qwen3_tts_1p7b
     from fq3hip.engine import Fq3Engine
@@ -133,7 +140,8 @@ def test_config4_full_depth_prefill_and_teacher_forced_frames(tag, dtype, golden
     d_l = float(np.abs(lg - ref_l).max()) / max(1.0, float(np.abs(ref_l).max()))
     print(f"[config4 full depth] {tag}: max |hidden - oracle| / scale {d_h:.2e}, logits {d_l:.2e}")
     assert d_h <= rel and d_l <= rel, (tag, d_h, d_l)
-    K_ULP = 3.0
+    K_ULP = 4.0                 # K_ULP_4096, frozen (see the docstring)
+    MIN_MATCHED_4096 = 121      # of 128, frozen: the first measurement (122) minus one
     res = {}
     for graph in (True, False):
         dec = TF.forced_decisions(eng, cfg, tie, tth, tpe, case["codes"], graph=graph)
@@ -143,7 +151,7 @@ def test_config4_full_depth_prefill_and_teacher_forced_frames(tag, dtype, golden
         if tag == "f32":
             assert s["matched_decisions"] == s["total"], s
         else:
-            assert s["unexplained"] == 0, s
+            assert s["unexplained"] == 0 and s["matched_decisions"] >= MIN_MATCHED_4096, s
     assert res[True]["matched_decisions"] == res[False]["matched_decisions"]
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)

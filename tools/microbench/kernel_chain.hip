@@ -248,7 +248,7 @@ int main(int argc, char** argv) {
             report("attn_pred_kernel KV append (group 0)", e2, 2e-2);
         }
         {   // talker attention + COMBINE o_proj against PLAIN o_proj fed by the reference merge is covered by pytest; here: finite + sane
-            hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 2>), dim3(NKV, 8), dim3(256), 0, st, tattn_args(0)); 
+            hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 2, false>), dim3(NKV, 8), dim3(256), 0, st, tattn_args(0)); 
             gemv<4, PRO_COMBINE, EPI_RESIDUAL, false>(o_args(0, 8), 1); CHK(hipStreamSynchronize(st));
             auto y = fetch_bf16(bufB, H); double s2 = 0; int bad = 0; for (float v : y) { if (!(fabs(v) < 1e4)) ++bad; s2 += (double)v * v; }
             report("attn_decode + COMBINE o_proj finite", bad, 0.5);
@@ -264,10 +264,21 @@ int main(int argc, char** argv) {
     }
     if (want("pattn")) {
         chain("pattn attn_pred_kernel        16 x 64 thr, pos 8 (final output)", N, [&](int) { hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(2 * NKV), dim3(64), 0, st, pattn_args(8)); });
-        chain("pattn attn_decode_kernel<2>    8 x 256 thr, pos 8 (1 worker)", N, [&](int) { hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 2>), dim3(NKV, 1), dim3(256), 0, st, pattn_args(8)); });
+        chain("pattn attn_decode_kernel<2>    8 x 256 thr, pos 8 (1 worker)", N, [&](int) { hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 2, false>), dim3(NKV, 1), dim3(256), 0, st, pattn_args(8)); });
     }
-    if (want("tattn"))
-        chain("tattn attn_decode_kernel<2>    8x8 x 256 thr, pos 300 (device pos)", N, [&](int i) { hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 2>), dim3(NKV, 8), dim3(256), 0, st, tattn_args(i)); });
+    if (want("tattn")) {
+        chain("tattn attn_decode_kernel<2>    8x8 x 256 thr, pos 300 (device pos), contiguous cache", N, [&](int i) { hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 2, false>), dim3(NKV, 8), dim3(256), 0, st, tattn_args(i)); });
+        // the product's form: the same buffers read as a pool of 64-key blocks through a (shuffled) block table
+        const int nblk = talk_seq / 64;
+        std::vector<int> tab(nblk);
+        for (int i = 0; i < nblk; ++i) tab[i] = (i * 7 + 3) % nblk;              // a permutation when nblk is not a multiple of 7
+        int* tab_dev = nullptr;
+        CHK(hipMalloc(&tab_dev, nblk * sizeof(int)));
+        CHK(hipMemcpy(tab_dev, tab.data(), nblk * sizeof(int), hipMemcpyHostToDevice));
+        chain("tattn attn_decode_kernel<2>    8x8 x 256 thr, pos 300 (device pos), PAGED (block table)", N, [&](int i) {
+            AttnArgs a = tattn_args(i); a.table = tab_dev; a.blk_stride = NKV * 64 * 128;
+            hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 2, true>), dim3(NKV, 8), dim3(256), 0, st, a); });
+    }
     if (want("oproj")) {
         chain("oproj gemv<4,COMBINE,RESID>   N=1024 K=2048 R=1 grid 256, 1 part", N, [&](int i) { gemv<4, PRO_COMBINE, EPI_RESIDUAL, false>(o_args(i, 1), 1); });
         chain("oproj gemv<4,COMBINE,RESID>   N=1024 K=2048 R=1 grid 256, 8 parts", N, [&](int i) { gemv<4, PRO_COMBINE, EPI_RESIDUAL, false>(o_args(i, 8), 1); });
