@@ -43,6 +43,10 @@ struct GemmArgs {
     // split-K (single-tap GEMMs with few rows, e.g. the 200-token prefill's o_proj / down): workgroup z multiplies channel
     // slice z and stores fp32 partials to ws[z][m - m_lo][n]; splitk_reduce_kernel sums them in order and runs the epilogue
     float* ws; long ws_floats; int ksplit;
+    // batched decode: n_seg > 1 independent problems of identical shape in one launch (grid.z / tile range = segment): segment g
+    // reads A + g * a_seg, writes Y / Y2 + g * y_seg, residual res + g * r_seg (strides in ELEMENTS of the respective tensor);
+    // rows, taps and zero padding are local to a segment, so utterance g never sees utterance g - 1's rows
+    int n_seg; long a_seg, y_seg, r_seg;
     int no_skinny;                                    // measurement switch: 1 = keep the tiled / split-K kernels where skinny_gemm.cuh would serve
     int epi_legacy;                                   // measurement switch: 1 = the register-layout epilogue (32-byte runs per row) instead of the
                                                       // LDS-parked one (whole tile rows per store instruction); 0 in the product
@@ -71,7 +75,7 @@ __device__ __forceinline__ float act_extra(int act, float v) {
 template <typename T>
 __device__ __forceinline__ float snake_sin(float x) {
     if constexpr (sizeof(T) == 2) return __sinf(x);
-    else return sinf(x);
+    else return sinf(x);                 // fp32 and the bf16 x 2 mode: both are compared with the fp32 oracle
 }
 template <typename T>
 __device__ __forceinline__ float snake_apply(float v, float a, float ib) {
@@ -198,6 +202,9 @@ __device__ __forceinline__ void epi_quad(const EpiQ& a, f32x4_t acc, int m, int 
             const uint2 rr = *reinterpret_cast<const uint2*>(p);
             f[0] = __uint_as_float(rr.x << 16); f[1] = __uint_as_float(rr.x & 0xFFFF0000u);
             f[2] = __uint_as_float(rr.y << 16); f[3] = __uint_as_float(rr.y & 0xFFFF0000u);
+        } else if constexpr (std::is_same<T, bfs_t>::value) {
+            const u32x4 rr = *reinterpret_cast<const u32x4*>(p);
+            f[0] = bfs_to_f(rr.x); f[1] = bfs_to_f(rr.y); f[2] = bfs_to_f(rr.z); f[3] = bfs_to_f(rr.w);
         } else {
             const f32x4_t rr = *reinterpret_cast<const f32x4_t*>(p);
             f[0] = rr[0]; f[1] = rr[1]; f[2] = rr[2]; f[3] = rr[3];
@@ -223,10 +230,25 @@ __device__ __forceinline__ void epi_quad(const EpiQ& a, f32x4_t acc, int m, int 
     if constexpr (sizeof(T) == 2) {
         if (a.Y) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + n) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         if (a.Y2) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(a.Y2) + (size_t)m * a.ldy + n) = uint2{pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3])};
+    } else if constexpr (std::is_same<T, bfs_t>::value) {
+        if (a.Y) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + n) = u32x4{f_to_bfs(v[0]), f_to_bfs(v[1]), f_to_bfs(v[2]), f_to_bfs(v[3])};
+        if (a.Y2) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.Y2) + (size_t)m * a.ldy + n) = u32x4{f_to_bfs(v2[0]), f_to_bfs(v2[1]), f_to_bfs(v2[2]), f_to_bfs(v2[3])};
     } else {
         if (a.Y) *reinterpret_cast<f32x4_t*>(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + n) = f32x4_t{v[0], v[1], v[2], v[3]};
         if (a.Y2) *reinterpret_cast<f32x4_t*>(reinterpret_cast<T*>(a.Y2) + (size_t)m * a.ldy + n) = f32x4_t{v2[0], v2[1], v2[2], v2[3]};
     }
+}
+// the arguments of segment `seg` of a batched launch (TA: element type of A, TY: of Y / Y2 / res)
+template <typename TA, typename TY>
+__device__ __forceinline__ GemmArgs gemm_segment(const GemmArgs& a, int seg) {
+    GemmArgs b = a;
+    if (a.n_seg > 1) {
+        b.A = reinterpret_cast<const TA*>(a.A) + (size_t)seg * a.a_seg;
+        if (a.Y) b.Y = reinterpret_cast<TY*>(a.Y) + (size_t)seg * a.y_seg;
+        if (a.Y2) b.Y2 = reinterpret_cast<TY*>(a.Y2) + (size_t)seg * a.y_seg;
+        if (a.res) b.res = reinterpret_cast<const TY*>(a.res) + (size_t)seg * a.r_seg;
+    }
+    return b;
 }
 // may the LDS-parked epilogue serve this GEMM?  (no split-K partials, no SwiGLU column pairing)
 __device__ __forceinline__ bool epi_can_park(const GemmArgs& a) { return !a.epi_legacy && a.ksplit <= 1 && a.act != 2; }
@@ -286,8 +308,10 @@ __device__ __forceinline__ void gemm_epilogue_parked(const GemmArgs& a, f32x4_t 
 // grid = (ceil(N / BN), ceil((M - m_lo) / BM)).
 // the K loop of conv_gemm_kernel: accumulates the BM x BN tile at (m0, n0) into acc; smem holds 2 * (BM + BN) * LD elements.
 // Ends with a workgroup barrier: the operand stages are dead afterwards.
+// `taps`: the kernel argument itself -- the tap table is indexed dynamically, which must go to the kernarg segment; `a` (a segment's
+// view: shifted pointers) is a register copy that is never indexed
 template <typename T, int BM, int BN, int PF>
-__device__ __forceinline__ void conv_gemm_mainloop(const GemmArgs& a, T* smem, f32x4_t (&acc)[BM / 32][BN / 32], int m0, int n0) {
+__device__ __forceinline__ void conv_gemm_mainloop(const GemmArgs& a, const GemmArgs& taps, T* smem, f32x4_t (&acc)[BM / 32][BN / 32], int m0, int n0) {
     constexpr int BK = 32;
     constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 4);          // padded LDS row (elements): breaks the 64/128-byte stride
     constexpr int TM = BM / 32, TN = BN / 32;
@@ -325,7 +349,7 @@ __device__ __forceinline__ void conv_gemm_mainloop(const GemmArgs& a, T* smem, f
     // issue cursor (step being loaded) and stage cursor (step being written to LDS): (tap, channel offset) walk K in order
     int i_step = 0, i_tap = 0, i_ci = 0, s_step = 0, s_tap = 0, s_ci = 0;
     auto issue = [&](int slot) {                       // loads of step i_step (clamped to the last real step) into `slot`
-        const int toff = a.tap_off[i_tap];
+        const int toff = taps.tap_off[i_tap];
 #pragma unroll
         for (int p = 0; p < NPA; ++p) {
             int ar = m0 + lr + p * RPP + toff;
@@ -338,7 +362,7 @@ __device__ __forceinline__ void conv_gemm_mainloop(const GemmArgs& a, T* smem, f
         else i_step = nsteps;                           // further issues re-read the last tile; staged as zeros
     };
     auto stage = [&](int slot, int buf) {               // slot -> LDS[buf]; rows outside the problem and tail steps become zeros
-        const int toff = a.tap_off[s_tap];
+        const int toff = taps.tap_off[s_tap];
         const bool real = s_step < nsteps;
 #pragma unroll
         for (int p = 0; p < NPA; ++p) {
@@ -398,25 +422,28 @@ __device__ __forceinline__ void conv_gemm_mainloop(const GemmArgs& a, T* smem, f
     }
 }
 
-template <typename T, int BM, int BN, int PF>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
+// T = operand type (bf16 | fp32), TE = storage type of the outputs / residual / per-column vectors (T itself, or bfs_t over bf16
+// operands: the bf16 x 2 mode, whose A operand is the [rows][2 Cin] bf16 image of a bfs_t tensor).
+template <typename T, int BM, int BN, int PF, typename TE = T>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a_in) {
     constexpr int BK = 32;
     constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 4);
     constexpr int TM = BM / 32, TN = BN / 32;
     __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LD];          // operand stages; the epilogue parks the tile here
+    const GemmArgs a = gemm_segment<T, TE>(a_in, a_in.n_seg > 1 ? (int)blockIdx.z : 0);      // (blockIdx.z is the K slice of a split-K launch: n_seg <= 1 there)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m0 = a.m_lo + blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wr = wave >> 1, wc = wave & 1;
     f32x4_t acc[TM][TN];
-    conv_gemm_mainloop<T, BM, BN, PF>(a, smem, acc, m0, n0);
+    conv_gemm_mainloop<T, BM, BN, PF>(a, a_in, smem, acc, m0, n0);
     constexpr int kParkFloats = (int)(sizeof(T) * 2 * (BM + BN) * LD / sizeof(float));
     if constexpr (BN % 64 != 0 && BN != 32) {
         // the 96-wide tile never serves split-K or SwiGLU GEMMs (gemm_launch), and a third register-layout epilogue copy for
         // its 12 accumulator tiles is more than the unroller takes (the accumulators would move to scratch)
-        gemm_epilogue_parked<T, BM, BN, TM, TN, kParkFloats>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(smem));
+        gemm_epilogue_parked<TE, BM, BN, TM, TN, kParkFloats>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(smem));
     } else {
-        if (epi_can_park(a)) gemm_epilogue_parked<T, BM, BN, TM, TN, kParkFloats>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(smem));
-        else gemm_epilogue<T, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
+        if (epi_can_park(a)) gemm_epilogue_parked<TE, BM, BN, TM, TN, kParkFloats>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(smem));
+        else gemm_epilogue<TE, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
     }
 }
 
@@ -435,8 +462,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 struct ResUnitArgs { GemmArgs c1, c2; };
 
 template <typename T, int C>
-__global__ __launch_bounds__(256) void resunit_kernel(ResUnitArgs u) {
+__global__ __launch_bounds__(256) void resunit_kernel(ResUnitArgs u_in) {
     static_assert(sizeof(T) == 2 && (C == 96 || C == 192), "bf16, 96 or 192 channels");
+    ResUnitArgs u;
+    u.c1 = gemm_segment<T, T>(u_in.c1, (int)blockIdx.y);                     // batched decode: one utterance per blockIdx.y
+    u.c2 = gemm_segment<T, T>(u_in.c2, (int)blockIdx.y);
     constexpr int BM = 128, BN = C, BK = 32, LD = BK + 8, TM = BM / 32, TN = BN / 32, KS = C / 32;
     constexpr int MLD = C + 8;                                            // mid tile row (elements): 16-byte rows, bank-spread
     constexpr int kOperandElems = 2 * (BM + BN) * LD, kMidElems = BM * MLD;
@@ -446,7 +476,7 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitArgs u) {
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = u.c1.m_lo + blockIdx.x * BM;
     f32x4_t acc[TM][TN];
-    conv_gemm_mainloop<T, BM, BN, 2>(u.c1, smem, acc, m0, 0);             // ends with a barrier: the operand stages are dead
+    conv_gemm_mainloop<T, BM, BN, 2>(u.c1, u_in.c1, smem, acc, m0, 0);   // ends with a barrier: the operand stages are dead
     // ---- mid = SnakeBeta(rnd(acc + b1)) -> LDS, row-major (the C layout holds column fr of rows fq * 4 + r) ----
     {
         const T* b1 = reinterpret_cast<const T*>(u.c1.bias);
@@ -514,7 +544,7 @@ inline bool resunit_launch(const GemmArgs& c1, const GemmArgs& c2, hipStream_t s
         if (rows <= 0) return true;
         ResUnitArgs u{c1, c2};
         u.c2.M = c1.M; u.c2.m_lo = c1.m_lo;
-        const dim3 grid((rows + 127) / 128);
+        const dim3 grid((rows + 127) / 128, c1.n_seg > 1 ? c1.n_seg : 1);
         if (C == 96) hipLaunchKernelGGL((resunit_kernel<T, 96>), grid, dim3(256), 0, s, u);
         else if (C == 192) hipLaunchKernelGGL((resunit_kernel<T, 192>), grid, dim3(256), 0, s, u);
         else return false;
@@ -532,10 +562,11 @@ inline bool resunit_launch(const GemmArgs& c1, const GemmArgs& c2, hipStream_t s
 // Requires Cin % 64 == 0 (a K step never straddles a tap).
 static __device__ u32x4 g_gemm_zero_page[8];      // 128 zero bytes (one copy per translation unit)
 
-template <int BN, int STAGES>
-__global__ __launch_bounds__(256) void glds_gemm_kernel(GemmArgs a) {
+template <int BN, int STAGES, typename TE = bf16_t>
+__global__ __launch_bounds__(256) void glds_gemm_kernel(GemmArgs a_in) {
     static_assert(STAGES == 2 || STAGES == 3, "two or three LDS stages");
     typedef bf16_t T;
+    const GemmArgs a = gemm_segment<T, TE>(a_in, (int)blockIdx.z);
     constexpr int BM = 128, BK = 64, TM = 4, TN = BN / 32, NPB = BN / 32;     // NPB: 16-byte copy slots per thread for the B tile
     extern __shared__ __attribute__((aligned(128))) unsigned char glds_smem[];
     T* As = reinterpret_cast<T*>(glds_smem);                                  // [STAGES][BM * BK]
@@ -574,7 +605,7 @@ __global__ __launch_bounds__(256) void glds_gemm_kernel(GemmArgs a) {
     auto issue = [&](int step, int buf) {
         const int k0 = step * BK;
         const int tap = k0 / a.Cin, ci = k0 - tap * a.Cin;
-        const int toff = a.tap_off[tap];
+        const int toff = a_in.tap_off[tap];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int ar = arow[p] + toff;
@@ -622,17 +653,17 @@ __global__ __launch_bounds__(256) void glds_gemm_kernel(GemmArgs a) {
     constexpr int kParkFloats = STAGES * (BM + BN) * BK * 2 / 4;
     if (epi_can_park(a)) {
         __syncthreads();                                 // everybody is done reading the last stage
-        gemm_epilogue_parked<T, BM, BN, TM, TN, kParkFloats>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(glds_smem));
-    } else gemm_epilogue<T, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
+        gemm_epilogue_parked<TE, BM, BN, TM, TN, kParkFloats>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(glds_smem));
+    } else gemm_epilogue<TE, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
 }
 
-template <int BN, int STAGES>
+template <int BN, int STAGES, typename TE = bf16_t>
 inline void glds_go(const GemmArgs& a, hipStream_t s) {
     const int rows = a.M - a.m_lo;
     const size_t shm = (size_t)STAGES * (128 + BN) * 64 * 2;
-    auto kern = glds_gemm_kernel<BN, STAGES>;
+    auto kern = glds_gemm_kernel<BN, STAGES, TE>;
     if (shm > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, (rows + 127) / 128), dim3(256), shm, s, a);
+    hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, (rows + 127) / 128, a.n_seg > 1 ? a.n_seg : 1), dim3(256), shm, s, a);
 }
 
 // Largest-M variant (bf16): 256 x 256 tile, 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 block of 8 x 4 MFMA tiles
@@ -645,9 +676,12 @@ inline void glds_go(const GemmArgs& a, hipStream_t s) {
 // the workgroups of one XCD (every 8th id) cover a compact range of tiles (shared A / W panels stay in that XCD's L2).
 // Per output element the same ascending chain of 32-wide MFMA products as conv_gemm_kernel: bit-identical results.
 constexpr int kBigBM = 256, kBigBN = 256, kBigBK = 32, kBigStages = 4;
-template <int ST, bool TR, int BN>
-__global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, int tiles_total) {
+// Batched decode: the grid holds n_seg x (tiles of one segment) workgroups; the XCD-aware remap runs over ALL of them (so that the
+// tiles of one utterance that share A / W panels stay on one XCD), then tile / tiles_seg selects the segment.
+template <int ST, bool TR, int BN, typename TE = bf16_t>
+__global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a_in, int tiles_x, int tiles_seg, int tiles_total) {
     typedef bf16_t T;
+    static_assert(!TR || std::is_same<TE, bf16_t>::value, "the register-layout (TR) epilogue stores bf16");
     // BN = 256: wave block 128 x 64 (8 x 4 tiles).  BN = 128 (TR only; N = 2048 at M = 4096 would fill half the CUs with 256-wide
     // tiles): wave block 128 x 32 (8 x 2 tiles), 3 copies per thread and step.
     constexpr int BM = kBigBM, BK = kBigBK, TM = 8, TN = BN / 64, WN = BN / 4, NPB = BN / 128, CP = 2 + NPB;
@@ -660,7 +694,9 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware tile id (bijective also when the tile count is not a multiple of 8)
     const int orig = blockIdx.x, xcd = orig & 7, q = tiles_total >> 3, r8 = tiles_total & 7;
-    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int tile_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int seg = tile_all / tiles_seg, tile = tile_all - seg * tiles_seg;
+    const GemmArgs a = gemm_segment<T, TE>(a_in, seg);
     const int m0 = a.m_lo + (tile / tiles_x) * BM, n0 = (tile % tiles_x) * BN;
     const int wr = wave >> 2, wc = wave & 3;
     const int K = a.n_taps * a.Cin, nsteps = K / BK;
@@ -692,7 +728,7 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
     auto issue = [&](int step, int buf) {
         const int k0 = step * BK;
         const int tap = k0 / a.Cin, ci = k0 - tap * a.Cin;
-        const int toff = a.tap_off[tap];
+        const int toff = a_in.tap_off[tap];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int ar = arow[p] + toff;
@@ -799,7 +835,15 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
         const int mb = m0 + wr * 128 + half * 64;
         const int nq = n0 + wc * 64 + (lane & 15) * 4;                   // this lane's 4 consecutive columns
         const bool vec_ok = (a.ldy & 3) == 0 && (!a.res || (a.ldr & 3) == 0) && nq + 3 < a.N && a.bias_mod >= 4 && (a.bias_mod & 3) == 0;
-        if (vec_ok) {
+        if (vec_ok && !std::is_same<TE, bf16_t>::value) {
+            // other storage types (the bf16 x 2 mode): the shared 4-column epilogue, one row of 16 lanes x 4 columns per step
+            const EpiQ e = epiq_of(a);
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 4 + (lane >> 4), m = mb + row;
+                if (m >= a.M) break;
+                epi_quad<TE>(e, *reinterpret_cast<const f32x4_t*>(park + row * 64 + (lane & 15) * 4), m, nq);
+            }
+        } else if (vec_ok) {
             const int ch = nq % a.bias_mod;
             float b[4], sc[4], sa[4], sib[4];
 #pragma unroll
@@ -841,7 +885,7 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
                 for (int row = 0; row < 64; ++row) {
                     const int m = mb + row;
                     if (m >= a.M) break;
-                    epilogue_elem<T>(a, park[row * 64 + lane], m, n);
+                    epilogue_elem<TE>(a, park[row * 64 + lane], m, n);
                 }
         }
         __builtin_amdgcn_wave_barrier();                 // before the second half overwrites the region
@@ -852,30 +896,35 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a, int tiles_x, 
     // output row (the register epilogue of the TR variant touches 32-byte runs and calls out of line per 4 columns).
     __syncthreads();
     constexpr int kParkFloats = ST * (BM + BN) * BK * 2 / 4;
-    gemm_epilogue_parked<T, BM, BN, TM, TN, kParkFloats, 4, 512>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(big_smem));
+    gemm_epilogue_parked<TE, BM, BN, TM, TN, kParkFloats, 4, 512>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(big_smem));
     }
 }
 
-template <bool TR, int BN>
+template <bool TR, int BN, typename TE = bf16_t>
 inline void big_go_t(const GemmArgs& a, hipStream_t s) {
-    const int rows = a.M - a.m_lo;
+    const int rows = a.M - a.m_lo, nseg = a.n_seg > 1 ? a.n_seg : 1;
     const int tx = (a.N + BN - 1) / BN, ty = (rows + kBigBM - 1) / kBigBM;
     const size_t shm = (size_t)kBigStages * (kBigBM + BN) * kBigBK * 2;
     static bool attr = false;
-    auto kern = big_gemm_kernel<kBigStages, TR, BN>;
+    auto kern = big_gemm_kernel<kBigStages, TR, BN, TE>;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = true; }
-    hipLaunchKernelGGL(kern, dim3(tx * ty), dim3(512), shm, s, a, tx, tx * ty);
+    hipLaunchKernelGGL(kern, dim3(tx * ty * nseg), dim3(512), shm, s, a, tx, tx * ty, tx * ty * nseg);
 }
 // wide plain outputs (prefill qkv / gate_up: 980 vs 872 TFLOP/s) store straight from the transposed accumulators; tall outputs
 // with the full epilogue (codec convs: 661 vs 584) go through the LDS walk with 128-byte row stores
+template <typename TE = bf16_t>
 inline void big_go(const GemmArgs& a, hipStream_t s) {
     const bool plain = a.act == 0 && !a.scale && !a.res && !a.Y2;
-    if (plain && a.N >= 1024 && a.N % kBigBN == 0) big_go_t<true, kBigBN>(a, s); else big_go_t<false, kBigBN>(a, s);
+    if constexpr (std::is_same<TE, bf16_t>::value) {
+        if (plain && a.N >= 1024 && a.N % kBigBN == 0) { big_go_t<true, kBigBN>(a, s); return; }
+    }
+    big_go_t<false, kBigBN, TE>(a, s);
 }
-// does a tiling into 256 x bn tiles use the chip well?  (fill of the tiles) x (fill of the last wave of workgroups)
-inline bool big_tiling_pays(int rows, int N, int bn) {
-    const long tx = (N + bn - 1) / bn, ty = (rows + kBigBM - 1) / kBigBM, tiles = tx * ty;
-    const double fill = (double)rows * N / ((double)tiles * kBigBM * bn);
+// does a tiling into 256 x bn tiles use the chip well?  (fill of the tiles) x (fill of the last wave of workgroups); nseg
+// independent problems of this shape share the launch
+inline bool big_tiling_pays(int rows, int N, int bn, int nseg = 1) {
+    const long tx = (N + bn - 1) / bn, ty = (rows + kBigBM - 1) / kBigBM, tiles = tx * ty * nseg;
+    const double fill = (double)rows * N / ((double)tx * ty * kBigBM * bn);
     const double eff = (double)tiles / (double)(((tiles + 255) / 256) * 256);
     return tiles >= 64 && fill * eff >= 0.66;
 }
@@ -902,28 +951,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs a) {
 }
 
 // ---- host-side launch: tile shape per layer ---------------------------------------------------------------------
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, typename TE = T>
 inline void gemm_go(const GemmArgs& a, hipStream_t s) {
     // register-prefetch depth: the small tiles serve skinny layers (few workgroups, long K) and need 8 tiles in flight; the
     // 128x64 tile runs with >= 2 workgroups per CU, where 2 is best (530 / 498 / 441 TFLOP/s at PF = 2 / 4 / 8, 4096^3)
     constexpr int PF = (BM + BN) > 160 ? 2 : ((BM + BN) > 128 ? 4 : 8);
-    dim3 grid((a.N + BN - 1) / BN, (a.M - a.m_lo + BM - 1) / BM);
-    hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, PF>), grid, dim3(256), 0, s, a);
+    dim3 grid((a.N + BN - 1) / BN, (a.M - a.m_lo + BM - 1) / BM, a.n_seg > 1 ? a.n_seg : 1);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, PF, TE>), grid, dim3(256), 0, s, a);
 }
 inline bool skinny_ok(const GemmArgs& a) {
     return a.ws && !a.no_skinny && a.n_taps == 1 && a.tap_off[0] == 0 && a.m_lo == 0 && a.M <= kSkinnyMaxRows && a.a_rows >= a.M && a.act == 0 &&
            !a.bias && !a.scale && !a.Y2 && a.Y && skinny_k_ok(a.Cin) && a.N % 32 == 0 && a.lda % 8 == 0 && a.ldy % 4 == 0 && (!a.res || a.ldr % 4 == 0);
 }
-template <typename T>
-inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
-    const int rows = a.M - a.m_lo;
+// T = operand type, TE = storage type of the outputs (see conv_gemm_kernel).  nseg independent problems share a launch
+// (batched decode): what counts for the tile choice is the number of workgroups the whole launch has.
+template <typename T, typename TE>
+inline void gemm_launch_te(const GemmArgs& a, hipStream_t s) {
+    const int rows = a.M - a.m_lo, nseg = a.n_seg > 1 ? a.n_seg : 1;
     if (rows <= 0) return;
     if constexpr (sizeof(T) == 4) { gemm_go<T, 64, 64>(a, s); return; }      // fp32 = parity mode, one shape
     else {
-        auto wgs = [&](int bm, int bn) { return (long)((rows + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+        constexpr bool kPlainBf16 = std::is_same<TE, bf16_t>::value;
+        auto wgs = [&](int bm, int bn) { return (long)((rows + bm - 1) / bm) * ((a.N + bn - 1) / bn) * nseg; };
         // few rows against a whole weight matrix (the short-prompt prefill): weight-stationary kernel (skinny_gemm.cuh).  Its
         // accumulation order is its own, so -- like split-K below -- only for callers that lend a workspace.
-        if (skinny_ok(a)) {
+        if constexpr (kPlainBf16) {
+        if (nseg == 1 && skinny_ok(a)) {
             SkinnyArgs k{};
             k.X = reinterpret_cast<const bf16_t*>(a.A); k.ldx = a.lda; k.M = a.M; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = a.N;
             k.res = reinterpret_cast<const bf16_t*>(a.res); k.ldr = a.ldr; k.Y = reinterpret_cast<bf16_t*>(a.Y); k.ldy = a.ldy;
@@ -932,7 +985,7 @@ inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
         }
         // few rows, one tap, long K, narrow N (the 200-token prefill's o_proj / down): split K over workgroups, two passes.
         // Only where the caller lends a workspace: the codec does not (a tail decode must stay bit-identical to a full one).
-        if (a.ws && a.n_taps == 1 && a.act != 2 && wgs(64, 32) < 384 && a.Cin >= 1536) {
+        if (nseg == 1 && a.ws && a.n_taps == 1 && a.act != 2 && wgs(64, 32) < 384 && a.Cin >= 1536) {
             int S = 0;
             for (int cand : {8, 6, 4, 3, 2})
                 if (a.Cin % (cand * 32) == 0 && a.Cin / (cand * 32) >= 12 && wgs(64, 32) * cand <= 1024 &&
@@ -946,6 +999,7 @@ inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
                 return;
             }
         }
+        }
         // Measured on MI355X (tools/microbench/gemm_bench.hip): the 128x64 tile reaches 390 TFLOP/s where 128x128 stays at
         // 80-110 (130 VGPRs / 40 KB LDS leave 3 workgroups per CU against 5: the one-barrier K step is latency-bound, so
         // residency beats arithmetic intensity here) -- the 128x128 shape is therefore not used.
@@ -953,23 +1007,36 @@ inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
         // 256 x 256 ring-of-four tile (932 TFLOP/s at 4096^3 on random operands against 622 for the 128 x 64 glds tile): one
         // workgroup per CU, so it pays only when the tiles are well filled AND the last wave of workgroups is mostly full
         if (a.act != 2 && a.Cin % 32 == 0) {
-            if (big_tiling_pays(rows, a.N, kBigBN)) { big_go(a, s); return; }
+            if (big_tiling_pays(rows, a.N, kBigBN, nseg)) { big_go<TE>(a, s); return; }
             // 256 x 128 tiles where the 256-wide ones would leave half the CUs idle (N = 2048 at M = 4096: o_proj / down at 1.7B)
-            if (rows >= 1024 && a.N % 128 == 0 && big_tiling_pays(rows, a.N, 128)) {
+            if (rows >= 1024 && a.N % 128 == 0 && big_tiling_pays(rows, a.N, 128, nseg)) {
                 const bool plain = a.act == 0 && !a.scale && !a.res && !a.Y2;
-                if (plain) big_go_t<true, 128>(a, s); else big_go_t<false, 128>(a, s);      // full epilogue: LDS-parked, whole rows per store
+                if constexpr (kPlainBf16) { if (plain) { big_go_t<true, 128>(a, s); return; } }
+                big_go_t<false, 128, TE>(a, s);      // full epilogue: LDS-parked, whole rows per store
                 return;
             }
         }
         if (a.N % 64 == 0 && a.Cin % 64 == 0 && wgs(128, 64) >= 512) {
-            glds_go<64, 2>(a, s);
-        } else if (n64 && wgs(128, 64) >= 512) gemm_go<T, 128, 64>(a, s);
-        else if (a.act != 2 && !n64 && a.N % 96 == 0 && wgs(128, 96) >= 256) gemm_go<T, 128, 96>(a, s);      // N = 96 / 288 (codec block 4): 3x fewer reads of the A tile than 32-wide tiles
-        else if (a.act != 2 && !n64 && wgs(128, 32) >= 256) gemm_go<T, 128, 32>(a, s);
-        else if (n64 && (wgs(64, 64) >= 256 || a.act == 2)) gemm_go<T, 64, 64>(a, s);
-        else if (a.act == 2) gemm_go<T, 64, 64>(a, s);
-        else gemm_go<T, 64, 32>(a, s);
+            glds_go<64, 2, TE>(a, s);
+        } else if (n64 && wgs(128, 64) >= 512) gemm_go<T, 128, 64, TE>(a, s);
+        else if (a.act != 2 && !n64 && a.N % 96 == 0 && wgs(128, 96) >= 256) gemm_go<T, 128, 96, TE>(a, s);      // N = 96 / 288 (codec block 4): 3x fewer reads of the A tile than 32-wide tiles
+        else if (a.act != 2 && !n64 && wgs(128, 32) >= 256) gemm_go<T, 128, 32, TE>(a, s);
+        else if (n64 && (wgs(64, 64) >= 256 || a.act == 2)) gemm_go<T, 64, 64, TE>(a, s);
+        else if (a.act == 2) gemm_go<T, 64, 64, TE>(a, s);
+        else gemm_go<T, 64, 32, TE>(a, s);
     }
+}
+// Storage type T in {bf16, fp32, bfs_t}.  bfs_t (the codec's bf16 x 2 mode): the A operand is the [rows][2 lda] bf16 image of the
+// bfs_t tensor -- hi / lo interleaved along K -- against a bf16 weight whose K columns are duplicated at pack time
+// ([N][taps][2 Cin]); everything else (bias, residual, outputs) is bfs_t.
+template <typename T>
+inline void gemm_launch(const GemmArgs& a, hipStream_t s) {
+    if constexpr (std::is_same<T, bfs_t>::value) {
+        GemmArgs b = a;
+        b.lda = 2 * a.lda; b.Cin = 2 * a.Cin; b.a_seg = 2 * a.a_seg;
+        b.ws = nullptr;
+        gemm_launch_te<bf16_t, bfs_t>(b, s);
+    } else gemm_launch_te<T, T>(a, s);
 }
 
 // forward declaration target of gemm_swiglu_halves
@@ -998,6 +1065,10 @@ struct RvqArgs { const void* books[32]; int nq; int n_first; int dim; };
 template <typename T>
 __global__ void rvq_gather_kernel(RvqArgs a, const int64_t* codes, T* first, T* rest, int Tn) {
     const int t = blockIdx.x;
+    {   // batched decode: utterance blockIdx.y (tensors compact per utterance: Tn rows each)
+        const size_t g = blockIdx.y;
+        codes += g * Tn * a.nq; first += g * Tn * a.dim; rest += g * Tn * a.dim;
+    }
     for (int d = threadIdx.x; d < a.dim; d += blockDim.x) {
         float f = 0.f, r = 0.f;
         bool hf = false, hr = false;
@@ -1016,6 +1087,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const T* x, const T* w, T* y, int row_lo, int rows, int C, float eps) {
     const int row = row_lo + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
+    x += (size_t)blockIdx.y * rows * C; y += (size_t)blockIdx.y * rows * C;       // batched decode: utterance blockIdx.y
     const T* xr = x + (size_t)row * C;
     float ss = 0.f;
     for (int c = lane; c < C; c += 64) { const float v = DT<T>::ld(xr + c); ss = fmaf(v, v, ss); }
@@ -1029,6 +1101,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const T* x, const T* w, const T* b, T* y, int row_lo, int rows, int C, float eps) {
     const int row = row_lo + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
+    x += (size_t)blockIdx.y * rows * C; y += (size_t)blockIdx.y * rows * C;       // batched decode: utterance blockIdx.y
     const T* xr = x + (size_t)row * C;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += DT<T>::ld(xr + c);
@@ -1045,6 +1118,7 @@ template <typename T>
 __global__ void dwconv7_kernel(const T* x, const T* w /*[C][7]*/, const T* b, T* y, int row_lo, int rows, int C) {
     const size_t i = (size_t)row_lo * C + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)rows * C) return;
+    x += (size_t)blockIdx.y * rows * C; y += (size_t)blockIdx.y * rows * C;       // batched decode: utterance blockIdx.y
     const int t = (int)(i / C), c = (int)(i % C);
     float acc = 0.f;
 #pragma unroll
@@ -1070,6 +1144,7 @@ __global__ void rope_rows_kernel(T* qkv, const float* cos_tab, const float* sin_
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int half = HD / 2, per_row = 2 * (QD / HD) * half;
     if (i >= (size_t)rows * per_row) return;
+    qkv += (size_t)blockIdx.y * rows * 3 * QD;                                     // batched decode: utterance blockIdx.y (positions restart at 0)
     const int t = (int)(i / per_row), r = (int)(i % per_row);
     const int head = r / half, j = r % half;              // heads 0..QD/HD-1 = q, then k
     T* p = qkv + (size_t)t * 3 * QD + (size_t)head * HD;
@@ -1090,6 +1165,7 @@ __global__ __launch_bounds__(256) void swa_attn_kernel(const T* qkv, T* out, int
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + wave, h = blockIdx.y;
     const int QD = NH * HD;
+    qkv += (size_t)blockIdx.z * Tn * 3 * QD; out += (size_t)blockIdx.z * Tn * QD;  // batched decode: utterance blockIdx.z
     const bool live = q < Tn;
     const int qq = live ? q : Tn - 1;
     const T* qp = qkv + (size_t)qq * 3 * QD + (size_t)h * HD;
@@ -1148,6 +1224,7 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const T* x, const T* w 
     float* ws = reinterpret_cast<float*>(fsm_raw + (((size_t)(spw + 6) * pitch * sizeof(T) + 15) & ~(size_t)15));       // [7][C]
     const int t0 = t_lo + blockIdx.x * spw;
     const int cpr = C / EPC;                                  // chunks per row
+    x += (size_t)blockIdx.y * rows * C; pcm += (size_t)blockIdx.y * (rows - t_lo);     // batched decode: utterance blockIdx.y
     for (int e = threadIdx.x; e < (spw + 6) * cpr; e += 256) {
         const int r = e / cpr, c = (e - r * cpr) * EPC, tt = t0 - 6 + r;
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
@@ -1168,6 +1245,10 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const T* x, const T* w 
             if constexpr (sizeof(T) == 2) {
                 Raw8<T> q;
                 q.v = *reinterpret_cast<const u32x4*>(xr + c);
+                unpack(q, xf);
+            } else if constexpr (std::is_same<T, bfs_t>::value) {
+                Raw8<T> q;
+                q.a = *reinterpret_cast<const u32x4*>(xr + c); q.b = *reinterpret_cast<const u32x4*>(xr + c + 4);
                 unpack(q, xf);
             } else {
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(xr + c), hi = *reinterpret_cast<const f32x4*>(xr + c + 4);

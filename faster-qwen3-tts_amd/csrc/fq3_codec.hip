@@ -41,7 +41,8 @@ struct fq3_codec {
     std::map<std::string, const void*> w;
     std::map<std::string, int64_t> wn;
     void* buf[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t buf_elems = 0;
+    size_t buf_elems = 0;                         // elements of one utterance's largest activation
+    int batch_cap = 1;                            // utterances the four workspaces hold (grown by fq3_codec_decode_batch)
     void* snake_consts = nullptr;                 // per-channel SnakeBeta constants (a, ib), built at finalize
     std::map<std::string, std::pair<const void*, const void*>> snake;     // "<prefix>" -> (a, ib)
     bool ready = false;
@@ -62,7 +63,7 @@ extern "C" int64_t fq3_codec_num_samples(const fq3_codec* c, int T) { return c ?
 
 extern "C" int fq3_codec_create(const fq3_codec_config* cfg, fq3_codec** out) {
     if (!cfg || !out) return cfail(FQ3_EINVAL, "null argument");
-    if (cfg->dtype != FQ3_BF16 && cfg->dtype != FQ3_F32) return cfail(FQ3_EINVAL, "dtype");
+    if (cfg->dtype != FQ3_BF16 && cfg->dtype != FQ3_F32 && cfg->dtype != FQ3_BF16X2) return cfail(FQ3_EINVAL, "dtype");
     if (cfg->n_upsample < 0 || cfg->n_upsample > 4 || cfg->n_rates < 1 || cfg->n_rates > 8) return cfail(FQ3_EINVAL, "upsample lists");
     if (cfg->num_quantizers > 32) return cfail(FQ3_EUNSUPPORTED, "codec dims");
     if (cfg->head_dim != 32 && cfg->head_dim != 64 && cfg->head_dim != 128) return cfail(FQ3_EUNSUPPORTED, "codec head_dim must be 32, 64 or 128");
@@ -75,7 +76,7 @@ extern "C" int fq3_codec_create(const fq3_codec_config* cfg, fq3_codec** out) {
     if (!ok) return cfail(FQ3_EUNSUPPORTED, "every channel count must be a multiple of 32 (MFMA K step)");
     fq3_codec* c = new fq3_codec();
     c->cfg = *cfg;
-    c->esz = cfg->dtype == FQ3_BF16 ? 2 : 4;
+    c->esz = cfg->dtype == FQ3_BF16 ? 2 : 4;      // (FQ3_BF16X2: one 32-bit word per element, bf16 high part + bf16 residual)
     // largest activation: walk the stages
     const int64_t T = cfg->max_frames;
     int64_t rows = T, mx = T * std::max(std::max(cfg->latent_dim * 4, 3 * cfg->n_heads * cfg->head_dim), cfg->decoder_dim);
@@ -168,6 +169,7 @@ extern "C" int fq3_codec_finalize(fq3_codec* c, void* stream) {
         char* base = (char*)c->snake_consts + off * c->esz;
         void* pa = base; void* pib = base + (size_t)s.second * c->esz;
         if (g.dtype == FQ3_BF16) hipLaunchKernelGGL((snake_consts_kernel<bf16_t>), dim3((s.second + 255) / 256), dim3(256), 0, st, (const bf16_t*)al, (const bf16_t*)be, (bf16_t*)pa, (bf16_t*)pib, s.second);
+        else if (g.dtype == FQ3_BF16X2) hipLaunchKernelGGL((snake_consts_kernel<bfs_t>), dim3((s.second + 255) / 256), dim3(256), 0, st, (const bfs_t*)al, (const bfs_t*)be, (bfs_t*)pa, (bfs_t*)pib, s.second);
         else hipLaunchKernelGGL((snake_consts_kernel<float>), dim3((s.second + 255) / 256), dim3(256), 0, st, (const float*)al, (const float*)be, (float*)pa, (float*)pib, s.second);
         c->snake[s.first] = {pa, pib};
         off += 2 * (size_t)s.second;
@@ -208,8 +210,18 @@ static GemmArgs conv(const void* A, int rows, int Cin, const void* W, int Cout, 
     a.bias = bias; a.bias_mod = Cout; a.Y = Y; a.ldy = Cout; return a;
 }
 
+// every GEMM of a batched decode: NS problems of this shape, tensors compact per utterance
+static GemmArgs segmented(GemmArgs a, int NS) {
+    a.n_seg = NS; a.a_seg = (long)a.a_rows * a.lda; a.y_seg = (long)a.M * a.ldy; a.r_seg = (long)a.M * a.ldr;
+    return a;
+}
+
+// NS utterances of Tn frames each in one set of launches (codes [NS][Tn][nq], pcm [NS][samples - first_sample]): every tensor
+// is laid out [utterance][rows][C], every launch carries the utterance in a grid dimension, rows / taps / causal padding are
+// local to an utterance.  Per utterance the arithmetic is that of a single decode (same tiles per row and column, same chains):
+// bit-identical PCM.
 template <typename T>
-static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, int64_t first_sample, float* pcm, hipStream_t s) {
+static int decode_t(fq3_codec* c, const int64_t* codes, int NS, int Tn, int64_t first_sample, float* pcm, hipStream_t s) {
     const auto& g = c->cfg;
     int err = 0;
     auto W = [&](const std::string& n) -> const void* { const void* p = nullptr; if (!err) err = need(c, n, 0, &p); return p; };
@@ -220,13 +232,16 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, int64_t first_sa
     };
     T* B0 = (T*)c->buf[0]; T* B1 = (T*)c->buf[1]; T* B2 = (T*)c->buf[2]; T* B3 = (T*)c->buf[3];
     const std::string D = "decoder.";
-    auto el = [&](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    auto el = [&](size_t n) { return dim3((unsigned)((n + 255) / 256), (unsigned)NS); };      // elementwise launches: utterance = blockIdx.y
+    const dim3 rows4((Tn + 3) / 4, NS);                                                        // one wave per row of the frame-level front end
     Plan P;
     auto gemm_op = [&](GemmArgs a, int out, int out2, std::vector<Dep> in, int unit = 1) {
         Op o; o.out = out; o.out2 = out2; o.in = std::move(in); o.unit = unit;
+        a = segmented(a, NS);
         o.run = [a, s](int lo) mutable { a.m_lo = lo; gemm_launch<T>(a, s); };
         P.add(std::move(o));
     };
+    auto G = [&](GemmArgs a) { gemm_launch<T>(segmented(a, NS), s); };
 
     // ---- frame-level front end: RVQ, pre_conv, transformer (all T rows: the attention stack sees the whole prefix) ----
     RvqArgs ra{}; ra.nq = g.num_quantizers; ra.n_first = g.num_semantic; ra.dim = g.rvq_dim;
@@ -258,29 +273,29 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, int64_t first_sa
         const void* w_out = W(TR + "output_proj.weight"); const void* b_out = W(TR + "output_proj.bias");
         if (err) return err;
         o.run = [=](int) {
-            T* qf = B1; T* qr = B1 + (size_t)Tn * g.rvq_dim;
-            hipLaunchKernelGGL((rvq_gather_kernel<T>), dim3(Tn), dim3(256), 0, s, ra, codes, qf, qr, Tn);
-            gemm_launch<T>(lin<T>(qf, Tn, g.rvq_dim, w_first, g.codebook_dim, nullptr, B0), s);
-            { GemmArgs a = lin<T>(qr, Tn, g.rvq_dim, w_rest, g.codebook_dim, nullptr, B0); a.res = B0; a.ldr = g.codebook_dim; gemm_launch<T>(a, s); }
-            gemm_launch<T>(conv(B0, Tn, g.codebook_dim, w_pre, g.latent_dim, b_pre, B1, 3, 1), s);
-            gemm_launch<T>(lin<T>(B1, Tn, g.latent_dim, w_in, g.hidden, b_in, B0), s);                     // x = B0
+            T* qf = B1; T* qr = B1 + (size_t)NS * Tn * g.rvq_dim;
+            hipLaunchKernelGGL((rvq_gather_kernel<T>), dim3(Tn, NS), dim3(256), 0, s, ra, codes, qf, qr, Tn);
+            G(lin<T>(qf, Tn, g.rvq_dim, w_first, g.codebook_dim, nullptr, B0));
+            { GemmArgs a = lin<T>(qr, Tn, g.rvq_dim, w_rest, g.codebook_dim, nullptr, B0); a.res = B0; a.ldr = g.codebook_dim; G(a); }
+            G(conv(B0, Tn, g.codebook_dim, w_pre, g.latent_dim, b_pre, B1, 3, 1));
+            G(lin<T>(B1, Tn, g.latent_dim, w_in, g.hidden, b_in, B0));                     // x = B0
             for (int i = 0; i < g.n_layers; ++i) {
                 const LayerW& w = LW[i];
-                hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Tn + 3) / 4), dim3(256), 0, s, (const T*)B0, (const T*)w.ln1, B1, 0, Tn, g.hidden, g.rms_eps);
-                gemm_launch<T>(lin<T>(B1, Tn, g.hidden, w.qkv, 3 * QD, nullptr, B2), s);
+                hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), rows4, dim3(256), 0, s, (const T*)B0, (const T*)w.ln1, B1, 0, Tn, g.hidden, g.rms_eps);
+                G(lin<T>(B1, Tn, g.hidden, w.qkv, 3 * QD, nullptr, B2));
                 hipLaunchKernelGGL((rope_rows_kernel<T>), el((size_t)Tn * 2 * g.n_heads * (g.head_dim / 2)), dim3(256), 0, s, B2, cosT, sinT, Tn, QD, g.head_dim);
-                const dim3 ag((Tn + 3) / 4, g.n_heads);
+                const dim3 ag((Tn + 3) / 4, g.n_heads, NS);
                 const float sc = 1.0f / sqrtf((float)g.head_dim);
                 if (g.head_dim == 32) hipLaunchKernelGGL((swa_attn_kernel<T, 32>), ag, dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.sliding_window, sc);
                 else if (g.head_dim == 64) hipLaunchKernelGGL((swa_attn_kernel<T, 64>), ag, dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.sliding_window, sc);
                 else hipLaunchKernelGGL((swa_attn_kernel<T, 128>), ag, dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.sliding_window, sc);
-                { GemmArgs a = lin<T>(B1, Tn, QD, w.o, g.hidden, nullptr, B0); a.scale = w.ls1; a.res = B0; a.ldr = g.hidden; gemm_launch<T>(a, s); }
-                hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Tn + 3) / 4), dim3(256), 0, s, (const T*)B0, (const T*)w.ln2, B1, 0, Tn, g.hidden, g.rms_eps);
-                { GemmArgs a = lin<T>(B1, Tn, g.hidden, w.gu, 2 * g.inter, nullptr, B2); a.act = 2; a.ldy = g.inter; gemm_launch<T>(a, s); }     // SwiGLU epilogue
-                { GemmArgs a = lin<T>(B2, Tn, g.inter, w.down, g.hidden, nullptr, B0); a.scale = w.ls2; a.res = B0; a.ldr = g.hidden; gemm_launch<T>(a, s); }
+                { GemmArgs a = lin<T>(B1, Tn, QD, w.o, g.hidden, nullptr, B0); a.scale = w.ls1; a.res = B0; a.ldr = g.hidden; G(a); }
+                hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), rows4, dim3(256), 0, s, (const T*)B0, (const T*)w.ln2, B1, 0, Tn, g.hidden, g.rms_eps);
+                { GemmArgs a = lin<T>(B1, Tn, g.hidden, w.gu, 2 * g.inter, nullptr, B2); a.act = 2; a.ldy = g.inter; G(a); }     // SwiGLU epilogue
+                { GemmArgs a = lin<T>(B2, Tn, g.inter, w.down, g.hidden, nullptr, B0); a.scale = w.ls2; a.res = B0; a.ldr = g.hidden; G(a); }
             }
-            hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), dim3((Tn + 3) / 4), dim3(256), 0, s, (const T*)B0, (const T*)w_norm, B1, 0, Tn, g.hidden, g.rms_eps);
-            gemm_launch<T>(lin<T>(B1, Tn, g.hidden, w_out, g.latent_dim, b_out, B0), s);                    // h = B0 [T, latent]
+            hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), rows4, dim3(256), 0, s, (const T*)B0, (const T*)w_norm, B1, 0, Tn, g.hidden, g.rms_eps);
+            G(lin<T>(B1, Tn, g.hidden, w_out, g.latent_dim, b_out, B0));                    // h = B0 [T, latent]
         };
         P.add(std::move(o));
     }
@@ -303,7 +318,7 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, int64_t first_sa
             P.add(std::move(o));
             const T* nw = (const T*)W(U + "1.norm.weight"); const T* nb = (const T*)W(U + "1.norm.bias");
             Op o2; o2.out = t_ln; o2.in = {{t_dw, DEP_SAME, 0}};
-            o2.run = [=](int lo) { if (lo < R) hipLaunchKernelGGL((layernorm_rows_kernel<T>), dim3((R - lo + 3) / 4), dim3(256), 0, s, (const T*)B2, nw, nb, B3, lo, R, Lc, 1e-6f); };
+            o2.run = [=](int lo) { if (lo < R) hipLaunchKernelGGL((layernorm_rows_kernel<T>), dim3((R - lo + 3) / 4, NS), dim3(256), 0, s, (const T*)B2, nw, nb, B3, lo, R, Lc, 1e-6f); };
             P.add(std::move(o2));
         }
         { GemmArgs a = lin<T>(B3, rows, Lc, W(U + "1.pwconv1.weight"), 4 * Lc, W(U + "1.pwconv1.bias"), B2); a.act = 1;
@@ -358,6 +373,7 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, int64_t first_sa
                 // the two narrowest blocks: the whole unit in one launch (resunit_kernel), `mid` stays in LDS.  The new activation goes
                 // to bufM (free now): other workgroups still read their halo rows of bufS while this one stores
                 Op o; o.out = t_hn; o.out2 = t_sn; o.in = {{t_s, DEP_BACK, 6 * dil}, {t_hraw, DEP_SAME, 0}};
+                a1 = segmented(a1, NS); af = segmented(af, NS);
                 o.run = [a1, af, s](int lo) mutable { a1.m_lo = lo; (void)resunit_launch<T>(a1, af, s); };
                 P.add(std::move(o));
                 std::swap(bufS, bufM);
@@ -386,7 +402,7 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, int64_t first_sa
             if (lo >= R) return;
             auto kern = final_conv_kernel<T>;
             if (shm > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            hipLaunchKernelGGL(kern, dim3((R - lo + spw - 1) / spw), dim3(256), shm, s, xin, fw, fb, pcm, lo, R, C, spw);
+            hipLaunchKernelGGL(kern, dim3((R - lo + spw - 1) / spw, NS), dim3(256), shm, s, xin, fw, fb, pcm, lo, R, C, spw);
         };
         P.add(std::move(o));
     }
@@ -420,23 +436,50 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int Tn, int64_t first_sa
     return 0;
 }
 
-static int decode_any(fq3_codec* c, const int64_t* codes, int T, int64_t first_sample, float* pcm, void* stream) {
+// the four activation workspaces hold `n` utterances (grown, never shrunk; a growth waits for the device: it happens on the first
+// batched decode of a new size, outside any graph capture)
+static int reserve_batch(fq3_codec* c, int n) {
+    if (n <= c->batch_cap) return 0;
+    CHIP(hipDeviceSynchronize());
+    void* nb[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; ++i)
+        if (hipMalloc(&nb[i], c->buf_elems * c->esz * (size_t)n) != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipFree(nb[j]);
+            return cfail(FQ3_EHIP, "codec: workspace for " + std::to_string(n) + " utterances could not be allocated");
+        }
+    for (int i = 0; i < 4; ++i) { (void)hipFree(c->buf[i]); c->buf[i] = nb[i]; }
+    c->batch_cap = n;
+    return 0;
+}
+
+static int decode_any(fq3_codec* c, const int64_t* codes, int B, int T, int64_t first_sample, float* pcm, void* stream) {
     if (!c || !codes || !pcm) return cfail(FQ3_EINVAL, "null argument");
     if (!c->ready) return cfail(FQ3_ESTATE, "codec weights not finalized");
     if (T < 1) return cfail(FQ3_EINVAL, "need at least 1 frame");
+    if (B < 1 || B > 1024) return cfail(FQ3_EINVAL, "codec decode: batch size must be 1..1024");
     if (T > c->cfg.max_frames) return cfail(FQ3_ETOOLONG, "codec decode: " + std::to_string(T) + " frames exceed max_frames=" + std::to_string(c->cfg.max_frames));
     if (first_sample < 0 || first_sample > samples_for(c->cfg, T)) return cfail(FQ3_EINVAL, "first_sample outside the waveform");
+    if (int r = reserve_batch(c, B)) return r;
     hipStream_t s = (hipStream_t)stream;
-    int r = c->cfg.dtype == FQ3_BF16 ? decode_t<bf16_t>(c, codes, T, first_sample, pcm, s) : decode_t<float>(c, codes, T, first_sample, pcm, s);
+    int r;
+    switch (c->cfg.dtype) {
+        case FQ3_BF16: r = decode_t<bf16_t>(c, codes, B, T, first_sample, pcm, s); break;
+        case FQ3_BF16X2: r = decode_t<bfs_t>(c, codes, B, T, first_sample, pcm, s); break;
+        default: r = decode_t<float>(c, codes, B, T, first_sample, pcm, s); break;
+    }
     if (r) return r;
     CHIP(hipGetLastError());
     return FQ3_OK;
 }
 
 extern "C" int fq3_codec_decode(fq3_codec* c, const int64_t* codes, int T, float* pcm, void* stream) {
-    return decode_any(c, codes, T, 0, pcm, stream);
+    return decode_any(c, codes, 1, T, 0, pcm, stream);
 }
 
 extern "C" int fq3_codec_decode_tail(fq3_codec* c, const int64_t* codes, int T, int64_t first_sample, float* pcm, void* stream) {
-    return decode_any(c, codes, T, first_sample, pcm, stream);
+    return decode_any(c, codes, 1, T, first_sample, pcm, stream);
+}
+
+extern "C" int fq3_codec_decode_batch(fq3_codec* c, const int64_t* codes, int B, int T, int64_t first_sample, float* pcm, void* stream) {
+    return decode_any(c, codes, B, T, first_sample, pcm, stream);
 }

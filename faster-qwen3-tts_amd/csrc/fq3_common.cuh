@@ -40,12 +40,34 @@ template <> struct DT<float> {
     static __device__ __forceinline__ void st8(float* p, const float (&f)[8]);
 };
 
+// "bf16 x 2": a value kept as a bf16 high part + a bf16 residual in one 32-bit word (low half = high part, so that in memory
+// the pair reads as two consecutive bf16: [hi, lo]).  16 mantissa bits: one rounding is 2^-17 relative, against 2^-9 for bf16.
+// The codec decoder's high-precision mode stores every activation like this (fq3_codec.hip, FQ3_BF16X2): a [rows][C] tensor of
+// bfs_t IS a [rows][2C] bf16 matrix, so a GEMM against bf16 weights whose K columns are duplicated ([.., w_c, w_c, ..]) runs on
+// v_mfma_f32_16x16x32_bf16 unchanged -- hi * w and lo * w are exact fp32 products -- at twice the bf16 MFMA count instead of the
+// 16x of v_mfma_f32_16x16x4_f32.
+struct bfs_t { uint32_t u; };
+__device__ __forceinline__ float bfs_to_f(uint32_t u) { return __uint_as_float(u << 16) + __uint_as_float(u & 0xFFFF0000u); }
+__device__ __forceinline__ uint32_t f_to_bfs(float v) {
+    const uint32_t hi = f_to_bf16(v);
+    const float r = v - __uint_as_float(hi << 16);           // exact in fp32
+    return hi | ((uint32_t)f_to_bf16(r) << 16);
+}
+template <> struct DT<bfs_t> {
+    static __device__ __forceinline__ float ld(const bfs_t* p) { return bfs_to_f(p->u); }
+    static __device__ __forceinline__ void st(bfs_t* p, float v) { p->u = f_to_bfs(v); }
+    static __device__ __forceinline__ float rnd(float v) { return bfs_to_f(f_to_bfs(v)); }
+    static __device__ __forceinline__ void rnd2(float& a, float& b) { a = rnd(a); b = rnd(b); }
+    static __device__ __forceinline__ void st8(bfs_t* p, const float (&f)[8]);
+};
+
 // ---- 8-element (one lane's chunk) raw loads: issue now, convert later ------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> { u32x4 v; };
 template <> struct Raw8<float> { f32x4 a, b; };
+template <> struct Raw8<bfs_t> { u32x4 a, b; };
 
 __device__ __forceinline__ void DT<bf16_t>::st8(bf16_t* p, const float (&f)[8]) {
     *reinterpret_cast<u32x4*>(p) = u32x4{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
@@ -53,6 +75,20 @@ __device__ __forceinline__ void DT<bf16_t>::st8(bf16_t* p, const float (&f)[8]) 
 __device__ __forceinline__ void DT<float>::st8(float* p, const float (&f)[8]) {
     reinterpret_cast<f32x4*>(p)[0] = f32x4{f[0], f[1], f[2], f[3]};
     reinterpret_cast<f32x4*>(p)[1] = f32x4{f[4], f[5], f[6], f[7]};
+}
+
+__device__ __forceinline__ void DT<bfs_t>::st8(bfs_t* p, const float (&f)[8]) {
+    reinterpret_cast<u32x4*>(p)[0] = u32x4{f_to_bfs(f[0]), f_to_bfs(f[1]), f_to_bfs(f[2]), f_to_bfs(f[3])};
+    reinterpret_cast<u32x4*>(p)[1] = u32x4{f_to_bfs(f[4]), f_to_bfs(f[5]), f_to_bfs(f[6]), f_to_bfs(f[7])};
+}
+template <bool NT> __device__ __forceinline__ void ldraw(Raw8<bfs_t>& r, const bfs_t* p) {
+    r.a = reinterpret_cast<const u32x4*>(p)[0];
+    r.b = reinterpret_cast<const u32x4*>(p)[1];
+}
+__device__ __forceinline__ void zero(Raw8<bfs_t>& r) { r.a = u32x4{0u, 0u, 0u, 0u}; r.b = r.a; }
+__device__ __forceinline__ void unpack(const Raw8<bfs_t>& r, float (&f)[8]) {
+    f[0] = bfs_to_f(r.a.x); f[1] = bfs_to_f(r.a.y); f[2] = bfs_to_f(r.a.z); f[3] = bfs_to_f(r.a.w);
+    f[4] = bfs_to_f(r.b.x); f[5] = bfs_to_f(r.b.y); f[6] = bfs_to_f(r.b.z); f[7] = bfs_to_f(r.b.w);
 }
 
 template <bool NT> __device__ __forceinline__ void ldraw(Raw8<bf16_t>& r, const bf16_t* p) {

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (loads libamdhip64 first; see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfq3hip.so")
 
-FQ3_BF16, FQ3_F32 = 0, 1
+FQ3_BF16, FQ3_F32, FQ3_BF16X2 = 0, 1, 2
 FQ3_OK, FQ3_EINVAL, FQ3_EHIP, FQ3_ESTATE, FQ3_ETOOLONG, FQ3_EUNSUPPORTED, FQ3_ENOMEM = 0, -1, -2, -3, -4, -5, -6
 
 vp = C.c_void_p
@@ -138,6 +138,7 @@ SIGNATURES = {
     "fq3_codec_num_samples": (C.c_int64, [vp, C.c_int]),
     "fq3_codec_decode": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "fq3_codec_decode_tail": (C.c_int, [vp, vp, C.c_int, C.c_int64, vp, vp]),
+    "fq3_codec_decode_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int64, vp, vp]),
     "fq3_refenc_create": (C.c_int, [C.POINTER(RefEncConfig), C.POINTER(vp)]),
     "fq3_refenc_destroy": (C.c_int, [vp]),
     "fq3_refenc_bind": (C.c_int, [vp, C.c_char_p, vp, C.c_int64]),

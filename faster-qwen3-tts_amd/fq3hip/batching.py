@@ -32,6 +32,15 @@ from .talker_graph import TalkerGraph
 MAX_LANES = 32          # kMaxLanes of csrc/batch_kernels.cuh (fq3_batch_create refuses more)
 
 
+def _more(queue: list):
+    """Pop the next event of a poll's batch and tell the consumer how many more of the SAME poll follow (``more_in_poll``): utterances
+    that finish / chunks that complete together can then be vocoded by one batched codec launch set."""
+    ev = queue.pop(0)
+    if isinstance(ev[2], dict):
+        ev[2]["more_in_poll"] = len(queue)
+    return ev
+
+
 @dataclass
 class BatchRequest:
     """One utterance: the tensors ``fast_generate`` takes plus its sampling arguments."""
@@ -155,19 +164,24 @@ class BatchDecoder:
         items = [(req.talker_input_embeds, req.attention_mask, req.config, kw["min_new_tokens"], kw["temperature"], kw["top_k"],
                   kw["top_p"], kw["do_sample"]) for (_st, req, _ev), kw in zip(group, kws)]
         engines = [st.engine for st, _req, _ev in group]
-        # the KV blocks of every member's whole utterance (prompt + max_new_tokens + 1 slots, capped at max_seq_len) are taken
-        # BEFORE anything is queued: a short pool raises Fq3Error(FQ3_ENOMEM) here with every context as it was
         taken = []
-        try:
-            for e, it, kw in zip(engines, items, kws):
-                reserve = getattr(e, "kv_reserve", None)
-                if reserve is not None:
-                    reserve(int(it[0].shape[1]) + int(kw["max_new_tokens"]) + 1)
-                    taken.append(e)
-        except Exception:
-            for e in taken:
-                e.kv_release()
-            raise
+
+        def reserve_all():
+            # the KV blocks of every member's whole utterance (prompt + max_new_tokens + 1 slots, capped at max_seq_len) are taken
+            # BEFORE anything is queued: a short pool raises Fq3Error(FQ3_ENOMEM) here with every context as it was.  Called on the
+            # stream the prefill runs on: the block-table entries are written by a launch on the CURRENT stream, and the prefill
+            # kernels read them.
+            try:
+                for e, it, kw in zip(engines, items, kws):
+                    reserve = getattr(e, "kv_reserve", None)
+                    if reserve is not None:
+                        reserve(int(it[0].shape[1]) + int(kw["max_new_tokens"]) + 1)
+                        taken.append(e)
+            except Exception:
+                for e in taken:
+                    e.kv_release()
+                del taken[:]
+                raise
 
         def run():
             if len(group) == 1 or not self.packed_prefill:
@@ -200,12 +214,14 @@ class BatchDecoder:
                     for st, _req, _ev in group:
                         if st.released is not None:
                             self._side.wait_event(st.released)              # the previous tenant's hand-over has been queued
+                    reserve_all()
                     res = run()
                     done = torch.cuda.Event()
                     done.record(self._side)
                 for st, _req, _ev in group:
                     st.ready = done
             else:
+                reserve_all()
                 res = run()
         except Exception:
             for e in taken:                                                 # a failed prefill keeps no blocks
@@ -429,7 +445,7 @@ class BatchDecoder:
             # streaming mode: the chunks found by the previous poll go out only now, with the next frames already queued, so
             # that whatever the consumer does with them (vocoding) overlaps the decode instead of stalling it
             while outbox:
-                yield outbox.pop(0)
+                yield _more(outbox)
             if self.stages:
                 stage_ahead(limit=max(1, self.poll_every // 4))       # prefills fly under the frames queued above
             still = []
@@ -456,12 +472,12 @@ class BatchDecoder:
                     still.append(ln)
             active = still
             while now:
-                yield now.pop(0)
+                yield _more(now)
             if not active and not ready and not pending:              # nothing left to overlap with
                 while outbox:
-                    yield outbox.pop(0)
+                    yield _more(outbox)
         while outbox:
-            yield outbox.pop(0)
+            yield _more(outbox)
         while failed:                                                 # belt and braces: no error event is ever dropped
             rid, info = failed.pop(0)
             yield rid, None, info

@@ -66,17 +66,53 @@ def pack_codec_weights(W: Weights, c: CodecConfig) -> Weights:
     return out
 
 
+_GEMM_SUFFIXES = ("output_proj.weight", "input_proj.weight", "qkv.weight", "o_proj.weight", "gate_up.weight", "down_proj.weight",
+                  "pwconv1.weight", "pwconv2.weight")
+_UNPACKED = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "gate_proj.weight", "up_proj.weight")      # superseded by qkv / gate_up
+
+
+def _is_gemm_weight(name: str, c: CodecConfig) -> bool:
+    """Is this packed tensor the B operand of a matrix-core GEMM (as opposed to a per-channel vector / table an elementwise kernel
+    reads)?  Follows the binding contract documented in csrc/fq3_codec.hip."""
+    if name.endswith(_GEMM_SUFFIXES):
+        return True
+    final = f"decoder.decoder.{len(c.upsample_rates) + 2}.conv.weight"
+    return name.endswith(".conv.weight") and ".dwconv." not in name and name != final
+
+
+def to_bf16x2(x: torch.Tensor) -> torch.Tensor:
+    """fp32 values -> int32 words ``bf16(x) | bf16(x - bf16(x)) << 16``: the storage type of the codec's high-precision mode
+    (``bfs_t`` of csrc/fq3_common.cuh; 16 mantissa bits)."""
+    x = x.float().contiguous()
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    hi_u = hi.view(torch.int16).to(torch.int32) & 0xFFFF
+    lo_u = lo.view(torch.int16).to(torch.int32) & 0xFFFF
+    return (hi_u | (lo_u << 16)).contiguous()
+
+
 class HipSpeechTokenizer:
-    """``speech_tokenizer`` replacement whose ``decode`` runs on the HIP codec kernels."""
+    """``speech_tokenizer`` replacement whose ``decode`` runs on the HIP codec kernels.
+
+    ``precision`` (default: follows ``dtype``): ``"bf16"`` -- the checkpoint dtype, what the reference's Torch path runs; ``"fp32"`` --
+    weights widened exactly, fp32 activations and fp32 matrix-core products; ``"bf16x2"`` -- the high-precision mode for serving:
+    bf16 weights, every activation kept as a bf16 high part + a bf16 residual, two bf16 MFMAs per product pair (``FQ3_BF16X2``):
+    within the north star's 1e-3 PCM RMS of an fp32 evaluation at about twice the bf16 decode time."""
 
     def __init__(self, cfg: CodecConfig, weights: Weights, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
-                 max_frames: int = 1024, share: "HipSpeechTokenizer" = None):
+                 max_frames: int = 1024, share: "HipSpeechTokenizer" = None, precision: str = None):
         self.lib = L.load()
+        if precision is None:
+            precision = "bf16" if dtype == torch.bfloat16 else "fp32"
+        if precision not in ("bf16", "fp32", "bf16x2"):
+            raise ValueError("codec precision must be 'bf16', 'fp32' or 'bf16x2'")
+        dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x2": torch.float32}[precision]
+        self.precision = precision
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         self.sample_rate = int(cfg.sample_rate)
         self.max_frames = int(max_frames)
         cc = L.CodecConfig()
-        cc.dtype = L.FQ3_BF16 if dtype == torch.bfloat16 else L.FQ3_F32
+        cc.dtype = {"bf16": L.FQ3_BF16, "fp32": L.FQ3_F32, "bf16x2": L.FQ3_BF16X2}[precision]
         cc.codebook_size, cc.codebook_dim, cc.rvq_dim = cfg.codebook_size, cfg.codebook_dim, cfg.rvq_dim
         cc.num_quantizers, cc.num_semantic = cfg.num_quantizers, cfg.num_semantic_quantizers
         cc.latent_dim, cc.hidden, cc.inter = cfg.latent_dim, cfg.hidden_size, cfg.intermediate_size
@@ -93,16 +129,29 @@ class HipSpeechTokenizer:
         with torch.cuda.device(self.device):
             L.check(self.lib.fq3_codec_create(C.byref(cc), C.byref(self.h)))
         self._bound: Dict[str, torch.Tensor] = {}
-        if share is not None and share.dtype == dtype and share.device == self.device and share.max_frames == self.max_frames:
-            self._bound = dict(share._bound)            # borrow the packed tensors of another decoder instance
+        self._numel: Dict[str, int] = {}                # logical element counts (what fq3_codec_bind checks)
+        if (share is not None and getattr(share, "precision", None) == precision and share.device == self.device
+                and share.max_frames == self.max_frames):
+            self._bound, self._numel = dict(share._bound), dict(share._numel)       # borrow the packed tensors of another decoder instance
         else:
             for name, t in pack_codec_weights(weights, cfg).items():
-                self._bound[name] = t.to(device=self.device, dtype=dtype).contiguous()
+                self._numel[name] = t.numel()
+                if precision != "bf16x2":
+                    self._bound[name] = t.to(device=self.device, dtype=dtype).contiguous()
+                elif name.endswith(_UNPACKED):
+                    del self._numel[name]               # only their packed forms are read
+                elif _is_gemm_weight(name, cfg):
+                    # B operand: bf16, every K column twice -- the [rows][2 Cin] bf16 image of a bf16x2 activation holds (hi, lo) pairs
+                    w = t.to(device=self.device, dtype=torch.bfloat16)
+                    self._bound[name] = torch.repeat_interleave(w, 2, dim=-1).contiguous()
+                else:
+                    self._bound[name] = to_bf16x2(t.to(self.device))
             cs, sn = rope_tables(cfg.head_dim, cfg.rope_theta, self.max_frames, dtype)
             self._bound["rope.cos"] = cs.to(self.device).contiguous()
             self._bound["rope.sin"] = sn.to(self.device).contiguous()
+            self._numel["rope.cos"], self._numel["rope.sin"] = cs.numel(), sn.numel()
         for name, t in self._bound.items():
-            L.check(self.lib.fq3_codec_bind(self.h, name.encode(), t.data_ptr(), t.numel()))
+            L.check(self.lib.fq3_codec_bind(self.h, name.encode(), t.data_ptr(), self._numel[name]))
         with torch.cuda.device(self.device):
             L.check(self.lib.fq3_codec_finalize(self.h, torch.cuda.current_stream(self.device).cuda_stream))
 
@@ -127,7 +176,8 @@ class HipSpeechTokenizer:
         return SimpleNamespace(audio_codes=out)
 
     def set_option(self, key: str, value: int):
-        """``fq3_codec_set_option``: "fuse_units" 0|1|2 (fused residual units of the 96- / 96- and 192-channel decoder blocks; bit-identical, default 0)."""
+        """``fq3_codec_set_option``: "fuse_units" 0|1|2 (two GEMMs per residual unit | the 96-channel block's units fused into one launch
+        each, the default | the 192-channel block's too); all settings give bit-identical waveforms."""
         L.check(self.lib.fq3_codec_set_option(self.h, key.encode(), int(value)))
 
     def num_samples(self, n_frames: int) -> int:
@@ -186,6 +236,38 @@ class HipSpeechTokenizer:
             return torch.empty(0, dtype=torch.float32, device=self.device)
         return torch.cat(wavs) if len(wavs) != 1 else wavs[0]
 
+    def _decode_piece_batch(self, codes: torch.Tensor, first_sample: int = 0) -> torch.Tensor:
+        """One decoder pass over codes [B, T <= max_frames, 16] (``fq3_codec_decode_batch``): [B, num_samples(T) - first_sample]."""
+        B, Tn = codes.shape[0], codes.shape[1]
+        n = self.num_samples(Tn)
+        first_sample = max(0, min(int(first_sample), n))
+        pcm = torch.empty(B, n - first_sample, dtype=torch.float32, device=self.device)
+        if first_sample < n:
+            L.check(self.lib.fq3_codec_decode_batch(self.h, codes.data_ptr(), int(B), int(Tn), int(first_sample), pcm.data_ptr(),
+                                                    torch.cuda.current_stream(self.device).cuda_stream))
+        return pcm
+
+    def decode_tensor_batch(self, codes: torch.Tensor, first_sample: int = 0) -> torch.Tensor:
+        """codes LongTensor[B, T, 16] -> float32 [B, samples] on the device: row b is, bit for bit, ``decode_tensor(codes[b],
+        first_sample)``, but the B utterances share every launch (one ``[B, T, 16]`` vocoder call as the reference's interface takes it,
+        model.py:924).  Utterances of different lengths: pad to the longest with valid ids and keep ``num_samples_total(T_b)`` samples
+        of each -- the decoder is causal."""
+        codes = codes.to(device=self.device, dtype=torch.long).contiguous()
+        if codes.dim() != 3:
+            raise ValueError("codes must be [B, T, num_quantizers]")
+        B, Tn = codes.shape[0], codes.shape[1]
+        up = self.cfg.total_upsample
+        wavs, pos = [], 0
+        for start, end, ctx in self._pieces(Tn):
+            n_piece = self.num_samples(end - start + ctx) - ctx * up
+            if pos + n_piece > first_sample:
+                skip = ctx * up + max(0, first_sample - pos)
+                wavs.append(self._decode_piece_batch(codes[:, start - ctx:end].contiguous(), skip))
+            pos += n_piece
+        if not wavs:
+            return torch.empty(B, 0, dtype=torch.float32, device=self.device)
+        return torch.cat(wavs, dim=1) if len(wavs) != 1 else wavs[0]
+
     def num_samples_total(self, Tn: int) -> int:
         """Length of ``decode_tensor(codes[Tn])`` (piecewise decodes drop the context samples of every later piece)."""
         up = self.cfg.total_upsample
@@ -195,7 +277,10 @@ class HipSpeechTokenizer:
         codes = payload["audio_codes"]
         if codes.dim() != 3:
             raise ValueError("audio_codes must be [B, T, num_quantizers]")
-        return [self.decode_tensor(codes[b]) for b in range(codes.shape[0])], self.sample_rate
+        if codes.shape[0] == 1:
+            return [self.decode_tensor(codes[0])], self.sample_rate
+        wav = self.decode_tensor_batch(codes)                  # one launch set for the whole [B, T, 16] payload
+        return [wav[b] for b in range(wav.shape[0])], self.sample_rate
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

@@ -60,6 +60,45 @@ class _SideVocoder:
             ev.record(self.stream)
         self.items.append((key, host, ev, pcm))          # pcm kept alive until its copy has completed
 
+    MAX_GROUP = 16          # utterances per batched codec launch set (the workspace grows with it; the gain saturates well before)
+
+    def add(self, key, codes: torch.Tensor, ref_len: int = 0, more: int = 0) -> None:
+        """Grouped form of ``submit``: utterances that finished in the same poll of the lock-step decode (``more`` = how many more of
+        that poll follow, ``timing["more_in_poll"]``) are held back and vocoded TOGETHER -- utterances of equal length through one
+        batched launch set (``decode_tensor_batch``: the [B, T, 16] form of the vocoder interface, model.py:924)."""
+        self._held = getattr(self, "_held", [])
+        self._held.append((key, codes, ref_len))
+        if more <= 0:
+            held, self._held = self._held, []
+            self.submit_many(held)
+
+    def submit_many(self, group) -> None:
+        if not self.async_ok or not hasattr(self.tok, "decode_tensor_batch") or not hasattr(self.tok, "num_samples_total"):
+            for key, codes, ref_len in group:
+                self.submit(key, codes, ref_len)
+            return
+        classes: Dict[Any, list] = {}
+        for key, codes, ref_len in group:
+            classes.setdefault((int(codes.shape[0]), int(ref_len)), []).append((key, codes))
+        for (T, ref_len), members in classes.items():
+            for i in range(0, len(members), self.MAX_GROUP):
+                part = members[i:i + self.MAX_GROUP]
+                if len(part) == 1:
+                    self.submit(part[0][0], part[0][1], ref_len)
+                    continue
+                cut = int(ref_len / max(T, 1) * self.tok.num_samples_total(T)) if ref_len > 0 else 0
+                self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+                for _k, c in part:
+                    c.record_stream(self.stream)
+                with torch.cuda.stream(self.stream):
+                    pcm = self.tok.decode_tensor_batch(torch.stack([c for _k, c in part]), cut)
+                    host = torch.empty(pcm.shape, dtype=torch.float32, pin_memory=True)
+                    host.copy_(pcm, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                for j, (key, _c) in enumerate(part):
+                    self.items.append((key, host[j], ev, pcm))
+
     def collect(self):
         for key, host, ev, _pcm in self.items:
             if ev is None:
@@ -109,10 +148,37 @@ class StreamingVocoder:
                 self.side.wait_stream(torch.cuda.current_stream(self.dev))
             return torch.cat(parts, dim=0)
 
+    def prepare(self, chunk: torch.Tensor, ready_event=None):
+        """Side-stream form of ``push`` in two halves: advances the windowing state by ``chunk`` and returns ``(codes_in,
+        first_sample)`` -- the decode whose ``waveform[first_sample:]`` is this chunk's audio -- so that a caller with several
+        utterances at the same point (the first chunks of lock-step lanes) can run those decodes as ONE batched launch set."""
+        assert self.side is not None
+        chunk.record_stream(self.side)
+        self.all_codes.append(chunk)
+        n_new = chunk.shape[0]
+        flat = self._cat(self.all_codes, ready_event)
+        n_total = flat.shape[0]
+        if self.spf is None:
+            rc = self.ref_codes
+            inp = self._cat([rc.to(flat.device), flat], ready_event) if rc is not None else flat
+            ref_len = rc.shape[0] if rc is not None else 0
+            n_audio = self.tok.num_samples_total(inp.shape[0])
+            cut = int(ref_len / max(inp.shape[0], 1) * n_audio) if ref_len else 0
+            first = cut + self.prev_len
+            self.prev_len = n_audio - cut
+            if n_total >= self.min_cal:
+                self.spf = self.prev_len / n_total
+            return inp, first
+        start = max(0, n_total - n_new - self.CONTEXT_FRAMES)
+        window = flat[start:]
+        n_ctx = window.shape[0] - n_new
+        return window, (int(round(n_ctx * self.spf)) if n_ctx > 0 else 0)
+
     def push(self, chunk: torch.Tensor, ready_event=None):
         """``chunk`` LongTensor[n_new, 16] (device) -> (new audio as a host array, sample_rate)."""
         if self.side is not None:
-            chunk.record_stream(self.side)
+            inp, first = self.prepare(chunk, ready_event)
+            return self._vocode(inp, first, ready_event)
         self.all_codes.append(chunk)
         n_new = chunk.shape[0]
         flat = self._cat(self.all_codes, ready_event)

@@ -162,9 +162,10 @@ class NativeQwen3TTS:
         checkpoint, what the reference's Torch path runs), ``"fp32"`` = the checkpoint's weights widened exactly to fp32, fp32
         activations and fp32 matrix-core products (v_mfma_f32_16x16x4_f32): the waveform of the fp32 oracle to ~1e-6 RMS at ~4x
         the decode time (the decode loop keeps the model dtype either way)."""
-        if codec_precision not in (None, "model", "bf16", "fp32"):
-            raise ValueError("codec_precision must be None, 'model', 'bf16' or 'fp32'")
-        codec_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(codec_precision, dtype)
+        if codec_precision not in (None, "model", "bf16", "fp32", "bf16x2"):
+            raise ValueError("codec_precision must be None, 'model', 'bf16', 'fp32' or 'bf16x2'")
+        codec_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "bf16x2": torch.float32}.get(codec_precision, dtype)
+        codec_prec = codec_precision if codec_precision in ("bf16", "fp32", "bf16x2") else None
         self.cfg = cfg
         self.device = torch.device(device)
         self.dtype = dtype
@@ -175,7 +176,7 @@ class NativeQwen3TTS:
         tok = None
         if any(k.startswith("decoder.") for k in weights):
             tok = HipSpeechTokenizer(cfg.codec, weights, device=device, dtype=codec_dtype, max_frames=codec_max_frames,
-                                     share=share.model.speech_tokenizer if share is not None else None)
+                                     share=share.model.speech_tokenizer if share is not None else None, precision=codec_prec)
         self.model = NativeInner(cfg, talker, tok)
         self.tokenizer = tokenizer or ByteTokenizer(cfg.text_vocab_size)
         # reference-audio analysers (first call per reference clip): one instance per GPU, shared by every lane

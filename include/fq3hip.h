@@ -30,7 +30,9 @@ extern "C" {
 
 #define FQ3_ABI_VERSION 4
 
-enum { FQ3_BF16 = 0, FQ3_F32 = 1 };
+enum { FQ3_BF16 = 0, FQ3_F32 = 1,
+       FQ3_BF16X2 = 2 };   /* codec decoder only: activations kept as a bf16 high part + a bf16 residual (16 mantissa bits), products of the
+                            * two halves with the bf16 weights on v_mfma_f32_16x16x32_bf16; see fq3_codec_config.dtype */
 enum { FQ3_OK = 0, FQ3_EINVAL = -1, FQ3_EHIP = -2, FQ3_ESTATE = -3, FQ3_ETOOLONG = -4, FQ3_EUNSUPPORTED = -5, FQ3_ENOMEM = -6 };
 
 typedef struct fq3_stack_dims {
@@ -300,7 +302,13 @@ int fq3_batch_set_option(fq3_batch* b, const char* key, int value);
 /* ---- 12 Hz codec decoder (speech_tokenizer.decode, model.py:924) ---------------------------- */
 typedef struct fq3_codec fq3_codec;
 typedef struct fq3_codec_config {
-    int32_t dtype;
+    int32_t dtype;              /* FQ3_BF16: the checkpoint dtype, what the reference's Torch path runs (PCM ~8e-3 RMS from an fp32 evaluation on a
+                                 * trained-vocoder-like network).  FQ3_F32: fp32 weights (a bf16 checkpoint widened exactly), activations and
+                                 * v_mfma_f32_16x16x4_f32 products: ~1e-6 RMS, ~4x the time.  FQ3_BF16X2: the high-precision mode for serving --
+                                 * weights stay bf16 (bound with every K column DUPLICATED: [N][taps][2 Cin]), every activation and
+                                 * per-channel vector is a 32-bit word (bf16 hi | bf16 lo << 16; bind those as such), a GEMM reads the
+                                 * activation tensor as a [rows][2 Cin] bf16 matrix and issues two bf16 MFMAs per K pair: <= 1e-3 PCM RMS
+                                 * (north star) at about twice the bf16 time */
     int32_t codebook_size, codebook_dim, rvq_dim, num_quantizers, num_semantic;
     int32_t latent_dim, hidden, inter, n_layers, n_heads, head_dim, sliding_window;
     float rms_eps;
@@ -328,6 +336,15 @@ int fq3_codec_decode(fq3_codec* c, const int64_t* codes, int T, float* pcm, void
  * The decoder is causal with a bounded receptive field after its transformer, so only the rows those samples depend on are
  * recomputed; the values are bit-identical to the corresponding tail of fq3_codec_decode's output. */
 int fq3_codec_decode_tail(fq3_codec* c, const int64_t* codes, int T, int64_t first_sample, float* pcm, void* stream);
+/* The batched form of the vocoder interface (speech_tokenizer.decode takes audio_codes [B, T, 16], model.py:924; payload shape pinned
+ * by the reference's tests/test_sample_rate.py:53-75): codes int64[B][T][16] (device), B utterances of T frames each, decoded by ONE
+ * set of launches -- every tensor is [utterance][rows][C], every launch carries the utterance in a grid dimension, so the
+ * latency-bound frame-level transformer and the skinny convs of short inputs fill the chip B times better.  pcm
+ * float32[B][num_samples(T) - first_sample]: per utterance exactly (bit for bit) what fq3_codec_decode_tail(codes[b], T,
+ * first_sample) produces.  Utterances of different lengths: pad the shorter ones with any valid ids -- the decoder is causal, a
+ * prefix of the codes gives the same prefix of the waveform -- and keep num_samples(T_b) samples of each.  The workspace grows to
+ * B utterances on first use (a device synchronisation; not inside a graph capture). */
+int fq3_codec_decode_batch(fq3_codec* c, const int64_t* codes, int B, int T, int64_t first_sample, float* pcm, void* stream);
 
 /* ---- reference-audio analysis (create_voice_clone_prompt, model.py:415-463 -> upstream qwen_tts) -----------------------
  * What the reference runs once per new (ref_audio, ref_text) pair and then caches (model.py:424-463):

@@ -238,3 +238,113 @@ def test_codec_tail_decode_is_bit_identical_real_shapes():
         tail = tok.decode_tensor(c, first)
         assert torch.equal(tail, full[first:]), (T, keep_frames)
     tok.close()
+
+
+# ---- the bf16 x 2 high-precision mode (FQ3_BF16X2) and the batched decode (fq3_codec_decode_batch) --------------------------
+@pytest.mark.parametrize("T", [40, 100])
+def test_codec_bf16x2_mode_meets_1e_3_at_real_shapes(T, golden_dir):
+    """codec_precision="bf16x2" on a bf16 weight table: weights stay bf16, every activation is a bf16 high part + a bf16 residual
+    (16 mantissa bits), every product runs as two bf16 MFMAs.  Against the fp32-ARITHMETIC oracle on the same bf16-valued weights
+    (tests/golden/codec_real_q.npz) the waveform must be within the north star's 1e-3 PCM RMS with a wide margin (gate 2e-4); a tail
+    decode stays bit-identical to the tail of the full decode (the property the streaming call sites rely on)."""
+    from fq3hip.codec import HipSpeechTokenizer
+    from fq3hip.config import qwen3_tts_0p6b
+    g = np.load(os.path.join(golden_dir, "codec_real_q.npz"))
+    cfg = qwen3_tts_0p6b()
+    W = synth_weights(cfg, 0, torch.bfloat16, parts=("codec",), codec_normalized=True)          # the "checkpoint": bf16
+    codes = torch.from_numpy(g[f"codes_{T}"].astype(np.int64)).cuda()
+    ref = g[f"pcm_f32q_{T}"]
+    tok = HipSpeechTokenizer(cfg.codec, W, "cuda", max_frames=208, precision="bf16x2")
+    full = tok.decode_tensor(codes)
+    wav = full.cpu().numpy()
+    err = _rms(wav - ref)
+    print(f"[parity] codec T={T} bf16x2 mode vs fp32-arithmetic oracle on the bf16 checkpoint weights: {err:.3e} (signal RMS {_rms(ref):.3f})")
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, f"parity_codec_bf16x2_T{T}.txt"), "w") as f:
+        f.write(f"bf16x2_mode_vs_f32q {err:.4e}\n")
+    assert wav.shape == ref.shape and err <= 2e-4, err
+    n = full.numel()
+    for first in (n - 8 * 1920, n // 2 + 7):
+        assert torch.equal(tok.decode_tensor(codes, first), full[first:]), first
+    tok.close()
+
+
+def test_codec_bf16x2_tiny_matches_fp32_oracle():
+    """The same mode on the tiny test decoder (other channel counts, head_dim 32, all tile shapes of small problems) against the fp32
+    oracle run on the bf16-valued weights."""
+    from fq3hip.codec import HipSpeechTokenizer
+    from oracle import qwen3tts_oracle as O
+    cfg = tiny_test_config()
+    Wb = synth_weights(cfg, 0, torch.bfloat16, parts=("codec",))
+    Wf = {k: v.float() for k, v in Wb.items()}
+    tok = HipSpeechTokenizer(cfg.codec, Wb, "cuda", max_frames=64, precision="bf16x2")
+    g = torch.Generator().manual_seed(17)
+    for T in (1, 7, 40):
+        codes = torch.randint(0, cfg.codec.codebook_size, (T, cfg.codec.num_quantizers), generator=g)
+        ref = O.codec_decode(codes, Wf, cfg.codec).numpy()
+        wav = tok.decode_tensor(codes.cuda()).cpu().numpy()
+        assert wav.shape == ref.shape
+        err, sig = _rms(wav - ref), _rms(ref)
+        print(f"[parity] tiny codec bf16x2 T={T}: RMS {err:.3e} (signal {sig:.3f})")
+        assert err <= 1e-3 * max(1.0, sig / 0.17), (T, err, sig)
+    tok.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32", "bf16x2"])
+def test_codec_batched_decode_is_bit_identical_per_utterance_tiny(precision):
+    """fq3_codec_decode_batch: B utterances through one set of launches == B single decodes, bit for bit -- full decodes, tail
+    decodes, the piecewise schedule, and the [B, T, 16] payload of the reference's vocoder interface (model.py:924)."""
+    from fq3hip.codec import HipSpeechTokenizer
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, torch.bfloat16, parts=("codec",))
+    tok = HipSpeechTokenizer(cfg.codec, W, "cuda", max_frames=64, precision=precision)
+    g = torch.Generator().manual_seed(23)
+    for B, T in ((3, 33), (5, 7), (2, 64)):
+        codes = torch.randint(0, cfg.codec.codebook_size, (B, T, cfg.codec.num_quantizers), generator=g).cuda()
+        single = [tok.decode_tensor(codes[b]) for b in range(B)]
+        batch = tok.decode_tensor_batch(codes)
+        assert batch.shape == (B, single[0].numel())
+        for b in range(B):
+            assert torch.equal(batch[b], single[b]), (B, T, b)
+        n = single[0].numel()
+        for first in (n // 2 + 3, max(0, n - 1921)):
+            tb = tok.decode_tensor_batch(codes, first)
+            for b in range(B):
+                assert torch.equal(tb[b], single[b][first:]), (B, T, b, first)
+        wavs, sr = tok.decode({"audio_codes": codes})
+        assert sr == 24000 and len(wavs) == B and all(torch.equal(w, s) for w, s in zip(wavs, single))
+    tok.CHUNK_FRAMES = 39                                         # pieces of 39 new + 25 context frames, batched piece by piece
+    codes = torch.randint(0, cfg.codec.codebook_size, (3, 100, cfg.codec.num_quantizers), generator=g).cuda()
+    batch = tok.decode_tensor_batch(codes)
+    for b in range(3):
+        assert torch.equal(batch[b], tok.decode_tensor(codes[b])), b
+    # utterances of different lengths: pad to the longest, keep each one's own sample count (the decoder is causal)
+    tok.CHUNK_FRAMES = 300
+    padded = codes[:, :64].clone()
+    padded[1, 61:] = 0                                            # utterance 1 has 61 frames; its tail is padding
+    got = tok.decode_tensor_batch(padded)[1]
+    assert torch.equal(got[: tok.num_samples_total(61)], tok.decode_tensor(padded[1, :61].contiguous()))
+    tok.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x2"])
+def test_codec_batched_decode_real_shapes(precision):
+    """The benchmark's shapes: 4 utterances of 100 frames (> the attention window; big 256-wide tiles, glds tiles, the fused residual
+    units all take their batched forms) and the first streaming chunk of 6 lanes (178 frames in, the last 8 frames' samples out)."""
+    from fq3hip.codec import HipSpeechTokenizer
+    from fq3hip.config import qwen3_tts_0p6b
+    cfg = qwen3_tts_0p6b()
+    W = synth_weights(cfg, 0, torch.bfloat16, parts=("codec",), codec_normalized=True)
+    tok = HipSpeechTokenizer(cfg.codec, W, "cuda", max_frames=208, precision=precision)
+    g = torch.Generator().manual_seed(29)
+    codes = torch.randint(0, cfg.codec.codebook_size, (4, 100, cfg.codec.num_quantizers), generator=g).cuda()
+    batch = tok.decode_tensor_batch(codes)
+    for b in range(4):
+        assert torch.equal(batch[b], tok.decode_tensor(codes[b])), b
+    codes = torch.randint(0, cfg.codec.codebook_size, (6, 178, cfg.codec.num_quantizers), generator=g).cuda()
+    first = tok.num_samples_total(178) - 8 * 1920
+    tail = tok.decode_tensor_batch(codes, first)
+    for b in range(6):
+        assert torch.equal(tail[b], tok.decode_tensor(codes[b], first)), b
+    tok.close()

@@ -262,11 +262,11 @@ int main(int argc, char** argv) {
             }
             hipFree(Y2);
             rung("big 256x128 ring-4 (random)", big_go_t<true, 128>);
-            rung("big 256x256 ring-4 (random)", big_go);
+            rung("big 256x256 ring-4 (random)", big_go<bf16_t>);
             rung("glds 128x64 2 st (random)", glds_go<64, 2>);
             hipMemset(A, 0x3c, (size_t)M * K * 2); hipMemset(W, 0x3c, (size_t)N * K * 2);
         }
-        rung("big 256x256 ring-4", big_go);
+        rung("big 256x256 ring-4", big_go<bf16_t>);
         rung("glds 128x64 2 stages", glds_go<64, 2>);
         rung("glds 128x64 3 stages", glds_go<64, 3>);
         rung("glds 128x128 2 stages", glds_go<128, 2>);
