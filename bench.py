@@ -307,8 +307,10 @@ def batched_run(model, prompt, n_utt, lanes=8, frames=FRAMES, seed0=2000, sync=N
         if codes is None:
             continue
         full = torch.cat([ref_codes.to(codes.device), codes], dim=0) if ref_codes is not None else codes
-        voc.submit(rid, full, ref_len=ref_codes.shape[0] if ref_codes is not None else 0)
+        # (as generate_voice_clone_batch does: utterances that finish in the same poll share one batched codec launch set)
+        voc.add(rid, full, ref_len=ref_codes.shape[0] if ref_codes is not None else 0, more=int(getattr(dec, "more_in_poll", 0)))
         n_frames += codes.shape[0]
+    voc.add_flush()
     for rid, a in voc.collect():                      # every waveform on the host before the clock stops
         lens[rid] = int(len(a))
     sync()

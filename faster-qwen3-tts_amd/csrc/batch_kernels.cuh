@@ -140,11 +140,16 @@ struct BatchGemvArgs {
 // One row per wave (4 rows per workgroup), weight rows loaded ONCE; the B <= kMaxLanes tokens pass through LDS in groups of
 // `a.group` <= 8 (so that B x K never has to fit the 160 KB LDS at once: 16 lanes, fp32, K = 6144 would need 393 KB).  Loops
 // are unrolled to the group maximum and guarded by uniform branches, so one instantiation serves every batch size.
+// tokens per LDS pass at most: 8, or 4 where 8 rows of K = 6144 fp32 would not fit the LDS anyway (and their staging registers --
+// 2 tokens x 12 chunks x 8 fp32 per lane next to 96 registers of weights -- sent the kernel to scratch)
+template <typename T> constexpr int batch_group_max_nch(int nch) { return (sizeof(T) == 4 && nch >= 12) ? 4 : kGroupLanes; }
+template <typename T> inline int batch_group_max(int need_chunks) { return batch_group_max_nch<T>(need_chunks > 6 ? 12 : need_chunks); }
+
 template <typename T, int NCH, int PRO, int EPI>
 __global__ __launch_bounds__(256) void gemv_batch_kernel(BatchGemvArgs a) {
     static_assert(PRO == PRO_PLAIN || PRO == PRO_NORM, "the split-KV merge is its own launch in the batch chain (combine_batch_kernel)");
     constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;
-    constexpr int GT = kGroupLanes, TPW = GT / 4;               // tokens prepared per wave and group
+    constexpr int GT = batch_group_max_nch<T>(NCH), TPW = GT / 4;               // tokens prepared per wave and group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* xs = reinterpret_cast<T*>(smem_raw);                     // [group][K], normalised + rounded
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

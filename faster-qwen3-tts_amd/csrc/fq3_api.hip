@@ -36,7 +36,7 @@ int fq3_dmalloc_(fq3_ctx* c, void** p, size_t bytes) { return dmalloc(c, p, byte
 static bool dims_ok(const fq3_stack_dims& d) {
     return d.head_dim == kHeadDim && d.hidden % 8 == 0 && d.inter % 8 == 0 && d.n_heads % d.n_kv_heads == 0 &&
            (d.n_heads / d.n_kv_heads == 1 || d.n_heads / d.n_kv_heads == 2 || d.n_heads / d.n_kv_heads == 4) &&
-           d.vocab <= kMaxVocab && d.vocab % 8 == 0 && d.hidden <= 8192 && d.inter <= 8192 * 3 && d.n_layers >= 1;
+           d.vocab <= kMaxVocab && d.vocab % 8 == 0 && d.hidden <= 2048 && d.inter <= 6144 && d.n_heads * kHeadDim <= 6144 && d.n_layers >= 1;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -46,7 +46,7 @@ static int cfg_check(const fq3_config* cfg) {
     if (cfg->dtype != FQ3_BF16 && cfg->dtype != FQ3_F32) return fail(FQ3_EINVAL, "dtype must be FQ3_BF16 or FQ3_F32");
     if (!dims_ok(cfg->talker) || !dims_ok(cfg->predictor))
         return fail(FQ3_EUNSUPPORTED, "unsupported dims (need head_dim 128, GQA ratio 1/2/4, vocab <= 4096 and a multiple of 8, "
-                                      "hidden / intermediate multiples of 8)");
+                                      "hidden <= 2048 and intermediate <= 6144, both multiples of 8)");
     if (cfg->num_code_groups < 2 || cfg->num_code_groups > 64) return fail(FQ3_EINVAL, "num_code_groups");
     if (cfg->max_seq_len < 8) return fail(FQ3_EINVAL, "max_seq_len");
     return 0;
@@ -332,16 +332,18 @@ static void launch_gemv_n(const GemvArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((gemv_kernel<T, NCH, PRO, EPI, NT, M, 1>), dim3(grid), dim3(256), shm, s, a);
 }
-// two-token launches: code predictor only (default cache policy), hidden sizes up to 2048 / intermediate up to 6144
+// two-token launches: code predictor only (default cache policy).  Inner dimensions: a normalising GEMV reads the hidden size
+// (<= 2048: four 512-element chunks per lane), the others q_dim / the intermediate size (<= 3072 for a two-token pass: the row
+// registers of both tokens would not fit beyond -- the 12-chunk instantiations of earlier rounds spilled and were never reached by a
+// supported model).
 template <typename T, int PRO, int EPI>
 static int launch_gemv2_t(const GemvArgs& a, hipStream_t s) {
     const int need = (a.K + 511) / 512;
     if (need <= 1) launch_gemv_n<T, 1, PRO, EPI, false, 2>(a, s);
     else if (need <= 2) launch_gemv_n<T, 2, PRO, EPI, false, 2>(a, s);
     else if (need <= 4) launch_gemv_n<T, 4, PRO, EPI, false, 2>(a, s);
-    else if (need <= 6) launch_gemv_n<T, 6, PRO, EPI, false, 2>(a, s);
-    else if (need <= 12) launch_gemv_n<T, 12, PRO, EPI, false, 2>(a, s);
-    else return fail(FQ3_EUNSUPPORTED, "GEMV inner dimension above 6144");
+    else if (PRO != PRO_NORM && need <= 6) { if constexpr (PRO != PRO_NORM) launch_gemv_n<T, 6, PRO, EPI, false, 2>(a, s); }
+    else return fail(FQ3_EUNSUPPORTED, PRO == PRO_NORM ? "code predictor hidden size above 2048" : "code predictor GEMV inner dimension above 3072");
     return 0;
 }
 template <int PRO, int EPI>
@@ -355,6 +357,7 @@ static int launch_gemv_t(const GemvArgs& a, hipStream_t s) {
     if (need <= 1) launch_gemv_n<T, 1, PRO, EPI, NT>(a, s);
     else if (need <= 2) launch_gemv_n<T, 2, PRO, EPI, NT>(a, s);
     else if (need <= 4) launch_gemv_n<T, 4, PRO, EPI, NT>(a, s);
+    else if constexpr (PRO == PRO_NORM) return fail(FQ3_EUNSUPPORTED, "hidden size above 2048");      // a normalising GEMV reads K = hidden
     else if (need <= 6) launch_gemv_n<T, 6, PRO, EPI, NT>(a, s);
     else if (need <= 12) launch_gemv_n<T, 12, PRO, EPI, NT>(a, s);
     else return fail(FQ3_EUNSUPPORTED, "GEMV inner dimension above 6144");

@@ -140,7 +140,7 @@ static int launch_gemv_batch_t(BatchGemvArgs a, int esz, hipStream_t s) {
     const int need = (a.K + 511) / 512;
     const int grid = (a.N + 3) / 4;
     // tokens per LDS pass: as many as fit ~150 KB (16 lanes x K = 6144 x fp32 would need 393 KB), at most kGroupLanes
-    int group = std::min(a.B, kGroupLanes);
+    int group = std::min(a.B, batch_group_max<T>(need));
     while (group > 1 && (size_t)group * a.K * esz > 150 * 1024) group = (group + 1) / 2;
     const size_t shm = (size_t)group * a.K * esz;
     if (shm > 150 * 1024) return fq3_fail_(FQ3_EUNSUPPORTED, "a single token of this inner dimension does not fit the 160 KB LDS");
@@ -155,9 +155,12 @@ static int launch_gemv_batch_t(BatchGemvArgs a, int esz, hipStream_t s) {
     if (need <= 1) return go(std::integral_constant<int, 1>{});
     if (need <= 2) return go(std::integral_constant<int, 2>{});
     if (need <= 4) return go(std::integral_constant<int, 4>{});
-    if (need <= 6) return go(std::integral_constant<int, 6>{});
-    if (need <= 12) return go(std::integral_constant<int, 12>{});
-    return fq3_fail_(FQ3_EUNSUPPORTED, "GEMV inner dimension above 6144");
+    if constexpr (PRO == PRO_NORM) return fq3_fail_(FQ3_EUNSUPPORTED, "hidden size above 2048");      // a normalising GEMV reads K = hidden
+    else {
+        if (need <= 6) return go(std::integral_constant<int, 6>{});
+        if (need <= 12) return go(std::integral_constant<int, 12>{});
+        return fq3_fail_(FQ3_EUNSUPPORTED, "GEMV inner dimension above 6144");
+    }
 }
 // matrix-core variants: bf16, built step counts; return -1000 when the shape is not covered (the VALU kernel takes over)
 template <int EPI>

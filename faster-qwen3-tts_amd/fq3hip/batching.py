@@ -32,15 +32,6 @@ from .talker_graph import TalkerGraph
 MAX_LANES = 32          # kMaxLanes of csrc/batch_kernels.cuh (fq3_batch_create refuses more)
 
 
-def _more(queue: list):
-    """Pop the next event of a poll's batch and tell the consumer how many more of the SAME poll follow (``more_in_poll``): utterances
-    that finish / chunks that complete together can then be vocoded by one batched codec launch set."""
-    ev = queue.pop(0)
-    if isinstance(ev[2], dict):
-        ev[2]["more_in_poll"] = len(queue)
-    return ev
-
-
 @dataclass
 class BatchRequest:
     """One utterance: the tensors ``fast_generate`` takes plus its sampling arguments."""
@@ -97,6 +88,7 @@ class BatchDecoder:
         self.lanes = [_Lane(i, e, TalkerGraph(e), PredictorGraph(e, **policy)) for i, e in enumerate(engines)]
         self.batch = batch_factory(engines)
         self.poll_every = max(1, int(poll_every))
+        self.more_in_poll = 0
         self.use_graph = use_graph
         self._captured = False
         # spare contexts (same weights, not part of the lock-step batch) for prefilling ahead of admission
@@ -113,6 +105,14 @@ class BatchDecoder:
         # tests/test_gpu_decode.py).  Measured with the workspaces reserved up front (profiles/r03_packed_prefill.txt, 0.6B shapes,
         # 200-row prompts): first-wave TTFA 82.5 -> 63.6 ms at 8 lanes and 125 -> 89 ms at 16, aggregate 153.5 -> 156x / 229 -> 234x.
         self.packed_prefill = bool(packed_prefill)
+
+    def _more(self, queue: list):
+        """Pop the next event of a poll's batch; ``self.more_in_poll`` tells the consumer (read it right after receiving the event) how
+        many more events of the SAME poll follow: utterances that finish / chunks that complete together can then be vocoded by one
+        batched codec launch set.  (An attribute, not a timing key: the timing dicts keep exactly the reference's keys.)"""
+        ev = queue.pop(0)
+        self.more_in_poll = len(queue)
+        return ev
 
     def set_predictor_policy(self, **policy):
         for ln in self.lanes:
@@ -401,6 +401,7 @@ class BatchDecoder:
                 stage_ahead()                                         # nothing is decoding: nothing to overlap with
             while failed:
                 rid, info = failed.pop(0)
+                self.more_in_poll = 0
                 yield rid, None, info
             while free and (ready or (pending and not self.stages)):  # admit at a frame boundary
                 ln = free.popleft()
@@ -420,9 +421,11 @@ class BatchDecoder:
                     free.appendleft(ln)
                     if on_error == "raise":
                         raise
+                    self.more_in_poll = 0
                     yield rid, None, {"error": repr(exc), "steps": 0}
                     continue
                 if ln.max_frames <= 0:
+                    self.more_in_poll = 0
                     yield self._finish(ln, 0, chunked)
                     free.append(ln)
                     continue
@@ -445,7 +448,7 @@ class BatchDecoder:
             # streaming mode: the chunks found by the previous poll go out only now, with the next frames already queued, so
             # that whatever the consumer does with them (vocoding) overlaps the decode instead of stalling it
             while outbox:
-                yield _more(outbox)
+                yield self._more(outbox)
             if self.stages:
                 stage_ahead(limit=max(1, self.poll_every // 4))       # prefills fly under the frames queued above
             still = []
@@ -472,12 +475,13 @@ class BatchDecoder:
                     still.append(ln)
             active = still
             while now:
-                yield _more(now)
+                yield self._more(now)
             if not active and not ready and not pending:              # nothing left to overlap with
                 while outbox:
-                    yield _more(outbox)
+                    yield self._more(outbox)
         while outbox:
-            yield _more(outbox)
+            yield self._more(outbox)
         while failed:                                                 # belt and braces: no error event is ever dropped
             rid, info = failed.pop(0)
+            self.more_in_poll = 0
             yield rid, None, info

@@ -72,6 +72,11 @@ class _SideVocoder:
             held, self._held = self._held, []
             self.submit_many(held)
 
+    def add_flush(self) -> None:
+        held, self._held = getattr(self, "_held", []), []
+        if held:
+            self.submit_many(held)
+
     def submit_many(self, group) -> None:
         if not self.async_ok or not hasattr(self.tok, "decode_tensor_batch") or not hasattr(self.tok, "num_samples_total"):
             for key, codes, ref_len in group:
@@ -785,14 +790,19 @@ class FasterQwen3TTS:
         head, source = self._batch_feed(prepared, gen_kwargs, len(dec.lanes), meta)
         out: List[Optional[Tuple[list, int]]] = [None] * count
         voc = self._side_vocoder()
-        for rid, codec_ids, _timing in dec.run(head, source=source):
+        for rid, codec_ids, timing in dec.run(head, source=source):
+            more = int(getattr(dec, "more_in_poll", 0))
             if codec_ids is None:
                 out[rid] = ([np.zeros(1, dtype=np.float32)], self.sample_rate)
+                if more <= 0:
+                    voc.add_flush()
                 continue
             rc = meta[rid]
             codes = torch.cat([rc.to(codec_ids.device), codec_ids], dim=0) if rc is not None else codec_ids
-            # side stream; the next frames of the other lanes are not held up
-            voc.submit(rid, codes, ref_len=rc.shape[0] if rc is not None else 0)
+            # side stream; the next frames of the other lanes are not held up.  Utterances that finished in the same poll are vocoded
+            # together (equal lengths: one batched launch set)
+            voc.add(rid, codes, ref_len=rc.shape[0] if rc is not None else 0, more=more)
+        voc.add_flush()
         for rid, a in voc.collect():
             out[rid] = ([a], voc.sample_rate)
         return out
@@ -805,20 +815,60 @@ class FasterQwen3TTS:
         vocs, n_chunks = {}, {}
         dec = self._batch_decoder(lanes)
         head, source = self._batch_feed(prepared, gen_kwargs, len(dec.lanes), meta)
+        tok = self.model.model.speech_tokenizer
+        side = self._vocoder_stream(tok)
+        batched = side is not None and hasattr(tok, "decode_tensor_batch")
+        jobs: list = []                                  # the events of one poll, in order: [rid, meta, audio | None, (codes_in, first, ev) | None]
+
+        def flush():
+            # chunks of different utterances that need the SAME decode shape (the first chunks of lanes that started together:
+            # reference + 8 frames in, the last 8 frames' samples out) go through one batched launch set on the vocoder stream
+            classes: Dict[Any, list] = {}
+            for j in jobs:
+                if j[3] is not None:
+                    classes.setdefault((int(j[3][0].shape[0]), int(j[3][1])), []).append(j)
+            for (_T, first), members in classes.items():
+                for i in range(0, len(members), _SideVocoder.MAX_GROUP):
+                    part = members[i:i + _SideVocoder.MAX_GROUP]
+                    for j in part:
+                        if j[3][2] is not None:
+                            side.wait_event(j[3][2])
+                        else:
+                            side.wait_stream(torch.cuda.current_stream(torch.device(self.device)))
+                    with torch.cuda.stream(side):
+                        if len(part) == 1:
+                            part[0][2] = _to_numpy(tok.decode_tensor(part[0][3][0], first))
+                        else:
+                            wav = tok.decode_tensor_batch(torch.stack([j[3][0] for j in part]), first).cpu().numpy()
+                            for k, j in enumerate(part):
+                                j[2] = wav[k]
+            done, jobs[:] = list(jobs), []
+            return done
+
         for rid, codes, info in dec.run(head, source=source, chunk_frames=chunk_size):
             if rid not in vocs:
                 vocs[rid], n_chunks[rid] = self.streaming_vocoder(meta[rid], chunk_size), 0
             ev = info.pop("codes_ready_event", None)
             final = bool(info.get("is_final"))
+            more = int(getattr(dec, "more_in_poll", 0))
+            out_meta = dict(chunk_index=n_chunks[rid], total_steps_so_far=int(info.get("total_steps_so_far", 0)),
+                            is_final=final, chunk_steps=0 if codes is None else int(codes.shape[0]))
             if codes is not None and codes.shape[0] > 0:
-                audio, sr = vocs[rid].push(codes, ev)
+                if batched:
+                    inp, first = vocs[rid].prepare(codes, ev)
+                    jobs.append([rid, out_meta, None, (inp, first, ev)])
+                else:
+                    audio, _sr = vocs[rid].push(codes, ev)
+                    jobs.append([rid, out_meta, audio, None])
+                n_chunks[rid] += 1
             elif final:
-                audio, sr = np.zeros(1 if codes is None else 0, dtype=np.float32), self.sample_rate
-            else:
-                continue
-            yield rid, audio, sr, dict(chunk_index=n_chunks[rid], total_steps_so_far=int(info.get("total_steps_so_far", 0)),
-                                       is_final=final, chunk_steps=0 if codes is None else int(codes.shape[0]))
-            n_chunks[rid] += 1
+                jobs.append([rid, out_meta, np.zeros(1 if codes is None else 0, dtype=np.float32), None])
+                n_chunks[rid] += 1
+            if more <= 0:
+                for r, m, audio, _job in flush():
+                    yield r, audio, self.sample_rate, m
+        for r, m, audio, _job in flush():
+            yield r, audio, self.sample_rate, m
 
     @staticmethod
     def _per_text(value, n: int, what: str) -> list:

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Codec decoder timing (development aid): full decode of 370 frames (two pieces: 300 + 95 with context), one 300-frame piece,
-a streaming phase-2 chunk (25 context + 8 new frames, tail decode) and the first streaming chunk (178 frames in, 8 out), bf16.
-usage: codec_time.py [fp32]"""
+a streaming phase-2 chunk (25 context + 8 new frames, tail decode) and the first streaming chunk (178 frames in, 8 out); then the
+BATCHED forms (fq3_codec_decode_batch): B utterances of 370 frames / B first chunks through one launch set, per utterance.
+usage: codec_time.py [bf16|bf16x2|fp32] [batch sizes, e.g. 4,16]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "faster-qwen3-tts_amd"))
@@ -22,19 +23,31 @@ def timed(fn, reps=5):
 
 
 def main():
-    dt = torch.float32 if len(sys.argv) > 1 and sys.argv[1] == "fp32" else torch.bfloat16
+    prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    Bs = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "4,16").split(",")]
     cfg = qwen3_tts_0p6b()
     W = synth_weights(cfg, 0, torch.bfloat16, parts=("codec",), codec_normalized=True)
-    tok = HipSpeechTokenizer(cfg.codec, W, "cuda", dt, max_frames=400)
+    tok = HipSpeechTokenizer(cfg.codec, W, "cuda", max_frames=400, precision=prec)
     g = torch.Generator().manual_seed(4)
     codes = torch.randint(0, cfg.codec.codebook_size, (370, 16), generator=g).cuda()
     n33 = tok.num_samples_total(33); n178 = tok.num_samples_total(178)
-    for fuse in ((0, 1, 2) if dt == torch.bfloat16 else (0,)):
+    for fuse in ((0, 1, 2) if prec == "bf16" else (1,)):
       tok.set_option("fuse_units", fuse)
       print(f"fused residual units = {fuse}: ", end="")
-      print(f"dtype {dt}: full 370 frames {timed(lambda: tok.decode_tensor(codes)):.3f} ms | one piece of 300 frames {timed(lambda: tok.decode_tensor(codes[:300].contiguous())):.3f} ms | "
+      print(f"precision {prec}: full 370 frames {timed(lambda: tok.decode_tensor(codes)):.3f} ms | one piece of 300 frames {timed(lambda: tok.decode_tensor(codes[:300].contiguous())):.3f} ms | "
           f"chunk 25+8 frames (tail of 8) {timed(lambda: tok.decode_tensor(codes[:33].contiguous(), n33 - 8 * 1920), 10):.3f} ms | "
-          f"first chunk 170+8 frames (tail of 8) {timed(lambda: tok.decode_tensor(codes[:178].contiguous(), n178 - 8 * 1920), 10):.3f} ms")
+          f"first chunk 170+8 frames (tail of 8) {timed(lambda: tok.decode_tensor(codes[:178].contiguous(), n178 - 8 * 1920), 10):.3f} ms", flush=True)
+    tok.set_option("fuse_units", 1)
+    cut = int(170 / 370 * tok.num_samples_total(370))
+    for B in Bs:
+        cb = torch.randint(0, cfg.codec.codebook_size, (B, 370, 16), generator=g).cuda()
+        full = timed(lambda: tok.decode_tensor_batch(cb), 3)
+        tail = timed(lambda: tok.decode_tensor_batch(cb, cut), 3)
+        first = timed(lambda: tok.decode_tensor_batch(cb[:, :178].contiguous(), n178 - 8 * 1920), 5)
+        ch = timed(lambda: tok.decode_tensor_batch(cb[:, :33].contiguous(), n33 - 8 * 1920), 5)
+        print(f"precision {prec} BATCH of {B}: full 370 frames {full:.3f} ms = {full / B:.3f} per utterance | tail after 170 reference frames "
+              f"{tail:.3f} ms = {tail / B:.3f} per utterance | first chunks 170+8 (tail of 8) {first:.3f} ms = {first / B:.3f} each | "
+              f"chunks 25+8 {ch:.3f} ms = {ch / B:.3f} each", flush=True)
 
 
 if __name__ == "__main__":
