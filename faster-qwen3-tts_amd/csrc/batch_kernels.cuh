@@ -26,6 +26,7 @@ struct LaneTab {
     unsigned char* seen[kMaxLanes];
     void* past_hidden[kMaxLanes];
 };
+struct LaneForced { const TeacherForcing* tf[kMaxLanes]; };       // teacher-forcing objects of the lanes (parity tests; null in product use)
 struct LaneKV { void* k[kMaxLanes]; void* v[kMaxLanes]; };       // per lane: the predictor's contiguous cache, or the base of the talker's block pool
 struct LaneTabs { const int* t[kMaxLanes]; int blk_stride; };     // talker: every lane's block table (paged KV, decode_kernels.cuh)
 
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void combine_batch_kernel(const float* part, s
 }
 
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void sample_pred_batch_kernel(LaneTab t, const T* logits, size_t logit_stride, int V, int cb,
+__global__ __launch_bounds__(256) void sample_pred_batch_kernel(LaneTab t, LaneForced f, const T* logits, size_t logit_stride, int V, int cb,
                                                                int G, const T* next_emb, T* next_in, int H) {
     const int l = blockIdx.x;
     SampleCfg c{};                       // policy comes from the lane's DecodeState
@@ -115,13 +116,13 @@ __global__ __launch_bounds__(256) void sample_pred_batch_kernel(LaneTab t, const
     // NUCLEUS = true: a lane whose policy asks for top_p < 1 takes the LDS sampler (sampler.cuh::sample_core) inside the same
     // launch; the register-resident path of the other lanes is unchanged
     sample_pred_wave_body<T, NC, true>(t.st[l], logits + (size_t)l * logit_stride, V, cb, c, (const T*)nullptr, t.codes[l], G,
-                                       (int64_t*)nullptr, next_emb, next_in + (size_t)l * H, H);
+                                       (int64_t*)nullptr, next_emb, next_in + (size_t)l * H, H, f.tf[l]);
 }
 
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void sample_talker_batch_kernel(LaneTab t, const T* logits, int V, int G) {
+__global__ __launch_bounds__(256) void sample_talker_batch_kernel(LaneTab t, LaneForced f, const T* logits, int V, int G) {
     const int l = blockIdx.x;
-    sample_talker_wave_body<T, NC, true>(t.st[l], logits + (size_t)l * V, V, t.seen[l], G);
+    sample_talker_wave_body<T, NC, true>(t.st[l], logits + (size_t)l * V, V, t.seen[l], G, f.tf[l]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -321,18 +322,26 @@ typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 // NT = token tiles of 16 lanes the launch walks (1: B <= 16, 2: 17..32).  The weight fragments are loaded once and stay in
 // registers; with NT = 2 the second tile's raw tokens are loaded up front as well when they fit (PRE2: K <= 1024), otherwise after
 // the first tile has been multiplied (one exposed L2 round trip).
-template <int KSTEPS, int EPI, int NT>            // K = KSTEPS * 128
+// DUAL (two token tiles, K <= 1024; round 4): BOTH tiles' tokens are normalised into their own LDS panels before the first MFMA --
+// i.e. while the weight fragments are still in flight, where the first tile's normalisation already ran -- then both tiles are
+// multiplied back to back, the K quarters of both meet in ONE exchange, and waves 0 / 1 run the two epilogues side by side.  The
+// second tile's ~1 us of normalisation arithmetic, two of the five barriers and one exposed pass over the partial sums leave the
+// critical path; every value is computed by the same instructions in the same order as in the one-panel form (bit-identical:
+// tests/test_gpu_batch.py).  2 x 33 KB of LDS at K = 1024.
+template <int KSTEPS, int EPI, int NT, bool DUAL = false>            // K = KSTEPS * 128
 __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs a) {
     typedef bf16_t T;
     constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr bool PRE2 = NT == 2 && KSTEPS <= 8;
+    static_assert(!DUAL || PRE2, "the two-panel form needs both tiles' raw tokens in registers");
     constexpr int NXR = PRE2 ? 2 : 1;
     constexpr int K = KSTEPS * 128, KP = K + 8;                 // padded LDS row: 16 tokens x same k would share a bank
     constexpr int NCH = (K + 511) / 512;
     constexpr int TPW = kTokTile / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* xs = reinterpret_cast<T*>(smem_raw);                     // [16][KP]
-    float* red = reinterpret_cast<float*>(smem_raw + (((size_t)kTokTile * KP * sizeof(T) + 15) & ~(size_t)15));   // [4][NR][64][4]
+    constexpr int NPANEL = DUAL ? 2 : 1;
+    T* xs = reinterpret_cast<T*>(smem_raw);                     // [NPANEL][16][KP]
+    float* red = reinterpret_cast<float*>(smem_raw + (((size_t)NPANEL * kTokTile * KP * sizeof(T) + 15) & ~(size_t)15));   // [NPANEL][4][NR][64][4]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int fr = lane & 15, fq = lane >> 4, B = a.B;
     const T* W = reinterpret_cast<const T*>(a.W);
@@ -377,6 +386,107 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
         biasv[i] = a.bias ? bv : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DUAL) {
+        // ---- 3'. both tiles' tokens -> their panels (while the weights fly) ----
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t0 = tt * kTokTile;
+            const int nb = B - t0 < kTokTile ? B - t0 : kTokTile;
+            T* xp = xs + (size_t)tt * kTokTile * KP;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int m = wave + 4 * t;
+                float xr[NCH][8];
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    if (j * 512 + lane * 8 >= K) zero(xraw[tt][t][j]);
+                    unpack(xraw[tt][t][j], xr[j]);
+                }
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
+                ss = wave_sum(ss);
+                const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    float nw[8];
+                    unpack(nraw[j], nw);
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) {
+                        float u = xr[j][i] * rs, v = xr[j][i + 1] * rs;
+                        DT<T>::rnd2(u, v);
+                        u *= nw[i]; v *= nw[i + 1];
+                        DT<T>::rnd2(u, v);
+                        xr[j][i] = u; xr[j][i + 1] = v;
+                    }
+                }
+                if (m < nb) {
+                    T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[t0 + m]) : nullptr;
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) {
+                        const int off = j * 512 + lane * 8;
+                        if (off < K) {
+                            DT<T>::st8(xp + (size_t)m * KP + off, xr[j]);
+                            if (xo) DT<T>::st8(xo + off, xr[j]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 4'. MFMA over this wave's K quarter, both tiles; 5'. one exchange, two epilogues side by side ----
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nb = B - tt * kTokTile < kTokTile ? B - tt * kTokTile : kTokTile;
+            const T* xp = xs + (size_t)tt * kTokTile * KP;
+            f32x4 acc[NR];
+#pragma unroll
+            for (int h = 0; h < NR; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int tokc = fr < nb ? fr : nb - 1;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const u32x4 bq = *reinterpret_cast<const u32x4*>(xp + (size_t)tokc * KP + wave * (K / 4) + s * 32 + fq * 8);
+                const mfma_bf16x8 bfrag = __builtin_bit_cast(mfma_bf16x8, bq);
+#pragma unroll
+                for (int h = 0; h < NR; ++h)
+                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wreg[h][s].v), bfrag, acc[h], 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < NR; ++h) *reinterpret_cast<f32x4*>(red + (((size_t)tt * 4 + wave) * NR + h) * 256 + (size_t)lane * 4) = acc[h];
+        }
+        __syncthreads();
+        if (wave < 2) {
+            const int tt = wave, t0 = tt * kTokTile;
+            const int nb = B - t0 < kTokTile ? B - t0 : kTokTile;
+            if (fr < nb) {
+                float tot[NR][4];
+#pragma unroll
+                for (int h = 0; h < NR; ++h) {
+                    f32x4 t = *reinterpret_cast<const f32x4*>(red + (((size_t)tt * 4 + 0) * NR + h) * 256 + (size_t)lane * 4);
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + (((size_t)tt * 4 + w) * NR + h) * 256 + (size_t)lane * 4);
+                    tot[h][0] = t.x; tot[h][1] = t.y; tot[h][2] = t.z; tot[h][3] = t.w;
+                }
+                T* yp = reinterpret_cast<T*>(a.y) + (size_t)(t0 + fr) * a.y_stride + row0 + fq * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v;
+                    if constexpr (EPI == EPI_SWIGLU) {
+                        const float g = DT<T>::rnd(tot[0][i]);
+                        const float u = DT<T>::rnd(tot[NR - 1][i]);
+                        const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
+                        v = sg * u;
+                    } else {
+                        v = DT<T>::rnd(tot[0][i] + biasv[i]);
+                    }
+                    if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {                           // one pass per token tile (a second one only above 16 lanes)
         const int t0 = tt * kTokTile;

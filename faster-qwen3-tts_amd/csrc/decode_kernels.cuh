@@ -610,15 +610,18 @@ struct DecodeState {
     const void* trailing_text; const void* tts_pad; const void* talker_noise; const void* pred_noise;
     const void* past_hidden_init;
     int n_pad, rope_delta;        // copies of the context's generation state for the batched frame (fq3_batch.hip)
-    // Teacher forcing (parity-test hook, fq3_decode_set_forced): when `forced` is set every sampler records its own
-    // decision in `decisions` and the loop continues with the forced id instead.  Both int[frames + 1][G]; slot
-    // [f][0] = first-codebook id of frame f, [f][1 + cb] = predictor codebook cb of frame f.
-    const int* forced; int* decisions;
 };
 
+// Teacher forcing (parity-test hook, fq3_decode_set_forced) lives OUTSIDE the loop state: a context that was never asked for it
+// has no such object and its samplers receive a null pointer (the captured graph holds that null).  When `forced` is set every
+// sampler records its own decision in `decisions` and the loop continues with the forced id instead.  Both int[frames + 1][G];
+// slot [f][0] = first-codebook id of frame f, [f][1 + cb] = predictor codebook cb of frame f.
+struct TeacherForcing { const int* forced; int* decisions; };
+
 // sampler epilogue of the teacher-forcing hook: returns the id the loop continues with (uniform across the block)
-__device__ __forceinline__ int forced_or(const DecodeState* st, int slot, int tok) {
-    const int* forced = st->forced; int* dec = st->decisions;
+__device__ __forceinline__ int forced_or(const TeacherForcing* tf, int slot, int tok) {
+    if (!tf) return tok;
+    const int* forced = tf->forced; int* dec = tf->decisions;
     if (dec && threadIdx.x == 0) dec[slot] = tok;
     return forced ? forced[slot] : tok;
 }

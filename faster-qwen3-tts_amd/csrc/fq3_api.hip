@@ -776,22 +776,23 @@ static void dispatch_nc(int V, F&& f) {
 template <typename T>
 static void launch_sample_pred(const DecodeState* st, const T* lg, int V, int cb, const SampleCfg& cfg, const T* nz,
                                int* codes, int G, int64_t* out64, const T* next_emb, T* next_in, int H, bool wave,
-                               hipStream_t s) {
+                               const TeacherForcing* tf, hipStream_t s) {
     if (wave) dispatch_nc(V, [&](auto nc) {
         constexpr int NC = decltype(nc)::value;
         hipLaunchKernelGGL((sample_pred_wave_kernel<T, NC>), dim3(1), dim3(256), 0, s, st, lg, V, cb, cfg, nz, codes, G,
-                           out64, next_emb, next_in, H);
+                           out64, next_emb, next_in, H, tf);
     });
     else hipLaunchKernelGGL((sample_pred_kernel<T>), dim3(1), dim3(256), 0, s, st, lg, V, cb, cfg, nz, codes, G, out64,
-                            next_emb, next_in, H);
+                            next_emb, next_in, H, tf);
 }
 template <typename T>
-static void launch_sample_talker(DecodeState* st, const T* lg, int V, const unsigned char* seen, int G, bool wave, hipStream_t s) {
+static void launch_sample_talker(DecodeState* st, const T* lg, int V, const unsigned char* seen, int G, bool wave,
+                                 const TeacherForcing* tf, hipStream_t s) {
     if (wave) dispatch_nc(V, [&](auto nc) {
         constexpr int NC = decltype(nc)::value;
-        hipLaunchKernelGGL((sample_talker_wave_kernel<T, NC>), dim3(1), dim3(256), 0, s, st, lg, V, seen, G);
+        hipLaunchKernelGGL((sample_talker_wave_kernel<T, NC>), dim3(1), dim3(256), 0, s, st, lg, V, seen, G, tf);
     });
-    else hipLaunchKernelGGL((sample_talker_kernel<T>), dim3(1), dim3(256), 0, s, st, lg, V, seen, G);
+    else hipLaunchKernelGGL((sample_talker_kernel<T>), dim3(1), dim3(256), 0, s, st, lg, V, seen, G, tf);
 }
 template <typename T>
 static void launch_sample_api(fq3_ctx* c, const T* lg, int V, const SampleCfg& cfg, const int64_t* history, int n_hist,
@@ -919,7 +920,7 @@ static int predictor_passes_t(fq3_ctx* c, const DecodeState* st_dev, const void*
         const T* nz = noise_imm ? (const T*)noise_imm + (size_t)cb * Vp : nullptr;
         const T* next_emb = cb + 1 < G - 1 ? (const T*)c->pemb[cb] : nullptr;     // codec_embeds[cb](tok) feeds pass cb+1
         launch_sample_pred<T>(st_dev, (const T*)lg, Vp, cb, scfg, nz, st_dev ? c->codes : nullptr, G, out64, next_emb,
-                              (T*)c->pred_next, Ht, c->pred_sampling.top_p >= 1.0f, s);
+                              (T*)c->pred_next, Ht, c->pred_sampling.top_p >= 1.0f, st_dev ? c->tf : nullptr, s);
     }
     return 0;
 }
@@ -946,8 +947,8 @@ __global__ __launch_bounds__(256) void decode_arm_kernel(DecodeState* st, Decode
     for (int i = threadIdx.x; i < ph_words; i += 256) past_hidden[i] = ph_src[i];
     if (threadIdx.x == 0) *st = init;
 }
-__global__ void decode_set_forced_kernel(DecodeState* st, const int* forced, int* decisions) {
-    st->forced = forced; st->decisions = decisions;
+__global__ void decode_set_forced_kernel(TeacherForcing* tf, const int* forced, int* decisions) {
+    tf->forced = forced; tf->decisions = decisions;
 }
 
 extern "C" int fq3_decode_begin(fq3_ctx* c, const fq3_decode_params* p, void* stream) {
@@ -996,7 +997,14 @@ extern "C" int fq3_decode_cancel(fq3_ctx* c, void* stream) {
 
 extern "C" int fq3_decode_set_forced(fq3_ctx* c, const int32_t* forced_codes, int32_t* decisions, void* stream) {
     NEED_BOUND(c);
-    hipLaunchKernelGGL(decode_set_forced_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, c->st, forced_codes, decisions);
+    if (!c->tf) {
+        // the first request for teacher forcing on this context: its samplers take the object's address from now on (a captured
+        // graph -- this context's, and a lock-step batch's that was captured before -- still holds the null it was built with)
+        if (!forced_codes && !decisions) return FQ3_OK;
+        if (int r = dmalloc(c, (void**)&c->tf, sizeof(TeacherForcing))) return r;
+        fq3_graph_reset(c);
+    }
+    hipLaunchKernelGGL(decode_set_forced_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, c->tf, forced_codes, decisions);
     LAUNCH_CHECK();
     return FQ3_OK;
 }
@@ -1022,7 +1030,7 @@ static int enqueue_frame_t(fq3_ctx* c, hipStream_t s) {
     g.eps = t.rms_eps; g.W = c->wt.codec_head; g.N = t.vocab; g.K = H; g.x = c->h;
     g.norm_w = c->wt.talker_final_norm; g.y = c->logits; g.xn_out = c->past_hidden;
     if (int r = launch_gemv<PRO_NORM, EPI_STORE>(c, g, true, s)) return r;
-    launch_sample_talker<T>(st, (const T*)c->logits, t.vocab, c->seen, G, c->talker_wave, s);
+    launch_sample_talker<T>(st, (const T*)c->logits, t.vocab, c->seen, G, c->talker_wave, c->tf, s);
     return 0;
 }
 static int enqueue_frame(fq3_ctx* c, hipStream_t s) {

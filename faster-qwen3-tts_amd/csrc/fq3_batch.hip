@@ -1,5 +1,6 @@
 // libfq3hip.so: batched decode -- B single-stream contexts ("lanes") advanced in lock-step by one launch chain.
 // See batch_kernels.cuh for the design; the C ABI is declared in include/fq3hip.h (fq3_batch_*).
+#define FQ3_SKINNY_EXTERN           // skinny_gemm.cuh: the weight-stationary GEMM kernels are instantiated in fq3_prefill.hip only
 #include "fq3_ctx.h"
 #include "batch_kernels.cuh"
 #include "skinny_gemm.cuh"
@@ -31,6 +32,7 @@ struct fq3_batch {
     hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr;
     std::vector<void*> allocs;
+    int norm_dual = 1;            // 17..32 lanes, hidden <= 1024: the normalising GEMVs prepare both token tiles before the first MFMA (bit-identical; "norm_dual" 0 = one panel, tile by tile)
     int use_skinny = 1;           // above 16 lanes the two residual GEMVs of a layer (o_proj, down) run on the weight-stationary prefill kernel
     int use_mfma = 0;             // bf16 GEMVs on the matrix cores: default ON for bf16 (ids verified against the oracle by teacher forcing
                                   // at full depth, 8 and 16 lanes); fq3_batch_set_option("mfma", 0) selects the VALU kernels, whose
@@ -42,6 +44,26 @@ static int bmalloc(fq3_batch* b, void** p, size_t bytes) {
     HIPCHK(hipMemset(*p, 0, bytes));
     b->allocs.push_back(*p);
     return 0;
+}
+
+// the two-panel normalising GEMVs need up to ~83 KB of dynamic LDS: raise the limit of every instantiation once, outside any capture
+template <int KS, int EPI>
+static bool norm_dual_attr() {
+    constexpr int NR = EPI == EPI_SWIGLU ? 2 : 1;
+    const size_t shm2 = (((size_t)2 * kTokTile * (KS * 128 + 8) * 2 + 15) & ~(size_t)15) + (size_t)2 * 4 * NR * 256 * sizeof(float);
+    if (shm2 <= 48 * 1024) return true;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_batch_mfma_norm_kernel<KS, EPI, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2) == hipSuccess;
+}
+static bool norm_dual_prepare() {
+    static int done = -1;
+    if (done < 0) {
+        const bool r[] = {norm_dual_attr<2, EPI_STORE>(), norm_dual_attr<4, EPI_STORE>(), norm_dual_attr<8, EPI_STORE>(),
+                          norm_dual_attr<2, EPI_SWIGLU>(), norm_dual_attr<4, EPI_SWIGLU>(), norm_dual_attr<8, EPI_SWIGLU>()};
+        bool ok = true;
+        for (bool b : r) ok = ok && b;
+        done = ok ? 1 : 0;
+    }
+    return done == 1;
 }
 
 extern "C" int fq3_batch_graph_reset(fq3_batch* b) {
@@ -118,6 +140,9 @@ extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** 
         fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "hipStreamCreateWithFlags");
     }
     b->use_mfma = c0->cfg.dtype == FQ3_BF16 ? 1 : 0;
+    if (c0->cfg.dtype == FQ3_BF16 && !norm_dual_prepare()) {
+        fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "batch: could not raise the LDS limit of the two-panel normalising GEMV kernels");
+    }
     if (c0->cfg.dtype == FQ3_BF16 && !skinny_prepare<SK_RESIDUAL>()) {
         fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "batch: could not raise the LDS limit of the weight-stationary GEMV kernels");
     }
@@ -127,7 +152,8 @@ extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** 
 
 extern "C" int fq3_batch_set_option(fq3_batch* b, const char* key, int value) {
     if (!b || !key) return fq3_fail_(FQ3_EINVAL, "null argument");
-    if (std::string(key) == "skinny") b->use_skinny = value;  // o_proj / down of 17..32 lanes on skinny_gemm_kernel (default 1); 0: gemv_batch_mfma_plain_kernel;
+    if (std::string(key) == "norm_dual") b->norm_dual = value;
+    else if (std::string(key) == "skinny") b->use_skinny = value;  // o_proj / down of 17..32 lanes on skinny_gemm_kernel (default 1); 0: gemv_batch_mfma_plain_kernel;
                                                               // 2: at every lane count (a measurement switch: below 17 lanes the kernel's two-tile group is half empty)
     else if (std::string(key) == "mfma") b->use_mfma = value;      // bf16 GEMVs on the matrix cores (fp32 summation order differs from the single-stream kernels)
     else return fq3_fail_(FQ3_EINVAL, std::string("unknown batch option: ") + key);
@@ -163,6 +189,7 @@ static int launch_gemv_batch_t(BatchGemvArgs a, int esz, hipStream_t s) {
     }
 }
 // matrix-core variants: bf16, built step counts; return -1000 when the shape is not covered (the VALU kernel takes over)
+static thread_local int g_batch_norm_dual = 1;   // set per enqueue from fq3_batch::norm_dual
 template <int EPI>
 static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
     if (a.K % 128) return -1000;
@@ -171,6 +198,15 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
     const size_t shm = (((size_t)kTokTile * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NR * 256 * sizeof(float);
     auto go = [&](auto ks) -> int {
         constexpr int KS = decltype(ks)::value;
+        if constexpr (KS <= 8) {
+            if (a.B > kTokTile && g_batch_norm_dual) {
+                // two panels + both tiles' partial sums (66 + 8..16 KB at K = 1024; the limit is raised in fq3_batch_create, never
+                // inside a graph capture)
+                const size_t shm2 = (((size_t)2 * kTokTile * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)2 * 4 * NR * 256 * sizeof(float);
+                hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<KS, EPI, 2, true>), dim3(grid), dim3(256), shm2, s, a);
+                return 0;
+            }
+        }
         if (a.B <= kTokTile) {
             auto kern = gemv_batch_mfma_norm_kernel<KS, EPI, 1>;
             if (shm > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -300,6 +336,8 @@ static int enqueue_batch_frame_t(fq3_batch* b, hipStream_t s) {
     fq3_ctx* c = b->lanes[0];
     const fq3_stack_dims &t = c->cfg.talker, &p = c->cfg.predictor;
     const int G = c->cfg.num_code_groups, H = t.hidden, Vp = p.vocab, B = b->B;
+    LaneForced lf{};                                   // teacher-forcing objects (parity tests): null for lanes that never asked
+    for (int l = 0; l < B; ++l) lf.tf[l] = b->lanes[l]->tf;
     hipLaunchKernelGGL((frame_begin_batch_kernel<T>), dim3(B), dim3(256), 0, s, b->tab, (const T*)c->wt.codec_embedding,
                        (T*)b->pred_in, H, G);
     // predictor: token A (past_hidden, slot 0), token B (embed(tok0), slot 1), then 14 single-token passes
@@ -325,8 +363,8 @@ static int enqueue_batch_frame_t(fq3_batch* b, hipStream_t s) {
         hg.norm_w = c->wt.predictor_final_norm; hg.y = lg; hg.y_stride = (int)lstride;
         if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, hg, s)) return r;
         const T* next_emb = cb + 1 < G - 1 ? (const T*)c->pemb[cb] : nullptr;
-        if (Vp <= 2048) hipLaunchKernelGGL((sample_pred_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, b->tab, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);
-        else hipLaunchKernelGGL((sample_pred_batch_kernel<T, 2>), dim3(B), dim3(256), 0, s, b->tab, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);
+        if (Vp <= 2048) hipLaunchKernelGGL((sample_pred_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, b->tab, lf, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);
+        else hipLaunchKernelGGL((sample_pred_batch_kernel<T, 2>), dim3(B), dim3(256), 0, s, b->tab, lf, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);
     }
     EmbTables tabs{};
     tabs.t[0] = c->wt.codec_embedding;
@@ -340,8 +378,8 @@ static int enqueue_batch_frame_t(fq3_batch* b, hipStream_t s) {
     g.norm_w = c->wt.talker_final_norm; g.y = b->logits; g.y_stride = t.vocab;
     for (int l = 0; l < B; ++l) g.xn_out[l] = b->tab.past_hidden[l];
     if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, g, s)) return r;
-    if (t.vocab <= 2048) hipLaunchKernelGGL((sample_talker_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, b->tab, (const T*)b->logits, t.vocab, G);
-    else hipLaunchKernelGGL((sample_talker_batch_kernel<T, 2>), dim3(B), dim3(256), 0, s, b->tab, (const T*)b->logits, t.vocab, G);
+    if (t.vocab <= 2048) hipLaunchKernelGGL((sample_talker_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, b->tab, lf, (const T*)b->logits, t.vocab, G);
+    else hipLaunchKernelGGL((sample_talker_batch_kernel<T, 2>), dim3(B), dim3(256), 0, s, b->tab, lf, (const T*)b->logits, t.vocab, G);
     return 0;
 }
 
@@ -355,6 +393,7 @@ static int check_lanes(fq3_batch* b) {
 static int enqueue_batch_frame(fq3_batch* b, hipStream_t s) {
     g_batch_mfma = b->use_mfma;
     g_batch_skinny = b->use_skinny;
+    g_batch_norm_dual = b->norm_dual;
     return b->lanes[0]->cfg.dtype == FQ3_BF16 ? enqueue_batch_frame_t<bf16_t>(b, s) : enqueue_batch_frame_t<float>(b, s);
 }
 

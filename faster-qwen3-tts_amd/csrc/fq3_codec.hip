@@ -16,6 +16,7 @@
 //
 // A decode is planned as a list of row-range ops (see Plan below): the transformer runs over all T frames (its
 // receptive field is the whole prefix), everything after it only over the rows the requested samples depend on.
+#define FQ3_SKINNY_EXTERN           // skinny_gemm.cuh: the weight-stationary GEMM kernels are instantiated in fq3_prefill.hip only
 #include "../../include/fq3hip.h"
 #include "codec_kernels.cuh"
 

@@ -53,6 +53,7 @@ struct fq3_ctx {
     float* rope_now = nullptr;
     unsigned char* seen_api = nullptr;
     fq3::DecodeState* st = nullptr;
+    fq3::TeacherForcing* tf = nullptr;     // allocated by the first fq3_decode_set_forced (parity tests); null for a product context
     unsigned char* seen = nullptr;
     int* codes = nullptr;
     int64_t* ids64 = nullptr;

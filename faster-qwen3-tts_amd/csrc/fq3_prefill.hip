@@ -4,6 +4,7 @@
 // static cache layout the decode kernels read, attention is causal over the live (non-padded) keys.
 // Rounding points are those of the decode path (one rounding to T per Linear / norm / RoPE / residual add),
 // so prefill + decode match the oracle's matrix-form prefill.
+#define FQ3_SKINNY_DEFINE           // skinny_gemm.cuh: the weight-stationary GEMM kernels are instantiated in fq3_prefill.hip only
 #include "fq3_ctx.h"
 #include <vector>
 #include "codec_kernels.cuh"

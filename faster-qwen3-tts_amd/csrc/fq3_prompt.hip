@@ -3,6 +3,7 @@
 // (called at model.py:699-712) with: one gather, two matrix-core GEMMs (text_projection: fc1 + SiLU, fc2) over ALL text
 // tokens of the prompt at once, and one row-assembly kernel.  Rounding points are those of the module-by-module Torch
 // execution: one rounding to T after fc1, after SiLU, after fc2, after the 16-way embedding sum, after text + codec.
+#define FQ3_SKINNY_EXTERN           // skinny_gemm.cuh: the weight-stationary GEMM kernels are instantiated in fq3_prefill.hip only
 #include "fq3_ctx.h"
 #include "codec_kernels.cuh"
 

@@ -22,6 +22,7 @@
 //   .blocks.<b>.res2net_block.blocks.<i>.conv.weight [C/s][k][C/s]; .blocks.<b>.se_block.conv{1,2}.weight;
 //   .mfa.conv.weight [Cm][1][Cm]; .asp.tdnn.conv.weight_h [A][Cm], .weight_ms [A][2*Cm]; .asp.conv.weight [Cm][A]; .fc.weight [E][2*Cm]
 //   (+ the matching .bias vectors)
+#define FQ3_SKINNY_EXTERN           // skinny_gemm.cuh: the weight-stationary GEMM kernels are instantiated in fq3_prefill.hip only
 #include "../../include/fq3hip.h"
 #include "refenc_kernels.cuh"
 

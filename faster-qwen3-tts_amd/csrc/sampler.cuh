@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void sample_api_kernel(const T* logits, int V,
 template <typename T>
 __global__ __launch_bounds__(256) void sample_pred_kernel(const DecodeState* st, const T* logits, int V, int cb,
                                                           SampleCfg c_imm, const T* noise_imm, int* codes, int G,
-                                                          int64_t* out64, const T* next_emb, T* next_in, int H) {
+                                                          int64_t* out64, const T* next_emb, T* next_in, int H, const TeacherForcing* tf) {
     if (st && st->done) return;
     __shared__ SampleSmem sm;
     __shared__ int s_tok;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void sample_pred_kernel(const DecodeState* st,
     for (int i = threadIdx.x; i < V; i += 256) sm.vals[i] = DT<T>::ld(logits + i);
     __syncthreads();
     int tok = sample_core<T>(sm, V, c, nullptr, noise);
-    if (st) tok = forced_or(st, frame * G + 1 + cb, tok);
+    if (st) tok = forced_or(tf, frame * G + 1 + cb, tok);
     if (threadIdx.x == 0) {
         if (codes) codes[(size_t)frame * G + 1 + cb] = tok;
         if (out64) out64[cb] = tok;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void sample_pred_kernel(const DecodeState* st,
 // ---- talker sampler at the end of a frame (generate.py:184-199) -----------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void sample_talker_kernel(DecodeState* st, const T* logits, int V,
-                                                            const unsigned char* seen, int G) {
+                                                            const unsigned char* seen, int G, const TeacherForcing* tf) {
     if (st->done) return;
     __shared__ SampleSmem sm;
     SampleCfg c;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void sample_talker_kernel(DecodeState* st, con
     __syncthreads();
     int tok = sample_core<T>(sm, V, c, seen, noise);
     __syncthreads();
-    tok = forced_or(st, (frame + 1) * G, tok);
+    tok = forced_or(tf, (frame + 1) * G, tok);
     if (threadIdx.x == 0) {
         st->token = tok; st->frame = frame + 1; st->pos += 1; st->gen_step += 1;
     }

@@ -195,7 +195,7 @@ __device__ __forceinline__ int sample_nucleus_from_regs(Raw8<T> (&xraw)[NC], int
 template <typename T, int NC, bool NUCLEUS = false>
 __device__ __forceinline__ void sample_pred_wave_body(const DecodeState* st, const T* logits, int V, int cb,
                                                       const SampleCfg& c_imm, const T* noise_imm, int* codes, int G,
-                                                      int64_t* out64, const T* next_emb, T* next_in, int H) {
+                                                      int64_t* out64, const T* next_emb, T* next_in, int H, const TeacherForcing* tf = nullptr) {
     __shared__ BlkSmem sm;
     Raw8<T> xraw[NC];
     issue_logits<T, NC>(xraw, logits, V);
@@ -217,7 +217,7 @@ __device__ __forceinline__ void sample_pred_wave_body(const DecodeState* st, con
     } else {
         tok = sample_wave_core<T, NC>(xraw, V, c, nullptr, noise, sm);
     }
-    if (st) tok = forced_or(st, frame * G + 1 + cb, tok);
+    if (st) tok = forced_or(tf, frame * G + 1 + cb, tok);
     if (threadIdx.x == 0) {
         if (codes) codes[(size_t)frame * G + 1 + cb] = tok;
         if (out64) out64[cb] = tok;
@@ -237,12 +237,13 @@ __device__ __forceinline__ void sample_pred_wave_body(const DecodeState* st, con
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void sample_pred_wave_kernel(const DecodeState* st, const T* logits, int V, int cb,
                                                               SampleCfg c_imm, const T* noise_imm, int* codes, int G,
-                                                              int64_t* out64, const T* next_emb, T* next_in, int H) {
-    sample_pred_wave_body<T, NC>(st, logits, V, cb, c_imm, noise_imm, codes, G, out64, next_emb, next_in, H);
+                                                              int64_t* out64, const T* next_emb, T* next_in, int H, const TeacherForcing* tf) {
+    sample_pred_wave_body<T, NC>(st, logits, V, cb, c_imm, noise_imm, codes, G, out64, next_emb, next_in, H, tf);
 }
 
 template <typename T, int NC, bool NUCLEUS = false>
-__device__ __forceinline__ void sample_talker_wave_body(DecodeState* st, const T* logits, int V, const unsigned char* seen, int G) {
+__device__ __forceinline__ void sample_talker_wave_body(DecodeState* st, const T* logits, int V, const unsigned char* seen, int G,
+                                                        const TeacherForcing* tf = nullptr) {
     __shared__ BlkSmem sm;
     Raw8<T> xraw[NC];
     issue_logits<T, NC>(xraw, logits, V);
@@ -263,13 +264,13 @@ __device__ __forceinline__ void sample_talker_wave_body(DecodeState* st, const T
     } else {
         tok = sample_wave_core<T, NC>(xraw, V, c, seen, noise, sm);
     }
-    tok = forced_or(st, (frame + 1) * G, tok);
+    tok = forced_or(tf, (frame + 1) * G, tok);
     if (threadIdx.x == 0) { st->token = tok; st->frame = frame + 1; st->pos += 1; st->gen_step += 1; }
 }
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void sample_talker_wave_kernel(DecodeState* st, const T* logits, int V,
-                                                                const unsigned char* seen, int G) {
-    sample_talker_wave_body<T, NC>(st, logits, V, seen, G);
+                                                                const unsigned char* seen, int G, const TeacherForcing* tf) {
+    sample_talker_wave_body<T, NC>(st, logits, V, seen, G, tf);
 }
 
 }  // namespace fq3

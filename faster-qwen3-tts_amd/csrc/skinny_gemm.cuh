@@ -44,6 +44,18 @@ struct SkinnyArgs {
     int no_stagger;                         // measurement switch: 1 = every workgroup walks the token tiles from tile 0 (see `rot` below)
 };
 
+// The 27 kernel instantiations live in ONE translation unit of the library (fq3_prefill.hip defines FQ3_SKINNY_DEFINE); the others
+// (FQ3_SKINNY_EXTERN: codec, batch, prompt, reference-audio TUs) see declarations only and call through skinny_launch_epi.  A
+// standalone tool that includes this header with neither macro gets everything inline.
+// K values served (the talker's hidden / q / intermediate widths at 0.6B and 1.7B)
+inline bool skinny_k_ok(int K) { return K == 1024 || K == 2048 || K == 3072 || K == 6144; }
+
+#ifdef FQ3_SKINNY_EXTERN
+void skinny_launch_epi(int epi, const SkinnyArgs& a, int K, hipStream_t s, int rb_force);
+bool skinny_prepare_epi(int epi);
+template <int EPI> inline void skinny_launch(const SkinnyArgs& a, int K, hipStream_t s, int rb_force = 0) { skinny_launch_epi(EPI, a, K, s, rb_force); }
+template <int EPI> inline bool skinny_prepare() { return skinny_prepare_epi(EPI); }
+#else
 typedef __bf16 sk_bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kSkKC = 1024;                 // columns of one unit (all 8 waves); a wave's share: 128 columns = 256 B per token row
 constexpr int kSkNW = 8;
@@ -234,8 +246,6 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
     }
 }
 
-// K values served (the talker's hidden / q / intermediate widths at 0.6B and 1.7B)
-inline bool skinny_k_ok(int K) { return K == 1024 || K == 2048 || K == 3072 || K == 6144; }
 
 // the kernels need more than the default 64 KB of dynamic LDS: raised once per process and instantiation
 template <int K, int RB, int EPI>
@@ -292,5 +302,18 @@ inline void skinny_launch(const SkinnyArgs& a0, int K, hipStream_t s, int rb_for
     }
 #undef FQ3_SK
 }
+
+
+#ifdef FQ3_SKINNY_DEFINE
+void skinny_launch_epi(int epi, const SkinnyArgs& a, int K, hipStream_t s, int rb_force) {
+    if (epi == SK_SWIGLU) skinny_launch<SK_SWIGLU>(a, K, s, rb_force);
+    else if (epi == SK_RESIDUAL) skinny_launch<SK_RESIDUAL>(a, K, s, rb_force);
+    else skinny_launch<SK_STORE>(a, K, s, rb_force);
+}
+bool skinny_prepare_epi(int epi) {
+    return epi == SK_SWIGLU ? skinny_prepare<SK_SWIGLU>() : (epi == SK_RESIDUAL ? skinny_prepare<SK_RESIDUAL>() : skinny_prepare<SK_STORE>());
+}
+#endif
+#endif      // FQ3_SKINNY_EXTERN
 
 }  // namespace fq3

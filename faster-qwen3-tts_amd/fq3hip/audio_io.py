@@ -58,37 +58,77 @@ def load_audio(path) -> Tuple[np.ndarray, int]:
     return np.asarray(audio, dtype=np.float32), int(sr)
 
 
-def _wav_format_tag(path: str) -> int:
-    """wFormatTag of a RIFF/WAVE file (1 = integer PCM, 3 = IEEE float, 85 = MP3, 0xFFFE = extensible), -1 if not RIFF/WAVE."""
+_PCM_SUBFORMAT = bytes.fromhex("0100000000001000800000aa00389b71")      # KSDATAFORMAT_SUBTYPE_PCM
+_FLOAT_SUBFORMAT = bytes.fromhex("0300000000001000800000aa00389b71")    # KSDATAFORMAT_SUBTYPE_IEEE_FLOAT
+
+
+def _wav_chunks(path: str):
+    """(fmt fields, raw data bytes) of a RIFF/WAVE file, or (None, None) if it is not one.  fmt = dict(tag, channels, rate,
+    block_align, bits, subformat) -- ``tag`` is the effective format: for WAVE_FORMAT_EXTENSIBLE (0xFFFE) the first two bytes of the
+    SubFormat GUID when it is one of the two KSDATAFORMAT subtypes, else 0xFFFE."""
     with open(path, "rb") as f:
         head = f.read(12)
         if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
-            return -1
+            return None, None
+        fmt, data = None, None
         while True:
             ck = f.read(8)
             if len(ck) < 8:
-                return -1
+                break
             cid, size = ck[:4], struct.unpack("<I", ck[4:])[0]
             if cid == b"fmt ":
-                return struct.unpack("<H", f.read(2))[0]
-            f.seek(size + (size & 1), 1)
+                body = f.read(size)
+                if len(body) < 16:
+                    return None, None
+                tag, ch, rate, _bps, align, bits = struct.unpack("<HHIIHH", body[:16])
+                sub = body[24:40] if tag == 0xFFFE and len(body) >= 40 else b""
+                if tag == 0xFFFE and sub in (_PCM_SUBFORMAT, _FLOAT_SUBFORMAT):
+                    tag = struct.unpack("<H", sub[:2])[0]
+                fmt = dict(tag=tag, channels=ch, rate=rate, block_align=align, bits=bits)
+                if size & 1:
+                    f.seek(1, 1)
+            elif cid == b"data":
+                data = f.read(size)
+                if size & 1:
+                    f.seek(1, 1)
+            else:
+                f.seek(size + (size & 1), 1)
+            if fmt is not None and data is not None:
+                break
+        return fmt, data
+
+
+def _wav_format_tag(path: str) -> int:
+    """Effective format tag of a RIFF/WAVE file (1 = integer PCM, 3 = IEEE float, 85 = MP3; an extensible header reports its
+    SubFormat's tag), -1 if not RIFF/WAVE."""
+    fmt, _ = _wav_chunks(path)
+    return -1 if fmt is None else fmt["tag"]
 
 
 def read_wav(path: str) -> Tuple[np.ndarray, int]:
-    """PCM WAV (8/16/32-bit integer) -> (mono float32 in [-1, 1], sample_rate)."""
-    tag = _wav_format_tag(str(path))
-    if tag not in (1, 0xFFFE):
-        what = {-1: "not a RIFF/WAVE file", 3: "IEEE-float WAV (format tag 3)", 85: "MP3-in-WAV (format tag 85)"}.get(
-            tag, f"WAV format tag {tag}")
+    """Integer-PCM WAV (8 / 16 / 24 / 32 bits; plain or WAVE_FORMAT_EXTENSIBLE headers -- what ffmpeg and soundfile write for 24- and
+    32-bit clips, and which the standard library's ``wave`` module refuses) -> (mono float32 in [-1, 1], sample_rate).  The chunks
+    are parsed here; anything that is not integer PCM fails with a message that says what to do."""
+    fmt, raw = _wav_chunks(str(path))
+    tag = -1 if fmt is None else fmt["tag"]
+    if tag != 1 or raw is None:
+        what = {-1: "not a RIFF/WAVE file", 3: "IEEE-float WAV (format tag 3)", 85: "MP3-in-WAV (format tag 85)",
+                0xFFFE: "WAVE_FORMAT_EXTENSIBLE with an unknown SubFormat"}.get(tag, f"WAV format tag {tag}")
+        if tag == 1:
+            what = "WAV file without a data chunk"
         raise ValueError(f"{path}: {what} cannot be read without the 'soundfile' package (not in this image); "
                          "convert the clip to 16-bit PCM WAV, or pass (waveform, sample_rate) / a voice_clone_prompt")
-    with wave.open(str(path), "rb") as w:
-        sr, n, ch, sw = w.getframerate(), w.getnframes(), w.getnchannels(), w.getsampwidth()
-        raw = w.readframes(n)
+    ch, sr, bits = max(1, fmt["channels"]), fmt["rate"], fmt["bits"]
+    sw = fmt["block_align"] // ch if fmt["block_align"] else (bits + 7) // 8      # container bytes per sample
+    raw = raw[: len(raw) - len(raw) % (sw * ch)]
     if sw == 2:
         a = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
     elif sw == 4:
         a = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif sw == 3:
+        b3 = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b3[:, 0] | (b3[:, 1] << 8) | (b3[:, 2] << 16)
+        a = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
     elif sw == 1:
         a = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
     else:

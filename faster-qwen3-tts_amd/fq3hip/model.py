@@ -978,6 +978,11 @@ class FasterQwen3TTS:
                                     temperature: float = 0.9, top_k: int = 50, top_p: float = 1.0, do_sample: bool = True,
                                     repetition_penalty: float = 1.05, lanes: int = 16) -> List[Tuple[list, int]]:
         """VoiceDesign for several texts in lock-step lanes; every utterance prepared like :meth:`generate_voice_design`."""
+        return self._run_batch_full(self._prepare_design_batch(texts, instruct, language, non_streaming_mode),
+                                    self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty),
+                                    lanes, len(texts))
+
+    def _prepare_design_batch(self, texts, instruct, language, non_streaming_mode):
         n = len(texts)
         inss, langs = self._per_text(instruct, n, "instruct"), self._per_text(language, n, "language")
         if self.model.model.tts_model_type != "voice_design":
@@ -988,8 +993,18 @@ class FasterQwen3TTS:
             for text, ins, lang in zip(texts, inss, langs):
                 _m, talker, config, tie, tam, tth, tpe = self._design_prepare(text, ins, lang, non_streaming_mode)
                 yield talker, config, tie, tam, tth, tpe, None
-        return self._run_batch_full(gen(), self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample,
-                                                            repetition_penalty), lanes, n)
+        return gen()
+
+    @torch.inference_mode()
+    def generate_voice_design_batch_streaming(self, texts: List[str], instruct: Union[str, List[str]],
+                                              language: Union[str, List[str]] = "English", non_streaming_mode: Optional[bool] = None,
+                                              max_new_tokens: int = 2048, min_new_tokens: int = 2, temperature: float = 0.9,
+                                              top_k: int = 50, top_p: float = 1.0, do_sample: bool = True, repetition_penalty: float = 1.05,
+                                              chunk_size: int = 12, lanes: int = 16) -> Generator[Tuple[int, np.ndarray, int, dict], None, None]:
+        """Streaming form of :meth:`generate_voice_design_batch`: ``(text_index, audio_chunk, sample_rate, timing)`` per chunk."""
+        prepared = self._prepare_design_batch(texts, instruct, language, non_streaming_mode)
+        yield from self._run_batch_streaming(prepared, self._gen_kwargs(max_new_tokens, min_new_tokens, temperature, top_k, top_p,
+                                                                         do_sample, repetition_penalty), chunk_size, lanes)
 
     @torch.inference_mode()
     def generate_voice_clone_streaming(self, text: str, language: str, ref_audio: Optional[Union[str, Path]] = None,

@@ -369,7 +369,39 @@ def test_custom_voice_and_voice_design_batch_equal_single_calls(kind):
         instr = ["a calm low voice", "a bright young voice", "a calm low voice", "an old tired voice", "a bright young voice"]
         single = [m.generate_voice_design(t, i, "English", **kw) for t, i in zip(texts, instr)]
         batch = m.generate_voice_design_batch(texts, instr, "English", lanes=3, **kw)
+        chunks = {}
+        for i, audio, sr, tm in m.generate_voice_design_batch_streaming(texts, instr, "English", lanes=3, chunk_size=4, **kw):
+            chunks.setdefault(i, []).append(audio)
+        for i, (t, ins) in enumerate(zip(texts, instr)):
+            ref = [a for a, _sr, _tm in m.generate_voice_design_streaming(t, ins, "English", chunk_size=4, **kw)]
+            assert len(chunks[i]) == len(ref) and all(np.array_equal(a, b) for a, b in zip(chunks[i], ref)), i
     assert len(batch) == len(texts)
     for (wa, sra), (wb, srb) in zip(single, batch):
         assert sra == srb and len(wa) == len(wb) == 1
         assert wa[0].shape == wb[0].shape and np.array_equal(wa[0], wb[0])
+
+
+def test_two_panel_normalising_gemv_is_bit_identical_at_32_lanes():
+    """fq3_batch_set_option("norm_dual", 0 | 1): above 16 lanes the normalising matrix-core GEMVs (qkv, gate | up, heads) prepare both
+    token tiles before the first MFMA (1, the default) or tile by tile over one LDS panel (0).  Same instructions on the same values
+    in the same order: 27 sampled / greedy lanes of a 32-lane batch produce identical ids either way."""
+    from fq3hip.engine import Fq3Batch
+    cfg = tiny_test_config()
+    dtype = torch.bfloat16
+    W = synth_weights(cfg, 0, dtype)
+    utts = [_utterance(cfg, dtype, 300 + i, 18 + (5 * i) % 61, (i % 3) * 2, 6 + (i * 5) % 9, 6 + (i * 5) % 9, i % 4 != 3) for i in range(27)]
+    lanes = _engines(cfg, W, dtype, 32)
+    batch = Fq3Batch(lanes)
+    got = []
+    for dual in (1, 0):
+        batch.set_option("norm_dual", dual)
+        for e, u in zip(lanes, utts):
+            _arm(e, cfg, u)
+        batch.graph_capture()
+        batch.frames(16)
+        got.append([e.decode_codes(0, e.decode_poll()[0]).cpu() for e in lanes[:27]])
+    for i, (a, b) in enumerate(zip(*got)):
+        assert a.shape == b.shape and a.shape[0] > 0 and torch.equal(a, b), i
+    batch.close()
+    for e in lanes:
+        e.close()

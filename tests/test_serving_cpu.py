@@ -39,6 +39,40 @@ def test_write_read_wav_roundtrip(tmp_path):
     assert sr == 24000 and y.shape == x.shape and np.abs(y - x).max() < 1.0 / 32768 + 1e-6
 
 
+def _extensible_wav(samples_bytes: bytes, channels: int, rate: int, bits: int, subformat_tag: int) -> bytes:
+    """A WAVE_FORMAT_EXTENSIBLE file (40-byte fmt chunk with a SubFormat GUID), as ffmpeg / soundfile write 24- and 32-bit clips."""
+    align = channels * bits // 8
+    guid = struct.pack("<H", subformat_tag) + bytes.fromhex("000000001000800000aa00389b71")
+    fmt = struct.pack("<HHIIHH", 0xFFFE, channels, rate, rate * align, align, bits) + struct.pack("<HHI", 22, bits, 3 if channels == 2 else 4) + guid
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"LIST" + struct.pack("<I", 4) + b"abcd" + \
+        b"data" + struct.pack("<I", len(samples_bytes)) + samples_bytes
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def test_read_wav_extensible_pcm_and_clear_errors(tmp_path):
+    """WAVE_FORMAT_EXTENSIBLE with the PCM SubFormat (24-bit stereo, 16-bit mono) is read by the package's own RIFF parser (the
+    standard library's `wave` refuses tag 0xFFFE); extensible IEEE float and unknown SubFormats fail with the clear message."""
+    x = (np.sin(np.arange(480) / 9.0) * 0.4).astype(np.float64)
+    v24 = np.round(x * 8388607).astype(np.int32)
+    st = np.stack([v24, v24 // 2], axis=1).reshape(-1)                                   # stereo: right channel at half level
+    raw24 = b"".join(int(v & 0xFFFFFF).to_bytes(3, "little") for v in st)
+    p = tmp_path / "e24.wav"
+    p.write_bytes(_extensible_wav(raw24, 2, 24000, 24, 1))
+    y, sr = audio_io.read_wav(str(p))
+    assert sr == 24000 and y.shape == (480,) and np.abs(y - 0.75 * x).max() < 2e-6
+    p16 = tmp_path / "e16.wav"
+    p16.write_bytes(_extensible_wav(np.round(x * 32767).astype("<i2").tobytes(), 1, 16000, 16, 1))
+    y, sr = audio_io.read_wav(str(p16))
+    assert sr == 16000 and np.abs(y - x).max() < 1.0 / 32768 + 1e-6
+    assert audio_io.load_audio(str(p16))[1] == 16000
+    for tag, needle in ((3, "IEEE-float"), (0x55, "unknown SubFormat")):
+        bad = tmp_path / f"bad{tag}.wav"
+        bad.write_bytes(_extensible_wav(np.zeros(64, "<f4").tobytes(), 1, 24000, 32, tag))
+        with pytest.raises(ValueError) as ei:
+            audio_io.read_wav(str(bad))
+        assert needle in str(ei.value) and "soundfile" in str(ei.value)
+
+
 # ---- voice-reference cache -----------------------------------------------------------------------------------------
 def test_voice_cache_roundtrip_and_staleness(tmp_path):
     audio = np.linspace(-1, 1, 24000, dtype=np.float32)

@@ -298,12 +298,12 @@ int main(int argc, char** argv) {
     if (want("sample")) {
         chain("sample sample_pred_wave_kernel<1>  V=2048 top_k=50 (immediate cfg)", N, [&](int i) {
             hipLaunchKernelGGL((sample_pred_wave_kernel<bf16_t, 1>), dim3(1), dim3(256), 0, st, (const DecodeState*)nullptr, (const bf16_t*)logits, Vp, i % 15, pc,
-                               (const bf16_t*)noise, (int*)nullptr, 16, out64, (const bf16_t*)emb, (bf16_t*)bufA, H); });
+                               (const bf16_t*)noise, (int*)nullptr, 16, out64, (const bf16_t*)emb, (bf16_t*)bufA, H, (const TeacherForcing*)nullptr); });
         chain("sample sample_pred_wave_kernel<1>  V=2048 (device state)", N, [&](int i) {
             hipLaunchKernelGGL((sample_pred_wave_kernel<bf16_t, 1>), dim3(1), dim3(256), 0, st, (const DecodeState*)st_dev, (const bf16_t*)logits, Vp, i % 15, pc,
-                               (const bf16_t*)nullptr, codes, 16, (int64_t*)nullptr, (const bf16_t*)emb, (bf16_t*)bufA, H); });
+                               (const bf16_t*)nullptr, codes, 16, (int64_t*)nullptr, (const bf16_t*)emb, (bf16_t*)bufA, H, (const TeacherForcing*)nullptr); });
         chain("sample sample_talker_wave_kernel<2> V=3072 top_k=50 rep 1.05", N, [&](int) {
-            hipLaunchKernelGGL((sample_talker_wave_kernel<bf16_t, 2>), dim3(1), dim3(256), 0, st, st_dev, (const bf16_t*)logits, Vt, (const unsigned char*)seen, 16); });
+            hipLaunchKernelGGL((sample_talker_wave_kernel<bf16_t, 2>), dim3(1), dim3(256), 0, st, st_dev, (const bf16_t*)logits, Vt, (const unsigned char*)seen, 16, (const TeacherForcing*)nullptr); });
         CHK(hipMemcpy(st_dev, &hs, sizeof hs, hipMemcpyHostToDevice));
     }
     if (want("layer")) {
@@ -474,6 +474,32 @@ int main(int argc, char** argv) {
             for (int kind = 0; kind < 4; ++kind) {
                 snprintf(nm, sizeof nm, "batch  B=%d MFMA %s alone", B, one[kind]); chain(nm, N, [&](int j) { run_m(kind, j, B, ym); });
             }
+        }
+        {   // round 4: the two-panel form of the normalising GEMVs at 17..32 lanes (both token tiles prepared before the first MFMA)
+            const int B = 32;
+            auto run_d = [&](int kind, int i, void* y) {
+                BatchGemvArgs g = bargs(kind, i, B, y);
+                const int grid = (g.N + 15) / 16; const int NRr = kind == 2 ? 2 : 1;
+                const size_t shm2 = (((size_t)2 * kTokTile * (g.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)2 * 4 * NRr * 256 * 4;
+                if (kind == 2) {
+                    auto k = gemv_batch_mfma_norm_kernel<8, EPI_SWIGLU, 2, true>;
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+                    hipLaunchKernelGGL(k, dim3(grid), dim3(256), shm2, st, g);
+                } else {
+                    auto k = gemv_batch_mfma_norm_kernel<8, EPI_STORE, 2, true>;
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+                    hipLaunchKernelGGL(k, dim3(grid), dim3(256), shm2, st, g);
+                }
+            };
+            for (int kind : {0, 2, 5}) {
+                CHK(hipMemset(yb, 0, (size_t)MB * 8192 * 2)); CHK(hipMemset(ym, 0, (size_t)MB * 8192 * 2));
+                run_m(kind, 0, B, ym); run_d(kind, 0, yb); CHK(hipStreamSynchronize(st));
+                auto a0 = fetch_bf16(ym, (size_t)MB * 8192), a1 = fetch_bf16(yb, (size_t)MB * 8192);
+                int bad = 0; for (size_t i = 0; i < a0.size(); ++i) bad += a0[i] != a1[i];
+                char nm[112]; snprintf(nm, sizeof nm, "batch MFMA B=32 %s: two panels == one panel (bit for bit)", kn[kind]); report(nm, bad, 0.5);
+            }
+            chain("batch  B=32 MFMA qkv NORM alone, two panels", N, [&](int j) { run_d(0, j, ym); });
+            chain("batch  B=32 MFMA gate_up NORM/SWIGLU alone, two panels", N, [&](int j) { run_d(2, j, ym); });
         }
     }
     return g_fail ? 1 : 0;
