@@ -15,7 +15,7 @@
 
 namespace fq3 {
 
-constexpr int kMaxLanes = 32;        // two token tiles
+constexpr int kMaxLanes = 64;        // four token tiles (round 4; 32 = two tiles in round 3)
 constexpr int kTokTile = 16;         // token columns of one v_mfma_f32_16x16x32_bf16 tile: lanes 0..15 / 16..31 of a batch are passes of the
                                      // same launch over register-resident weight fragments
 constexpr int kGroupLanes = 8;       // VALU batch GEMV: tokens staged in LDS per pass over the register-resident weight rows
@@ -26,6 +26,7 @@ struct LaneTab {
     unsigned char* seen[kMaxLanes];
     void* past_hidden[kMaxLanes];
 };
+struct LaneSt { DecodeState* st[kMaxLanes]; };                    // the loop states alone (talker attention: 0.5 KB of kernel arguments instead of LaneTab's 2 KB)
 struct LaneForced { const TeacherForcing* tf[kMaxLanes]; };       // teacher-forcing objects of the lanes (parity tests; null in product use)
 struct LaneKV { void* k[kMaxLanes]; void* v[kMaxLanes]; };       // per lane: the predictor's contiguous cache, or the base of the talker's block pool
 struct LaneTabs { const int* t[kMaxLanes]; int blk_stride; };     // talker: every lane's block table (paged KV, decode_kernels.cuh)
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(64) void attn_pred_batch_kernel(AttnArgs a, LaneKV 
 
 // talker attention: grid (n_kv, workers, B); position, pad count and RoPE row are the lane's own
 template <typename T, int REP>
-__global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, LaneKV kv, LaneTabs tabs, LaneTab t, int qkv_stride,
+__global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, LaneKV kv, LaneTabs tabs, LaneSt t, int qkv_stride,
                                                                 const float* rope_now, size_t part_stride) {
     const int l = blockIdx.z;
     a.part = a.part + (size_t)l * part_stride;
@@ -328,12 +329,14 @@ typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 // second tile's ~1 us of normalisation arithmetic, two of the five barriers and one exposed pass over the partial sums leave the
 // critical path; every value is computed by the same instructions in the same order as in the one-panel form (bit-identical:
 // tests/test_gpu_batch.py).  2 x 33 KB of LDS at K = 1024.
+// Three and four token tiles (33..64 lanes, round 4) repeat the two-panel scheme per PAIR of tiles: the next pair's raw tokens are
+// requested as soon as this pair's have been normalised and fly under its MFMAs and exchange.
 template <int KSTEPS, int EPI, int NT, bool DUAL = false>            // K = KSTEPS * 128
 __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs a) {
     typedef bf16_t T;
     constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;
-    constexpr bool PRE2 = NT == 2 && KSTEPS <= 8;
-    static_assert(!DUAL || PRE2, "the two-panel form needs both tiles' raw tokens in registers");
+    constexpr bool PRE2 = (NT == 2 || (DUAL && NT >= 2)) && KSTEPS <= 8;
+    static_assert(!DUAL || PRE2, "the two-panel form needs a pair of tiles' raw tokens in registers");
     constexpr int NXR = PRE2 ? 2 : 1;
     constexpr int K = KSTEPS * 128, KP = K + 8;                 // padded LDS row: 16 tokens x same k would share a bank
     constexpr int NCH = (K + 511) / 512;
@@ -360,8 +363,9 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
             }
         }
     };
-    issue_tokens(0, 0, B < kTokTile ? B : kTokTile);
-    if constexpr (PRE2) issue_tokens(1, kTokTile, B - kTokTile);
+    auto tile_nb = [&](int tile) { const int n = B - tile * kTokTile; return n < kTokTile ? (n < 1 ? 1 : n) : kTokTile; };
+    issue_tokens(0, 0, tile_nb(0));
+    if constexpr (PRE2) issue_tokens(1, kTokTile, tile_nb(1));
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int off = j * 512 + lane * 8;
@@ -387,101 +391,112 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DUAL) {
-        // ---- 3'. both tiles' tokens -> their panels (while the weights fly) ----
+        constexpr int NPAIR = (NT + 1) / 2;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int t0 = tt * kTokTile;
-            const int nb = B - t0 < kTokTile ? B - t0 : kTokTile;
-            T* xp = xs + (size_t)tt * kTokTile * KP;
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            // ---- 3'. this pair's tokens -> the two panels (first pair: while the weights fly) ----
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int m = wave + 4 * t;
-                float xr[NCH][8];
+            for (int tt = 0; tt < 2; ++tt) {
+                if (2 * pr + tt >= NT) continue;                // (compile-time after unrolling: an odd tile count has a single last tile)
+                const int t0 = (2 * pr + tt) * kTokTile;
+                const int nb = tile_nb(2 * pr + tt);
+                T* xp = xs + (size_t)tt * kTokTile * KP;
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) {
-                    if (j * 512 + lane * 8 >= K) zero(xraw[tt][t][j]);
-                    unpack(xraw[tt][t][j], xr[j]);
-                }
-                float ss = 0.f;
-#pragma unroll
-                for (int j = 0; j < NCH; ++j)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
-                ss = wave_sum(ss);
-                const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) {
-                    float nw[8];
-                    unpack(nraw[j], nw);
-#pragma unroll
-                    for (int i = 0; i < 8; i += 2) {
-                        float u = xr[j][i] * rs, v = xr[j][i + 1] * rs;
-                        DT<T>::rnd2(u, v);
-                        u *= nw[i]; v *= nw[i + 1];
-                        DT<T>::rnd2(u, v);
-                        xr[j][i] = u; xr[j][i + 1] = v;
-                    }
-                }
-                if (m < nb) {
-                    T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[t0 + m]) : nullptr;
+                for (int t = 0; t < TPW; ++t) {
+                    const int m = wave + 4 * t;
+                    float xr[NCH][8];
 #pragma unroll
                     for (int j = 0; j < NCH; ++j) {
-                        const int off = j * 512 + lane * 8;
-                        if (off < K) {
-                            DT<T>::st8(xp + (size_t)m * KP + off, xr[j]);
-                            if (xo) DT<T>::st8(xo + off, xr[j]);
+                        if (j * 512 + lane * 8 >= K) zero(xraw[tt][t][j]);
+                        unpack(xraw[tt][t][j], xr[j]);
+                    }
+                    float ss = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
+                    ss = wave_sum(ss);
+                    const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) {
+                        float nw[8];
+                        unpack(nraw[j], nw);
+#pragma unroll
+                        for (int i = 0; i < 8; i += 2) {
+                            float u = xr[j][i] * rs, v = xr[j][i + 1] * rs;
+                            DT<T>::rnd2(u, v);
+                            u *= nw[i]; v *= nw[i + 1];
+                            DT<T>::rnd2(u, v);
+                            xr[j][i] = u; xr[j][i + 1] = v;
+                        }
+                    }
+                    if (m < nb) {
+                        T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[t0 + m]) : nullptr;
+#pragma unroll
+                        for (int j = 0; j < NCH; ++j) {
+                            const int off = j * 512 + lane * 8;
+                            if (off < K) {
+                                DT<T>::st8(xp + (size_t)m * KP + off, xr[j]);
+                                if (xo) DT<T>::st8(xo + off, xr[j]);
+                            }
                         }
                     }
                 }
             }
-        }
-        __syncthreads();
-        // ---- 4'. MFMA over this wave's K quarter, both tiles; 5'. one exchange, two epilogues side by side ----
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int nb = B - tt * kTokTile < kTokTile ? B - tt * kTokTile : kTokTile;
-            const T* xp = xs + (size_t)tt * kTokTile * KP;
-            f32x4 acc[NR];
-#pragma unroll
-            for (int h = 0; h < NR; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int tokc = fr < nb ? fr : nb - 1;
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                const u32x4 bq = *reinterpret_cast<const u32x4*>(xp + (size_t)tokc * KP + wave * (K / 4) + s * 32 + fq * 8);
-                const mfma_bf16x8 bfrag = __builtin_bit_cast(mfma_bf16x8, bq);
-#pragma unroll
-                for (int h = 0; h < NR; ++h)
-                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wreg[h][s].v), bfrag, acc[h], 0, 0, 0);
+            // the next pair's raw tokens: in flight under this pair's MFMAs and exchange
+            if (pr + 1 < NPAIR) {
+                issue_tokens(0, (2 * pr + 2) * kTokTile, tile_nb(2 * pr + 2));
+                if (2 * pr + 3 < NT) issue_tokens(1, (2 * pr + 3) * kTokTile, tile_nb(2 * pr + 3));
             }
+            __syncthreads();            // panels published; (from the second pair on) the previous pair's epilogues are done with `red`
+            // ---- 4'. MFMA over this wave's K quarter, both tiles; 5'. one exchange, two epilogues side by side ----
 #pragma unroll
-            for (int h = 0; h < NR; ++h) *reinterpret_cast<f32x4*>(red + (((size_t)tt * 4 + wave) * NR + h) * 256 + (size_t)lane * 4) = acc[h];
-        }
-        __syncthreads();
-        if (wave < 2) {
-            const int tt = wave, t0 = tt * kTokTile;
-            const int nb = B - t0 < kTokTile ? B - t0 : kTokTile;
-            if (fr < nb) {
-                float tot[NR][4];
+            for (int tt = 0; tt < 2; ++tt) {
+                if (2 * pr + tt >= NT) continue;
+                const int nb = tile_nb(2 * pr + tt);
+                const T* xp = xs + (size_t)tt * kTokTile * KP;
+                f32x4 acc[NR];
 #pragma unroll
-                for (int h = 0; h < NR; ++h) {
-                    f32x4 t = *reinterpret_cast<const f32x4*>(red + (((size_t)tt * 4 + 0) * NR + h) * 256 + (size_t)lane * 4);
+                for (int h = 0; h < NR; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int tokc = fr < nb ? fr : nb - 1;
 #pragma unroll
-                    for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + (((size_t)tt * 4 + w) * NR + h) * 256 + (size_t)lane * 4);
-                    tot[h][0] = t.x; tot[h][1] = t.y; tot[h][2] = t.z; tot[h][3] = t.w;
+                for (int s = 0; s < KSTEPS; ++s) {
+                    const u32x4 bq = *reinterpret_cast<const u32x4*>(xp + (size_t)tokc * KP + wave * (K / 4) + s * 32 + fq * 8);
+                    const mfma_bf16x8 bfrag = __builtin_bit_cast(mfma_bf16x8, bq);
+#pragma unroll
+                    for (int h = 0; h < NR; ++h)
+                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wreg[h][s].v), bfrag, acc[h], 0, 0, 0);
                 }
-                T* yp = reinterpret_cast<T*>(a.y) + (size_t)(t0 + fr) * a.y_stride + row0 + fq * 4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v;
-                    if constexpr (EPI == EPI_SWIGLU) {
-                        const float g = DT<T>::rnd(tot[0][i]);
-                        const float u = DT<T>::rnd(tot[NR - 1][i]);
-                        const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
-                        v = sg * u;
-                    } else {
-                        v = DT<T>::rnd(tot[0][i] + biasv[i]);
+                for (int h = 0; h < NR; ++h) *reinterpret_cast<f32x4*>(red + (((size_t)tt * 4 + wave) * NR + h) * 256 + (size_t)lane * 4) = acc[h];
+            }
+            __syncthreads();            // every wave is done with the panels and has written its partial sums
+            if (wave < 2 && 2 * pr + wave < NT) {
+                const int tt = wave, t0 = (2 * pr + tt) * kTokTile;
+                const int nb = tile_nb(2 * pr + tt);
+                if (fr < nb) {
+                    float tot[NR][4];
+#pragma unroll
+                    for (int h = 0; h < NR; ++h) {
+                        f32x4 t = *reinterpret_cast<const f32x4*>(red + (((size_t)tt * 4 + 0) * NR + h) * 256 + (size_t)lane * 4);
+#pragma unroll
+                        for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + (((size_t)tt * 4 + w) * NR + h) * 256 + (size_t)lane * 4);
+                        tot[h][0] = t.x; tot[h][1] = t.y; tot[h][2] = t.z; tot[h][3] = t.w;
                     }
-                    if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
+                    T* yp = reinterpret_cast<T*>(a.y) + (size_t)(t0 + fr) * a.y_stride + row0 + fq * 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v;
+                        if constexpr (EPI == EPI_SWIGLU) {
+                            const float g = DT<T>::rnd(tot[0][i]);
+                            const float u = DT<T>::rnd(tot[NR - 1][i]);
+                            const float sg = DT<T>::rnd(g / (1.0f + expf(-g)));
+                            v = sg * u;
+                        } else {
+                            v = DT<T>::rnd(tot[0][i] + biasv[i]);
+                        }
+                        if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
+                    }
                 }
             }
         }

@@ -26,6 +26,7 @@ struct fq3_batch {
     size_t part_stride = 0;
     int Hm = 0, Im = 0, qkvm = 0;
     LaneTab tab{};
+    LaneSt lst{};                 // the loop states alone (talker attention)
     std::vector<LaneKV> tkv, pkv;
     LaneTabs ttab{};              // the lanes' block tables (paged talker KV)
     hipGraph_t graph = nullptr;
@@ -52,7 +53,10 @@ static bool norm_dual_attr() {
     constexpr int NR = EPI == EPI_SWIGLU ? 2 : 1;
     const size_t shm2 = (((size_t)2 * kTokTile * (KS * 128 + 8) * 2 + 15) & ~(size_t)15) + (size_t)2 * 4 * NR * 256 * sizeof(float);
     if (shm2 <= 48 * 1024) return true;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_batch_mfma_norm_kernel<KS, EPI, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2) == hipSuccess;
+    const bool r2 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_batch_mfma_norm_kernel<KS, EPI, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2) == hipSuccess;
+    const bool r3 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_batch_mfma_norm_kernel<KS, EPI, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2) == hipSuccess;
+    const bool r4 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_batch_mfma_norm_kernel<KS, EPI, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2) == hipSuccess;
+    return r2 && r3 && r4;
 }
 static bool norm_dual_prepare() {
     static int done = -1;
@@ -85,7 +89,7 @@ extern "C" int fq3_batch_destroy(fq3_batch* b) {
 
 extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out) {
     if (!lanes || !out) return fq3_fail_(FQ3_EINVAL, "null argument");
-    if (n_lanes < 1 || n_lanes > kMaxLanes) return fq3_fail_(FQ3_EINVAL, "n_lanes must be 1..32");
+    if (n_lanes < 1 || n_lanes > kMaxLanes) return fq3_fail_(FQ3_EINVAL, "n_lanes must be 1..64");
     for (int i = 0; i < n_lanes; ++i) {
         if (!lanes[i] || !lanes[i]->bound) return fq3_fail_(FQ3_ESTATE, "every lane needs a context with bound weights");
         for (int j = 0; j < i; ++j) if (lanes[i] == lanes[j]) return fq3_fail_(FQ3_EINVAL, "a context can fill only one lane");
@@ -130,6 +134,7 @@ extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** 
     for (int l = 0; l < B; ++l) {
         fq3_ctx* c = lanes[l];
         b->tab.st[l] = c->st; b->tab.codes[l] = c->codes; b->tab.seen[l] = c->seen; b->tab.past_hidden[l] = c->past_hidden;
+        b->lst.st[l] = c->st;
     }
     b->tkv.resize(t.n_layers); b->pkv.resize(p.n_layers);
     for (int i = 0; i < t.n_layers; ++i) for (int l = 0; l < B; ++l) { b->tkv[i].k[l] = lanes[l]->tk.k[i]; b->tkv[i].v[l] = lanes[l]->tk.v[i]; }
@@ -196,27 +201,33 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
     const int grid = (a.N + 15) / 16;
     constexpr int NR = EPI == EPI_SWIGLU ? 2 : 1;
     const size_t shm = (((size_t)kTokTile * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NR * 256 * sizeof(float);
+    const int nt = (a.B + kTokTile - 1) / kTokTile;            // token tiles: 1..4
     auto go = [&](auto ks) -> int {
         constexpr int KS = decltype(ks)::value;
         if constexpr (KS <= 8) {
-            if (a.B > kTokTile && g_batch_norm_dual) {
-                // two panels + both tiles' partial sums (66 + 8..16 KB at K = 1024; the limit is raised in fq3_batch_create, never
-                // inside a graph capture)
+            if (nt >= 2 && g_batch_norm_dual) {
+                // two panels + a pair of tiles' partial sums (66 + 8..16 KB at K = 1024; the limit is raised in fq3_batch_create, never
+                // inside a graph capture); three and four tiles repeat the scheme per pair
                 const size_t shm2 = (((size_t)2 * kTokTile * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)2 * 4 * NR * 256 * sizeof(float);
-                hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<KS, EPI, 2, true>), dim3(grid), dim3(256), shm2, s, a);
+                if (nt == 2) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<KS, EPI, 2, true>), dim3(grid), dim3(256), shm2, s, a);
+                else if (nt == 3) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<KS, EPI, 3, true>), dim3(grid), dim3(256), shm2, s, a);
+                else hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<KS, EPI, 4, true>), dim3(grid), dim3(256), shm2, s, a);
                 return 0;
             }
         }
-        if (a.B <= kTokTile) {
-            auto kern = gemv_batch_mfma_norm_kernel<KS, EPI, 1>;
+        auto one = [&](auto ntc) -> int {
+            constexpr int NTC = decltype(ntc)::value;
+            auto kern = gemv_batch_mfma_norm_kernel<KS, EPI, NTC>;
             if (shm > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, a);
-        } else {
-            auto kern = gemv_batch_mfma_norm_kernel<KS, EPI, 2>;
-            if (shm > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, a);
+            return 0;
+        };
+        switch (nt) {
+            case 1: return one(std::integral_constant<int, 1>{});
+            case 2: return one(std::integral_constant<int, 2>{});
+            case 3: return one(std::integral_constant<int, 3>{});
+            default: return one(std::integral_constant<int, 4>{});
         }
-        return 0;
     };
     switch (a.K / 128) {                      // hidden sizes: 256 (tests), 512, 1024 (0.6B, predictor), 2048 (1.7B)
         case 2: return go(std::integral_constant<int, 2>{});
@@ -245,8 +256,12 @@ static int launch_gemv_batch_mfma_plain(const BatchGemvArgs& a, hipStream_t s) {
     const int grid = (a.N + 15) / 16;
     auto go = [&](auto ks, auto nw) -> int {
         constexpr int KS = decltype(ks)::value, NW = decltype(nw)::value;
-        if (a.B <= kTokTile) hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 1>), dim3(grid), dim3(64 * NW), 0, s, a);
-        else hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 2>), dim3(grid), dim3(64 * NW), 0, s, a);
+        switch ((a.B + kTokTile - 1) / kTokTile) {          // token tiles
+            case 1: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 1>), dim3(grid), dim3(64 * NW), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 2>), dim3(grid), dim3(64 * NW), 0, s, a); break;
+            case 3: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 3>), dim3(grid), dim3(64 * NW), 0, s, a); break;
+            default: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 4>), dim3(grid), dim3(64 * NW), 0, s, a); break;
+        }
         return 0;
     };
 #define FQ3_PLAIN(KS, NW) return go(std::integral_constant<int, KS>{}, std::integral_constant<int, NW>{})
@@ -302,9 +317,9 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
         if (talker) {
             a.max_seq = c->tk.max_seq; a.part = b->part;
             const dim3 grid(d.n_kv_heads, c->tk.workers, B);
-            if (rep == 1) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 1>), grid, dim3(256), 0, s, a, b->tkv[i], b->ttab, b->tab, b->qkvm, b->rope_now, b->part_stride);
-            else if (rep == 2) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 2>), grid, dim3(256), 0, s, a, b->tkv[i], b->ttab, b->tab, b->qkvm, b->rope_now, b->part_stride);
-            else hipLaunchKernelGGL((attn_decode_batch_kernel<T, 4>), grid, dim3(256), 0, s, a, b->tkv[i], b->ttab, b->tab, b->qkvm, b->rope_now, b->part_stride);
+            if (rep == 1) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 1>), grid, dim3(256), 0, s, a, b->tkv[i], b->ttab, b->lst, b->qkvm, b->rope_now, b->part_stride);
+            else if (rep == 2) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 2>), grid, dim3(256), 0, s, a, b->tkv[i], b->ttab, b->lst, b->qkvm, b->rope_now, b->part_stride);
+            else hipLaunchKernelGGL((attn_decode_batch_kernel<T, 4>), grid, dim3(256), 0, s, a, b->tkv[i], b->ttab, b->lst, b->qkvm, b->rope_now, b->part_stride);
             hipLaunchKernelGGL((combine_batch_kernel<T>), dim3((q_dim / 8 + 255) / 256, B), dim3(256), 0, s, (const float*)b->part, b->part_stride,
                                c->tk.workers, rep, q_dim, (T*)b->attn_out, b->qkvm);
             o.x = b->attn_out; o.x_stride = b->qkvm;
