@@ -723,7 +723,8 @@ def model_1p7b_block(cfg, model, device, lanes=16):
     _c, model_lo = build_model(device, max_seq_len=model.max_seq_len, share=model)          # bf16 vocoder over the same weight replica
     model_lo.model.model.tts_model_type = model.model.model.tts_model_type
     one_utterance(model, req, 900)
-    one_utterance(model_lo, req, 901)
+    for i in range(2):
+        one_utterance(model_lo, req, 901 + i)
     prompt = prepared_prompt(model, req)
     frame_ms, p_mid = measure_frame_graph(model, prompt)
     res = [one_utterance(model, req, 910 + i) for i in range(3)]
@@ -976,6 +977,13 @@ def main():
                 out["streaming"] = batched_streaming_run(model, req, lanes, 2 * lanes)
             except Exception as e:
                 out["streaming"] = {"error": repr(e)}
+            if lanes > 32:
+                # the latency-oriented operating point: 32 simultaneous requests (first-wave TTFA bar: < 150 ms)
+                try:
+                    batched_streaming_run(model, req, 32, 32)
+                    out["streaming_32_lanes"] = batched_streaming_run(model, req, 32, 64)
+                except Exception as e:
+                    out["streaming_32_lanes"] = {"error": repr(e)}
             try:
                 ms2, p2 = batched_frame_time(model, cfg, prompt, lanes, mfma=0)
                 out["valu_gemv"] = {"ms_per_lockstep_frame": round(ms2, 3), "decode_only_value": round(lanes * 80.0 / ms2, 1),

@@ -104,6 +104,97 @@ class _SideVocoder:
                 for j, (key, _c) in enumerate(part):
                     self.items.append((key, host[j], ev, pcm))
 
+    # ---- incremental (exact) vocoding of utterances that are still decoding ------------------------------------------------
+    # The codec decoder is causal: decode(codes[:p]) is bit for bit the prefix of decode(codes), and a tail decode from sample s is
+    # the tail of the full decode.  So the waveform of a running utterance can be produced in slices -- every ``inc`` frames the
+    # samples that became final, by ``decode_tensor_batch(codes so far, first_sample = samples already produced)`` -- on the side
+    # stream, under the lock-step decode of the following frames, and across all lanes that reached the boundary together as ONE
+    # batched launch set.  What is left when the utterance ends is the last slice, not the whole waveform.  The concatenation
+    # is exactly ``decode_tensor(ref + codes)[cut:]``; the reference's cut of an ICL waveform (``int(ref_len / T * n_samples)``,
+    # model.py:927-930) depends on the final length T, so slices start at a lower bound of it and the few samples in front of
+    # the real cut are dropped at the end.
+    def _cut_floor(self, ref_len: int, max_total: int) -> int:
+        if ref_len <= 0:
+            return 0
+        key = (ref_len, max_total)
+        cache = self.__dict__.setdefault("_cut_cache", {})
+        if key not in cache:
+            cache[key] = min(int(ref_len / T * self.tok.num_samples_total(T)) for T in range(ref_len + 1, max(ref_len + 2, max_total + 1)))
+        return cache[key]
+
+    def inc_add(self, key, chunk, ref_codes, ready_event, final: bool, more: int, max_new: int) -> None:
+        """``chunk``: the frames of utterance ``key`` that completed since the last call (LongTensor[n, 16] on the device, or None / empty).
+        ``final``: the utterance is over.  ``more``: events of the same poll still to come (the slice is decoded when it reaches 0)."""
+        inc = self.__dict__.setdefault("_inc", {})
+        st = inc.get(key)
+        if st is None:
+            ref_len = int(ref_codes.shape[0]) if ref_codes is not None else 0
+            st = inc[key] = dict(ref=ref_codes, ref_len=ref_len, chunks=[], T=0, done=0, parts=[], final=False,
+                                 floor=self._cut_floor(ref_len, ref_len + int(max_new)))
+        if chunk is not None and chunk.shape[0] > 0:
+            chunk.record_stream(self.stream)
+            st["chunks"].append(chunk)
+            st["T"] += int(chunk.shape[0])
+            self.__dict__.setdefault("_inc_held", []).append((key, ready_event))
+        st["final"] = st["final"] or bool(final)
+        if more <= 0:
+            self.inc_flush()
+
+    def inc_flush(self) -> None:
+        held, self._inc_held = self.__dict__.get("_inc_held", []), []
+        if not held:
+            return
+        main = torch.cuda.current_stream(self.dev)
+        jobs, seen = {}, set()
+        for key, ev in held:
+            if ev is not None:
+                self.stream.wait_event(ev)
+            else:
+                self.stream.wait_stream(main)
+            if key in seen:
+                continue
+            seen.add(key)
+            st = self._inc[key]
+            T = st["ref_len"] + st["T"]
+            first = st["floor"] + st["done"]
+            n = self.tok.num_samples_total(T)
+            if first < n:
+                jobs.setdefault((T, first), []).append((key, st, n))
+        with torch.cuda.stream(self.stream):
+            for (T, first), members in jobs.items():
+                for i in range(0, len(members), self.MAX_GROUP):
+                    part = members[i:i + self.MAX_GROUP]
+                    fulls = [torch.cat(([st["ref"].to(st["chunks"][0].device)] if st["ref"] is not None else []) + st["chunks"], dim=0)
+                             for _k, st, _n in part]
+                    if len(part) == 1:
+                        pcm = self.tok.decode_tensor(fulls[0], first).unsqueeze(0)
+                    else:
+                        pcm = self.tok.decode_tensor_batch(torch.stack(fulls), first)
+                    host = torch.empty(pcm.shape, dtype=torch.float32, pin_memory=True)
+                    host.copy_(pcm, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                    for j, (_k, st, n) in enumerate(part):
+                        st["parts"].append((host[j], ev, pcm))
+                        st["done"] = n - st["floor"]
+
+    def inc_collect(self):
+        """-> (key, waveform) of every utterance handed to ``inc_add``, in first-seen order (waits for the side stream)."""
+        self.inc_flush()
+        inc, self._inc = self.__dict__.get("_inc", {}), {}
+        for key, st in inc.items():
+            if not st["parts"]:
+                yield key, np.zeros(1, dtype=np.float32)
+                continue
+            rows = []
+            for host, ev, _pcm in st["parts"]:
+                ev.synchronize()
+                rows.append(host.numpy())
+            a = np.concatenate(rows) if len(rows) > 1 else rows[0].copy()
+            T = st["ref_len"] + st["T"]
+            cut = int(st["ref_len"] / max(T, 1) * self.tok.num_samples_total(T)) if st["ref_len"] > 0 else 0
+            yield key, a[cut - st["floor"]:]
+
     def collect(self):
         for key, host, ev, _pcm in self.items:
             if ev is None:
@@ -790,6 +881,18 @@ class FasterQwen3TTS:
         head, source = self._batch_feed(prepared, gen_kwargs, len(dec.lanes), meta)
         out: List[Optional[Tuple[list, int]]] = [None] * count
         voc = self._side_vocoder()
+        # batch_vocode_every (attribute, default 64 frames; 0 = vocode an utterance when it has ended): the waveform is produced in
+        # slices while the utterance still decodes -- exact, see _SideVocoder.inc_add -- so that what is left at the end is the last
+        # slice only
+        inc = int(getattr(self, "batch_vocode_every", 64) or 0)
+        if inc > 0 and voc.async_ok and hasattr(voc.tok, "decode_tensor_batch") and hasattr(voc.tok, "num_samples_total"):
+            max_new = min(int(gen_kwargs.get("max_new_tokens", 2048)), int(self.talker_graph.engine.max_frames))
+            for rid, codes, info in dec.run(head, source=source, chunk_frames=inc):
+                more = int(getattr(dec, "more_in_poll", 0))
+                voc.inc_add(rid, codes, meta.get(rid), info.pop("codes_ready_event", None), bool(info.get("is_final")), more, max_new)
+            for rid, a in voc.inc_collect():
+                out[rid] = ([a], voc.sample_rate)
+            return [o if o is not None else ([np.zeros(1, dtype=np.float32)], self.sample_rate) for o in out]
         for rid, codec_ids, timing in dec.run(head, source=source):
             more = int(getattr(dec, "more_in_poll", 0))
             if codec_ids is None:

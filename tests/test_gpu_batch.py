@@ -413,3 +413,46 @@ def test_two_panel_normalising_gemv_is_bit_identical_at_32_lanes():
         batch.close()
     for e in lanes:
         e.close()
+
+
+def test_batch_incremental_vocoding_is_exact():
+    """generate_voice_clone_batch produces an utterance's waveform in slices while it still decodes (every `batch_vocode_every` frames,
+    all lanes that reached the boundary as one batched codec launch set; _SideVocoder.inc_add).  ICL prompts (reference frames in front,
+    the proportional cut of model.py:927-930), a piecewise decode schedule that the utterances cross (CHUNK_FRAMES 21), utterances of
+    different lengths: the result is bit for bit the waveform of the single call, which decodes once at the end."""
+    import numpy as np
+    from fq3hip.model import FasterQwen3TTS
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, torch.float32, parts=("talker", "predictor", "codec", "text"))
+    m = FasterQwen3TTS.from_weights(cfg, W, device="cuda", dtype=torch.float32, max_seq_len=200, codec_max_frames=128, max_frames=64)
+    m.predictor_graph.do_sample = False
+    m.predictor_graph.top_k = 0
+    m.model.model.speech_tokenizer.CHUNK_FRAMES = 21
+    g = torch.Generator().manual_seed(8)
+    ref_code = torch.cat([torch.randint(0, cfg.talker.vocab_size - 1024, (9, 1), generator=g),
+                          torch.randint(0, cfg.codec.codebook_size, (9, cfg.num_code_groups - 1), generator=g)], 1).cuda()
+    vcp = dict(ref_code=[ref_code], ref_spk_embedding=[torch.randn(cfg.talker.hidden_size, generator=g)], x_vector_only_mode=[False], icl_mode=[True])
+    texts = ["One.", "A second, longer line to speak.", "Three words here.", "Four.", "The fifth and last line of this batch."]
+    lens = [41, 17, 33, 8, 26]
+    single = []
+    for t, n in zip(texts, lens):
+        kw = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0, repetition_penalty=1.0, min_new_tokens=n, max_new_tokens=n)
+        single.append(m.generate_voice_clone(text=t, language="English", ref_text="the reference text", voice_clone_prompt=vcp, **kw)[0][0])
+    for every in (8, 0, 64):
+        m.batch_vocode_every = every
+        got = []
+        for n in sorted(set(lens)):                    # one batch call per length class keeps min/max_new_tokens per utterance
+            idx = [i for i, x in enumerate(lens) if x == n]
+            kw = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0, repetition_penalty=1.0, min_new_tokens=n, max_new_tokens=n)
+            res = m.generate_voice_clone_batch([texts[i] for i in idx], language="English", ref_text="the reference text", voice_clone_prompt=vcp, lanes=3, **kw)
+            got += [(i, r[0][0]) for i, r in zip(idx, res)]
+        # all five in ONE call too (every utterance may run to the common budget: compare what the shorter budgets share is not
+        # possible, so this call uses the longest budget for everybody and is compared with itself across `every`)
+        for i, w in got:
+            assert w.shape == single[i].shape and np.array_equal(w, single[i]), (every, i)
+    kw = dict(do_sample=False, top_k=0, top_p=1.0, temperature=1.0, repetition_penalty=1.0, min_new_tokens=2, max_new_tokens=41)
+    runs = []
+    for every in (8, 0):
+        m.batch_vocode_every = every
+        runs.append([r[0][0] for r in m.generate_voice_clone_batch(texts, language="English", ref_text="the reference text", voice_clone_prompt=vcp, lanes=3, **kw)])
+    assert all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(*runs))
