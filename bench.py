@@ -293,33 +293,26 @@ def concurrent_throughput(cfg, model, req, device, streams=4, utterances=2):
 
 
 def batched_run(model, prompt, n_utt, lanes=8, frames=FRAMES, seed0=2000, sync=None):
-    """`n_utt` synthetic utterances (seeds seed0 + i) through `lanes` lock-step lanes (fq3_batch_*,
-    continuous batching), each vocoded (non-streaming call) as it finishes.  Returns (audio_s, wall_s, pcm lengths)."""
-    from fq3hip.batching import BatchRequest
+    """`n_utt` synthetic utterances (seeds seed0 + i) through `lanes` lock-step lanes (fq3_batch_*, continuous batching)
+    and the vocoder, exactly as generate_voice_clone_batch runs them behind its prompt builder (FasterQwen3TTS._run_batch_full:
+    staged admission, waveforms produced in slices on the side stream while the utterances decode, utterances at the same point
+    vocoded as one batch).  Returns (audio_s, wall_s, pcm lengths)."""
     tie, tam, tth, tpe, ref_codes = prompt
     m = model.model.model
     talker, config = m.talker, m.config.talker_config
     kw = model._gen_kwargs(frames, frames, 0.9, 50, 1.0, True, 1.05)
-    dec = model._batch_decoder(lanes)
-    reqs = [BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(kw)) for i in range(n_utt)]
     sync = sync or torch.cuda.synchronize
     torch.manual_seed(seed0)
     sync()
     t0 = time.perf_counter()
-    n_frames, lens = 0, [0] * n_utt
-    voc = model._side_vocoder()                       # what generate_voice_clone_batch uses: codec + D2H copy on a side stream
-    for rid, codes, timing in dec.run(reqs):
-        if codes is None:
-            continue
-        full = torch.cat([ref_codes.to(codes.device), codes], dim=0) if ref_codes is not None else codes
-        # (as generate_voice_clone_batch does: utterances that finish in the same poll share one batched codec launch set)
-        voc.add(rid, full, ref_len=ref_codes.shape[0] if ref_codes is not None else 0, more=int(getattr(dec, "more_in_poll", 0)))
-        n_frames += codes.shape[0]
-    voc.add_flush()
-    for rid, a in voc.collect():                      # every waveform on the host before the clock stops
-        lens[rid] = int(len(a))
+    outs = model._run_batch_full([(talker, config, tie, tam, tth, tpe, ref_codes)] * n_utt, kw, lanes, n_utt)
     sync()
-    return n_frames * FRAME_S, time.perf_counter() - t0, lens
+    wall = time.perf_counter() - t0
+    lens = [int(len(w[0])) for w, _sr in outs]
+    want = model.model.model.speech_tokenizer.num_samples_total(ref_codes.shape[0] + frames)
+    want -= int(ref_codes.shape[0] / (ref_codes.shape[0] + frames) * want)
+    assert all(n == want for n in lens), (sorted(set(lens)), want)          # every utterance ran its `frames` frames (EOS suppressed)
+    return n_utt * frames * FRAME_S, wall, lens
 
 
 def batched_streaming_run(model, req, lanes=8, n_utt=16):

@@ -33,12 +33,15 @@ class _SideVocoder:
     waveforms in submission order.  Tokenizers without ``decode_tensor`` (a foreign ``speech_tokenizer``) are decoded
     synchronously through the upstream call."""
 
-    def __init__(self, tok, device):
+    def __init__(self, tok, device, stream=None):
         self.tok = tok
         self.sample_rate = int(getattr(tok, "sample_rate", 24000))
         self.dev = torch.device(device) if not isinstance(device, torch.device) else device
         self.async_ok = torch.cuda.is_available() and hasattr(tok, "decode_tensor")
-        self.stream = torch.cuda.Stream(device=self.dev) if self.async_ok else None
+        if self.async_ok and stream is None:
+            from .streams import concurrent_stream
+            stream = concurrent_stream(self.dev)               # verified to run beside the decode stream (fq3hip/streams.py)
+        self.stream = stream if self.async_ok else None
         self.items: list = []
 
     def submit(self, key, codes: torch.Tensor, ref_len: int = 0) -> None:
@@ -753,7 +756,10 @@ class FasterQwen3TTS:
             # vocoder_stream_priority (attribute, default None = the device default): HIP stream priority of the vocoder
             # stream, larger = lower.  Set it before the first streaming call.
             prio = getattr(self, "vocoder_stream_priority", None)
-            self._voc_stream = torch.cuda.Stream(device=dev) if prio is None else torch.cuda.Stream(device=dev, priority=int(prio))
+            from .streams import concurrent_stream
+            # a stream VERIFIED to execute beside the decode stream: one that shares its hardware queue would hold the first audio chunk
+            # back until the next chunk's frames -- queued before it -- have run (fq3hip/streams.py)
+            self._voc_stream = concurrent_stream(dev, prio)
         return self._voc_stream
 
     def streaming_vocoder(self, ref_codes, chunk_size: int) -> "StreamingVocoder":
@@ -846,7 +852,11 @@ class FasterQwen3TTS:
     def _side_vocoder(self):
         """Vocoder for finished utterances of a batched run: decodes on its own HIP stream (the lock-step decode of the
         remaining / next utterances goes on meanwhile) and copies the waveform to pinned host memory asynchronously."""
-        return _SideVocoder(self.model.model.speech_tokenizer, self.device)
+        tok = self.model.model.speech_tokenizer
+        if getattr(self, "_side_voc_stream", None) is None and torch.cuda.is_available() and hasattr(tok, "decode_tensor"):
+            from .streams import concurrent_stream
+            self._side_voc_stream = concurrent_stream(self.device)            # probed once per model (fq3hip/streams.py)
+        return _SideVocoder(tok, self.device, getattr(self, "_side_voc_stream", None))
 
     def _batch_feed(self, prepared, gen_kwargs, lanes: int, meta: dict):
         """``prepared``: an iterable (usually a generator: the prompt of utterance i is built when the scheduler asks for it) of
