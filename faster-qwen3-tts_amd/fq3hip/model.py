@@ -891,10 +891,12 @@ class FasterQwen3TTS:
         head, source = self._batch_feed(prepared, gen_kwargs, len(dec.lanes), meta)
         out: List[Optional[Tuple[list, int]]] = [None] * count
         voc = self._side_vocoder()
-        # batch_vocode_every (attribute, default 64 frames; 0 = vocode an utterance when it has ended): the waveform is produced in
-        # slices while the utterance still decodes -- exact, see _SideVocoder.inc_add -- so that what is left at the end is the last
-        # slice only
-        inc = int(getattr(self, "batch_vocode_every", 64) or 0)
+        # batch_vocode_every (attribute; default 0 = vocode an utterance when it has ended; N > 0 = produce the waveform in slices every N
+        # frames while the utterance still decodes -- exact, see _SideVocoder.inc_add -- so that what is left at the end is the last slice
+        # only).  Measured on MI355X (profiles/r04_batch_e2e_vocode_every_*.txt): the slices contend with the latency-bound lock-step
+        # frames for more than they save at the end -- 64 lanes x 128 utterances, 0.6B: 561x at 0, 537x at 64, 552x at 100; 1.7B: 458x vs
+        # 443x -- so it is OFF by default; a server whose lanes finish at different times has nothing to gain from it either.
+        inc = int(getattr(self, "batch_vocode_every", 0) or 0)
         if inc > 0 and voc.async_ok and hasattr(voc.tok, "decode_tensor_batch") and hasattr(voc.tok, "num_samples_total"):
             max_new = min(int(gen_kwargs.get("max_new_tokens", 2048)), int(self.talker_graph.engine.max_frames))
             for rid, codes, info in dec.run(head, source=source, chunk_frames=inc):
