@@ -320,6 +320,22 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(BatchGemvArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 
+// RMSNorm of 8 values straight to packed bf16: bf16(bf16(x * rs) * w), the two roundings of the reference's norm (and of the loop it
+// replaces: same products, same roundings), in 5 VALU operations per value instead of 8 -- packed fp32 multiplies (v_pk_mul_f32:
+// IEEE products, two per instruction) and no unpack / re-pack round trip after the second rounding.  The normalisation prologue is
+// VALU time every workgroup spends on every token (~1700 instructions per wave at 32 lanes x K = 1024).
+__device__ __forceinline__ u32x4 norm8_pack(const float (&x)[8], float rs, const float (&w)[8]) {
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const fq3_f32x2 p = fq3_f32x2{x[2 * i], x[2 * i + 1]} * fq3_f32x2{rs, rs};
+        const uint32_t u = pack_bf16x2(p.x, p.y);
+        const fq3_f32x2 q = fq3_f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)} * fq3_f32x2{w[2 * i], w[2 * i + 1]};
+        o[i] = pack_bf16x2(q.x, q.y);
+    }
+    return u32x4{o[0], o[1], o[2], o[3]};
+}
+
 // NT = token tiles of 16 lanes the launch walks (1: B <= 16, 2: 17..32).  The weight fragments are loaded once and stay in
 // registers; with NT = 2 the second tile's raw tokens are loaded up front as well when they fit (PRE2: K <= 1024), otherwise after
 // the first tile has been multiplied (one exposed L2 round trip).
@@ -417,18 +433,12 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                         for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
                     ss = wave_sum(ss);
                     const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+                    u32x4 xn[NCH];
 #pragma unroll
                     for (int j = 0; j < NCH; ++j) {
                         float nw[8];
                         unpack(nraw[j], nw);
-#pragma unroll
-                        for (int i = 0; i < 8; i += 2) {
-                            float u = xr[j][i] * rs, v = xr[j][i + 1] * rs;
-                            DT<T>::rnd2(u, v);
-                            u *= nw[i]; v *= nw[i + 1];
-                            DT<T>::rnd2(u, v);
-                            xr[j][i] = u; xr[j][i + 1] = v;
-                        }
+                        xn[j] = norm8_pack(xr[j], rs, nw);
                     }
                     if (m < nb) {
                         T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[t0 + m]) : nullptr;
@@ -436,8 +446,8 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                         for (int j = 0; j < NCH; ++j) {
                             const int off = j * 512 + lane * 8;
                             if (off < K) {
-                                DT<T>::st8(xp + (size_t)m * KP + off, xr[j]);
-                                if (xo) DT<T>::st8(xo + off, xr[j]);
+                                *reinterpret_cast<u32x4*>(xp + (size_t)m * KP + off) = xn[j];
+                                if (xo) *reinterpret_cast<u32x4*>(xo + off) = xn[j];
                             }
                         }
                     }
@@ -526,18 +536,12 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                 for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
             ss = wave_sum(ss);
             const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+            u32x4 xn[NCH];
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 float nw[8];
                 unpack(nraw[j], nw);
-#pragma unroll
-                for (int i = 0; i < 8; i += 2) {
-                    float u = xr[j][i] * rs, v = xr[j][i + 1] * rs;
-                    DT<T>::rnd2(u, v);
-                    u *= nw[i]; v *= nw[i + 1];
-                    DT<T>::rnd2(u, v);
-                    xr[j][i] = u; xr[j][i + 1] = v;
-                }
+                xn[j] = norm8_pack(xr[j], rs, nw);
             }
             if (m < nb) {
                 T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[t0 + m]) : nullptr;
@@ -545,8 +549,8 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                 for (int j = 0; j < NCH; ++j) {
                     const int off = j * 512 + lane * 8;
                     if (off < K) {
-                        DT<T>::st8(xs + (size_t)m * KP + off, xr[j]);
-                        if (xo) DT<T>::st8(xo + off, xr[j]);
+                        *reinterpret_cast<u32x4*>(xs + (size_t)m * KP + off) = xn[j];
+                        if (xo) *reinterpret_cast<u32x4*>(xo + off) = xn[j];
                     }
                 }
             }

@@ -38,6 +38,20 @@ struct fq3_batch {
     int use_mfma = 0;             // bf16 GEMVs on the matrix cores: default ON for bf16 (ids verified against the oracle by teacher forcing
                                   // at full depth, 8 and 16 lanes); fq3_batch_set_option("mfma", 0) selects the VALU kernels, whose
                                   // lanes are bit-identical to the single-stream path
+    // ---- lane groups (round 4): the lanes split into 2..4 independent lock-step chains, each a batch of its own ("kid") with its own
+    // activations and frame graph, advanced CONCURRENTLY on streams that were probed for a hardware queue of their own.  A chain is a
+    // string of ~600 dependent launches of 128-256 workgroups each, 5-9 us apiece, most of it latency (ramp, exposed round trips,
+    // barriers, tail): two chains side by side fill the idle half of the chip and each other's bubbles.  Lanes are independent, so the
+    // groups meet only at the end of an fq3_batch_frames call (one event each way).  A lane's values do not depend on its group.
+    int groups_opt = 0;           // "groups": 0 = automatic (see auto_groups), 1..4 = as told
+    bool is_kid = false;
+    std::vector<fq3_batch*> kids;
+    std::vector<hipStream_t> kid_streams;       // [g] for kid g >= 1 ([0] unused: kid 0 runs on the caller's stream)
+    std::vector<hipStream_t> given_streams;     // fq3_batch_set_group_streams: the host's own (probed) streams, not owned
+    hipStream_t probed_for = nullptr;           // the caller's stream the kid streams were probed against
+    bool probed = false;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
 };
 
 static int bmalloc(fq3_batch* b, void** p, size_t bytes) {
@@ -74,20 +88,84 @@ extern "C" int fq3_batch_graph_reset(fq3_batch* b) {
     if (!b) return fq3_fail_(FQ3_EINVAL, "null batch");
     if (b->exec) { (void)hipGraphExecDestroy(b->exec); b->exec = nullptr; }
     if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
+    for (fq3_batch* k : b->kids) fq3_batch_graph_reset(k);
     return FQ3_OK;
+}
+
+static void drop_group_streams(fq3_batch* b) {
+    for (size_t g = 1; g < b->kid_streams.size(); ++g) {
+        bool mine = true;
+        for (hipStream_t h : b->given_streams) if (h == b->kid_streams[g]) mine = false;
+        if (mine && b->kid_streams[g]) (void)hipStreamDestroy(b->kid_streams[g]);
+    }
+    b->kid_streams.clear();
+    b->probed = false; b->probed_for = nullptr;
+}
+static void drop_kids(fq3_batch* b) {
+    for (fq3_batch* k : b->kids) fq3_batch_destroy(k);
+    b->kids.clear();
+    drop_group_streams(b);
+    for (hipEvent_t e : b->ev_join) if (e) (void)hipEventDestroy(e);
+    b->ev_join.clear();
+    if (b->ev_fork) { (void)hipEventDestroy(b->ev_fork); b->ev_fork = nullptr; }
 }
 
 extern "C" int fq3_batch_destroy(fq3_batch* b) {
     if (!b) return FQ3_OK;
-    (void)hipDeviceSynchronize();
+    if (!b->is_kid) (void)hipDeviceSynchronize();
     fq3_batch_graph_reset(b);
+    drop_kids(b);
     if (b->cap_stream) (void)hipStreamDestroy(b->cap_stream);
     for (void* p : b->allocs) (void)hipFree(p);
     delete b;
     return FQ3_OK;
 }
 
+// 33..64 lanes: two chains of up to 32 lanes each (measured, profiles/r04_batch_groups.txt); up to 32 lanes: one chain
+static int auto_groups(int B) { return B > 2 * kTokTile ? 2 : 1; }
+
+static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bool is_kid);
+// a lane group runs the kernels the whole batch would run: the choice "above 16 lanes o_proj / down take the weight-stationary kernel"
+// follows the BATCH's lane count, not the group's (a last group of a few lanes must not change its lanes' summation order)
+static void sync_kid_options(fq3_batch* b) {
+    for (fq3_batch* k : b->kids) {
+        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma;
+        k->use_skinny = (b->use_skinny == 1 && b->B > kTokTile) ? 2 : b->use_skinny;
+    }
+}
+// (re)build the lane groups: `groups` chains of whole 16-lane token tiles, as even as the tile count allows
+static int build_groups(fq3_batch* b, int groups) {
+    drop_kids(b);
+    const int tiles = (b->B + kTokTile - 1) / kTokTile;
+    groups = std::max(1, std::min(groups, tiles));
+    if (groups <= 1) return FQ3_OK;
+    int l0 = 0;
+    for (int g = 0; g < groups; ++g) {
+        const int gt = tiles / groups + (g < tiles % groups ? 1 : 0);
+        const int n = std::min(gt * kTokTile, b->B - l0);
+        fq3_batch* k = nullptr;
+        if (int r = batch_create_(b->lanes.data() + l0, n, &k, true)) { drop_kids(b); return r; }
+        b->kids.push_back(k);
+        l0 += n;
+    }
+    sync_kid_options(b);
+    if (hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess) { drop_kids(b); return fq3_fail_(FQ3_EHIP, "hipEventCreate"); }
+    b->ev_join.assign(groups, nullptr);
+    for (int g = 1; g < groups; ++g)
+        if (hipEventCreateWithFlags(&b->ev_join[g], hipEventDisableTiming) != hipSuccess) { drop_kids(b); return fq3_fail_(FQ3_EHIP, "hipEventCreate"); }
+    return FQ3_OK;
+}
+
 extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out) {
+    if (!lanes || !out) return fq3_fail_(FQ3_EINVAL, "null argument");
+    fq3_batch* b = nullptr;
+    if (int r = batch_create_(lanes, n_lanes, &b, false)) return r;
+    if (b->use_mfma) if (int r = build_groups(b, auto_groups(b->B))) { fq3_batch_destroy(b); return r; }
+    *out = b;
+    return FQ3_OK;
+}
+
+static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bool is_kid) {
     if (!lanes || !out) return fq3_fail_(FQ3_EINVAL, "null argument");
     if (n_lanes < 1 || n_lanes > kMaxLanes) return fq3_fail_(FQ3_EINVAL, "n_lanes must be 1..64");
     for (int i = 0; i < n_lanes; ++i) {
@@ -112,6 +190,7 @@ extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** 
     }
     if (c0->cfg.num_code_groups != 16) return fq3_fail_(FQ3_EUNSUPPORTED, "the fused loop is built for 16 code groups");
     fq3_batch* b = new fq3_batch();
+    b->is_kid = is_kid;
     b->lanes.assign(lanes, lanes + n_lanes);
     b->B = n_lanes;
     const fq3_stack_dims &t = c0->cfg.talker, &p = c0->cfg.predictor;
@@ -161,8 +240,28 @@ extern "C" int fq3_batch_set_option(fq3_batch* b, const char* key, int value) {
     else if (std::string(key) == "skinny") b->use_skinny = value;  // o_proj / down of 17..32 lanes on skinny_gemm_kernel (default 1); 0: gemv_batch_mfma_plain_kernel;
                                                               // 2: at every lane count (a measurement switch: below 17 lanes the kernel's two-tile group is half empty)
     else if (std::string(key) == "mfma") b->use_mfma = value;      // bf16 GEMVs on the matrix cores (fp32 summation order differs from the single-stream kernels)
+    else if (std::string(key) == "groups") {                       // lane groups on concurrent streams: 0 = automatic, 1 = one chain, 2..4
+        if (value < 0 || value > 4) return fq3_fail_(FQ3_EINVAL, "groups must be 0..4");
+        if (b->is_kid) return fq3_fail_(FQ3_EINVAL, "not an option of a lane group");
+        (void)hipDeviceSynchronize();
+        b->groups_opt = value;
+        if (int r = build_groups(b, value ? value : (b->use_mfma ? auto_groups(b->B) : 1))) return r;
+    }
     else return fq3_fail_(FQ3_EINVAL, std::string("unknown batch option: ") + key);
+    sync_kid_options(b);
     return fq3_batch_graph_reset(b);
+}
+
+// The host's own side streams for the lane groups 1.. (e.g. probed against every other stream it keeps busy); without them the
+// library probes streams of its own against the stream of the first fq3_batch_frames call.
+extern "C" int fq3_batch_set_group_streams(fq3_batch* b, void* const* streams, int n) {
+    if (!b || (n > 0 && !streams)) return fq3_fail_(FQ3_EINVAL, "null argument");
+    if (n < 0 || n > 3) return fq3_fail_(FQ3_EINVAL, "at most three side streams");
+    (void)hipDeviceSynchronize();
+    drop_group_streams(b);
+    b->given_streams.clear();
+    for (int i = 0; i < n; ++i) b->given_streams.push_back((hipStream_t)streams[i]);
+    return FQ3_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -414,6 +513,10 @@ static int enqueue_batch_frame(fq3_batch* b, hipStream_t s) {
 
 extern "C" int fq3_batch_graph_capture(fq3_batch* b, void* stream) {
     if (!b) return fq3_fail_(FQ3_EINVAL, "null batch");
+    if (!b->kids.empty()) {
+        for (fq3_batch* k : b->kids) if (int r = fq3_batch_graph_capture(k, stream)) return r;
+        return FQ3_OK;
+    }
     if (b->exec) return FQ3_OK;
     (void)stream;
     if (int r = check_lanes(b)) return r;
@@ -429,10 +532,84 @@ extern "C" int fq3_batch_graph_capture(fq3_batch* b, void* stream) {
     return FQ3_OK;
 }
 
+// ---- side streams of the lane groups: HIP multiplexes streams onto a few hardware queues (four by default) and two streams on one
+// queue run in submission order, so a side stream is only worth having when it PROVABLY runs beside the caller's: a spin on the
+// caller's stream (and on the side streams already chosen), an empty kernel on the candidate -- the candidate's kernel finishing
+// while the spins still run is the proof.  ~2 ms per candidate, once per batch.
+namespace {
+__global__ void group_probe_spin_kernel(long long ticks) {      // wall_clock64: a constant 100 MHz counter
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+__global__ void group_probe_touch_kernel() {}
+}
+static bool runs_beside(hipStream_t cand, hipStream_t main, const std::vector<hipStream_t>& others) {
+    hipEvent_t e_main = nullptr, e_cand = nullptr;
+    if (hipEventCreateWithFlags(&e_main, hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&e_cand, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(e_main); return false; }
+    hipLaunchKernelGGL(group_probe_touch_kernel, dim3(1), dim3(64), 0, cand);          // code object resident, queue created
+    (void)hipStreamSynchronize(cand);
+    (void)hipStreamSynchronize(main);
+    for (hipStream_t o : others) if (o) hipLaunchKernelGGL(group_probe_spin_kernel, dim3(1), dim3(64), 0, o, 200000LL);
+    hipLaunchKernelGGL(group_probe_spin_kernel, dim3(1), dim3(64), 0, main, 200000LL);
+    (void)hipEventRecord(e_main, main);
+    hipLaunchKernelGGL(group_probe_touch_kernel, dim3(1), dim3(64), 0, cand);
+    (void)hipEventRecord(e_cand, cand);
+    (void)hipEventSynchronize(e_cand);
+    const bool beside = hipEventQuery(e_main) == hipErrorNotReady;
+    (void)hipStreamSynchronize(main);
+    for (hipStream_t o : others) if (o) (void)hipStreamSynchronize(o);
+    (void)hipEventDestroy(e_main); (void)hipEventDestroy(e_cand);
+    (void)hipGetLastError();
+    return beside;
+}
+// kid_streams for the caller's stream s (probed once; again when the caller changes streams); false = run the groups one after another
+static bool group_streams_for(fq3_batch* b, hipStream_t s) {
+    if (b->probed && b->probed_for == s) return b->kid_streams.size() == b->kids.size();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+    drop_group_streams(b);
+    b->probed = true; b->probed_for = s;
+    std::vector<hipStream_t> chosen{nullptr};
+    for (size_t g = 1; g < b->kids.size(); ++g) {
+        hipStream_t got = nullptr;
+        if (g - 1 < b->given_streams.size()) got = b->given_streams[g - 1];           // the host vouches for its own streams
+        for (int t = 0; t < 8 && !got; ++t) {
+            hipStream_t cand = nullptr;
+            if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+            if (runs_beside(cand, s, std::vector<hipStream_t>(chosen.begin() + 1, chosen.end()))) got = cand;
+            else (void)hipStreamDestroy(cand);
+        }
+        if (!got) break;
+        chosen.push_back(got);
+    }
+    b->kid_streams = chosen;
+    return b->kid_streams.size() == b->kids.size();
+}
+
+static int batch_frames_one(fq3_batch* b, int n_frames, hipStream_t s);
 extern "C" int fq3_batch_frames(fq3_batch* b, int n_frames, void* stream) {
     if (!b) return fq3_fail_(FQ3_EINVAL, "null batch");
-    if (int r = check_lanes(b)) return r;
     hipStream_t s = (hipStream_t)stream;
+    if (b->kids.empty()) return batch_frames_one(b, n_frames, s);
+    if (n_frames <= 0) return FQ3_OK;
+    if (!group_streams_for(b, s)) {                       // no stream with a queue of its own: the chains one after another
+        for (fq3_batch* k : b->kids) if (int r = batch_frames_one(k, n_frames, s)) return r;
+        return FQ3_OK;
+    }
+    HIPCHK(hipEventRecord(b->ev_fork, s));
+    for (size_t g = 1; g < b->kids.size(); ++g) {
+        HIPCHK(hipStreamWaitEvent(b->kid_streams[g], b->ev_fork, 0));
+        if (int r = batch_frames_one(b->kids[g], n_frames, b->kid_streams[g])) return r;
+        HIPCHK(hipEventRecord(b->ev_join[g], b->kid_streams[g]));
+    }
+    if (int r = batch_frames_one(b->kids[0], n_frames, s)) return r;
+    for (size_t g = 1; g < b->kids.size(); ++g) HIPCHK(hipStreamWaitEvent(s, b->ev_join[g], 0));
+    return FQ3_OK;
+}
+
+static int batch_frames_one(fq3_batch* b, int n_frames, hipStream_t s) {
+    if (int r = check_lanes(b)) return r;
     for (int i = 0; i < n_frames; ++i) {
         if (b->exec) { HIPCHK(hipGraphLaunch(b->exec, s)); }
         else if (int r = enqueue_batch_frame(b, s)) return r;

@@ -130,6 +130,7 @@ SIGNATURES = {
     "fq3_batch_graph_capture": (C.c_int, [vp, vp]),
     "fq3_batch_graph_reset": (C.c_int, [vp]),
     "fq3_batch_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
+    "fq3_batch_set_group_streams": (C.c_int, [vp, C.POINTER(vp), C.c_int]),
     "fq3_codec_create": (C.c_int, [C.POINTER(CodecConfig), C.POINTER(vp)]),
     "fq3_codec_destroy": (C.c_int, [vp]),
     "fq3_codec_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),

@@ -94,6 +94,9 @@ class BatchDecoder:
         # spare contexts (same weights, not part of the lock-step batch) for prefilling ahead of admission
         self.stages = [_Stage(e) for e in (staging or [])]
         self._side = None
+        # other streams the host keeps busy while the batch decodes (the vocoder's): the prefill stream and the lane groups' stream are
+        # probed for a hardware queue shared with none of them (fq3hip/streams.py)
+        self.beside: list = []
         # every context this scheduler will ever PREFILL into gets its workspace NOW: a lazy device allocation inside a staged
         # prefill would land in the middle of the running lanes' decode.  With spare contexts the lanes never prefill (they only
         # adopt), so their workspaces would be dead memory (~100 MB each at 0.6B / 2048 slots, ~380 MB at 1.7B / 6144).
@@ -105,6 +108,22 @@ class BatchDecoder:
         # tests/test_gpu_decode.py).  Measured with the workspaces reserved up front (profiles/r03_packed_prefill.txt, 0.6B shapes,
         # 200-row prompts): first-wave TTFA 82.5 -> 63.6 ms at 8 lanes and 125 -> 89 ms at 16, aggregate 153.5 -> 156x / 229 -> 234x.
         self.packed_prefill = bool(packed_prefill)
+
+    def _group_streams(self):
+        """Above 32 lanes the library advances two lane groups concurrently (``fq3_batch_set_option("groups")``); the second group's
+        stream is ours, so that it shares a hardware queue neither with the decode stream nor with the vocoder / prefill streams."""
+        eng = self.lanes[0].engine
+        n_groups = getattr(self, "n_groups", None)                 # None: the library's choice (two groups above 32 lanes)
+        grouped = (len(self.lanes) > 32) if n_groups is None else (n_groups > 1)
+        if not grouped or not self._on_gpu(eng) or not hasattr(self.batch, "set_group_streams"):
+            return
+        from .streams import concurrent_stream
+        if self._side is None and self.stages:
+            self._side = concurrent_stream(eng.device, beside=self.beside)
+        self._group_side = [concurrent_stream(eng.device, beside=list(self.beside) + [self._side])]
+        for _ in range(2, n_groups or 2):                           # further groups (measurement): beside the decode stream at least
+            self._group_side.append(concurrent_stream(eng.device, beside=self._group_side))
+        self.batch.set_group_streams(self._group_side)
 
     def _more(self, queue: list):
         """Pop the next event of a poll's batch; ``self.more_in_poll`` tells the consumer (read it right after receiving the event) how
@@ -204,7 +223,8 @@ class BatchDecoder:
             if self._on_gpu(engines[0]):
                 dev = engines[0].device
                 if self._side is None:
-                    self._side = torch.cuda.Stream(device=dev)
+                    from .streams import concurrent_stream
+                    self._side = concurrent_stream(dev, beside=self.beside)     # verified to run beside the decode (and vocoder) stream
                 for _st, _req, ev in group:
                     if ev is not None:
                         self._side.wait_event(ev)                           # the request's tensors were produced on the main stream
@@ -433,6 +453,7 @@ class BatchDecoder:
             if not active:
                 continue
             if self.use_graph and not self._captured:
+                self._group_streams()
                 self.batch.graph_capture()
                 self._captured = True
             # lock-step frames, never across a lane's noise-ring boundary (each lane refills its own rings)

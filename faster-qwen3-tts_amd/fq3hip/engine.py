@@ -495,8 +495,14 @@ class Fq3Batch:
 
     def set_option(self, key: str, value: int):
         """``fq3_batch_set_option``: "mfma" 0|1 (matrix-core batch GEMVs, bf16), "skinny" 0|1 (o_proj / down of 17..32 lanes on
-        the weight-stationary prefill kernel)."""
+        the weight-stationary prefill kernel), "groups" 0..4 (lane groups advanced concurrently; 0 = automatic)."""
         L.check(self.lib.fq3_batch_set_option(self.handle, key.encode(), int(value)))
+
+    def set_group_streams(self, streams):
+        """``fq3_batch_set_group_streams``: the caller's own side streams for lane groups 1.. (kept alive here)."""
+        self._group_streams = list(streams)
+        arr = (L.vp * max(1, len(self._group_streams)))(*[s.cuda_stream for s in self._group_streams])
+        L.check(self.lib.fq3_batch_set_group_streams(self.handle, arr, len(self._group_streams)))
 
     def close(self):
         if getattr(self, "handle", None) and self.handle.value:

@@ -830,8 +830,10 @@ class FasterQwen3TTS:
         full = (lanes + staging) * Fq3KvPool.blocks_for(first.max_seq_len)
         want = getattr(self, "batch_kv_blocks", None)
         blocks = full if want is None else max(Fq3KvPool.blocks_for(first.max_seq_len), min(int(want), full))
+        # batch_groups (attribute, default None = the library's choice: two concurrent lane groups above 32 lanes): fq3_batch_set_option("groups")
+        groups = getattr(self, "batch_groups", None)
         cached = getattr(self, "_batch_cache", None)
-        if cached is not None and cached[0] == (lanes, staging, blocks):
+        if cached is not None and cached[0] == (lanes, staging, blocks, groups):
             # the lanes follow this model's CURRENT predictor policy (it is copied into the loop state when a lane is armed)
             pg = self.predictor_graph
             cached[1].set_predictor_policy(do_sample=pg.do_sample, top_k=pg.top_k, top_p=pg.top_p, temperature=pg.temperature)
@@ -846,7 +848,13 @@ class FasterQwen3TTS:
                                                           temperature=pg.temperature),
                            staging=[mk() for _ in range(staging)])
         dec.kv_pool = pool
-        self._batch_cache = ((lanes, staging, blocks), dec)
+        if groups is not None and hasattr(dec.batch, "set_option"):
+            dec.batch.set_option("groups", int(groups))
+            dec.n_groups = int(groups)
+        if torch.cuda.is_available():
+            tok = self.model.model.speech_tokenizer
+            dec.beside = [st for st in (self._vocoder_stream(tok),) if st is not None]
+        self._batch_cache = ((lanes, staging, blocks, groups), dec)
         return dec
 
     def _side_vocoder(self):
@@ -855,7 +863,9 @@ class FasterQwen3TTS:
         tok = self.model.model.speech_tokenizer
         if getattr(self, "_side_voc_stream", None) is None and torch.cuda.is_available() and hasattr(tok, "decode_tensor"):
             from .streams import concurrent_stream
-            self._side_voc_stream = concurrent_stream(self.device)            # probed once per model (fq3hip/streams.py)
+            # ONE vocoder stream per model (probed once, fq3hip/streams.py): hardware queues are few, and the scheduler's prefill
+            # stream and the lane groups' stream have to stay clear of it
+            self._side_voc_stream = self._vocoder_stream(tok) or concurrent_stream(self.device)
         return _SideVocoder(tok, self.device, getattr(self, "_side_voc_stream", None))
 
     def _batch_feed(self, prepared, gen_kwargs, lanes: int, meta: dict):

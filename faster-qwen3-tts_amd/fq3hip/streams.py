@@ -5,7 +5,8 @@ submission order.  A vocoder stream that shares its queue with the decode stream
 waits for the NEXT chunk's frames, which were queued before it (measured on MI355X: p50 TTFA 28.6 -> 44-47 ms and RTF -10 % at the
 1.7B shapes, for whichever of two model instances drew the unlucky stream).  ``concurrent_stream`` therefore PROBES: a spin on the
 current stream, a trivial kernel on the candidate -- a candidate whose kernel finishes while the spin is still running has its own
-queue.  The probe costs ~10 ms per candidate, once per component.
+queue.  The probe costs ~10 ms per candidate, once per component.  ``beside=`` names further streams the candidate must not share
+a queue with (the batch scheduler's prefill stream and the lane groups' stream are probed against the vocoder's as well).
 """
 from __future__ import annotations
 
@@ -16,27 +17,41 @@ import torch
 _SPIN_CYCLES = 20_000_000          # ~10 ms
 
 
-def concurrent_stream(device, priority: Optional[int] = None, tries: int = 8) -> "torch.cuda.Stream":
-    """A new stream on ``device`` that executes concurrently with the CURRENT stream (verified), or the last candidate tried."""
+def _spin(stream):
+    with torch.cuda.stream(stream):
+        torch.cuda._sleep(_SPIN_CYCLES)
+
+
+def concurrent_stream(device, priority: Optional[int] = None, tries: int = 8, beside=()) -> "torch.cuda.Stream":
+    """A new stream on ``device`` that executes concurrently with the CURRENT stream and with every stream in ``beside`` (verified:
+    all of them spin while the candidate's kernel completes).  There are only a few hardware queues: when no candidate runs beside
+    all of them, one that at least runs beside the current stream is returned, else the last candidate tried."""
     dev = torch.device(device) if not isinstance(device, torch.device) else device
     main = torch.cuda.current_stream(dev)
-    cand = None
+    others = [s for s in beside if s is not None and s != main]
+    cand, beside_main = None, None
     for _ in range(max(1, tries)):
         cand = torch.cuda.Stream(device=dev) if priority is None else torch.cuda.Stream(device=dev, priority=int(priority))
         try:
-            main.synchronize()
-            done_main, done_cand = torch.cuda.Event(), torch.cuda.Event()
+            torch.cuda.synchronize(dev)
+            done = [torch.cuda.Event() for _ in range(1 + len(others))]
+            done_cand = torch.cuda.Event()
+            for st, ev in zip(others, done[1:]):
+                _spin(st)
+                ev.record(st)
             torch.cuda._sleep(_SPIN_CYCLES)
-            done_main.record(main)
+            done[0].record(main)
             with torch.cuda.stream(cand):
                 x = torch.zeros(8, device=dev)
                 x.add_(1)
                 done_cand.record(cand)
             done_cand.synchronize()
-            overlapped = not done_main.query()
-            main.synchronize()
+            running = [not ev.query() for ev in done]
+            torch.cuda.synchronize(dev)
         except Exception:               # no spin kernel on this build: take the stream as it is
             return cand
-        if overlapped:
+        if all(running):
             return cand
-    return cand
+        if running[0] and beside_main is None:
+            beside_main = cand
+    return beside_main if beside_main is not None else cand

@@ -296,8 +296,16 @@ int fq3_batch_graph_reset(fq3_batch* b);
  * forcing) or on the VALU kernels (0: every lane bit-identical to the same utterance decoded alone).
  * "skinny" 0|1 (with "mfma" 1, more than 16 lanes): o_proj / down through the weight-stationary kernel of the short-prompt prefill
  * (default 1) or through the one-row-block-per-workgroup batch GEMV (0); 2 takes the weight-stationary kernel at every lane count
- * (measurement switch). */
+ * (measurement switch).
+ * "groups" 0..4: LANE GROUPS.  The lanes split into that many independent lock-step chains of whole 16-lane tiles, each with its own
+ * frame graph, advanced concurrently on streams the library probes for a hardware queue of their own (they fork from / join
+ * `stream` inside fq3_batch_frames, so the caller sees one stream as before); 0 (default) = automatic: two chains above 32 lanes,
+ * one otherwise.  A lane's values do not depend on the grouping.  When no stream with its own queue is found, or `stream` is being
+ * captured, the chains run one after another on `stream`. */
 int fq3_batch_set_option(fq3_batch* b, const char* key, int value);
+/* The caller's own side streams for lane groups 1..n (n <= 3), e.g. streams it has probed against every other stream it keeps
+ * busy (a vocoder stream, a prefill stream); they are borrowed, not owned.  n = 0 returns to the library's own probing. */
+int fq3_batch_set_group_streams(fq3_batch* b, void* const* streams, int n);
 
 /* ---- 12 Hz codec decoder (speech_tokenizer.decode, model.py:924) ---------------------------- */
 typedef struct fq3_codec fq3_codec;

@@ -415,6 +415,42 @@ def test_two_panel_normalising_gemv_is_bit_identical_at_32_lanes():
         e.close()
 
 
+def test_lane_groups_are_bit_identical():
+    """fq3_batch_set_option("groups", g): the lanes advance as g independent lock-step chains on concurrent streams (the default above
+    32 lanes: two).  Lanes are independent and a group runs the kernels the whole batch would run, so every lane's ids are the ids of
+    the one-chain batch -- for whole and ragged tile counts, a last group of a single lane, frames queued over several calls, with and
+    without the frame graphs."""
+    from fq3hip.engine import Fq3Batch
+    cfg = tiny_test_config()
+    dtype = torch.bfloat16
+    W = synth_weights(cfg, 0, dtype)
+    utts = [_utterance(cfg, dtype, 500 + i, 18 + (7 * i) % 53, (i % 3) * 2, 7 + (i * 5) % 9, 7 + (i * 5) % 9, i % 4 != 1) for i in range(64)]
+    lanes = _engines(cfg, W, dtype, 64)
+    for n_lanes, n_armed in ((33, 33), (48, 41), (64, 64)):
+        batch = Fq3Batch(lanes[:n_lanes])
+        ref = None
+        for groups, graph in ((1, True), (2, True), (3, False), (4, True), (0, True)):
+            batch.set_option("groups", groups)
+            for e, u in zip(lanes[:n_armed], utts):
+                _arm(e, cfg, u)
+            if graph:
+                batch.graph_capture()
+            batch.frames(5)
+            batch.frames(1)
+            batch.frames(10)
+            torch.cuda.synchronize()
+            got = [e.decode_codes(0, e.decode_poll()[0]).cpu() for e in lanes[:n_armed]]
+            assert all(g.shape[0] > 0 for g in got)
+            if ref is None:
+                ref = got
+            else:
+                for i, (a, b) in enumerate(zip(ref, got)):
+                    assert a.shape == b.shape and torch.equal(a, b), (n_lanes, groups, i)
+        batch.close()
+    for e in lanes:
+        e.close()
+
+
 def test_batch_incremental_vocoding_is_exact():
     """generate_voice_clone_batch produces an utterance's waveform in slices while it still decodes (every `batch_vocode_every` frames,
     all lanes that reached the boundary as one batched codec launch set; _SideVocoder.inc_add).  ICL prompts (reference frames in front,

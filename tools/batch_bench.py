@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Batched decode timing (development aid): B lanes of the 0.6B / 1.7B-shape model in lock-step, one hipGraph per frame.
-usage: batch_bench.py [size=0.6b|1.7b] [B list, e.g. 8,16] [frames=48] [graph=1|0] [skinny=0|1|2 -> fq3_batch_set_option("skinny", v)]"""
+usage: batch_bench.py [size=0.6b|1.7b] [B list, e.g. 8,16] [frames=48] [graph=1|0] [skinny=-|0|1|2 -> fq3_batch_set_option("skinny", v)]
+                      [groups list, e.g. 1,2,4 -> fq3_batch_set_option("groups", g); the codes of every lane are compared across the list]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "faster-qwen3-tts_amd"))
@@ -15,7 +16,8 @@ def main():
     Bs = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "8").split(",")]
     frames = int(sys.argv[3]) if len(sys.argv) > 3 else 48
     graph = (sys.argv[4] if len(sys.argv) > 4 else "1") != "0"
-    skinny = int(sys.argv[5]) if len(sys.argv) > 5 else None
+    skinny = int(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] != "-" else None
+    groups = [int(x) for x in sys.argv[6].split(",")] if len(sys.argv) > 6 else [None]
     cfg = qwen3_tts_0p6b() if size == "0.6b" else qwen3_tts_1p7b()
     dt = torch.bfloat16
     W = synth_weights(cfg, 0, dt, parts=("talker", "predictor"))
@@ -25,6 +27,9 @@ def main():
     kw = dict(temperature=0.9, top_k=50, top_p=1.0, do_sample=True)
     nf = 64
     for B in Bs:
+      ref_codes = None
+      for G in groups:
+        torch.manual_seed(1000 + B)
         keep = []
         for i, eng in enumerate(lanes[:B]):
             tie, tam, tth, tpe, _ = synth_prompt(cfg, 200, 32, 0, dtype=dt, seed=1234 + 10 * i)
@@ -41,13 +46,22 @@ def main():
         batch = Fq3Batch(lanes[:B])
         if skinny is not None:
             batch.set_option("skinny", skinny)
+        if G is not None:
+            batch.set_option("groups", G)
         if graph:
             batch.graph_capture()
         batch.frames(8); torch.cuda.synchronize()
         t0 = time.perf_counter(); batch.frames(frames); torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0) / frames
         n = [e.decode_poll()[0] for e in lanes[:B]]
-        print(f"{size} B={B} graph={int(graph)}{'' if skinny is None else f' skinny={skinny}'}: {ms:.3f} ms per lock-step frame -> {B * 80.0 / ms:.1f}x real-time aggregate "
-              f"({80.0 / ms:.1f}x per lane), frames per lane {sorted(set(n))}", flush=True)
+        same = ""
+        if len(groups) > 1:
+            codes = [e.decode_codes(0, min(n)).cpu() for e in lanes[:B]]
+            if ref_codes is None:
+                ref_codes = codes
+            else:
+                same = f", codes of all {B} lanes == groups={groups[0]}: {all(torch.equal(a, b) for a, b in zip(codes, ref_codes))}"
+        print(f"{size} B={B} graph={int(graph)}{'' if skinny is None else f' skinny={skinny}'}{'' if G is None else f' groups={G}'}: {ms:.3f} ms per lock-step frame -> {B * 80.0 / ms:.1f}x real-time aggregate "
+              f"({80.0 / ms:.1f}x per lane), frames per lane {sorted(set(n))}{same}", flush=True)
         batch.close()
 
 

@@ -10,7 +10,7 @@ tot = sum(r[2] for r in rows)
 names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.split("\n")
 print(f"{'kernel':90s} {'calls':>7s} {'total_ms':>9s} {'avg_us':>8s} {'min_us':>8s} {'max_us':>8s} {'%':>5s} {'grid':>7s}")
 for r, n in zip(rows, names):
-    n = re.sub(r"\(.*", "", n.replace("fq3::", "").replace("unsigned short", "bf16").replace("void ", ""))
+    n = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("fq3::", "").replace("unsigned short", "bf16").replace("void ", ""))
     print(f"{n[:90]:90s} {r[1]:7d} {r[2]/1e6:9.3f} {r[2]/r[1]/1e3:8.2f} {r[3]/1e3:8.2f} {r[4]/1e3:8.2f} {100*r[2]/tot:5.1f} {int(r[5]/max(r[6],1)):7d}")
 print(f"total kernel time {tot/1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
 span = cur.execute("select min(start), max(end) from rocpd_kernel_dispatch").fetchone()
