@@ -38,12 +38,11 @@ struct fq3_batch {
     int use_mfma = 0;             // bf16 GEMVs on the matrix cores: default ON for bf16 (ids verified against the oracle by teacher forcing
                                   // at full depth, 8 and 16 lanes); fq3_batch_set_option("mfma", 0) selects the VALU kernels, whose
                                   // lanes are bit-identical to the single-stream path
-    // ---- lane groups (round 4): the lanes split into 2..4 independent lock-step chains, each a batch of its own ("kid") with its own
-    // activations and frame graph, advanced CONCURRENTLY on streams that were probed for a hardware queue of their own.  A chain is a
-    // string of ~600 dependent launches of 128-256 workgroups each, 5-9 us apiece, most of it latency (ramp, exposed round trips,
-    // barriers, tail): two chains side by side fill the idle half of the chip and each other's bubbles.  Lanes are independent, so the
-    // groups meet only at the end of an fq3_batch_frames call (one event each way).  A lane's values do not depend on its group.
-    int groups_opt = 0;           // "groups": 0 = automatic (see auto_groups), 1..4 = as told
+    // ---- lane groups (round 4; a measurement switch, OFF by default -- see auto_groups): the lanes split into 2..4 independent lock-step
+    // chains, each a batch of its own ("kid") with its own activations and frame graph, advanced CONCURRENTLY on streams that were probed
+    // for a hardware queue of their own.  Lanes are independent, so the groups meet only at the end of an fq3_batch_frames call (one
+    // event each way).  A lane's values do not depend on its group (tests/test_gpu_batch.py::test_lane_groups_are_bit_identical).
+    int groups_opt = 0;           // "groups": 0 = automatic (one chain, see auto_groups), 1..4 = as told
     bool is_kid = false;
     std::vector<fq3_batch*> kids;
     std::vector<hipStream_t> kid_streams;       // [g] for kid g >= 1 ([0] unused: kid 0 runs on the caller's stream)
@@ -121,8 +120,12 @@ extern "C" int fq3_batch_destroy(fq3_batch* b) {
     return FQ3_OK;
 }
 
-// 33..64 lanes: two chains of up to 32 lanes each (measured, profiles/r04_batch_groups.txt); up to 32 lanes: one chain
-static int auto_groups(int B) { return B > 2 * kTokTile ? 2 : 1; }
+// One chain at every lane count.  Measured on MI355X (profiles/r04_batch_groups.txt): two concurrent chains LOSE -- 0.6B 64 lanes 5.57 ms
+// per frame as one chain, 7.15 ms as 2 x 32; 32 lanes 4.36 vs 6.16 ms (2 x 16); 1.7B 64 lanes 7.09 vs 9.00 ms; three and four chains
+// worse still -- only ~20 % better than running the chains one after another.  One chain's launches already occupy every CU with
+// per-token work (normalisation VALU, token reads L2 -> CU, epilogues); a second chain does not find idle units, it queues behind the
+// same ones, and a further token tile in the SAME launch (+0.6 ms per 16 lanes) shares the weight fragments, the launch and the ramp.
+static int auto_groups(int B) { (void)B; return 1; }
 
 static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bool is_kid);
 // a lane group runs the kernels the whole batch would run: the choice "above 16 lanes o_proj / down take the weight-stationary kernel"

@@ -110,11 +110,12 @@ class BatchDecoder:
         self.packed_prefill = bool(packed_prefill)
 
     def _group_streams(self):
-        """Above 32 lanes the library advances two lane groups concurrently (``fq3_batch_set_option("groups")``); the second group's
-        stream is ours, so that it shares a hardware queue neither with the decode stream nor with the vocoder / prefill streams."""
+        """When the batch was told to advance several lane groups concurrently (``fq3_batch_set_option("groups")``, a measurement switch:
+        one chain is faster at every lane count), the further groups' streams are ours, so that they share a hardware queue neither
+        with the decode stream nor with the vocoder / prefill streams."""
         eng = self.lanes[0].engine
-        n_groups = getattr(self, "n_groups", None)                 # None: the library's choice (two groups above 32 lanes)
-        grouped = (len(self.lanes) > 32) if n_groups is None else (n_groups > 1)
+        n_groups = getattr(self, "n_groups", None)                 # None: the library's choice (one chain)
+        grouped = n_groups is not None and n_groups > 1
         if not grouped or not self._on_gpu(eng) or not hasattr(self.batch, "set_group_streams"):
             return
         from .streams import concurrent_stream

@@ -830,7 +830,7 @@ class FasterQwen3TTS:
         full = (lanes + staging) * Fq3KvPool.blocks_for(first.max_seq_len)
         want = getattr(self, "batch_kv_blocks", None)
         blocks = full if want is None else max(Fq3KvPool.blocks_for(first.max_seq_len), min(int(want), full))
-        # batch_groups (attribute, default None = the library's choice: two concurrent lane groups above 32 lanes): fq3_batch_set_option("groups")
+        # batch_groups (attribute, default None = the library's choice: one chain): fq3_batch_set_option("groups"), a measurement switch
         groups = getattr(self, "batch_groups", None)
         cached = getattr(self, "_batch_cache", None)
         if cached is not None and cached[0] == (lanes, staging, blocks, groups):

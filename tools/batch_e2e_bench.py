@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end batched throughput A/B (development aid): bench.batched_run -- the product's _run_batch_full -- at a lane count, for
 several `batch_vocode_every` settings (0 = vocode when an utterance ends; N = exact slices every N frames while it decodes).
-usage: batch_e2e_bench.py [0p6b|1p7b] [lanes=64] [every list, e.g. 0,64,100] [codec=bf16x2] [groups list, e.g. 1,2: model.batch_groups]"""
+usage: batch_e2e_bench.py [0p6b|1p7b] [lanes=64] [every list, e.g. 0,64,100] [codec=bf16x2] [groups list, e.g. 1,2: model.batch_groups | -] [timed runs=2] [decode stream priority: 0 = the current stream | -1 = a high-priority stream]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,8 +14,12 @@ def main():
     lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     everys = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0,64,100").split(",")]
     codec = sys.argv[4] if len(sys.argv) > 4 else bench.HEADLINE_CODEC
-    groups = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [None]
+    groups = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 and sys.argv[5] != "-" else [None]
+    runs = int(sys.argv[6]) if len(sys.argv) > 6 else 2
+    prio = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     dev = "cuda:0"
+    if prio:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=prio))
     cfg, model = bench.build_model(dev, size, max_seq_len=2048, codec_precision=codec)
     req = bench.build_request(cfg, dev)
     prompt = bench.prepared_prompt(model, req)
@@ -26,7 +30,7 @@ def main():
       for ev in everys:
         model.batch_vocode_every = ev
         bench.batched_run(model, prompt, lanes, lanes)
-        res = [bench.batched_run(model, prompt, 2 * lanes, lanes, seed0=2000 + i) for i in range(2)]
+        res = [bench.batched_run(model, prompt, 2 * lanes, lanes, seed0=2000 + i) for i in range(runs)]
         print(f"{size} lanes={lanes} codec={codec} batch_vocode_every={ev}{'' if G is None else f' groups={G}'}: {[round(a / w, 1) for a, w, _l in res]} x real-time end to end "
               f"({2 * lanes} utterances, wall {[round(w, 3) for _a, w, _l in res]} s)", flush=True)
 
