@@ -109,6 +109,9 @@ HEADLINE_CODEC = "bf16x2"         # vocoder arithmetic of EVERY figure of this l
                                   # (parity_pcm: ~1e-5) at ~1.9x the bf16 decode time; the bf16-codec figures are reported beside the headline
 
 
+BATCH_LOOKAHEAD = None
+
+
 def build_model(device, size="0p6b", frames=FRAMES, max_seq_len=2048, model_type="base", codec_precision=None, share=None):
     """`share`: a model built before on this device whose weight replica (and config) the new instance borrows -- e.g. the same
     decode path with another vocoder precision."""
@@ -130,6 +133,8 @@ def build_model(device, size="0p6b", frames=FRAMES, max_seq_len=2048, model_type
     # frames per request, 64 lanes + 64 spare contexts) instead of (lanes + spares) x max_seq_len slots: 1024 blocks of 64 keys
     # against 4096 (max_seq_len 2048) or 12288 (6144)
     model.batch_kv_blocks = 128 * ((PROMPT_LEN + frames + 64 + 63) // 64)
+    if BATCH_LOOKAHEAD is not None:
+        model.batch_lookahead = BATCH_LOOKAHEAD           # --batch-lookahead (measurement switch)
     return cfg, model
 
 
@@ -844,6 +849,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
     ap.add_argument("--batch", type=int, default=64, help="lock-step lanes of the batched figures, <= 64 (0 = skip them)")
     ap.add_argument("--batch-groups", type=int, default=1, help="opt-in: concurrent lock-step batches on one GPU, `batched_groups_one_gpu` (1 = skip; measured: two host-threaded groups of 8 give 159x vs 159x for one)")
+    ap.add_argument("--batch-lookahead", type=int, default=None, help="measurement switch: 0 = the batch scheduler waits for every batch of frames right after queuing it (default: it keeps one batch queued ahead)")
     ap.add_argument("--config3-utterances", type=int, default=64, help="utterances of the sharded batched run (0 = skip)")
     ap.add_argument("--concurrent", type=int, default=4,
                     help="extra figure (N=1 only, after the timed region): utterances in flight on one GPU (0 = skip)")
@@ -851,6 +857,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc FETCH_SIZE pass (roofline.traffic)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    global BATCH_LOOKAHEAD
+    BATCH_LOOKAHEAD = args.batch_lookahead
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -131,6 +131,8 @@ SIGNATURES = {
     "fq3_batch_graph_reset": (C.c_int, [vp]),
     "fq3_batch_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "fq3_batch_set_group_streams": (C.c_int, [vp, C.POINTER(vp), C.c_int]),
+    "fq3_batch_poll_async": (C.c_int, [vp, C.c_int, vp]),
+    "fq3_batch_poll_wait": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fq3_codec_create": (C.c_int, [C.POINTER(CodecConfig), C.POINTER(vp)]),
     "fq3_codec_destroy": (C.c_int, [vp]),
     "fq3_codec_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),

@@ -59,6 +59,8 @@ class _Lane:
     max_frames: int = 0
     t_arm: float = 0.0
     prefill_ms: float = 0.0
+    first_batch: int = 0         # index of the first batch of frames queued after this tenant was armed (polls of earlier batches show its predecessor)
+    copied: Any = None           # event: the last side-stream read of this lane's code buffer (a new tenant is armed after it)
 
 
 @dataclass
@@ -97,6 +99,16 @@ class BatchDecoder:
         # other streams the host keeps busy while the batch decodes (the vocoder's): the prefill stream and the lane groups' stream are
         # probed for a hardware queue shared with none of them (fq3hip/streams.py)
         self.beside: list = []
+        # LOOK-AHEAD (round 4): the next batch of frames is queued BEFORE the host waits for the previous batch's poll, so the GPU works
+        # while the host digests a poll (finishes, chunk events, admissions, staged prefills: ~2 ms per poll of 64 lanes, ~5 ms with a
+        # staging group; measured on MI355X: 13 % of a 64-lane end-to-end run was an idle decode queue, profiles/r04_e2e_timeline_*.txt).
+        # The poll is one launch + one copy in stream order (fq3_batch_poll_async), read when its event has fired.  A batch that is
+        # EXPECTED to finish a lane (its frame limit falls in it) is waited for at once -- queuing past a known finish would only burn
+        # frames on idle lanes.  0 = wait for every batch right after queuing it (the behaviour up to round 3; what a batch object
+        # without poll_async gets).
+        self.lookahead = 1 if hasattr(self.batch, "poll_async") else 0
+        self._copy = None           # side stream the codes of streaming chunks are read out on while the look-ahead frames run
+        self._polls: set = set()    # poll slots queued and not read yet (an abandoned run leaves some behind)
         # every context this scheduler will ever PREFILL into gets its workspace NOW: a lazy device allocation inside a staged
         # prefill would land in the middle of the running lanes' decode.  With spare contexts the lanes never prefill (they only
         # adopt), so their workspaces would be dead memory (~100 MB each at 0.6B / 2048 slots, ~380 MB at 1.7B / 6144).
@@ -274,10 +286,28 @@ class BatchDecoder:
         ln.t_arm, ln.prefill_ms = st.t0, st.prefill_ms
         st.req, st.kw, st.hidden = None, None, None
 
-    def _finish(self, ln: _Lane, n: int, chunked: bool = False) -> Tuple[Any, Optional[torch.Tensor], Dict[str, float]]:
+    def _fetch(self, ln: _Lane, first: int, count: int, ev_done=None):
+        """``(codes LongTensor[count, 16] from frame `first`, event after which they are complete)``.  With look-ahead frames in flight
+        (``ev_done``: the event behind the batch that produced them) the read-out runs on the copy stream, beside those frames."""
+        eng = ln.engine
+        if self._copy is None or ev_done is None:
+            return eng.decode_codes(first, count), self._mark(eng)
+        with torch.cuda.stream(self._copy):
+            self._copy.wait_event(ev_done)
+            codes = eng.decode_codes(first, count)
+            ev = torch.cuda.Event()
+            ev.record(self._copy)
+        ln.copied = ev
+        return codes, ev
+
+    def _finish(self, ln: _Lane, n: int, chunked: bool = False, ev_done=None) -> Tuple[Any, Optional[torch.Tensor], Dict[str, float]]:
         first = ln.emitted if chunked else 0
+        ready_ev = None
         if n > first:
-            codes = ln.engine.decode_codes(first, n - first)
+            if chunked:
+                codes, ready_ev = self._fetch(ln, first, n - first, ev_done)
+            else:
+                codes = ln.engine.decode_codes(first, n - first)
         elif chunked and n > 0:                      # every frame already went out as a partial chunk
             codes = torch.empty(0, ln.engine.cfg.num_code_groups, dtype=torch.long, device=ln.engine.device)
         else:
@@ -287,10 +317,12 @@ class BatchDecoder:
                   "ms_per_step": (1000 * wall / n) if n else 0.0, "steps_per_s": (n / wall) if wall > 0 else 0.0}
         if chunked:
             timing.update(is_final=True, total_steps_so_far=n)
+            if codes is not None:
+                timing["codes_ready_event"] = ready_ev if ready_ev is not None else self._mark(ln.engine)
         rid = ln.req.rid
         ln.req, ln.tn, ln.pn, ln.emitted = None, None, None, 0
-        # the lane's KV blocks go back to the pool now (its queued frames have completed: the poll that found it finished waited for
-        # them; a done lane never touches the cache again, csrc/batch_kernels.cuh)
+        # the lane's KV blocks go back to the pool now: the poll that found it finished waited for its last frame, and a done lane never
+        # touches the cache again -- not in look-ahead frames still in flight either (done-lane guard, csrc/batch_kernels.cuh)
         release = getattr(ln.engine, "kv_release", None)
         if release is not None:
             release()
@@ -339,6 +371,9 @@ class BatchDecoder:
                 release = getattr(x.engine, "kv_release", None)
                 if release is not None:
                     release()
+        for slot in sorted(self._polls):                  # polls an abandoned run queued and never read
+            self.batch.poll_wait(slot)
+        self._polls.clear()
         for ln in self.lanes:
             ln.req, ln.tn, ln.pn, ln.issued, ln.emitted = None, None, None, 0, 0
         for st in self.stages:
@@ -414,9 +449,62 @@ class BatchDecoder:
                 idle.appendleft(st)
                 pending.appendleft((req, ev))
 
+        depth = int(self.lookahead) if hasattr(self.batch, "poll_async") else 0
+        if chunked and depth and gpu and self._copy is None:
+            # streaming: the codes of a chunk are read out beside the look-ahead frames, not behind them -- on the consumer's own stream
+            # (the vocoder's, `beside[0]`: hardware queues are few), else on a stream probed for a queue of its own
+            if self.beside:
+                self._copy = self.beside[0]
+            else:
+                from .streams import concurrent_stream
+                dev = self.lanes[0].engine.device
+                if self._side is None and self.stages:
+                    self._side = concurrent_stream(dev, beside=self.beside)
+                self._copy = concurrent_stream(dev, beside=[self._side])
+        inflight: deque = deque()           # batches of frames whose poll has not been read yet: (batch index, poll slot | None, event | None)
+        batch_no = 0
+
+        def arm_after_copy(ln):
+            # a side-stream read of this lane's code buffer (streaming look-ahead) must be over before a new tenant's frames overwrite it
+            if ln.copied is not None:
+                torch.cuda.current_stream(ln.engine.device).wait_event(ln.copied)
+                ln.copied = None
+
+        def digest(entry):
+            """Read one batch's poll: chunk events and finishes of the lanes that were armed before it was queued."""
+            nonlocal active
+            bno, slot, ev_done = entry
+            if slot is not None:
+                n_all, d_all = self.batch.poll_wait(slot)               # waits for THIS batch's frames only: later ones keep running
+                self._polls.discard(slot)
+            still = []
+            for ln in active:
+                if ln.first_batch > bno:                                # armed after this batch was queued: the poll shows its predecessor
+                    still.append(ln)
+                    continue
+                n, done = (n_all[ln.index], d_all[ln.index]) if slot is not None else ln.engine.decode_poll()
+                fin = done or n >= ln.max_frames
+                if chunked:
+                    # whole chunks, one event each (a poll can complete several); a finished utterance's last event carries
+                    # the remainder (at most one chunk) and the timing
+                    c = int(chunk_frames)
+                    upto = n if fin else (n // c) * c
+                    while (upto - ln.emitted > c) if fin else (upto - ln.emitted >= c):
+                        codes, ready_ev = self._fetch(ln, ln.emitted, c, ev_done)
+                        ln.emitted += c
+                        outbox.append((ln.req.rid, codes, {"is_final": False, "total_steps_so_far": ln.emitted,
+                                                           "codes_ready_event": ready_ev}))
+                if fin:
+                    ev = self._finish(ln, n, chunked, ev_done)
+                    (outbox.append if chunked else now.append)(ev)
+                    free.append(ln)
+                else:
+                    still.append(ln)
+            active = still
+
         while True:
             pull()
-            if not (pending or active or ready or failed):
+            if not (pending or active or ready or failed or inflight):
                 break
             if self.stages and not active and not ready:
                 stage_ahead()                                         # nothing is decoding: nothing to overlap with
@@ -427,6 +515,7 @@ class BatchDecoder:
             while free and (ready or (pending and not self.stages)):  # admit at a frame boundary
                 ln = free.popleft()
                 try:
+                    arm_after_copy(ln)
                     if ready:
                         st = ready.popleft()
                         rid = st.req.rid
@@ -438,6 +527,7 @@ class BatchDecoder:
                         req, _ev = pending.popleft()
                         rid = req.rid
                         self._arm(ln, req)
+                    ln.first_batch = batch_no                         # the frames queued from now on are this tenant's
                 except Exception as exc:
                     free.appendleft(ln)
                     if on_error == "raise":
@@ -451,54 +541,54 @@ class BatchDecoder:
                     free.append(ln)
                     continue
                 active.append(ln)
-            if not active:
+            if not active and not inflight:
                 continue
             if self.use_graph and not self._captured:
                 self._group_streams()
                 self.batch.graph_capture()
                 self._captured = True
-            # lock-step frames, never across a lane's noise-ring boundary (each lane refills its own rings)
-            step = self.poll_every
-            for ln in active:
-                if ln.issued % NOISE_RING == 0:
-                    _refill(ln.engine, ln.tn, ln.pn)
-                step = min(step, NOISE_RING - ln.issued % NOISE_RING, max(ln.max_frames - ln.issued, 1))
-            pull()                                                    # stamp new arrivals before the frames are queued
-            self.batch.frames(step)
-            for ln in active:
-                ln.issued += step
+            # lock-step frames, never across a lane's noise-ring boundary (each lane refills its own rings); lanes whose frame limit is
+            # already covered by the frames in flight need no more (they wait for their poll)
+            need = [ln for ln in active if ln.issued < ln.max_frames]
+            if need:
+                step = self.poll_every
+                for ln in need:
+                    if ln.issued % NOISE_RING == 0:
+                        _refill(ln.engine, ln.tn, ln.pn)
+                    step = min(step, NOISE_RING - ln.issued % NOISE_RING, max(ln.max_frames - ln.issued, 1))
+                pull()                                                # stamp new arrivals before the frames are queued
+                self.batch.frames(step)
+                for ln in need:
+                    ln.issued += step
+                slot = ev_done = None
+                if depth:
+                    slot = batch_no % 4
+                    self.batch.poll_async(slot)                       # in stream order: behind these frames, in front of the next batch
+                    self._polls.add(slot)
+                    if self._copy is not None and chunked:
+                        ev_done = self._mark(self.lanes[0].engine)
+                inflight.append((batch_no, slot, ev_done))
+                batch_no += 1
             # streaming mode: the chunks found by the previous poll go out only now, with the next frames already queued, so
             # that whatever the consumer does with them (vocoding) overlaps the decode instead of stalling it
             while outbox:
                 yield self._more(outbox)
-            if self.stages:
+            if self.stages and active:
                 stage_ahead(limit=max(1, self.poll_every // 4))       # prefills fly under the frames queued above
-            still = []
-            for ln in active:
-                n, done = ln.engine.decode_poll()                     # first poll waits for the stream, the rest are free
-                fin = done or ln.issued >= ln.max_frames
-                if chunked:
-                    # whole chunks, one event each (a poll can complete several); a finished utterance's last event carries
-                    # the remainder (at most one chunk) and the timing
-                    c = int(chunk_frames)
-                    upto = n if fin else (n // c) * c
-                    while (upto - ln.emitted > c) if fin else (upto - ln.emitted >= c):
-                        codes = ln.engine.decode_codes(ln.emitted, c)
-                        ln.emitted += c
-                        outbox.append((ln.req.rid, codes, {"is_final": False, "total_steps_so_far": ln.emitted,
-                                                           "codes_ready_event": self._mark(ln.engine)}))
-                if fin:
-                    ev = self._finish(ln, n, chunked)
-                    if chunked and ev[1] is not None:
-                        ev[2]["codes_ready_event"] = self._mark(ln.engine)
-                    (outbox.append if chunked else now.append)(ev)
-                    free.append(ln)
-                else:
-                    still.append(ln)
-            active = still
+            # wait for the oldest batch; for ALL of them when a lane's frame limit falls in the newest (a finish is expected: queuing
+            # past it would burn frames on idle lanes) or when nothing more could be queued
+            expect = any(ln.issued >= ln.max_frames for ln in active)
+            while inflight and (len(inflight) > depth or expect or not need):
+                digest(inflight.popleft())
+                if not active:
+                    while inflight:                                   # frames queued past the last finish: nothing left to read in them
+                        _b, slot, _e = inflight.popleft()
+                        if slot is not None:
+                            self.batch.poll_wait(slot)
+                            self._polls.discard(slot)
             while now:
                 yield self._more(now)
-            if not active and not ready and not pending:              # nothing left to overlap with
+            if inflight or (not active and not ready and not pending):   # frames are running (or nothing is left to overlap with)
                 while outbox:
                     yield self._more(outbox)
         while outbox:

@@ -498,6 +498,17 @@ class Fq3Batch:
         the weight-stationary prefill kernel), "groups" 0..4 (lane groups advanced concurrently; 0 = automatic)."""
         L.check(self.lib.fq3_batch_set_option(self.handle, key.encode(), int(value)))
 
+    def poll_async(self, slot: int):
+        """``fq3_batch_poll_async``: queue a poll of every lane (one launch, one copy) in stream order into ``slot`` (0..3)."""
+        L.check(self.lib.fq3_batch_poll_async(self.handle, int(slot), self._stream()))
+
+    def poll_wait(self, slot: int):
+        """``fq3_batch_poll_wait``: ``([frames done per lane], [finished per lane])`` of the poll queued in ``slot``."""
+        n = len(self.lanes)
+        a, d = (C.c_int * n)(), (C.c_int * n)()
+        L.check(self.lib.fq3_batch_poll_wait(self.handle, int(slot), a, d))
+        return list(a), [bool(x) for x in d]
+
     def set_group_streams(self, streams):
         """``fq3_batch_set_group_streams``: the caller's own side streams for lane groups 1.. (kept alive here)."""
         self._group_streams = list(streams)

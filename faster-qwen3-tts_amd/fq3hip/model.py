@@ -834,6 +834,8 @@ class FasterQwen3TTS:
         groups = getattr(self, "batch_groups", None)
         cached = getattr(self, "_batch_cache", None)
         if cached is not None and cached[0] == (lanes, staging, blocks, groups):
+            la = getattr(self, "batch_lookahead", None)
+            cached[1].lookahead = (int(la) if la is not None else 1) if hasattr(cached[1].batch, "poll_async") else 0
             # the lanes follow this model's CURRENT predictor policy (it is copied into the loop state when a lane is armed)
             pg = self.predictor_graph
             cached[1].set_predictor_policy(do_sample=pg.do_sample, top_k=pg.top_k, top_p=pg.top_p, temperature=pg.temperature)
@@ -848,6 +850,11 @@ class FasterQwen3TTS:
                                                           temperature=pg.temperature),
                            staging=[mk() for _ in range(staging)])
         dec.kv_pool = pool
+        # batch_lookahead (attribute, default None = the scheduler's default, 1: the next batch of frames is queued before the previous
+        # batch's poll is read; 0 = wait for every batch right after queuing it) -- see BatchDecoder.lookahead
+        la = getattr(self, "batch_lookahead", None)
+        if la is not None:
+            dec.lookahead = int(la) if hasattr(dec.batch, "poll_async") else 0
         if groups is not None and hasattr(dec.batch, "set_option"):
             dec.batch.set_option("groups", int(groups))
             dec.n_groups = int(groups)

@@ -292,6 +292,13 @@ int fq3_batch_size(const fq3_batch* b);
 int fq3_batch_frames(fq3_batch* b, int n_frames, void* stream);
 int fq3_batch_graph_capture(fq3_batch* b, void* stream);
 int fq3_batch_graph_reset(fq3_batch* b);
+/* Every lane's fq3_decode_poll in one go, split in two so that a scheduler can keep the GPU fed: fq3_batch_poll_async enqueues ONE
+ * gather launch + ONE small copy on `stream` (in stream order: it sees the frames queued before it) into slot 0..3;
+ * fq3_batch_poll_wait blocks until that slot's copy has landed and fills n_frames_total[fq3_batch_size] / done[fq3_batch_size]
+ * (either may be NULL).  Frames queued AFTER the poll run while the host waits for and digests it.  FQ3_ESTATE: nothing was queued
+ * in the slot. */
+int fq3_batch_poll_async(fq3_batch* b, int slot, void* stream);
+int fq3_batch_poll_wait(fq3_batch* b, int slot, int* n_frames_total, int* done);
 /* "mfma" 0|1: batch GEMVs on the matrix cores (bf16 contexts; default 1: ids checked against the oracle by teacher
  * forcing) or on the VALU kernels (0: every lane bit-identical to the same utterance decoded alone).
  * "skinny" 0|1 (with "mfma" 1, more than 16 lanes): o_proj / down through the weight-stationary kernel of the short-prompt prefill

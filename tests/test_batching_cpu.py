@@ -42,8 +42,31 @@ class FakeBatch:
             e.frames += n
 
 
-@pytest.fixture
-def sched(monkeypatch):
+class LookAheadBatch(FakeBatch):
+    """A batch object with the batch poll (fq3_batch_poll_async / _wait): the scheduler then queues the NEXT frames before it reads a
+    poll.  The poll is a snapshot taken in stream order, i.e. when poll_async is called here."""
+
+    def __init__(self, engines):
+        super().__init__(engines)
+        self.slots, self.trace = {}, []
+
+    def frames(self, n):
+        super().frames(n)
+        self.trace.append(("frames", n))
+
+    def poll_async(self, slot):
+        assert slot not in self.slots, "a poll slot is re-used before it was read"
+        self.slots[slot] = [e.decode_poll() for e in self.engines]
+        self.trace.append(("poll", slot))
+
+    def poll_wait(self, slot):
+        snap = self.slots.pop(slot)
+        self.trace.append(("wait", slot))
+        return [n for n, _d in snap], [d for _n, d in snap]
+
+
+@pytest.fixture(params=["sync", "lookahead"])
+def sched(monkeypatch, request):
     log = []
     engines = [FakeLaneEngine(log, i) for i in range(3)]
     refills = []
@@ -61,7 +84,8 @@ def sched(monkeypatch):
     monkeypatch.setattr(Bt, "_refill", lambda eng, tn, pn: refills.append((eng.idx, eng.frames)))
     monkeypatch.setattr(Bt, "TalkerGraph", lambda e: SimpleNamespace(engine=e))
     monkeypatch.setattr(Bt, "PredictorGraph", lambda e, **kw: SimpleNamespace(engine=e, top_p=kw.get("top_p", 1.0), **{k: v for k, v in kw.items() if k != "top_p"}))
-    dec = Bt.BatchDecoder(engines, poll_every=8, batch_factory=FakeBatch)
+    dec = Bt.BatchDecoder(engines, poll_every=8, batch_factory=FakeBatch if request.param == "sync" else LookAheadBatch)
+    assert dec.lookahead == (0 if request.param == "sync" else 1)
     return dec, engines, log, refills
 
 
@@ -256,3 +280,37 @@ def test_late_failure_during_the_last_poll_is_still_reported(monkeypatch):
     out = {rid: (c, t) for rid, c, t in dec.run([_req(0, 8)], on_error="yield", source=source)}
     assert out[0][0].shape[0] == 8
     assert 9 in out and out[9][0] is None and "too long" in out[9][1]["error"]
+
+
+def test_look_ahead_keeps_a_batch_of_frames_queued_but_never_past_a_known_finish(monkeypatch):
+    """With the batch poll the scheduler reads poll k only after batch k + 1 has been queued (the GPU works while the host digests a
+    poll) -- except when a lane's frame limit falls in the batch just queued: then it waits at once, and not one frame is queued for
+    idle lanes.  An EOS (not predictable) costs at most the one batch already in flight."""
+    log, refills = [], []
+    engines = [FakeLaneEngine(log, i) for i in range(2)]
+
+    def fake_arm(talker, tie, tam, tth, tpe, config, pg, tg, max_new, min_new, temperature, top_k, top_p, do_sample, rp, use_graph):
+        eng = tg.engine
+        eng.frames, eng.budget, eng.eos_after, eng.rid = 0, int(max_new), config.eos_after, config.rid
+        return eng, torch.zeros(1), torch.zeros(1), int(max_new)
+
+    monkeypatch.setattr(Bt, "_prefill_and_arm", fake_arm)
+    monkeypatch.setattr(Bt, "_refill", lambda eng, tn, pn: None)
+    monkeypatch.setattr(Bt, "TalkerGraph", lambda e: SimpleNamespace(engine=e))
+    monkeypatch.setattr(Bt, "PredictorGraph", lambda e, **kw: SimpleNamespace(engine=e, **kw))
+    dec = Bt.BatchDecoder(engines, poll_every=8, batch_factory=LookAheadBatch)
+    out = {rid: c.shape[0] for rid, c, _t in dec.run([_req(0, 40), _req(1, 40)])}
+    assert out == {0: 40, 1: 40} and sum(dec.batch.calls) == 40              # fixed lengths: no frame beyond the limit
+    tr = dec.batch.trace
+    # batch 1 is queued before poll 0 is read, batch 2 before poll 1, ...; the last batch (the limit falls in it) is read at once
+    assert tr[:7] == [("frames", 8), ("poll", 0), ("frames", 8), ("poll", 1), ("wait", 0), ("frames", 8), ("poll", 2)]
+    assert tr[-2:] == [("wait", 3), ("wait", 0)] and not dec.batch.slots
+    # an utterance that ends by EOS at frame 13 of 200: found by the poll of the second batch, read while the third is in flight
+    dec.batch.calls.clear()
+    out = {rid: c.shape[0] for rid, c, _t in dec.run([_req(2, 200, eos_after=13)])}
+    assert out == {2: 13} and sum(dec.batch.calls) == 24 and not dec.batch.slots
+    # a lane re-armed while a batch is in flight: the poll of that batch still shows its predecessor and is ignored for it
+    dec.batch.calls.clear()
+    reqs = [_req(3, 200, eos_after=5), _req(4, 16), _req(5, 24)]
+    out = {rid: c.shape[0] for rid, c, _t in dec.run(reqs)}
+    assert out == {3: 5, 4: 16, 5: 24}

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end batched throughput A/B (development aid): bench.batched_run -- the product's _run_batch_full -- at a lane count, for
 several `batch_vocode_every` settings (0 = vocode when an utterance ends; N = exact slices every N frames while it decodes).
-usage: batch_e2e_bench.py [0p6b|1p7b] [lanes=64] [every list, e.g. 0,64,100] [codec=bf16x2] [groups list, e.g. 1,2: model.batch_groups | -] [timed runs=2] [decode stream priority: 0 = the current stream | -1 = a high-priority stream]"""
+usage: batch_e2e_bench.py [0p6b|1p7b] [lanes=64] [every list, e.g. 0,64,100] [codec=bf16x2] [groups list, e.g. 1,2: model.batch_groups | -] [timed runs=2] [decode stream priority: 0 = the current stream | -1 = a high-priority stream]
+                          [lookahead list, e.g. 1,0: model.batch_lookahead]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,6 +18,7 @@ def main():
     groups = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 and sys.argv[5] != "-" else [None]
     runs = int(sys.argv[6]) if len(sys.argv) > 6 else 2
     prio = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+    las = [int(x) for x in sys.argv[8].split(",")] if len(sys.argv) > 8 else [None]
     dev = "cuda:0"
     if prio:
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=prio))
@@ -24,14 +26,16 @@ def main():
     req = bench.build_request(cfg, dev)
     prompt = bench.prepared_prompt(model, req)
     bench.batched_run(model, prompt, lanes, lanes)
-    for G in groups:
+    for G, la in [(g, l) for g in groups for l in las]:
       if G is not None:
         model.batch_groups = G
+      if la is not None:
+        model.batch_lookahead = la
       for ev in everys:
         model.batch_vocode_every = ev
         bench.batched_run(model, prompt, lanes, lanes)
         res = [bench.batched_run(model, prompt, 2 * lanes, lanes, seed0=2000 + i) for i in range(runs)]
-        print(f"{size} lanes={lanes} codec={codec} batch_vocode_every={ev}{'' if G is None else f' groups={G}'}: {[round(a / w, 1) for a, w, _l in res]} x real-time end to end "
+        print(f"{size} lanes={lanes} codec={codec} batch_vocode_every={ev}{'' if G is None else f' groups={G}'}{'' if la is None else f' lookahead={la}'}: {[round(a / w, 1) for a, w, _l in res]} x real-time end to end "
               f"({2 * lanes} utterances, wall {[round(w, 3) for _a, w, _l in res]} s)", flush=True)
 
 
