@@ -385,7 +385,10 @@ class BatchDecoder:
         ready: deque = deque()
         failed: List[Tuple[Any, Dict[str, Any]]] = []
         outbox: List[Tuple[Any, Any, Dict[str, Any]]] = []            # streaming-mode events waiting for the next frames to be queued
-        now: List[Tuple[Any, Any, Dict[str, Any]]] = []
+        # host-time breakdown of this run (seconds; development aid, read by tools/batch_e2e_bench.py): where the scheduler's thread spends
+        # its time between two batches of frames
+        prof = self.host_s = {"stage": 0.0, "admit": 0.0, "queue": 0.0, "poll_wait": 0.0, "digest": 0.0, "consumer": 0.0}
+        clock = time.perf_counter
 
         def pull():
             # while lanes decode, at most two new requests per frame boundary: whatever the source does to produce one (a
@@ -475,7 +478,9 @@ class BatchDecoder:
             nonlocal active
             bno, slot, ev_done = entry
             if slot is not None:
+                t_ = clock()
                 n_all, d_all = self.batch.poll_wait(slot)               # waits for THIS batch's frames only: later ones keep running
+                prof["poll_wait"] += clock() - t_
                 self._polls.discard(slot)
             still = []
             for ln in active:
@@ -495,8 +500,10 @@ class BatchDecoder:
                         outbox.append((ln.req.rid, codes, {"is_final": False, "total_steps_so_far": ln.emitted,
                                                            "codes_ready_event": ready_ev}))
                 if fin:
-                    ev = self._finish(ln, n, chunked, ev_done)
-                    (outbox.append if chunked else now.append)(ev)
+                    # like the chunk events, a finish goes out only once the next frames are queued: whatever the consumer does with
+                    # it (a vocoder launch set for a whole wave of utterances is ~15 ms of host time) then runs beside the decode of
+                    # the lanes' next tenants instead of in front of it
+                    outbox.append(self._finish(ln, n, chunked, ev_done))
                     free.append(ln)
                 else:
                     still.append(ln)
@@ -507,11 +514,14 @@ class BatchDecoder:
             if not (pending or active or ready or failed or inflight):
                 break
             if self.stages and not active and not ready:
+                t_ = clock()
                 stage_ahead()                                         # nothing is decoding: nothing to overlap with
+                prof["stage"] += clock() - t_
             while failed:
                 rid, info = failed.pop(0)
                 self.more_in_poll = 0
                 yield rid, None, info
+            t_admit = clock()
             while free and (ready or (pending and not self.stages)):  # admit at a frame boundary
                 ln = free.popleft()
                 try:
@@ -541,6 +551,7 @@ class BatchDecoder:
                     free.append(ln)
                     continue
                 active.append(ln)
+            prof["admit"] += clock() - t_admit
             if not active and not inflight:
                 continue
             if self.use_graph and not self._captured:
@@ -550,6 +561,7 @@ class BatchDecoder:
             # lock-step frames, never across a lane's noise-ring boundary (each lane refills its own rings); lanes whose frame limit is
             # already covered by the frames in flight need no more (they wait for their poll)
             need = [ln for ln in active if ln.issued < ln.max_frames]
+            t_ = clock()
             if need:
                 step = self.poll_every
                 for ln in need:
@@ -569,25 +581,30 @@ class BatchDecoder:
                         ev_done = self._mark(self.lanes[0].engine)
                 inflight.append((batch_no, slot, ev_done))
                 batch_no += 1
-            # streaming mode: the chunks found by the previous poll go out only now, with the next frames already queued, so
+            prof["queue"] += clock() - t_
+            # the chunks and finishes found by the previous poll go out only now, with the next frames already queued, so
             # that whatever the consumer does with them (vocoding) overlaps the decode instead of stalling it
+            t_ = clock()
             while outbox:
                 yield self._more(outbox)
+            prof["consumer"] += clock() - t_
             if self.stages and active:
+                t_ = clock()
                 stage_ahead(limit=max(1, self.poll_every // 4))       # prefills fly under the frames queued above
+                prof["stage"] += clock() - t_
             # wait for the oldest batch; for ALL of them when a lane's frame limit falls in the newest (a finish is expected: queuing
             # past it would burn frames on idle lanes) or when nothing more could be queued
             expect = any(ln.issued >= ln.max_frames for ln in active)
             while inflight and (len(inflight) > depth or expect or not need):
+                t_, w_ = clock(), prof["poll_wait"]
                 digest(inflight.popleft())
+                prof["digest"] += clock() - t_ - (prof["poll_wait"] - w_)
                 if not active:
                     while inflight:                                   # frames queued past the last finish: nothing left to read in them
                         _b, slot, _e = inflight.popleft()
                         if slot is not None:
                             self.batch.poll_wait(slot)
                             self._polls.discard(slot)
-            while now:
-                yield self._more(now)
             if inflight or (not active and not ready and not pending):   # frames are running (or nothing is left to overlap with)
                 while outbox:
                     yield self._more(outbox)
