@@ -72,6 +72,7 @@ class _Stage:
     token: int = 0
     hidden: Optional[torch.Tensor] = None
     n_rows: int = 0
+    n_pad: int = 0               # left padding of the staged prompt (counted by the prefill)
     ready: Any = None            # event: prefill + first token done (side stream)
     released: Any = None         # event: the lane has copied the KV rows out (main stream)
     t0: float = 0.0
@@ -261,8 +262,8 @@ class BatchDecoder:
                 e.kv_release()
             raise
         ms = (time.time() - t0) * 1000
-        for (st, req, _ev), kw, (token, hidden, n_rows, _pad) in zip(group, kws, res):
-            st.req, st.kw, st.token, st.hidden, st.n_rows = req, kw, token, hidden, n_rows
+        for (st, req, _ev), kw, (token, hidden, n_rows, n_pad) in zip(group, kws, res):
+            st.req, st.kw, st.token, st.hidden, st.n_rows, st.n_pad = req, kw, token, hidden, n_rows, int(n_pad)
             st.t0, st.prefill_ms = t0, ms
 
     def _admit(self, ln: _Lane, st: _Stage):
@@ -281,7 +282,7 @@ class BatchDecoder:
         _eng, tn, pn, max_frames = _arm_decode(
             req.talker, req.config, st.token, st.hidden, st.n_rows, req.attention_mask, req.trailing_text_hiddens, req.tts_pad_embed,
             ln.predictor_graph, ln.talker_graph, kw["max_new_tokens"], kw["min_new_tokens"], kw["temperature"], kw["top_k"],
-            kw["top_p"], kw["do_sample"], kw["repetition_penalty"], use_graph=False)
+            kw["top_p"], kw["do_sample"], kw["repetition_penalty"], use_graph=False, n_pad=st.n_pad)
         ln.req, ln.tn, ln.pn, ln.issued, ln.emitted, ln.max_frames = req, tn, pn, 0, 0, max_frames
         ln.t_arm, ln.prefill_ms = st.t0, st.prefill_ms
         st.req, st.kw, st.hidden = None, None, None
@@ -396,10 +397,19 @@ class BatchDecoder:
             # what the first wave can take (one request per lane) -- every further prompt built now would delay the first frame
             budget = max(0, len(self.lanes) - len(pending) - len(ready)) if not active else 2
             while source is not None and budget > 0 and len(pending) < len(self.lanes) + len(self.stages):
-                r = source()
+                # with spare contexts the source runs under the PREFILL stream: whatever device work it does to produce a request (a
+                # model's prompt build) neither queues behind the lock-step frames in flight nor -- where it waits for a value --
+                # makes the host wait for them; the staged prefill that consumes it is on that stream anyway
+                if feed_stream is not None:
+                    with torch.cuda.stream(feed_stream):
+                        r = source()
+                        r = None if r is None else stamped(r)
+                else:
+                    r = source()
+                    r = None if r is None else stamped(r)
                 if r is None:
                     break
-                pending.append(stamped(r))
+                pending.append(r)
                 budget -= 1
 
         def stage_ahead(limit: int = 1 << 30):
@@ -453,6 +463,12 @@ class BatchDecoder:
                 pending.appendleft((req, ev))
 
         depth = int(self.lookahead) if hasattr(self.batch, "poll_async") else 0
+        feed_stream = None
+        if gpu and self.stages:
+            if self._side is None:
+                from .streams import concurrent_stream
+                self._side = concurrent_stream(self.lanes[0].engine.device, beside=self.beside)    # verified to run beside the decode (and vocoder) stream
+            feed_stream = self._side
         if chunked and depth and gpu and self._copy is None:
             # streaming: the codes of a chunk are read out beside the look-ahead frames, not behind them -- on the consumer's own stream
             # (the vocoder's, `beside[0]`: hardware queues are few), else on a stream probed for a queue of its own

@@ -63,14 +63,19 @@ def _prefill_first_tokens_packed(engines, items):
 
 
 def _arm_decode(talker, config, token, hidden, n_rows, attention_mask, trailing_text_hiddens, tts_pad_embed, predictor_graph, talker_graph,
-                max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty, use_graph):
-    """Arms the on-device loop of ``talker_graph.engine`` behind a prefill whose KV rows are already in its cache."""
+                max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty, use_graph, n_pad=None):
+    """Arms the on-device loop of ``talker_graph.engine`` behind a prefill whose KV rows are already in its cache.
+    ``n_pad``: the prompt's left padding when the caller already counted it (the prefill did): counting it here from the device mask
+    is a host wait for the CURRENT stream -- in a batch scheduler that is every lock-step frame queued ahead."""
     eng = talker_graph.engine
     dt, dev = eng.dtype, eng.device
     V = config.vocab_size
     prefill_len = talker_graph.prefill_kv(n_rows)
     rope_deltas = getattr(talker, "rope_deltas", None)
-    talker_graph.set_generation_state(attention_mask, rope_deltas)
+    if n_pad is not None and rope_deltas is None:
+        eng.set_generation_state(int(n_pad), -int(n_pad))          # TalkerGraph.set_generation_state without the device reduction
+    else:
+        talker_graph.set_generation_state(attention_mask, rope_deltas)
     need_pred_noise = bool(predictor_graph.do_sample)
     tn = torch.empty(NOISE_RING, V, dtype=dt, device=dev) if do_sample else None
     pn = (torch.empty(NOISE_RING, eng.cfg.num_code_groups - 1, eng.cfg.predictor.vocab_size, dtype=dt, device=dev)
@@ -93,11 +98,11 @@ def _arm_decode(talker, config, token, hidden, n_rows, attention_mask, trailing_
 def _prefill_and_arm(talker, talker_input_embeds, attention_mask, trailing_text_hiddens, tts_pad_embed, config,
                      predictor_graph, talker_graph, max_new_tokens, min_new_tokens, temperature, top_k, top_p,
                      do_sample, repetition_penalty, use_graph):
-    token, hidden, n_rows, _n_pad = _prefill_first_token(talker_graph.engine, talker_input_embeds, attention_mask, config,
-                                                         min_new_tokens, temperature, top_k, top_p, do_sample)
+    token, hidden, n_rows, n_pad = _prefill_first_token(talker_graph.engine, talker_input_embeds, attention_mask, config,
+                                                        min_new_tokens, temperature, top_k, top_p, do_sample)
     return _arm_decode(talker, config, token, hidden, n_rows, attention_mask, trailing_text_hiddens, tts_pad_embed, predictor_graph,
                        talker_graph, max_new_tokens, min_new_tokens, temperature, top_k, top_p, do_sample, repetition_penalty,
-                       use_graph)
+                       use_graph, n_pad=n_pad)
 
 
 def run_frames(eng, tn, pn, issued: int, count: int):

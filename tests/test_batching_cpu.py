@@ -162,7 +162,7 @@ def test_staged_admission_prefills_ahead_and_reuses_spare_contexts(monkeypatch):
         log.append(("prefill", eng.idx, config.rid, sum(e.frames for e in lanes)))
         return 7, torch.zeros(8), tie.shape[1], 0
 
-    def fake_arm(talker, config, token, hidden, n_rows, tam, tth, tpe, pg, tg, max_new, min_new, temperature, top_k, top_p, do_sample, rp, use_graph):
+    def fake_arm(talker, config, token, hidden, n_rows, tam, tth, tpe, pg, tg, max_new, min_new, temperature, top_k, top_p, do_sample, rp, use_graph, n_pad=None):
         eng = tg.engine
         cfg = eng.next_cfg
         eng.frames, eng.budget, eng.eos_after, eng.rid = 0, int(max_new), cfg.eos_after, cfg.rid
@@ -258,7 +258,7 @@ def test_late_failure_during_the_last_poll_is_still_reported(monkeypatch):
             raise RuntimeError("Input is too long")
         return 7, torch.zeros(8), tie.shape[1], 0
 
-    def fake_arm(talker, config, token, hidden, n_rows, tam, tth, tpe, pg, tg, max_new, min_new, temperature, top_k, top_p, do_sample, rp, use_graph):
+    def fake_arm(talker, config, token, hidden, n_rows, tam, tth, tpe, pg, tg, max_new, min_new, temperature, top_k, top_p, do_sample, rp, use_graph, n_pad=None):
         eng = tg.engine
         eng.frames, eng.budget, eng.eos_after, eng.rid = 0, int(max_new), 10 ** 9, config.rid
         return eng, torch.zeros(1), torch.zeros(1), int(max_new)
