@@ -72,8 +72,8 @@ def _arm_decode(talker, config, token, hidden, n_rows, attention_mask, trailing_
     V = config.vocab_size
     prefill_len = talker_graph.prefill_kv(n_rows)
     rope_deltas = getattr(talker, "rope_deltas", None)
-    if n_pad is not None and rope_deltas is None:
-        eng.set_generation_state(int(n_pad), -int(n_pad))          # TalkerGraph.set_generation_state without the device reduction
+    if n_pad is not None:
+        talker_graph.set_generation_state(attention_mask, rope_deltas, n_pad=int(n_pad))      # no device reduction over the mask
     else:
         talker_graph.set_generation_state(attention_mask, rope_deltas)
     need_pred_noise = bool(predictor_graph.do_sample)

@@ -59,11 +59,14 @@ class TalkerGraph:
         self._prefill_len = seq_len
         return seq_len
 
-    def set_generation_state(self, attention_mask: Optional[torch.Tensor], rope_deltas: Optional[torch.Tensor]):
-        """talker_graph.py:172-196: pad-aware masking + rope delta."""
-        n_pad = 0
-        if attention_mask is not None:
-            n_pad = int((attention_mask[0] == 0).sum())
+    def set_generation_state(self, attention_mask: Optional[torch.Tensor], rope_deltas: Optional[torch.Tensor],
+                             n_pad: Optional[int] = None):
+        """talker_graph.py:172-196: pad-aware masking + rope delta.  ``n_pad``: the mask's pad count when the caller already has it
+        (counting it from a device mask makes the host wait for the current stream)."""
+        if n_pad is None:
+            n_pad = 0
+            if attention_mask is not None:
+                n_pad = int((attention_mask[0] == 0).sum())
         delta = 0
         if rope_deltas is not None:
             delta = int(round(float(torch.as_tensor(rope_deltas).reshape(-1)[0])))

@@ -61,7 +61,7 @@ class FakeTG:
     def prefill_kv(self, n):
         return n
 
-    def set_generation_state(self, mask, deltas):
+    def set_generation_state(self, mask, deltas, n_pad=None):
         self.state = (None if mask is None else int((mask[0] == 0).sum()), deltas)
 
 
