@@ -15,50 +15,55 @@
 
 namespace fq3 {
 
-constexpr int kMaxLanes = 64;        // four token tiles (round 4; 32 = two tiles in round 3)
+constexpr int kMaxLanes = 128;       // eight token tiles (round 4: 64, then 128; 32 = two tiles in round 3)
 constexpr int kTokTile = 16;         // token columns of one v_mfma_f32_16x16x32_bf16 tile: lanes 0..15 / 16..31 of a batch are passes of the
                                      // same launch over register-resident weight fragments
 constexpr int kGroupLanes = 8;       // VALU batch GEMV: tokens staged in LDS per pass over the register-resident weight rows
 
+// The per-lane pointer tables live in DEVICE memory, one set per batch (written once in fq3_batch_create), and the kernels take
+// their addresses: 128 lanes x (state, codes, history, past_hidden) alone are the whole 4 KB a launch may carry as arguments.  A
+// lane-local kernel reads its own entries with scalar loads (uniform per workgroup).
 struct LaneTab {
     DecodeState* st[kMaxLanes];
     int* codes[kMaxLanes];
     unsigned char* seen[kMaxLanes];
     void* past_hidden[kMaxLanes];
 };
-struct LaneSt { DecodeState* st[kMaxLanes]; };                    // the loop states alone (talker attention: 0.5 KB of kernel arguments instead of LaneTab's 2 KB)
+struct LaneSt { DecodeState* st[kMaxLanes]; };                    // the loop states alone (batch poll)
 struct LaneForced { const TeacherForcing* tf[kMaxLanes]; };       // teacher-forcing objects of the lanes (parity tests; null in product use)
 struct LaneKV { void* k[kMaxLanes]; void* v[kMaxLanes]; };       // per lane: the predictor's contiguous cache, or the base of the talker's block pool
 struct LaneTabs { const int* t[kMaxLanes]; int blk_stride; };     // talker: every lane's block table (paged KV, decode_kernels.cuh)
 
 template <typename T>
-__global__ __launch_bounds__(256) void frame_begin_batch_kernel(LaneTab t, const T* codec_emb, T* pred_in, int H, int G) {
+__global__ __launch_bounds__(256) void frame_begin_batch_kernel(const LaneTab* __restrict__ t, const T* codec_emb, T* pred_in, int H, int G) {
     const int l = blockIdx.x;
-    frame_begin_body<T>(t.st[l], codec_emb, reinterpret_cast<const T*>(t.past_hidden[l]), pred_in + (size_t)l * 2 * H,
-                        t.codes[l], t.seen[l], H, G);
+    frame_begin_body<T>(t->st[l], codec_emb, reinterpret_cast<const T*>(t->past_hidden[l]), pred_in + (size_t)l * 2 * H,
+                        t->codes[l], t->seen[l], H, G);
 }
 
 template <typename T, int G>
-__global__ __launch_bounds__(256) void embed_sum_batch_kernel(LaneTab t, EmbTables tabs, T* x, int H, const float* cos_tab,
+__global__ __launch_bounds__(256) void embed_sum_batch_kernel(const LaneTab* __restrict__ t, EmbTables tabs, T* x, int H, const float* cos_tab,
                                                               const float* sin_tab, int rope_len, float* rope_now) {
     const int l = blockIdx.x;
-    embed_sum_body<T, G>(t.st[l], tabs, t.codes[l], x + (size_t)l * H, H, cos_tab, sin_tab, rope_len, t.st[l]->rope_delta,
+    DecodeState* st = t->st[l];
+    embed_sum_body<T, G>(st, tabs, t->codes[l], x + (size_t)l * H, H, cos_tab, sin_tab, rope_len, st->rope_delta,
                          rope_now + (size_t)l * kHeadDim);
 }
 
 // code-predictor attention: grid (n_heads, B)
 template <typename T>
-__global__ __launch_bounds__(64) void attn_pred_batch_kernel(AttnArgs a, LaneKV kv, int qkv_stride, int out_stride) {
+__global__ __launch_bounds__(64) void attn_pred_batch_kernel(AttnArgs a, const LaneKV* __restrict__ kv, int qkv_stride, int out_stride) {
     const int l = blockIdx.y;
     a.qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)l * qkv_stride;
     a.out = reinterpret_cast<T*>(a.out) + (size_t)l * out_stride;
-    a.kcache = kv.k[l]; a.vcache = kv.v[l];
+    a.kcache = kv->k[l]; a.vcache = kv->v[l];
     attn_pred_body<T>(a);
 }
 
 // talker attention: grid (n_kv, workers, B); position, pad count and RoPE row are the lane's own
 template <typename T, int REP>
-__global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, LaneKV kv, LaneTabs tabs, LaneSt t, int qkv_stride,
+__global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, const LaneKV* __restrict__ kv, const LaneTabs* __restrict__ tabs,
+                                                                const LaneTab* __restrict__ t, int qkv_stride,
                                                                 const float* rope_now, size_t part_stride) {
     const int l = blockIdx.z;
     a.part = a.part + (size_t)l * part_stride;
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, Lane
     // stale -- the scheduler returns a finished lane's blocks to the pool, and they may already belong to another context -- so the
     // append of the single-stream body would land in somebody else's rows.  It leaves neutral partials ({0, m = 0, l = 1}: the merge
     // yields zeros, not 0 / 0) and exits.
-    const DecodeState* stl = t.st[l];
+    const DecodeState* stl = t->st[l];
     const int pos = stl->pos, lane_done = stl->done;
     const bool no_keys = (int)blockIdx.y * kKeysPerTile > pos;
     if (lane_done || no_keys) {
@@ -84,10 +89,10 @@ __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, Lane
         return;
     }
     a.qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)l * qkv_stride;
-    a.kcache = kv.k[l]; a.vcache = kv.v[l];
-    a.table = tabs.t[l]; a.blk_stride = tabs.blk_stride;
+    a.kcache = kv->k[l]; a.vcache = kv->v[l];
+    a.table = tabs->t[l]; a.blk_stride = tabs->blk_stride;
     a.pos_ptr = nullptr; a.pos_imm = pos;
-    a.n_pad = t.st[l]->n_pad;
+    a.n_pad = stl->n_pad;
     a.cos_row = rope_now + (size_t)l * kHeadDim; a.sin_row = a.cos_row + 64;
     attn_decode_body<T, REP, true>(a);
 }
@@ -109,21 +114,22 @@ __global__ __launch_bounds__(256) void combine_batch_kernel(const float* part, s
 }
 
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void sample_pred_batch_kernel(LaneTab t, LaneForced f, const T* logits, size_t logit_stride, int V, int cb,
+__global__ __launch_bounds__(256) void sample_pred_batch_kernel(const LaneTab* __restrict__ t, const LaneForced* __restrict__ f, const T* logits,
+                                                               size_t logit_stride, int V, int cb,
                                                                int G, const T* next_emb, T* next_in, int H) {
     const int l = blockIdx.x;
     SampleCfg c{};                       // policy comes from the lane's DecodeState
     c.rep_penalty = 1.0f; c.sup_lo = 0; c.sup_hi = 0; c.keep_id = -1; c.sup_extra = -1;
     // NUCLEUS = true: a lane whose policy asks for top_p < 1 takes the LDS sampler (sampler.cuh::sample_core) inside the same
     // launch; the register-resident path of the other lanes is unchanged
-    sample_pred_wave_body<T, NC, true>(t.st[l], logits + (size_t)l * logit_stride, V, cb, c, (const T*)nullptr, t.codes[l], G,
-                                       (int64_t*)nullptr, next_emb, next_in + (size_t)l * H, H, f.tf[l]);
+    sample_pred_wave_body<T, NC, true>(t->st[l], logits + (size_t)l * logit_stride, V, cb, c, (const T*)nullptr, t->codes[l], G,
+                                       (int64_t*)nullptr, next_emb, next_in + (size_t)l * H, H, f->tf[l]);
 }
 
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void sample_talker_batch_kernel(LaneTab t, LaneForced f, const T* logits, int V, int G) {
+__global__ __launch_bounds__(256) void sample_talker_batch_kernel(const LaneTab* __restrict__ t, const LaneForced* __restrict__ f, const T* logits, int V, int G) {
     const int l = blockIdx.x;
-    sample_talker_wave_body<T, NC, true>(t.st[l], logits + (size_t)l * V, V, t.seen[l], G, f.tf[l]);
+    sample_talker_wave_body<T, NC, true>(t->st[l], logits + (size_t)l * V, V, t->seen[l], G, f->tf[l]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -136,7 +142,8 @@ struct BatchGemvArgs {
     const void* res; int res_stride;               // T[B][res_stride]        (EPI_RESIDUAL), may alias y
     int up_off;
     int group;                                     // VALU kernel: tokens per LDS pass (1..kGroupLanes; the launcher sizes the LDS for it)
-    void* xn_out[kMaxLanes];                       // optional per-lane copy of the prepared token (codec_head -> past_hidden)
+    void* const* xn_out;                           // optional per-lane copy of the prepared token (codec_head -> past_hidden): a device table, or null
+    int ntiles;                                    // token tiles of 16 lanes (the matrix-core kernels' runtime-count variants, NT = 0)
 };
 
 // One row per wave (4 rows per workgroup), weight rows loaded ONCE; the B <= kMaxLanes tokens pass through LDS in groups of
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(BatchGemvArgs a) {
                 }
             }
             if (m < nb) {
-                T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[g0 + m]) : nullptr;
+                T* xo = (blockIdx.x == 0 && a.xn_out) ? reinterpret_cast<T*>(a.xn_out[g0 + m]) : nullptr;
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     const int off = j * 512 + lane * 8;
@@ -351,7 +358,7 @@ template <int KSTEPS, int EPI, int NT, bool DUAL = false>            // K = KSTE
 __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs a) {
     typedef bf16_t T;
     constexpr int NR = (EPI == EPI_SWIGLU) ? 2 : 1;
-    constexpr bool PRE2 = (NT == 2 || (DUAL && NT >= 2)) && KSTEPS <= 8;
+    constexpr bool PRE2 = (NT == 2 || (DUAL && NT != 1)) && KSTEPS <= 8;
     static_assert(!DUAL || PRE2, "the two-panel form needs a pair of tiles' raw tokens in registers");
     constexpr int NXR = PRE2 ? 2 : 1;
     constexpr int K = KSTEPS * 128, KP = K + 8;                 // padded LDS row: 16 tokens x same k would share a bank
@@ -406,14 +413,16 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
         biasv[i] = a.bias ? bv : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
+    // NT = 0: the tile count is a launch argument (a.ntiles; 5..8 tiles = 65..128 lanes) and the loop over pairs / tiles stays rolled --
+    // one instantiation instead of four more per shape, same instructions per tile
+    const int ntl = NT ? NT : a.ntiles;
     if constexpr (DUAL) {
-        constexpr int NPAIR = (NT + 1) / 2;
-#pragma unroll
-        for (int pr = 0; pr < NPAIR; ++pr) {
+        const int npair = (ntl + 1) / 2;
+        auto do_pair = [&](int pr) {
             // ---- 3'. this pair's tokens -> the two panels (first pair: while the weights fly) ----
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                if (2 * pr + tt >= NT) continue;                // (compile-time after unrolling: an odd tile count has a single last tile)
+                if (2 * pr + tt >= ntl) continue;                // (compile-time after unrolling: an odd tile count has a single last tile)
                 const int t0 = (2 * pr + tt) * kTokTile;
                 const int nb = tile_nb(2 * pr + tt);
                 T* xp = xs + (size_t)tt * kTokTile * KP;
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                         xn[j] = norm8_pack(xr[j], rs, nw);
                     }
                     if (m < nb) {
-                        T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[t0 + m]) : nullptr;
+                        T* xo = (blockIdx.x == 0 && a.xn_out) ? reinterpret_cast<T*>(a.xn_out[t0 + m]) : nullptr;
 #pragma unroll
                         for (int j = 0; j < NCH; ++j) {
                             const int off = j * 512 + lane * 8;
@@ -454,15 +463,15 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                 }
             }
             // the next pair's raw tokens: in flight under this pair's MFMAs and exchange
-            if (pr + 1 < NPAIR) {
+            if (pr + 1 < npair) {
                 issue_tokens(0, (2 * pr + 2) * kTokTile, tile_nb(2 * pr + 2));
-                if (2 * pr + 3 < NT) issue_tokens(1, (2 * pr + 3) * kTokTile, tile_nb(2 * pr + 3));
+                if (2 * pr + 3 < ntl) issue_tokens(1, (2 * pr + 3) * kTokTile, tile_nb(2 * pr + 3));
             }
             __syncthreads();            // panels published; (from the second pair on) the previous pair's epilogues are done with `red`
             // ---- 4'. MFMA over this wave's K quarter, both tiles; 5'. one exchange, two epilogues side by side ----
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                if (2 * pr + tt >= NT) continue;
+                if (2 * pr + tt >= ntl) continue;
                 const int nb = tile_nb(2 * pr + tt);
                 const T* xp = xs + (size_t)tt * kTokTile * KP;
                 f32x4 acc[NR];
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                 for (int h = 0; h < NR; ++h) *reinterpret_cast<f32x4*>(red + (((size_t)tt * 4 + wave) * NR + h) * 256 + (size_t)lane * 4) = acc[h];
             }
             __syncthreads();            // every wave is done with the panels and has written its partial sums
-            if (wave < 2 && 2 * pr + wave < NT) {
+            if (wave < 2 && 2 * pr + wave < ntl) {
                 const int tt = wave, t0 = (2 * pr + tt) * kTokTile;
                 const int nb = tile_nb(2 * pr + tt);
                 if (fr < nb) {
@@ -509,11 +518,17 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                     }
                 }
             }
+        };
+        if constexpr (NT > 0) {
+#pragma unroll
+            for (int pr = 0; pr < (NT + 1) / 2; ++pr) do_pair(pr);
+        } else {
+#pragma unroll 1
+            for (int pr = 0; pr < npair; ++pr) do_pair(pr);
         }
         return;
     }
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {                           // one pass per token tile (a second one only above 16 lanes)
+    auto do_tile = [&](int tt) {                                // one pass per token tile (a second one only above 16 lanes)
         const int t0 = tt * kTokTile;
         const int nb = B - t0 < kTokTile ? B - t0 : kTokTile;
         constexpr int kNoSlot = 0;
@@ -544,7 +559,7 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                 xn[j] = norm8_pack(xr[j], rs, nw);
             }
             if (m < nb) {
-                T* xo = blockIdx.x == 0 ? reinterpret_cast<T*>(a.xn_out[t0 + m]) : nullptr;
+                T* xo = (blockIdx.x == 0 && a.xn_out) ? reinterpret_cast<T*>(a.xn_out[t0 + m]) : nullptr;
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     const int off = j * 512 + lane * 8;
@@ -597,7 +612,14 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                 if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
             }
         }
-        if (tt + 1 < NT) __syncthreads();                       // the next tile overwrites the token panel and the partial sums
+        if (tt + 1 < ntl) __syncthreads();                      // the next tile overwrites the token panel and the partial sums
+    };
+    if constexpr (NT > 0) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) do_tile(tt);
+    } else {
+#pragma unroll 1
+        for (int tt = 0; tt < ntl; ++tt) do_tile(tt);
     }
 }
 
@@ -647,8 +669,8 @@ __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGem
         }
     };
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {                           // one pass per token tile; the weight fragments stay in registers
+    const int ntl = NT ? NT : a.ntiles;                         // NT = 0: runtime tile count, rolled loop (see the NORM kernel)
+    auto do_tile = [&](int tt) {                                // one pass per token tile; the weight fragments stay in registers
         const int t0 = tt * kTokTile;
         const int nb = B - t0 < kTokTile ? B - t0 : kTokTile;
         const int slot = PRE2 ? tt : 0;
@@ -682,7 +704,14 @@ __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGem
                 if (row0 + fq * 4 + i < a.N) DT<T>::st(yp + i, v);
             }
         }
-        if (tt + 1 < NT) __syncthreads();                       // the next tile's partial sums reuse `red`
+        if (tt + 1 < ntl) __syncthreads();                      // the next tile's partial sums reuse `red`
+    };
+    if constexpr (NT > 0) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) do_tile(tt);
+    } else {
+#pragma unroll 1
+        for (int tt = 0; tt < ntl; ++tt) do_tile(tt);
     }
 }
 

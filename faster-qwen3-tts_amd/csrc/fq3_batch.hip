@@ -25,10 +25,16 @@ struct fq3_batch {
     float *part = nullptr, *rope_now = nullptr;
     size_t part_stride = 0;
     int Hm = 0, Im = 0, qkvm = 0;
-    LaneTab tab{};
-    LaneSt lst{};                 // the loop states alone (talker attention)
+    LaneTab tab{};                // host copies of the per-lane pointer tables ...
+    LaneSt lst{};                 // (the loop states alone: batch poll)
     std::vector<LaneKV> tkv, pkv;
-    LaneTabs ttab{};              // the lanes' block tables (paged talker KV)
+    LaneTabs ttab{};              // (the lanes' block tables, paged talker KV)
+    LaneForced lf{};              // (teacher-forcing objects as of the last upload: null in product use)
+    // ... and the device copies the kernels read (batch_kernels.cuh: 128 lanes of pointers do not fit a launch's 4 KB of arguments)
+    LaneTab* d_tab = nullptr;
+    LaneKV *d_tkv = nullptr, *d_pkv = nullptr;      // [n_layers]
+    LaneTabs* d_ttab = nullptr;
+    LaneForced* d_lf = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr;
@@ -77,7 +83,8 @@ static bool norm_dual_attr() {
     const bool r2 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_batch_mfma_norm_kernel<KS, EPI, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2) == hipSuccess;
     const bool r3 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_batch_mfma_norm_kernel<KS, EPI, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2) == hipSuccess;
     const bool r4 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_batch_mfma_norm_kernel<KS, EPI, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2) == hipSuccess;
-    return r2 && r3 && r4;
+    const bool r0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_batch_mfma_norm_kernel<KS, EPI, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2) == hipSuccess;
+    return r2 && r3 && r4 && r0;
 }
 static bool norm_dual_prepare() {
     static int done = -1;
@@ -180,7 +187,7 @@ extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** 
 
 static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bool is_kid) {
     if (!lanes || !out) return fq3_fail_(FQ3_EINVAL, "null argument");
-    if (n_lanes < 1 || n_lanes > kMaxLanes) return fq3_fail_(FQ3_EINVAL, "n_lanes must be 1..64");
+    if (n_lanes < 1 || n_lanes > kMaxLanes) return fq3_fail_(FQ3_EINVAL, "n_lanes must be 1..128");
     for (int i = 0; i < n_lanes; ++i) {
         if (!lanes[i] || !lanes[i]->bound) return fq3_fail_(FQ3_ESTATE, "every lane needs a context with bound weights");
         for (int j = 0; j < i; ++j) if (lanes[i] == lanes[j]) return fq3_fail_(FQ3_EINVAL, "a context can fill only one lane");
@@ -233,6 +240,17 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
     for (int l = 0; l < B; ++l) b->ttab.t[l] = lanes[l]->tk.d_table;
     b->ttab.blk_stride = (int)c0->tk.pool->blk_elems;
     for (int i = 0; i < p.n_layers; ++i) for (int l = 0; l < B; ++l) { b->pkv[i].k[l] = lanes[l]->pk.k[i]; b->pkv[i].v[l] = lanes[l]->pk.v[i]; }
+    {   // the device copies (once: the pointers never change while the batch lives)
+        auto up = [&](void** d, const void* h, size_t bytes) -> int {
+            if (int rr = bmalloc(b, d, bytes)) return rr;
+            HIPCHK(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+            return 0;
+        };
+        if ((r = up((void**)&b->d_tab, &b->tab, sizeof(LaneTab))) || (r = up((void**)&b->d_ttab, &b->ttab, sizeof(LaneTabs))) ||
+            (r = up((void**)&b->d_tkv, b->tkv.data(), sizeof(LaneKV) * t.n_layers)) ||
+            (r = up((void**)&b->d_pkv, b->pkv.data(), sizeof(LaneKV) * p.n_layers)) ||
+            (r = up((void**)&b->d_lf, &b->lf, sizeof(LaneForced)))) { fq3_batch_destroy(b); return r; }
+    }
     if (hipStreamCreateWithFlags(&b->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "hipStreamCreateWithFlags");
     }
@@ -323,7 +341,8 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
                 const size_t shm2 = (((size_t)2 * kTokTile * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)2 * 4 * NR * 256 * sizeof(float);
                 if (nt == 2) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<KS, EPI, 2, true>), dim3(grid), dim3(256), shm2, s, a);
                 else if (nt == 3) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<KS, EPI, 3, true>), dim3(grid), dim3(256), shm2, s, a);
-                else hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<KS, EPI, 4, true>), dim3(grid), dim3(256), shm2, s, a);
+                else if (nt == 4) hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<KS, EPI, 4, true>), dim3(grid), dim3(256), shm2, s, a);
+                else { BatchGemvArgs an = a; an.ntiles = nt; hipLaunchKernelGGL((gemv_batch_mfma_norm_kernel<KS, EPI, 0, true>), dim3(grid), dim3(256), shm2, s, an); }   // 65..128 lanes: rolled pair loop
                 return 0;
             }
         }
@@ -331,14 +350,16 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
             constexpr int NTC = decltype(ntc)::value;
             auto kern = gemv_batch_mfma_norm_kernel<KS, EPI, NTC>;
             if (shm > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, a);
+            BatchGemvArgs an = a; an.ntiles = nt;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, an);
             return 0;
         };
         switch (nt) {
             case 1: return one(std::integral_constant<int, 1>{});
             case 2: return one(std::integral_constant<int, 2>{});
             case 3: return one(std::integral_constant<int, 3>{});
-            default: return one(std::integral_constant<int, 4>{});
+            case 4: return one(std::integral_constant<int, 4>{});
+            default: return one(std::integral_constant<int, 0>{});          // 65..128 lanes: rolled tile loop
         }
     };
     switch (a.K / 128) {                      // hidden sizes: 256 (tests), 512, 1024 (0.6B, predictor), 2048 (1.7B)
@@ -368,11 +389,14 @@ static int launch_gemv_batch_mfma_plain(const BatchGemvArgs& a, hipStream_t s) {
     const int grid = (a.N + 15) / 16;
     auto go = [&](auto ks, auto nw) -> int {
         constexpr int KS = decltype(ks)::value, NW = decltype(nw)::value;
-        switch ((a.B + kTokTile - 1) / kTokTile) {          // token tiles
-            case 1: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 1>), dim3(grid), dim3(64 * NW), 0, s, a); break;
-            case 2: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 2>), dim3(grid), dim3(64 * NW), 0, s, a); break;
-            case 3: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 3>), dim3(grid), dim3(64 * NW), 0, s, a); break;
-            default: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 4>), dim3(grid), dim3(64 * NW), 0, s, a); break;
+        BatchGemvArgs an = a;
+        an.ntiles = (a.B + kTokTile - 1) / kTokTile;         // token tiles
+        switch (an.ntiles) {
+            case 1: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 1>), dim3(grid), dim3(64 * NW), 0, s, an); break;
+            case 2: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 2>), dim3(grid), dim3(64 * NW), 0, s, an); break;
+            case 3: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 3>), dim3(grid), dim3(64 * NW), 0, s, an); break;
+            case 4: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 4>), dim3(grid), dim3(64 * NW), 0, s, an); break;
+            default: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 0>), dim3(grid), dim3(64 * NW), 0, s, an); break;   // 65..128 lanes
         }
         return 0;
     };
@@ -429,9 +453,11 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
         if (talker) {
             a.max_seq = c->tk.max_seq; a.part = b->part;
             const dim3 grid(d.n_kv_heads, c->tk.workers, B);
-            if (rep == 1) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 1>), grid, dim3(256), 0, s, a, b->tkv[i], b->ttab, b->lst, b->qkvm, b->rope_now, b->part_stride);
-            else if (rep == 2) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 2>), grid, dim3(256), 0, s, a, b->tkv[i], b->ttab, b->lst, b->qkvm, b->rope_now, b->part_stride);
-            else hipLaunchKernelGGL((attn_decode_batch_kernel<T, 4>), grid, dim3(256), 0, s, a, b->tkv[i], b->ttab, b->lst, b->qkvm, b->rope_now, b->part_stride);
+            const LaneKV* kvp = b->d_tkv + i;
+            const LaneTabs* ttp = b->d_ttab; const LaneTab* tp = b->d_tab;
+            if (rep == 1) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 1>), grid, dim3(256), 0, s, a, kvp, ttp, tp, b->qkvm, b->rope_now, b->part_stride);
+            else if (rep == 2) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 2>), grid, dim3(256), 0, s, a, kvp, ttp, tp, b->qkvm, b->rope_now, b->part_stride);
+            else hipLaunchKernelGGL((attn_decode_batch_kernel<T, 4>), grid, dim3(256), 0, s, a, kvp, ttp, tp, b->qkvm, b->rope_now, b->part_stride);
             hipLaunchKernelGGL((combine_batch_kernel<T>), dim3((q_dim / 8 + 255) / 256, B), dim3(256), 0, s, (const float*)b->part, b->part_stride,
                                c->tk.workers, rep, q_dim, (T*)b->attn_out, b->qkvm);
             o.x = b->attn_out; o.x_stride = b->qkvm;
@@ -441,7 +467,7 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
             rp = rp < 0 ? 0 : (rp >= rl ? rl - 1 : rp);
             a.cos_row = c->wt.pred_cos + (size_t)rp * 64; a.sin_row = c->wt.pred_sin + (size_t)rp * 64;
             a.max_seq = c->pk.max_seq; a.pos_ptr = nullptr; a.pos_imm = src.pos_imm; a.n_pad = 0; a.out = b->attn_out;
-            hipLaunchKernelGGL((attn_pred_batch_kernel<T>), dim3(d.n_heads, B), dim3(64), 0, s, a, b->pkv[i], b->qkvm, b->qkvm);
+            hipLaunchKernelGGL((attn_pred_batch_kernel<T>), dim3(d.n_heads, B), dim3(64), 0, s, a, (const LaneKV*)(b->d_pkv + i), b->qkvm, b->qkvm);
             if (tail_skip) break;
             o.x = b->attn_out; o.x_stride = b->qkvm;
             if (int r = launch_gemv_batch<PRO_PLAIN, EPI_RESIDUAL>(c, o, s)) return r;
@@ -463,9 +489,9 @@ static int enqueue_batch_frame_t(fq3_batch* b, hipStream_t s) {
     fq3_ctx* c = b->lanes[0];
     const fq3_stack_dims &t = c->cfg.talker, &p = c->cfg.predictor;
     const int G = c->cfg.num_code_groups, H = t.hidden, Vp = p.vocab, B = b->B;
-    LaneForced lf{};                                   // teacher-forcing objects (parity tests): null for lanes that never asked
-    for (int l = 0; l < B; ++l) lf.tf[l] = b->lanes[l]->tf;
-    hipLaunchKernelGGL((frame_begin_batch_kernel<T>), dim3(B), dim3(256), 0, s, b->tab, (const T*)c->wt.codec_embedding,
+    const LaneTab* tab = b->d_tab;
+    const LaneForced* lf = b->d_lf;                    // teacher-forcing objects (parity tests; uploaded by sync_forced): null for lanes that never asked
+    hipLaunchKernelGGL((frame_begin_batch_kernel<T>), dim3(B), dim3(256), 0, s, tab, (const T*)c->wt.codec_embedding,
                        (T*)b->pred_in, H, G);
     // predictor: token A (past_hidden, slot 0), token B (embed(tok0), slot 1), then 14 single-token passes
     for (int pass = 0; pass < G; ++pass) {
@@ -490,23 +516,23 @@ static int enqueue_batch_frame_t(fq3_batch* b, hipStream_t s) {
         hg.norm_w = c->wt.predictor_final_norm; hg.y = lg; hg.y_stride = (int)lstride;
         if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, hg, s)) return r;
         const T* next_emb = cb + 1 < G - 1 ? (const T*)c->pemb[cb] : nullptr;
-        if (Vp <= 2048) hipLaunchKernelGGL((sample_pred_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, b->tab, lf, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);
-        else hipLaunchKernelGGL((sample_pred_batch_kernel<T, 2>), dim3(B), dim3(256), 0, s, b->tab, lf, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);
+        if (Vp <= 2048) hipLaunchKernelGGL((sample_pred_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, tab, lf, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);
+        else hipLaunchKernelGGL((sample_pred_batch_kernel<T, 2>), dim3(B), dim3(256), 0, s, tab, lf, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);
     }
     EmbTables tabs{};
     tabs.t[0] = c->wt.codec_embedding;
     for (int i = 1; i < G; ++i) tabs.t[i] = c->pemb[i - 1];
-    hipLaunchKernelGGL((embed_sum_batch_kernel<T, 16>), dim3(B), dim3(256), 0, s, b->tab, tabs, (T*)b->xin, H, c->wt.talker_cos,
+    hipLaunchKernelGGL((embed_sum_batch_kernel<T, 16>), dim3(B), dim3(256), 0, s, tab, tabs, (T*)b->xin, H, c->wt.talker_cos,
                        c->wt.talker_sin, c->wt.talker_rope_len, b->rope_now);
     BatchSrc src{b->xin, H, 0, true, false};
     if (int r = run_stack_batch<T>(b, src, s)) return r;
     BatchGemvArgs g{};
     g.B = B; g.eps = t.rms_eps; g.W = c->wt.codec_head; g.N = t.vocab; g.K = H; g.x = b->h; g.x_stride = b->Hm;
     g.norm_w = c->wt.talker_final_norm; g.y = b->logits; g.y_stride = t.vocab;
-    for (int l = 0; l < B; ++l) g.xn_out[l] = b->tab.past_hidden[l];
+    g.xn_out = b->d_tab->past_hidden;                  // (an address inside the device table: never dereferenced on the host)
     if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, g, s)) return r;
-    if (t.vocab <= 2048) hipLaunchKernelGGL((sample_talker_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, b->tab, lf, (const T*)b->logits, t.vocab, G);
-    else hipLaunchKernelGGL((sample_talker_batch_kernel<T, 2>), dim3(B), dim3(256), 0, s, b->tab, lf, (const T*)b->logits, t.vocab, G);
+    if (t.vocab <= 2048) hipLaunchKernelGGL((sample_talker_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, tab, lf, (const T*)b->logits, t.vocab, G);
+    else hipLaunchKernelGGL((sample_talker_batch_kernel<T, 2>), dim3(B), dim3(256), 0, s, tab, lf, (const T*)b->logits, t.vocab, G);
     return 0;
 }
 
@@ -515,6 +541,18 @@ static int check_lanes(fq3_batch* b) {
         if (c->tk.max_seq > 0 && (c->cfg.talker.n_heads * kHeadDim > 2048))
             return fq3_fail_(FQ3_EUNSUPPORTED, "q_dim above 2048");
     }
+    return 0;
+}
+// the lanes' teacher-forcing objects (parity tests; all null in product use) as the device table the samplers read: uploaded when it
+// differs from the last upload -- outside any capture, behind whatever the batch still has in flight on `s`
+static int sync_forced(fq3_batch* b, hipStream_t s) {
+    LaneForced now{};
+    bool same = true;
+    for (int l = 0; l < b->B; ++l) { now.tf[l] = b->lanes[l]->tf; same = same && now.tf[l] == b->lf.tf[l]; }
+    if (same) return 0;
+    if (s) HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(b->d_lf, &now, sizeof now, hipMemcpyHostToDevice));
+    b->lf = now;
     return 0;
 }
 static int enqueue_batch_frame(fq3_batch* b, hipStream_t s) {
@@ -531,8 +569,8 @@ extern "C" int fq3_batch_graph_capture(fq3_batch* b, void* stream) {
         return FQ3_OK;
     }
     if (b->exec) return FQ3_OK;
-    (void)stream;
     if (int r = check_lanes(b)) return r;
+    if (int r = sync_forced(b, (hipStream_t)stream)) return r;
     hipStream_t cs = b->cap_stream;
     HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
     int r = enqueue_batch_frame(b, cs);
@@ -623,6 +661,9 @@ extern "C" int fq3_batch_frames(fq3_batch* b, int n_frames, void* stream) {
 
 static int batch_frames_one(fq3_batch* b, int n_frames, hipStream_t s) {
     if (int r = check_lanes(b)) return r;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap == hipStreamCaptureStatusNone) if (int r = sync_forced(b, s)) return r;
     for (int i = 0; i < n_frames; ++i) {
         if (b->exec) { HIPCHK(hipGraphLaunch(b->exec, s)); }
         else if (int r = enqueue_batch_frame(b, s)) return r;

@@ -29,7 +29,7 @@ from .predictor_graph import PredictorGraph
 from .talker_graph import TalkerGraph
 
 
-MAX_LANES = 64          # kMaxLanes of csrc/batch_kernels.cuh (fq3_batch_create refuses more)
+MAX_LANES = 128         # kMaxLanes of csrc/batch_kernels.cuh (fq3_batch_create refuses more)
 
 
 @dataclass

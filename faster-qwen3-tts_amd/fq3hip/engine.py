@@ -467,8 +467,8 @@ class Fq3Batch:
 
     def __init__(self, lanes):
         lanes = list(lanes)
-        if not 1 <= len(lanes) <= 64:
-            raise ValueError("a batch holds 1..64 lanes")
+        if not 1 <= len(lanes) <= 128:
+            raise ValueError("a batch holds 1..128 lanes")
         self.lanes = lanes
         self.lib = lanes[0].lib
         self.device = lanes[0].device

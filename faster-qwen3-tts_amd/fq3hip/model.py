@@ -1033,7 +1033,7 @@ class FasterQwen3TTS:
                                    instruct: Optional[str] = None,
                                    voice_clone_prompt: Optional[Union[Dict[str, Any], List[Any]]] = None,
                                    lanes: int = 8) -> List[Tuple[list, int]]:
-        """Voice cloning of several texts with one voice: up to ``lanes`` (<= 64) utterances decode in lock-step over
+        """Voice cloning of several texts with one voice: up to ``lanes`` (<= 128) utterances decode in lock-step over
         one pass of the weights per frame (``fq3_batch_*``), finished lanes are refilled from the queue.  Returns one
         ``([np.float32 waveform], sample_rate)`` per text, in input order; each utterance follows exactly the
         single-utterance semantics of :meth:`generate_voice_clone`, nucleus sampling (``top_p < 1``) included."""

@@ -274,7 +274,7 @@ int fq3_prompt_rows(fq3_ctx* ctx, const void* text_rows, int n_text, const int32
 
 /* ---- batched decode: B utterances in lock-step over one weight stream ------------------------------
  * No reference equivalent (the reference fixes batch = 1: talker_graph.py:46, predictor_graph.py:70; SURVEY.md
- * section 8f rank 3).  A batch borrows n_lanes (1..64) ordinary contexts that share ONE weight table, ONE config and
+ * section 8f rank 3).  A batch borrows n_lanes (1..128) ordinary contexts that share ONE weight table, ONE config and
  * ONE max_seq_len.  Each lane is prepared with the single-stream entry points (fq3_prefill, fq3_set_generation_state,
  * fq3_decode_begin) and read back with fq3_decode_poll / fq3_decode_codes on ITS context; fq3_batch_frames replaces
  * fq3_decode_frames for all lanes at once.  Lanes that are done (EOS, limits, or never begun) idle on device and can be
@@ -282,8 +282,8 @@ int fq3_prompt_rows(fq3_ctx* ctx, const void* text_rows, int n_text, const int32
  * its fq3_decode_begin / fq3_set_predictor_sampling set): top_p < 1 (sampling.py:57-65) is honoured per lane inside the
  * same launch.  With the VALU GEMVs ("mfma" 0, the fp32 default) a lane's ids are bit-identical to the same utterance
  * decoded alone with the same noise; the bf16 default multiplies one 16-column token tile per v_mfma_f32_16x16x32_bf16,
- * so 9..16 lanes read the weights once and issue the MFMAs of 1..8; lanes 17..32, 33..48 and 49..64 are further token tiles of
- * the same launch over the register-resident weight fragments. */
+ * so 9..16 lanes read the weights once and issue the MFMAs of 1..8; lanes 17..32, 33..48, ... 113..128 are further token tiles
+ * of the same launch over the register-resident weight fragments. */
 typedef struct fq3_batch fq3_batch;
 int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out);
 int fq3_batch_destroy(fq3_batch* b);

@@ -58,7 +58,7 @@ def test_null_arguments_are_errors_not_crashes(lib):
     lanes = (ctypes.c_void_p * 2)(None, None)
     lib.fq3_batch_create.restype = ctypes.c_int
     assert lib.fq3_batch_create(None, 2, ctypes.byref(h)) == -1
-    assert lib.fq3_batch_create(lanes, 65, ctypes.byref(h)) == -1          # more than four 16-column MFMA token tiles
+    assert lib.fq3_batch_create(lanes, 129, ctypes.byref(h)) == -1         # more than eight 16-column MFMA token tiles
     assert lib.fq3_batch_create(lanes, 2, ctypes.byref(h)) == -3          # FQ3_ESTATE: lanes without bound weights
     assert lib.fq3_batch_frames(None, 1, None) == -1 and lib.fq3_batch_graph_capture(None, None) == -1
     assert lib.fq3_batch_size(None) == 0 and lib.fq3_batch_destroy(None) == 0

@@ -89,7 +89,7 @@ def test_lanes_equal_single_stream(dtype, graph):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("n_lanes,n_armed", [(16, 13), (32, 27), (48, 41), (64, 59)])
+@pytest.mark.parametrize("n_lanes,n_armed", [(16, 13), (32, 27), (48, 41), (64, 59), (96, 83), (128, 121)])
 def test_sixteen_lanes_equal_single_stream(dtype, n_lanes, n_armed):
     """More than 8 lanes: the VALU batch GEMV walks the tokens in LDS groups of 8 over register-resident weight rows -- 13 armed
     lanes of a 16-lane batch / 27 of a 32-lane batch (sampled and greedy, padded, short budgets, > 64 keys) are still bit-identical
@@ -384,17 +384,17 @@ def test_custom_voice_and_voice_design_batch_equal_single_calls(kind):
 def test_two_panel_normalising_gemv_is_bit_identical_at_32_lanes():
     """fq3_batch_set_option("norm_dual", 0 | 1): above 16 lanes the normalising matrix-core GEMVs (qkv, gate | up, heads) prepare a PAIR
     of token tiles before its first MFMA (1, the default) or go tile by tile over one LDS panel (0).  Same instructions on the same
-    values in the same order: the sampled / greedy lanes of a 32-, 48- (an odd tile count) and 64-lane batch produce identical ids
-    either way -- and a lane's ids do not depend on how many lanes the batch has (the 27 lanes of the 32-lane batch reappear
-    unchanged in the 64-lane one)."""
+    values in the same order: the sampled / greedy lanes of a 32-, 48- (an odd tile count), 64-, 96- and 128-lane batch produce
+    identical ids either way -- and a lane's ids do not depend on how many lanes the batch has (the 27 lanes of the 32-lane batch
+    reappear unchanged in the 128-lane one)."""
     from fq3hip.engine import Fq3Batch
     cfg = tiny_test_config()
     dtype = torch.bfloat16
     W = synth_weights(cfg, 0, dtype)
-    utts = [_utterance(cfg, dtype, 300 + i, 18 + (5 * i) % 61, (i % 3) * 2, 6 + (i * 5) % 9, 6 + (i * 5) % 9, i % 4 != 3) for i in range(59)]
-    lanes = _engines(cfg, W, dtype, 64)
+    utts = [_utterance(cfg, dtype, 300 + i, 18 + (5 * i) % 61, (i % 3) * 2, 6 + (i * 5) % 9, 6 + (i * 5) % 9, i % 4 != 3) for i in range(121)]
+    lanes = _engines(cfg, W, dtype, 128)
     first27 = None
-    for n_lanes, n_armed in ((32, 27), (48, 41), (64, 59)):
+    for n_lanes, n_armed in ((32, 27), (48, 41), (64, 59), (96, 83), (128, 121)):       # 5..8 tiles: the rolled-loop instantiations (NT = 0)
         batch = Fq3Batch(lanes[:n_lanes])
         got = []
         for dual in (1, 0):

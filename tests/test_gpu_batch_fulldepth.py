@@ -1,5 +1,5 @@
 """Parity of the LOCK-STEP BATCH at the benchmarked configurations: full-depth 0.6B / 1.7B (28 talker + 5 predictor layers at
-the real shapes), 8, 16, 32 AND 64 lanes, the matrix-core batch GEMVs the bench line uses (the template instantiations selected by
+the real shapes), 8, 16, 32, 64 AND 128 lanes, the matrix-core batch GEMVs the bench line uses (the template instantiations selected by
 H = 1024 / 2048, I = 3072 / 6144: gemv_batch_mfma_norm_kernel<8|16, *>, gemv_batch_mfma_plain_kernel<8|12|24, 8, *>), every lane
 teacher-forced with golden oracle ids and every one of its 16 x frames decisions scored (oracle/teacher_forced.py).
 
@@ -26,8 +26,10 @@ K_ULP = 3.0                 # frozen (round 3)
 # frozen (round 4): identical decisions per lane for (utterance A: 384 decisions, utterance B: 256), round-3 measurement minus one
 LANE_FLOOR = {("0p6b", 8): (373, 240), ("0p6b", 16): (373, 240), ("0p6b", 32): (374, 245), ("0p6b", 64): (374, 245),
               ("1p7b", 8): (367, 248), ("1p7b", 16): (367, 248), ("1p7b", 32): (363, 246), ("1p7b", 64): (363, 246)}
-# (64 lanes, added in round 4 with the four-tile kernels: a lane's arithmetic does not depend on the number of token tiles of the
-#  launch, so its counts are the 32-lane ones and it inherits their floors)
+LANE_FLOOR[("0p6b", 128)] = LANE_FLOOR[("0p6b", 32)]
+LANE_FLOOR[("1p7b", 128)] = LANE_FLOOR[("1p7b", 32)]
+# (64 and 128 lanes, added in round 4 with the four- and eight-tile kernels: a lane's arithmetic does not depend on the number of token
+#  tiles of the launch, so its counts are the 32-lane ones and it inherits their floors)
 
 from fq3hip.config import qwen3_tts_0p6b, qwen3_tts_1p7b
 from fq3hip.weights import synth_weights, synth_prompt
@@ -121,10 +123,10 @@ def test_batch_full_depth_bf16_mfma_lanes_vs_oracle(size, golden_dir):
     frames = max(c[0]["codes"].shape[0] for c in cases) + 8
     first = Fq3Engine(cfg, W, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames)
     del W
-    engines = [first] + [Fq3Engine(cfg, first.weights, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames, share=first) for _ in range(63)]
+    engines = [first] + [Fq3Engine(cfg, first.weights, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames, share=first) for _ in range(127)]
     for e in engines:
         e.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
-    for B in (8, 16, 32, 64):
+    for B in (8, 16, 32, 64, 128):
         scores = _run_batch(engines, cfg, cases, B, mfma=1)
         tot = sum(s["total"] for s in scores); ok = sum(s["matched_decisions"] for s in scores)
         worst = max(s["worst_mismatch_ulp"] for s in scores)

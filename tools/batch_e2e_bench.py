@@ -23,6 +23,7 @@ def main():
     if prio:
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=prio))
     cfg, model = bench.build_model(dev, size, max_seq_len=2048, codec_precision=codec)
+    model.batch_kv_blocks = max(model.batch_kv_blocks, 2 * lanes * ((bench.PROMPT_LEN + bench.FRAMES + 64 + 63) // 64))   # lanes + as many spare contexts
     req = bench.build_request(cfg, dev)
     prompt = bench.prepared_prompt(model, req)
     bench.batched_run(model, prompt, lanes, lanes)

@@ -379,6 +379,13 @@ int main(int argc, char** argv) {
         void* ym = dev_bf16((size_t)MB * 8192, 1.f);          // MFMA kernel out
         void* bias = dev_bf16(8192, 0.3f);
         void* xn8 = dev_bf16((size_t)MB * 8192, 0.f);
+        void** xn_tab = nullptr;                               // device table of the per-lane xn_out rows (BatchGemvArgs::xn_out)
+        {
+            std::vector<void*> h(MB);
+            for (int m = 0; m < MB; ++m) h[m] = (bf16_t*)xn8 + (size_t)m * 8192;
+            CHK(hipMalloc((void**)&xn_tab, MB * sizeof(void*)));
+            CHK(hipMemcpy(xn_tab, h.data(), MB * sizeof(void*), hipMemcpyHostToDevice));
+        }
         const size_t pstride = (size_t)NKV * kMaxWorkers * 4 * kPartStride;
         float* part8 = (float*)dev_f32((size_t)MB * pstride, 0.5f);
         {   // make the softmax denominators of the synthetic partial slots positive (l in [0.5, 1.5))
@@ -393,7 +400,7 @@ int main(int argc, char** argv) {
             else if (kind == 1) { g.W = Wo[i % NL]; g.N = H; g.K = QD; }
             else if (kind == 2) { g.W = Wgu[i % NL]; g.N = I; g.K = H; g.up_off = I; }
             else if (kind == 3) { g.W = Wdn[i % NL]; g.N = H; g.K = I; }
-            else { g.W = Whead[i % NL]; g.N = Vp; g.K = H; g.bias = bias; for (int m = 0; m < B; ++m) g.xn_out[m] = (bf16_t*)xn8 + (size_t)m * 8192; } // head + bias + xn_out
+            else { g.W = Whead[i % NL]; g.N = Vp; g.K = H; g.bias = bias; g.xn_out = xn_tab; } // head + bias + xn_out
             return g;
         };
         auto run_v = [&](int kind, int i, int B, void* y) {      // VALU batch kernel (bit-identical to single-token launches)
