@@ -414,11 +414,13 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
     }
     __builtin_amdgcn_sched_barrier(0);
     // NT = 0: the tile count is a launch argument (a.ntiles; 5..8 tiles = 65..128 lanes) and the loop over pairs / tiles stays rolled --
-    // one instantiation instead of four more per shape, same instructions per tile
+    // one instantiation instead of four more per shape, same instructions per tile (NT > 0: a constant trip count, fully unrolled)
     const int ntl = NT ? NT : a.ntiles;
+    constexpr int kTileUnroll = NT > 0 ? 8 : 1;
     if constexpr (DUAL) {
         const int npair = (ntl + 1) / 2;
-        auto do_pair = [&](int pr) {
+#pragma unroll kTileUnroll
+        for (int pr = 0; pr < npair; ++pr) {
             // ---- 3'. this pair's tokens -> the two panels (first pair: while the weights fly) ----
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
@@ -518,17 +520,11 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                     }
                 }
             }
-        };
-        if constexpr (NT > 0) {
-#pragma unroll
-            for (int pr = 0; pr < (NT + 1) / 2; ++pr) do_pair(pr);
-        } else {
-#pragma unroll 1
-            for (int pr = 0; pr < npair; ++pr) do_pair(pr);
         }
         return;
     }
-    auto do_tile = [&](int tt) {                                // one pass per token tile (a second one only above 16 lanes)
+#pragma unroll kTileUnroll
+    for (int tt = 0; tt < ntl; ++tt) {                          // one pass per token tile (a second one only above 16 lanes)
         const int t0 = tt * kTokTile;
         const int nb = B - t0 < kTokTile ? B - t0 : kTokTile;
         constexpr int kNoSlot = 0;
@@ -613,13 +609,6 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
             }
         }
         if (tt + 1 < ntl) __syncthreads();                      // the next tile overwrites the token panel and the partial sums
-    };
-    if constexpr (NT > 0) {
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) do_tile(tt);
-    } else {
-#pragma unroll 1
-        for (int tt = 0; tt < ntl; ++tt) do_tile(tt);
     }
 }
 
@@ -670,7 +659,9 @@ __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGem
     };
     __builtin_amdgcn_sched_barrier(0);
     const int ntl = NT ? NT : a.ntiles;                         // NT = 0: runtime tile count, rolled loop (see the NORM kernel)
-    auto do_tile = [&](int tt) {                                // one pass per token tile; the weight fragments stay in registers
+    constexpr int kTileUnroll = NT > 0 ? 8 : 1;
+#pragma unroll kTileUnroll
+    for (int tt = 0; tt < ntl; ++tt) {                          // one pass per token tile; the weight fragments stay in registers
         const int t0 = tt * kTokTile;
         const int nb = B - t0 < kTokTile ? B - t0 : kTokTile;
         const int slot = PRE2 ? tt : 0;
@@ -705,13 +696,6 @@ __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGem
             }
         }
         if (tt + 1 < ntl) __syncthreads();                      // the next tile's partial sums reuse `red`
-    };
-    if constexpr (NT > 0) {
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) do_tile(tt);
-    } else {
-#pragma unroll 1
-        for (int tt = 0; tt < ntl; ++tt) do_tile(tt);
     }
 }
 
