@@ -130,9 +130,9 @@ def build_model(device, size="0p6b", frames=FRAMES, max_seq_len=2048, model_type
                                         codec_precision=codec_precision)
     model._bench_weights, model._bench_cfg = W, cfg
     # paged KV: the batch schedulers of this model draw from a pool sized for the traffic of this bench (a ~200-row prompt + `frames`
-    # frames per request, 64 lanes + 64 spare contexts) instead of (lanes + spares) x max_seq_len slots: 1024 blocks of 64 keys
-    # against 4096 (max_seq_len 2048) or 12288 (6144)
-    model.batch_kv_blocks = 128 * ((PROMPT_LEN + frames + 64 + 63) // 64)
+    # frames per request, 128 lanes + 128 spare contexts) instead of (lanes + spares) x max_seq_len slots: 2048 blocks of 64 keys
+    # against 8192 (max_seq_len 2048) or 24576 (6144)
+    model.batch_kv_blocks = 256 * ((PROMPT_LEN + frames + 64 + 63) // 64)
     if BATCH_LOOKAHEAD is not None:
         model.batch_lookahead = BATCH_LOOKAHEAD           # --batch-lookahead (measurement switch)
     return cfg, model
@@ -756,7 +756,7 @@ def model_1p7b_block(cfg, model, device, lanes=16):
                                "frac": round((gemm_fl + attn_fl) / (pms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "bound": "mfma"}
     except Exception as e:
         out["prefill_4096"] = {"error": repr(e)}
-    for B in sorted({8, 16, 32, lanes}):
+    for B in sorted({16, 32, 64, lanes}):
         try:
             ms, p = batched_frame_time(model, cfg, prompt, lanes=B)
             out[f"batched_b{B}"] = {"ms_per_lockstep_frame": round(ms, 3), "value": round(B * 80.0 / ms, 1),
@@ -847,7 +847,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
-    ap.add_argument("--batch", type=int, default=64, help="lock-step lanes of the batched figures, <= 64 (0 = skip them)")
+    ap.add_argument("--batch", type=int, default=128, help="lock-step lanes of the batched figures, <= 128 (0 = skip them)")
     ap.add_argument("--batch-groups", type=int, default=1, help="opt-in: concurrent lock-step batches on one GPU, `batched_groups_one_gpu` (1 = skip; measured: two host-threaded groups of 8 give 159x vs 159x for one)")
     ap.add_argument("--batch-lookahead", type=int, default=None, help="measurement switch: 0 = the batch scheduler waits for every batch of frames right after queuing it (default: it keeps one batch queued ahead)")
     ap.add_argument("--config3-utterances", type=int, default=64, help="utterances of the sharded batched run (0 = skip)")
@@ -950,7 +950,7 @@ def main():
         guarded("roofline_mfma", lambda: measure_mfma(cfg, model_bf16, prompt))
     if solo and args.batch > 1:
         def _batched():
-            lanes = min(args.batch, 64)
+            lanes = min(args.batch, 128)
             batched_run(model, prompt, lanes, lanes)                                   # warm-up: contexts, graph capture
             audio_s, wall, _ = batched_run(model, prompt, 2 * lanes, lanes)
             ms, p = batched_frame_time(model, cfg, prompt, lanes)
@@ -991,7 +991,7 @@ def main():
                                     "note": "VALU batch GEMVs: lanes bit-identical to single-stream decoding"}
             except Exception as e:
                 out["valu_gemv"] = {"error": repr(e)}
-            for other in (8, 16, 32, 64):
+            for other in (16, 32, 64, 128):
                 if other == lanes:
                     continue
                 try:
@@ -1003,7 +1003,7 @@ def main():
         guarded("batched_decode_one_gpu", _batched)
         if args.batch_groups > 1:
             guarded("batched_groups_one_gpu", lambda: batched_groups_run(cfg, model, prompt, device, args.config3_utterances or 64,
-                                                                         groups=args.batch_groups, lanes=min(args.batch, 64)))
+                                                                         groups=args.batch_groups, lanes=min(args.batch, 128)))
 
     # ---- BASELINE configs[3]: 1.7B-CustomVoice shapes, 64 utterances sharded over the ranks, 16 lock-step lanes per GPU (all
     #      ranks take part), through the public generate_custom_voice_batch ----
@@ -1012,7 +1012,8 @@ def main():
     if args.config3_utterances > 0 and args.batch > 1 and not args.no_extras:
         from fq3hip.sharding import shard_indices
         mine = shard_indices(args.config3_utterances, rank, world)
-        lanes = min(args.batch, 64)
+        # one wave: as many lanes as this rank has utterances (a lock-step frame costs what its token tiles cost, filled or not)
+        lanes = min(args.batch, 128, max(16, 16 * ((len(mine) + 15) // 16)))
         err, c3_audio, c3_lens = None, 0.0, []
         texts = sentences(args.config3_utterances)
         try:
@@ -1117,7 +1118,7 @@ def main():
                     cfg17, model17 = build_model(device, "1p7b", max_seq_len=6144, model_type="custom_voice", codec_precision=HEADLINE_CODEC)
                 inner17 = model17.model.model
                 inner17.tts_model_type = "base"                # configs[2] is the Base model: same weights, voice-clone entry points
-                out["model_1p7b"] = model_1p7b_block(cfg17, model17, device, lanes=min(max(args.batch, 8), 64))
+                out["model_1p7b"] = model_1p7b_block(cfg17, model17, device, lanes=min(max(args.batch, 8), 128))
             except Exception as e:
                 out["model_1p7b"] = {"error": repr(e)}
         if world == 1 and not stub and not args.no_cpu_baseline:
