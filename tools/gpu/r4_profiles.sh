@@ -24,4 +24,5 @@ for P in bf16 bf16x2; do
 done
 cd $GRAFT_REPO_ROOT
 timeout 400 bash tools/pmc_pass.sh "batch 32" gpurun_out/r4p/pmc_batch32_fetch.txt FETCH_SIZE; tail -4 gpurun_out/r4p/pmc_batch32_fetch.txt | cut -c1-250
+for L in ${EXTRA_LANES}; do timeout 400 bash tools/pmc_pass.sh "batch $L" gpurun_out/r4p/pmc_batch${L}_fetch.txt FETCH_SIZE; tail -3 gpurun_out/r4p/pmc_batch${L}_fetch.txt | cut -c1-250; done
 timeout 400 bash tools/pmc_pass.sh codec gpurun_out/r4p/pmc_codec_mfma.txt SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; tail -6 gpurun_out/r4p/pmc_codec_mfma.txt | cut -c1-250
