@@ -144,6 +144,7 @@ struct BatchGemvArgs {
     int group;                                     // VALU kernel: tokens per LDS pass (1..kGroupLanes; the launcher sizes the LDS for it)
     void* const* xn_out;                           // optional per-lane copy of the prepared token (codec_head -> past_hidden): a device table, or null
     int ntiles;                                    // token tiles of 16 lanes (the matrix-core kernels' runtime-count variants, NT = 0)
+    void* xn_ws;                                   // [B][K] workspace for pre-normalised tokens (above 64 lanes: rmsnorm_batch_kernel + weight-stationary GEMM), or null
 };
 
 // One row per wave (4 rows per workgroup), weight rows loaded ONCE; the B <= kMaxLanes tokens pass through LDS in groups of
@@ -341,6 +342,55 @@ __device__ __forceinline__ u32x4 norm8_pack(const float (&x)[8], float rs, const
         o[i] = pack_bf16x2(q.x, q.y);
     }
     return u32x4{o[0], o[1], o[2], o[3]};
+}
+
+// Above 64 lanes the normalising GEMVs (qkv, gate | up, heads) stop paying for themselves: every one of their 192-256 workgroups
+// normalises ALL the batch's tokens and walks the token tiles one pair after the other (19.6 / 21.2 us per launch at 128 lanes,
+// 54 % of the frame, profiles/r04_batch128_kernel_trace.txt).  There the tokens are normalised ONCE by this kernel -- one wave per
+// token, the very operations of gemv_batch_mfma_norm_kernel's prologue in the same order (a lane owns 8 consecutive elements of
+// every 512-chunk, one sequential fma chain, wave_sum): the rows are bit-identical to the panels that kernel builds -- and the GEMM
+// runs on the prefill's weight-stationary kernel (skinny_gemm.cuh: SK_STORE / SK_SWIGLU), which streams token tiles past
+// register-resident weight rows on every CU.  Only the fp32 summation order of the products changes (8 waves x two chains instead
+// of 4 waves x one), which is why the switch sits at a lane count of its own: up to 64 lanes nothing moves.
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_batch_kernel(const bf16_t* __restrict__ x, int x_stride, const bf16_t* __restrict__ norm_w, float eps,
+                                                            int K, int B, bf16_t* __restrict__ y, int y_stride, void* const* xn_out) {
+    typedef bf16_t T;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= B) return;
+    Raw8<T> xraw[NCH], nraw[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int off = j * 512 + lane * 8, offc = off < K ? off : 0;
+        ldraw<false>(xraw[j], x + (size_t)m * x_stride + offc);
+        ldraw<false>(nraw[j], norm_w + offc);
+    }
+    float xr[NCH][8];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (j * 512 + lane * 8 >= K) zero(xraw[j]);
+        unpack(xraw[j], xr[j]);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
+    ss = wave_sum(ss);
+    const float rs = 1.0f / sqrtf(ss / (float)K + eps);
+    T* xo = xn_out ? reinterpret_cast<T*>(xn_out[m]) : nullptr;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        float nw[8];
+        unpack(nraw[j], nw);
+        const u32x4 v = norm8_pack(xr[j], rs, nw);
+        const int off = j * 512 + lane * 8;
+        if (off < K) {
+            *reinterpret_cast<u32x4*>(y + (size_t)m * y_stride + off) = v;
+            if (xo) *reinterpret_cast<u32x4*>(xo + off) = v;
+        }
+    }
 }
 
 // NT = token tiles of 16 lanes the launch walks (1: B <= 16, 2: 17..32).  The weight fragments are loaded once and stay in

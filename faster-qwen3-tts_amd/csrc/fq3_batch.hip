@@ -39,6 +39,8 @@ struct fq3_batch {
     hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr;
     std::vector<void*> allocs;
+    void* xn = nullptr;           // [B][Hm]: pre-normalised tokens of the weight-stationary form of the normalising GEMVs (above 64 lanes)
+    int norm_skinny = 1;          // above 64 lanes: qkv / gate | up / heads as rmsnorm_batch_kernel + skinny_gemm_kernel ("norm_skinny" 0: the panel kernels at every lane count)
     int norm_dual = 1;            // 17..32 lanes, hidden <= 1024: the normalising GEMVs prepare both token tiles before the first MFMA (bit-identical; "norm_dual" 0 = one panel, tile by tile)
     int use_skinny = 1;           // above 16 lanes the two residual GEMVs of a layer (o_proj, down) run on the weight-stationary prefill kernel
     int use_mfma = 0;             // bf16 GEMVs on the matrix cores: default ON for bf16 (ids verified against the oracle by teacher forcing
@@ -149,7 +151,7 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
 // follows the BATCH's lane count, not the group's (a last group of a few lanes must not change its lanes' summation order)
 static void sync_kid_options(fq3_batch* b) {
     for (fq3_batch* k : b->kids) {
-        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma;
+        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma; k->norm_skinny = b->norm_skinny;
         k->use_skinny = (b->use_skinny == 1 && b->B > kTokTile) ? 2 : b->use_skinny;
     }
 }
@@ -221,7 +223,7 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
     int r;
     auto A = [&](void** ptr, size_t n) { return bmalloc(b, ptr, n); };
     if ((r = A(&b->h, (size_t)B * b->Hm * esz)) || (r = A(&b->xin, (size_t)B * b->Hm * esz)) ||
-        (r = A(&b->qkv, (size_t)B * b->qkvm * esz)) || (r = A(&b->act, (size_t)B * b->Im * esz)) ||
+        (r = A(&b->xn, (size_t)B * b->Hm * esz)) || (r = A(&b->qkv, (size_t)B * b->qkvm * esz)) || (r = A(&b->act, (size_t)B * b->Im * esz)) ||
         (r = A(&b->attn_out, (size_t)B * b->qkvm * esz)) || (r = A(&b->logits, (size_t)B * Vm * esz)) ||
         (r = A(&b->pred_in, (size_t)B * 2 * t.hidden * esz)) || (r = A(&b->pred_x, (size_t)B * p.hidden * esz)) ||
         (r = A(&b->pred_next, (size_t)B * t.hidden * esz)) || (r = A(&b->plogits, (size_t)B * (G - 1) * p.vocab * esz))) {
@@ -258,6 +260,9 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
     if (c0->cfg.dtype == FQ3_BF16 && !norm_dual_prepare()) {
         fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "batch: could not raise the LDS limit of the two-panel normalising GEMV kernels");
     }
+    if (c0->cfg.dtype == FQ3_BF16 && !(skinny_prepare<SK_STORE>() && skinny_prepare<SK_SWIGLU>())) {
+        fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "batch: could not raise the LDS limit of the weight-stationary GEMM kernels");
+    }
     if (c0->cfg.dtype == FQ3_BF16 && !skinny_prepare<SK_RESIDUAL>()) {
         fq3_batch_destroy(b); return fq3_fail_(FQ3_EHIP, "batch: could not raise the LDS limit of the weight-stationary GEMV kernels");
     }
@@ -268,6 +273,7 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
 extern "C" int fq3_batch_set_option(fq3_batch* b, const char* key, int value) {
     if (!b || !key) return fq3_fail_(FQ3_EINVAL, "null argument");
     if (std::string(key) == "norm_dual") b->norm_dual = value;
+    else if (std::string(key) == "norm_skinny") b->norm_skinny = value;   // above 64 lanes: the normalising GEMVs as pre-normalise + weight-stationary GEMM (default 1)
     else if (std::string(key) == "skinny") b->use_skinny = value;  // o_proj / down of 17..32 lanes on skinny_gemm_kernel (default 1); 0: gemv_batch_mfma_plain_kernel;
                                                               // 2: at every lane count (a measurement switch: below 17 lanes the kernel's two-tile group is half empty)
     else if (std::string(key) == "mfma") b->use_mfma = value;      // bf16 GEMVs on the matrix cores (fp32 summation order differs from the single-stream kernels)
@@ -325,9 +331,25 @@ static int launch_gemv_batch_t(BatchGemvArgs a, int esz, hipStream_t s) {
 }
 // matrix-core variants: bf16, built step counts; return -1000 when the shape is not covered (the VALU kernel takes over)
 static thread_local int g_batch_norm_dual = 1;   // set per enqueue from fq3_batch::norm_dual
+static thread_local int g_batch_norm_skinny = 1; // set per enqueue from fq3_batch::norm_skinny
 template <int EPI>
 static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
     if (a.K % 128) return -1000;
+    // above 64 lanes (five token tiles and more): normalise once, then the weight-stationary GEMM (batch_kernels.cuh::rmsnorm_batch_kernel)
+    const int n_w = EPI == EPI_SWIGLU ? 2 * a.N : a.N;                  // weight rows: [gate | up] for SwiGLU
+    if (g_batch_norm_skinny && a.xn_ws && a.B > 4 * kTokTile && !a.bias && skinny_k_ok(a.K) && a.K <= 2048 && n_w % 32 == 0 &&
+        a.x_stride % 8 == 0 && a.y_stride % 4 == 0 && (EPI == EPI_STORE || EPI == EPI_SWIGLU)) {
+        bf16_t* xn = reinterpret_cast<bf16_t*>(a.xn_ws);
+        const dim3 grid((a.B + 3) / 4);
+        if (a.K <= 1024) hipLaunchKernelGGL((rmsnorm_batch_kernel<2>), grid, dim3(256), 0, s, (const bf16_t*)a.x, a.x_stride, (const bf16_t*)a.norm_w, a.eps, a.K, a.B, xn, a.K, a.xn_out);
+        else hipLaunchKernelGGL((rmsnorm_batch_kernel<4>), grid, dim3(256), 0, s, (const bf16_t*)a.x, a.x_stride, (const bf16_t*)a.norm_w, a.eps, a.K, a.B, xn, a.K, a.xn_out);
+        SkinnyArgs k{};
+        k.X = xn; k.ldx = a.K; k.M = a.B; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = n_w;
+        k.Y = reinterpret_cast<bf16_t*>(a.y); k.ldy = a.y_stride;
+        if constexpr (EPI == EPI_SWIGLU) skinny_launch<SK_SWIGLU>(k, a.K, s);
+        else skinny_launch<SK_STORE>(k, a.K, s);
+        return 0;
+    }
     const int grid = (a.N + 15) / 16;
     constexpr int NR = EPI == EPI_SWIGLU ? 2 : 1;
     const size_t shm = (((size_t)kTokTile * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NR * 256 * sizeof(float);
@@ -442,7 +464,7 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
         const int xin_stride = i == 0 ? src.x0_stride : b->Hm;
         BatchGemvArgs g{};
         g.B = B; g.eps = d.rms_eps; g.W = w.qkv; g.N = q_dim + 2 * kv_dim; g.K = d.hidden; g.x = xin; g.x_stride = xin_stride;
-        g.norm_w = w.input_norm; g.y = b->qkv; g.y_stride = b->qkvm;
+        g.norm_w = w.input_norm; g.y = b->qkv; g.y_stride = b->qkvm; g.xn_ws = b->xn;
         if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, g, s)) return r;
         const bool tail_skip = src.kv_only_tail && i == d.n_layers - 1;
         AttnArgs a{};
@@ -474,7 +496,7 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
         }
         BatchGemvArgs m{};
         m.B = B; m.eps = d.rms_eps; m.W = w.gate_up; m.N = d.inter; m.K = d.hidden; m.x = b->h; m.x_stride = b->Hm;
-        m.norm_w = w.post_norm; m.y = b->act; m.y_stride = b->Im; m.up_off = d.inter;
+        m.norm_w = w.post_norm; m.y = b->act; m.y_stride = b->Im; m.up_off = d.inter; m.xn_ws = b->xn;
         if (int r = launch_gemv_batch<PRO_NORM, EPI_SWIGLU>(c, m, s)) return r;
         BatchGemvArgs dn{};
         dn.B = B; dn.W = w.down; dn.N = d.hidden; dn.K = d.inter; dn.x = b->act; dn.x_stride = b->Im; dn.y = b->h; dn.y_stride = b->Hm;
@@ -513,7 +535,7 @@ static int enqueue_batch_frame_t(fq3_batch* b, hipStream_t s) {
         const size_t lstride = (size_t)(G - 1) * Vp;
         BatchGemvArgs hg{};
         hg.B = B; hg.eps = p.rms_eps; hg.W = c->lmh[cb]; hg.N = Vp; hg.K = p.hidden; hg.x = b->h; hg.x_stride = b->Hm;
-        hg.norm_w = c->wt.predictor_final_norm; hg.y = lg; hg.y_stride = (int)lstride;
+        hg.norm_w = c->wt.predictor_final_norm; hg.y = lg; hg.y_stride = (int)lstride; hg.xn_ws = b->xn;
         if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, hg, s)) return r;
         const T* next_emb = cb + 1 < G - 1 ? (const T*)c->pemb[cb] : nullptr;
         if (Vp <= 2048) hipLaunchKernelGGL((sample_pred_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, tab, lf, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);
@@ -528,7 +550,7 @@ static int enqueue_batch_frame_t(fq3_batch* b, hipStream_t s) {
     if (int r = run_stack_batch<T>(b, src, s)) return r;
     BatchGemvArgs g{};
     g.B = B; g.eps = t.rms_eps; g.W = c->wt.codec_head; g.N = t.vocab; g.K = H; g.x = b->h; g.x_stride = b->Hm;
-    g.norm_w = c->wt.talker_final_norm; g.y = b->logits; g.y_stride = t.vocab;
+    g.norm_w = c->wt.talker_final_norm; g.y = b->logits; g.y_stride = t.vocab; g.xn_ws = b->xn;
     g.xn_out = b->d_tab->past_hidden;                  // (an address inside the device table: never dereferenced on the host)
     if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, g, s)) return r;
     if (t.vocab <= 2048) hipLaunchKernelGGL((sample_talker_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, tab, lf, (const T*)b->logits, t.vocab, G);
@@ -559,6 +581,7 @@ static int enqueue_batch_frame(fq3_batch* b, hipStream_t s) {
     g_batch_mfma = b->use_mfma;
     g_batch_skinny = b->use_skinny;
     g_batch_norm_dual = b->norm_dual;
+    g_batch_norm_skinny = b->norm_skinny;
     return b->lanes[0]->cfg.dtype == FQ3_BF16 ? enqueue_batch_frame_t<bf16_t>(b, s) : enqueue_batch_frame_t<float>(b, s);
 }
 

@@ -85,12 +85,14 @@ def _arm_forced(eng, cfg, case, tie, tth, tpe):
     return int(tok0), forced, dec
 
 
-def _run_batch(engines, cfg, cases, B, mfma, graph=True):
+def _run_batch(engines, cfg, cases, B, mfma, graph=True, options=()):
     from fq3hip.engine import Fq3Batch
     from oracle import teacher_forced as TF
     lanes = engines[:B]
     batch = Fq3Batch(lanes)
     batch.set_option("mfma", mfma)
+    for k, v in options:
+        batch.set_option(k, v)
     armed = []
     for i, e in enumerate(lanes):
         case, tie, tth, tpe = cases[i % len(cases)]
@@ -126,8 +128,19 @@ def test_batch_full_depth_bf16_mfma_lanes_vs_oracle(size, golden_dir):
     engines = [first] + [Fq3Engine(cfg, first.weights, device="cuda", dtype=dtype, max_seq_len=seq, max_frames=frames, share=first) for _ in range(127)]
     for e in engines:
         e.set_predictor_sampling(do_sample=False, top_k=0, top_p=1.0, temperature=1.0)
+    per_lane_32 = None
     for B in (8, 16, 32, 64, 128):
+        if B == 128:
+            # the panel kernels' rolled-loop instantiations (five to eight tiles) at the real shapes: a lane's arithmetic does not depend on
+            # the tile count, so its counts are EXACTLY those it has in the 32-lane batch
+            panel = _run_batch(engines, cfg, cases, B, mfma=1, options=(("norm_skinny", 0),))
+            got = [s["matched_decisions"] for s in panel]
+            _note(f"{size}_bf16_mfma_B{B}_panel_kernels", dict(per_lane=got))
+            assert all(s["unexplained"] == 0 for s in panel)
+            assert got == [per_lane_32[i % len(cases)] for i in range(B)], got
         scores = _run_batch(engines, cfg, cases, B, mfma=1)
+        if B == 32:
+            per_lane_32 = [s["matched_decisions"] for s in scores]
         tot = sum(s["total"] for s in scores); ok = sum(s["matched_decisions"] for s in scores)
         worst = max(s["worst_mismatch_ulp"] for s in scores)
         print(f"[parity] batch {size} bf16 mfma B={B}: {ok}/{tot} decisions identical, worst mismatch margin {worst} ulps, "
