@@ -93,6 +93,8 @@ def _run_batch(engines, cfg, cases, B, mfma, graph=True, options=()):
     batch.set_option("mfma", mfma)
     for k, v in options:
         batch.set_option(k, v)
+    if os.environ.get("FQ3_TEST_NORM_SKINNY_ABOVE") is not None:      # development: where the weight-stationary form would start
+        batch.set_option("norm_skinny_above", int(os.environ["FQ3_TEST_NORM_SKINNY_ABOVE"]))
     armed = []
     for i, e in enumerate(lanes):
         case, tie, tth, tpe = cases[i % len(cases)]

@@ -48,6 +48,8 @@ def main():
             batch.set_option("skinny", skinny)
         if G is not None:
             batch.set_option("groups", G)
+        if os.environ.get("FQ3_BENCH_NORM_SKINNY_ABOVE") is not None:
+            batch.set_option("norm_skinny_above", int(os.environ["FQ3_BENCH_NORM_SKINNY_ABOVE"]))
         if os.environ.get("FQ3_BENCH_NORM_SKINNY") is not None:       # A/B: 0 = the panel kernels above 64 lanes as well
             batch.set_option("norm_skinny", int(os.environ["FQ3_BENCH_NORM_SKINNY"]))
         if graph:
