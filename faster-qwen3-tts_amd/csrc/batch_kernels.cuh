@@ -144,7 +144,7 @@ struct BatchGemvArgs {
     int group;                                     // VALU kernel: tokens per LDS pass (1..kGroupLanes; the launcher sizes the LDS for it)
     void* const* xn_out;                           // optional per-lane copy of the prepared token (codec_head -> past_hidden): a device table, or null
     int ntiles;                                    // token tiles of 16 lanes (the matrix-core kernels' runtime-count variants, NT = 0)
-    void* xn_ws;                                   // [B][K] workspace for pre-normalised tokens (above 64 lanes: rmsnorm_batch_kernel + weight-stationary GEMM), or null
+    void* xn_ws;                                   // [B][K] workspace for pre-normalised tokens (above 32 lanes: rmsnorm_batch_kernel + weight-stationary GEMM), or null
 };
 
 // One row per wave (4 rows per workgroup), weight rows loaded ONCE; the B <= kMaxLanes tokens pass through LDS in groups of
@@ -344,14 +344,17 @@ __device__ __forceinline__ u32x4 norm8_pack(const float (&x)[8], float rs, const
     return u32x4{o[0], o[1], o[2], o[3]};
 }
 
-// Above 64 lanes the normalising GEMVs (qkv, gate | up, heads) stop paying for themselves: every one of their 192-256 workgroups
+// Above 32 lanes the normalising GEMVs (qkv, gate | up, heads) stop paying for themselves: every one of their 192-256 workgroups
 // normalises ALL the batch's tokens and walks the token tiles one pair after the other (19.6 / 21.2 us per launch at 128 lanes,
-// 54 % of the frame, profiles/r04_batch128_kernel_trace.txt).  There the tokens are normalised ONCE by this kernel -- one wave per
+// 54 % of the frame, profiles/r04_batch128_panel_kernel_trace.txt).  There the tokens are normalised ONCE by this kernel -- one wave per
 // token, the very operations of gemv_batch_mfma_norm_kernel's prologue in the same order (a lane owns 8 consecutive elements of
 // every 512-chunk, one sequential fma chain, wave_sum): the rows are bit-identical to the panels that kernel builds -- and the GEMM
 // runs on the prefill's weight-stationary kernel (skinny_gemm.cuh: SK_STORE / SK_SWIGLU), which streams token tiles past
 // register-resident weight rows on every CU.  Only the fp32 summation order of the products changes (8 waves x two chains instead
-// of 4 waves x one), which is why the switch sits at a lane count of its own: up to 64 lanes nothing moves.
+// of 4 waves x one), which is why the switch sits at a lane count of its own: up to 32 lanes -- the configurations whose parity floors
+// were frozen in round 3 -- nothing moves.  Measured (profiles/r04_batch_norm_skinny.txt): 0.6B 48 lanes 5.18 -> 4.99 ms per frame, 64 lanes
+// 5.79 -> 5.14, 128 lanes 8.39 -> 6.21; 1.7B 64 lanes 7.37 -> 5.93, 128 lanes 11.1 -> 7.48; at 16 / 32 lanes the panel kernels win (3.87 vs 4.54,
+// 4.43 vs 4.72 ms).
 template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_batch_kernel(const bf16_t* __restrict__ x, int x_stride, const bf16_t* __restrict__ norm_w, float eps,
                                                             int K, int B, bf16_t* __restrict__ y, int y_stride, void* const* xn_out) {

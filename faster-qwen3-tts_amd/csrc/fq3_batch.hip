@@ -39,9 +39,9 @@ struct fq3_batch {
     hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr;
     std::vector<void*> allocs;
-    void* xn = nullptr;           // [B][Hm]: pre-normalised tokens of the weight-stationary form of the normalising GEMVs (above 64 lanes)
+    void* xn = nullptr;           // [B][Hm]: pre-normalised tokens of the weight-stationary form of the normalising GEMVs (above 32 lanes)
     int norm_skinny = 1;          // above norm_skinny_above lanes: qkv / gate | up / heads as rmsnorm_batch_kernel + skinny_gemm_kernel ("norm_skinny" 0: the panel kernels at every lane count)
-    int norm_skinny_above = 4 * kTokTile;
+    int norm_skinny_above = 2 * kTokTile;       // measured (profiles/r04_batch_norm_skinny.txt): the panel kernels win up to 32 lanes, the weight-stationary form from 48
     int norm_dual = 1;            // 17..32 lanes, hidden <= 1024: the normalising GEMVs prepare both token tiles before the first MFMA (bit-identical; "norm_dual" 0 = one panel, tile by tile)
     int use_skinny = 1;           // above 16 lanes the two residual GEMVs of a layer (o_proj, down) run on the weight-stationary prefill kernel
     int use_mfma = 0;             // bf16 GEMVs on the matrix cores: default ON for bf16 (ids verified against the oracle by teacher forcing
@@ -152,7 +152,8 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
 // follows the BATCH's lane count, not the group's (a last group of a few lanes must not change its lanes' summation order)
 static void sync_kid_options(fq3_batch* b) {
     for (fq3_batch* k : b->kids) {
-        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma; k->norm_skinny = b->norm_skinny; k->norm_skinny_above = b->norm_skinny_above;
+        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma; k->norm_skinny = b->norm_skinny;
+        k->norm_skinny_above = b->B > b->norm_skinny_above ? 0 : (1 << 30);      // the BATCH's lane count decides, as for "skinny"
         k->use_skinny = (b->use_skinny == 1 && b->B > kTokTile) ? 2 : b->use_skinny;
     }
 }
@@ -274,8 +275,8 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
 extern "C" int fq3_batch_set_option(fq3_batch* b, const char* key, int value) {
     if (!b || !key) return fq3_fail_(FQ3_EINVAL, "null argument");
     if (std::string(key) == "norm_dual") b->norm_dual = value;
-    else if (std::string(key) == "norm_skinny_above") b->norm_skinny_above = value;   // the lane count above which "norm_skinny" applies (default 64; measurement switch)
-    else if (std::string(key) == "norm_skinny") b->norm_skinny = value;   // above 64 lanes: the normalising GEMVs as pre-normalise + weight-stationary GEMM (default 1)
+    else if (std::string(key) == "norm_skinny_above") b->norm_skinny_above = value;   // the lane count above which "norm_skinny" applies (default 32; measurement switch)
+    else if (std::string(key) == "norm_skinny") b->norm_skinny = value;   // above 32 lanes: the normalising GEMVs as pre-normalise + weight-stationary GEMM (default 1)
     else if (std::string(key) == "skinny") b->use_skinny = value;  // o_proj / down of 17..32 lanes on skinny_gemm_kernel (default 1); 0: gemv_batch_mfma_plain_kernel;
                                                               // 2: at every lane count (a measurement switch: below 17 lanes the kernel's two-tile group is half empty)
     else if (std::string(key) == "mfma") b->use_mfma = value;      // bf16 GEMVs on the matrix cores (fp32 summation order differs from the single-stream kernels)
@@ -334,11 +335,11 @@ static int launch_gemv_batch_t(BatchGemvArgs a, int esz, hipStream_t s) {
 // matrix-core variants: bf16, built step counts; return -1000 when the shape is not covered (the VALU kernel takes over)
 static thread_local int g_batch_norm_dual = 1;   // set per enqueue from fq3_batch::norm_dual
 static thread_local int g_batch_norm_skinny = 1; // set per enqueue from fq3_batch::norm_skinny
-static thread_local int g_batch_norm_skinny_above = 4 * kTokTile;
+static thread_local int g_batch_norm_skinny_above = 2 * kTokTile;
 template <int EPI>
 static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
     if (a.K % 128) return -1000;
-    // above 64 lanes (five token tiles and more): normalise once, then the weight-stationary GEMM (batch_kernels.cuh::rmsnorm_batch_kernel)
+    // above 32 lanes (three token tiles and more): normalise once, then the weight-stationary GEMM (batch_kernels.cuh::rmsnorm_batch_kernel)
     const int n_w = EPI == EPI_SWIGLU ? 2 * a.N : a.N;                  // weight rows: [gate | up] for SwiGLU
     if (g_batch_norm_skinny && a.xn_ws && a.B > g_batch_norm_skinny_above && !a.bias && skinny_k_ok(a.K) && a.K <= 2048 && n_w % 32 == 0 &&
         a.x_stride % 8 == 0 && a.y_stride % 4 == 0 && (EPI == EPI_STORE || EPI == EPI_SWIGLU)) {

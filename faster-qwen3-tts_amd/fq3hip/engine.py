@@ -495,7 +495,7 @@ class Fq3Batch:
 
     def set_option(self, key: str, value: int):
         """``fq3_batch_set_option``: "mfma" 0|1 (matrix-core batch GEMVs, bf16), "skinny" 0|1 (o_proj / down of 17..32 lanes on
-        the weight-stationary prefill kernel), "groups" 0..4 (lane groups advanced concurrently; 0 = automatic), "norm_skinny" 0|1 (above 64 lanes: normalise once + weight-stationary
+        the weight-stationary prefill kernel), "groups" 0..4 (lane groups advanced concurrently; 0 = automatic), "norm_skinny" 0|1 (above 32 lanes: normalise once + weight-stationary
         GEMM for qkv / gate | up / heads)."""
         L.check(self.lib.fq3_batch_set_option(self.handle, key.encode(), int(value)))
 

@@ -304,8 +304,9 @@ int fq3_batch_poll_wait(fq3_batch* b, int slot, int* n_frames_total, int* done);
  * "skinny" 0|1 (with "mfma" 1, more than 16 lanes): o_proj / down through the weight-stationary kernel of the short-prompt prefill
  * (default 1) or through the one-row-block-per-workgroup batch GEMV (0); 2 takes the weight-stationary kernel at every lane count
  * (measurement switch).
- * "norm_skinny" 0|1 (more than 64 lanes): the normalising GEMVs (qkv, gate | up, heads) as ONE normalisation launch + the
- * weight-stationary GEMM kernel (default 1) or as the per-workgroup-panel kernels of the lower lane counts (0).
+ * "norm_skinny" 0|1 (more than 32 lanes): the normalising GEMVs (qkv, gate | up, heads) as ONE normalisation launch + the
+ * weight-stationary GEMM kernel (default 1) or as the per-workgroup-panel kernels of the lower lane counts (0);
+ * "norm_skinny_above" n moves that lane count (measurement switch).
  * "groups" 0..4: LANE GROUPS (a measurement switch).  The lanes split into that many independent lock-step chains of whole 16-lane
  * tiles, each with its own frame graph, advanced concurrently on streams the library probes for a hardware queue of their own (they
  * fork from / join `stream` inside fq3_batch_frames, so the caller sees one stream as before); 0 (default) = automatic = ONE chain:
