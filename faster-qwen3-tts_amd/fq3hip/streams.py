@@ -29,6 +29,14 @@ def concurrent_stream(device, priority: Optional[int] = None, tries: int = 8, be
     dev = torch.device(device) if not isinstance(device, torch.device) else device
     main = torch.cuda.current_stream(dev)
     others = [s for s in beside if s is not None and s != main]
+    # the probe synchronises the device and creates streams: never while ANOTHER thread captures a hipGraph (several model instances
+    # warming up side by side -- the capture would be invalidated: "operation failed due to a previous error during capture")
+    from .engine import _CAPTURE_LOCK
+    with _CAPTURE_LOCK:
+        return _probe(dev, main, others, priority, tries)
+
+
+def _probe(dev, main, others, priority, tries):
     cand, beside_main = None, None
     for _ in range(max(1, tries)):
         cand = torch.cuda.Stream(device=dev) if priority is None else torch.cuda.Stream(device=dev, priority=int(priority))
