@@ -8,7 +8,7 @@ objects hold a single static context.  Here there are two schedulers:
 * ``lock``   one request at a time, audio streamed chunk by chunk as it is generated (the reference's behaviour);
 * ``batch``  a worker thread owns the model and runs the continuous-batching decoder (``fq3hip/batching.py`` over
              ``fq3_batch_*``): requests that arrive while others are decoding join at the next frame boundary, up to
-             ``lanes`` (<= 64) utterances advance in lock-step over ONE pass of the weights per frame; each response is
+             ``lanes`` (<= 128) utterances advance in lock-step over ONE pass of the weights per frame; each response is
              sent when its utterance finishes.
 
 ``create_app(model, voices, ...)`` is the testable core; ``main()`` is the command line (same flags as the reference plus
