@@ -148,6 +148,7 @@ extern "C" int fq3_batch_destroy(fq3_batch* b) {
 static int auto_groups(int B) { (void)B; return 1; }
 
 static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bool is_kid);
+static int poll_prepare(fq3_batch* b);
 // a lane group runs the kernels the whole batch would run: the choice "above 16 lanes o_proj / down take the weight-stationary kernel"
 // follows the BATCH's lane count, not the group's (a last group of a few lanes must not change its lanes' summation order)
 static void sync_kid_options(fq3_batch* b) {
@@ -185,6 +186,7 @@ extern "C" int fq3_batch_create(fq3_ctx* const* lanes, int n_lanes, fq3_batch** 
     fq3_batch* b = nullptr;
     if (int r = batch_create_(lanes, n_lanes, &b, false)) return r;
     if (b->use_mfma) if (int r = build_groups(b, auto_groups(b->B))) { fq3_batch_destroy(b); return r; }
+    if (int r = poll_prepare(b)) { fq3_batch_destroy(b); return r; }        // the poll slots exist before the first frame: no allocation under a running batch
     *out = b;
     return FQ3_OK;
 }

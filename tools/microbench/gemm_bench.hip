@@ -212,26 +212,26 @@ int main(int argc, char** argv) {
     if (argc > 2) {        // variant sweep on 4096 x 4096 x 4096: tile shape x prefetch depth
         const int M = 4096, N = 4096, K = 4096;
         void *A, *W, *Y;
-        hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&W, (size_t)N * K * 2); hipMalloc(&Y, (size_t)M * N * 2);
-        hipMemset(A, 0x3c, (size_t)M * K * 2); hipMemset(W, 0x3c, (size_t)N * K * 2);
+        (void)hipMalloc(&A, (size_t)M * K * 2); (void)hipMalloc(&W, (size_t)N * K * 2); (void)hipMalloc(&Y, (size_t)M * N * 2);
+        (void)hipMemset(A, 0x3c, (size_t)M * K * 2); (void)hipMemset(W, 0x3c, (size_t)N * K * 2);
         GemmArgs a{};
         a.A = A; a.lda = K; a.M = M; a.a_rows = M; a.n_taps = 1; a.Cin = K; a.W = W; a.N = N; a.bias_mod = N; a.Y = Y; a.ldy = N;
         auto run = [&](const char* name, auto kern, int bm, int bn) {
             dim3 grid((N + bn - 1) / bn, (M + bm - 1) / bm);
             hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, a);
-            hipStreamSynchronize(s);
-            hipEventRecord(e0, s);
+            (void)hipStreamSynchronize(s);
+            (void)hipEventRecord(e0, s);
             for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, a);
-            hipEventRecord(e1, s); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+            (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
             printf("%-28s %9.3f us  %8.1f TFLOP/s\n", name, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
         };
         auto rung = [&](const char* name, auto go) {
-            go(a, s); hipStreamSynchronize(s);
-            hipEventRecord(e0, s);
+            go(a, s); (void)hipStreamSynchronize(s);
+            (void)hipEventRecord(e0, s);
             for (int r = 0; r < reps; ++r) go(a, s);
-            hipEventRecord(e1, s); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+            (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
             printf("%-28s %9.3f us  %8.1f TFLOP/s\n", name, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
         };
         {   // big tile vs the register-staged kernel on random operands: must agree bit for bit (same MFMA chain per element)
@@ -240,31 +240,31 @@ int main(int argc, char** argv) {
             auto rnd = [&]() { x = x * 1664525u + 1013904223u; return x >> 16; };
             for (auto& v : ha) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 128.f);
             for (auto& v : hw) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 1024.f);
-            hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice); hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
-            void* Y2; hipMalloc(&Y2, (size_t)M * N * 2);
+            (void)hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice); (void)hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+            void* Y2; (void)hipMalloc(&Y2, (size_t)M * N * 2);
             glds_go<64, 2>(a, s);
             GemmArgs b = a; b.Y = Y2;
             big_go(b, s);
-            hipStreamSynchronize(s);
+            (void)hipStreamSynchronize(s);
             std::vector<uint16_t> y1((size_t)M * N), y2((size_t)M * N);
-            hipMemcpy(y1.data(), Y, y1.size() * 2, hipMemcpyDeviceToHost); hipMemcpy(y2.data(), Y2, y2.size() * 2, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(y1.data(), Y, y1.size() * 2, hipMemcpyDeviceToHost); (void)hipMemcpy(y2.data(), Y2, y2.size() * 2, hipMemcpyDeviceToHost);
             size_t bad = 0, first = 0;
             for (size_t i = 0; i < y1.size(); ++i) if (y1[i] != y2[i]) { if (!bad) first = i; ++bad; }
             printf("big 256x256 vs glds 128x64 on random operands: %zu / %zu elements differ%s\n", bad, y1.size(), bad ? "  <-- MISMATCH" : " (bit-identical)");
             if (bad) printf("  first at row %zu col %zu: %04x vs %04x\n", first / N, first % N, y1[first], y2[first]);
             {   // the 256 x 128 variant on the same operands
                 big_go_t<true, 128>(b, s);
-                hipStreamSynchronize(s);
-                hipMemcpy(y2.data(), Y2, y2.size() * 2, hipMemcpyDeviceToHost);
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(y2.data(), Y2, y2.size() * 2, hipMemcpyDeviceToHost);
                 size_t bad2 = 0;
                 for (size_t i = 0; i < y1.size(); ++i) bad2 += y1[i] != y2[i];
                 printf("big 256x128 vs glds 128x64 on random operands: %zu / %zu elements differ%s\n", bad2, y1.size(), bad2 ? "  <-- MISMATCH" : " (bit-identical)");
             }
-            hipFree(Y2);
+            (void)hipFree(Y2);
             rung("big 256x128 ring-4 (random)", big_go_t<true, 128>);
             rung("big 256x256 ring-4 (random)", big_go<bf16_t>);
             rung("glds 128x64 2 st (random)", glds_go<64, 2>);
-            hipMemset(A, 0x3c, (size_t)M * K * 2); hipMemset(W, 0x3c, (size_t)N * K * 2);
+            (void)hipMemset(A, 0x3c, (size_t)M * K * 2); (void)hipMemset(W, 0x3c, (size_t)N * K * 2);
         }
         rung("big 256x256 ring-4", big_go<bf16_t>);
         rung("glds 128x64 2 stages", glds_go<64, 2>);
@@ -289,24 +289,24 @@ int main(int argc, char** argv) {
         for (auto& v : ha) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 128.f);
         for (auto& v : hw) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 1024.f);
         void *A, *W, *Y;
-        hipMalloc(&A, na * 2); hipMalloc(&W, nw * 2); hipMalloc(&Y, ny * 2);
-        hipMemcpy(A, ha.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(W, hw.data(), nw * 2, hipMemcpyHostToDevice);
+        (void)hipMalloc(&A, na * 2); (void)hipMalloc(&W, nw * 2); (void)hipMalloc(&Y, ny * 2);
+        (void)hipMemcpy(A, ha.data(), na * 2, hipMemcpyHostToDevice); (void)hipMemcpy(W, hw.data(), nw * 2, hipMemcpyHostToDevice);
         GemmArgs a{};
         a.A = A; a.lda = sh.Cin; a.M = sh.M; a.a_rows = sh.M; a.n_taps = sh.taps; a.Cin = sh.Cin; a.W = W; a.N = sh.N;
         for (int i = 0; i < sh.taps; ++i) a.tap_off[i] = -(sh.taps - 1 - i) * sh.dil;
         a.bias_mod = sh.N; a.Y = Y; a.ldy = sh.N;
         void* ws = nullptr;
-        if (sh.ws) { hipMalloc(&ws, (size_t)(8 << 20) * 4); a.ws = (float*)ws; a.ws_floats = 8 << 20; }
+        if (sh.ws) { (void)hipMalloc(&ws, (size_t)(8 << 20) * 4); a.ws = (float*)ws; a.ws_floats = 8 << 20; }
         gemm_launch<bf16_t>(a, s);
-        hipStreamSynchronize(s);
-        hipEventRecord(e0, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipEventRecord(e0, s);
         for (int r = 0; r < reps; ++r) gemm_launch<bf16_t>(a, s);
-        hipEventRecord(e1, s);
-        hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
         // spot check of 16 outputs against a host dot product
         std::vector<uint16_t> hy(ny);
-        hipMemcpy(hy.data(), Y, ny * 2, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hy.data(), Y, ny * 2, hipMemcpyDeviceToHost);
         double maxerr = 0;
         for (int t = 0; t < 16; ++t) {
             const int m = (int)(((uint64_t)t * 7919 + 13) % sh.M), n = (int)(((uint64_t)t * 104729 + 7) % sh.N);
@@ -323,7 +323,7 @@ int main(int argc, char** argv) {
         const double fl = 2.0 * sh.M * sh.N * K;
         printf("%-24s M=%7d N=%5d K=%5zu  %9.3f us  %8.1f TFLOP/s  check %.2e %s\n", sh.name, sh.M, sh.N, K, ms * 1e3, fl / (ms * 1e-3) / 1e12,
                maxerr, maxerr < 2e-2 ? "ok" : "MISMATCH");
-        hipFree(A); hipFree(W); hipFree(Y); if (ws) hipFree(ws);
+        (void)hipFree(A); (void)hipFree(W); (void)hipFree(Y); if (ws) (void)hipFree(ws);
     }
     return 0;
 }
