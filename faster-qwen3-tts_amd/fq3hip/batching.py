@@ -391,17 +391,29 @@ class BatchDecoder:
         prof = self.host_s = {"stage": 0.0, "admit": 0.0, "queue": 0.0, "poll_wait": 0.0, "digest": 0.0, "consumer": 0.0}
         clock = time.perf_counter
 
-        # requests taken from the source / staged per batch of frames while lanes decode: enough for the spare contexts to be full again
-        # by the time a wave of utterances ends (lanes / 16 per poll refills every lane within 16 polls = 128 frames; two per poll -- the
-        # rule up to round 3 -- starves a scheduler of more than ~50 lanes at 200-frame utterances: 128 lanes ran half empty), yet few
-        # enough that the host work of one poll stays well inside the batch of frames queued ahead
+        # Requests taken from the source / staged per batch of frames while lanes decode.  A floor that keeps long utterances flowing
+        # (lanes / 16 per poll refills every lane within 16 polls = 128 frames; two per poll -- the rule up to round 3 -- starves a
+        # scheduler of more than ~50 lanes at 200-frame utterances: 128 lanes ran half empty), topped up by DEMAND: lanes that are
+        # free now, lanes whose frame limit falls within the next four polls, and the recent rate of early (EOS) finishes, minus what
+        # is staged already -- at most a quarter of the lanes per poll, so that the host work of one poll stays inside the batch of
+        # frames queued ahead.  Short utterances (a 48-lane scheduler of 40-frame utterances turns over every 5 polls) are what
+        # needs the top-up.
         per_poll = max(2, (len(self.lanes) + 15) // 16)
+        per_poll_cap = max(per_poll, len(self.lanes) // 4)
+        finish_rate = [0.0]                                             # finishes per poll, exponentially averaged
+
+        def stage_limit():
+            """Requests to stage in this poll (the source is asked for what `pending` does not hold already)."""
+            horizon = 4 * self.poll_every
+            soon = sum(1 for ln in active if ln.max_frames - ln.issued <= horizon)
+            need = len(free) + soon + int(finish_rate[0] + 0.999) - len(ready)
+            return max(per_poll, min(need, per_poll_cap))
 
         def pull():
             # while lanes decode, at most two new requests per frame boundary: whatever the source does to produce one (a
             # model's prompt build, say) runs on the host between two batches of queued frames.  Before anything decodes: only
             # what the first wave can take (one request per lane) -- every further prompt built now would delay the first frame
-            budget = max(0, len(self.lanes) - len(pending) - len(ready)) if not active else per_poll
+            budget = max(0, len(self.lanes) - len(pending) - len(ready)) if not active else max(0, stage_limit() - len(pending))
             while source is not None and budget > 0 and len(pending) < len(self.lanes) + len(self.stages):
                 # with spare contexts the source runs under the PREFILL stream: whatever device work it does to produce a request (a
                 # model's prompt build) neither queues behind the lock-step frames in flight nor -- where it waits for a value --
@@ -529,6 +541,7 @@ class BatchDecoder:
                     free.append(ln)
                 else:
                     still.append(ln)
+            finish_rate[0] = 0.5 * finish_rate[0] + 0.5 * (len(active) - len(still))
             active = still
 
         while True:
@@ -612,7 +625,7 @@ class BatchDecoder:
             prof["consumer"] += clock() - t_
             if self.stages and active:
                 t_ = clock()
-                stage_ahead(limit=per_poll)                           # prefills fly under the frames queued above
+                stage_ahead(limit=stage_limit())      # prefills fly under the frames queued above
                 prof["stage"] += clock() - t_
             # wait for the oldest batch; for ALL of them when a lane's frame limit falls in the newest (a finish is expected: queuing
             # past it would burn frames on idle lanes) or when nothing more could be queued

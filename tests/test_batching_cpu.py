@@ -314,3 +314,48 @@ def test_look_ahead_keeps_a_batch_of_frames_queued_but_never_past_a_known_finish
     reqs = [_req(3, 200, eos_after=5), _req(4, 16), _req(5, 24)]
     out = {rid: c.shape[0] for rid, c, _t in dec.run(reqs)}
     assert out == {3: 5, 4: 16, 5: 24}
+
+
+def test_staging_keeps_a_wide_scheduler_full(monkeypatch):
+    """The requests staged per batch of frames scale with the lane count (max(2, lanes / 16)): with two per poll -- the rule up to
+    round 3 -- a 48-lane scheduler refilled ~10 lanes per 40-frame wave and ran mostly empty (measured on the GPU at 128 lanes: 533x
+    instead of 817x end to end).  Three waves of 48 fixed-length utterances must take little more than three waves of frames."""
+    log = []
+
+    class Eng(FakeLaneEngine):
+        def kv_adopt(self, src, n_rows):
+            pass
+
+    n_lanes, frames, waves = 48, 40, 3
+    lanes = [Eng(log, i) for i in range(n_lanes)]
+    spares = [Eng(log, 100 + i) for i in range(n_lanes)]
+
+    def fake_prefill(eng, tie, tam, config, min_new, temperature, top_k, top_p, do_sample):
+        return 7, torch.zeros(8), tie.shape[1], 0
+
+    def fake_arm(talker, config, token, hidden, n_rows, tam, tth, tpe, pg, tg, max_new, min_new, temperature, top_k, top_p, do_sample, rp, use_graph, n_pad=None):
+        eng = tg.engine
+        cfg = eng.next_cfg
+        eng.frames, eng.budget, eng.eos_after, eng.rid = 0, int(max_new), cfg.eos_after, cfg.rid
+        return eng, torch.zeros(1), torch.zeros(1), int(max_new)
+
+    monkeypatch.setattr(Bt, "_prefill_first_token", fake_prefill)
+    monkeypatch.setattr(Bt, "_prefill_first_tokens_packed", lambda engs, items: [fake_prefill(e, *it) for e, it in zip(engs, items)])
+    monkeypatch.setattr(Bt, "_arm_decode", fake_arm)
+    monkeypatch.setattr(Bt, "_refill", lambda eng, tn, pn: None)
+    monkeypatch.setattr(Bt, "TalkerGraph", lambda e: SimpleNamespace(engine=e))
+    monkeypatch.setattr(Bt, "PredictorGraph", lambda e, **kw: SimpleNamespace(engine=e, **kw))
+    dec = Bt.BatchDecoder(lanes, poll_every=8, batch_factory=LookAheadBatch, staging=spares)
+    orig_admit = dec._admit
+
+    def admit(ln, st):
+        ln.engine.next_cfg = st.req.config
+        return orig_admit(ln, st)
+
+    dec._admit = admit
+    reqs = [_req(i, frames) for i in range(waves * n_lanes)]
+    later = list(reversed(reqs[n_lanes:]))
+    out = {rid: c.shape[0] for rid, c, _t in dec.run(reqs[:n_lanes], source=lambda: later.pop() if later else None)}
+    assert len(out) == waves * n_lanes and set(out.values()) == {frames}
+    total = sum(dec.batch.calls)
+    assert total <= waves * frames + 2 * 8, total          # three full waves; with two requests per poll this took > 400 frames
