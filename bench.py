@@ -490,6 +490,20 @@ def parity_pcm(cfg, model_bf16, model, device):
     return out
 
 
+def frame_rows(per_dispatch, first_name):
+    """[(kernel name, order key, counter value)] in dispatch order -> [(kernel name, dispatches, summed value)] over the dispatches
+    from the first one whose name contains `first_name` on (a frame's first kernel): whatever ran before it -- model set-up, the
+    lanes' prefills -- is not frame traffic even where it shares kernels with the frame."""
+    start = next((i for i, (name, _k, _v) in enumerate(per_dispatch) if first_name in name), None)
+    if start is None:
+        return []
+    acc = {}
+    for name, _k, v in per_dispatch[start:]:
+        n, s = acc.get(name, (0, 0.0))
+        acc[name] = (n + 1, s + float(v))
+    return [(name, n, s) for name, (n, s) in acc.items()]
+
+
 def measure_frame_traffic(timeout_s=300, lanes=0):
     """`lanes` > 0: the lock-step frame of that many lanes (tools/pmc_workload.py batch <lanes>) instead of the single-stream one.
     HBM-side traffic of one decode frame, measured in THIS run: a separate `rocprofv3 --pmc FETCH_SIZE` pass (counters only,
@@ -513,11 +527,17 @@ def measure_frame_traffic(timeout_s=300, lanes=0):
         if not dbs:
             return None, "the counter pass produced no database"
         cur = sqlite3.connect(dbs[0]).cursor()
-        rows = cur.execute("""select s.kernel_name, count(*), sum(e.value) from rocpd_pmc_event e
+        # one row per dispatch, in dispatch order: the lanes' PREFILLS run through some of the frame's kernels too (the
+        # weight-stationary GEMM serves both), so only dispatches from the first frame's first kernel on are frame traffic
+        dcols = [r[1] for r in cur.execute("pragma table_info(rocpd_kernel_dispatch)")]
+        order = next((c for c in ("dispatch_id", "start", "id") if c in dcols), "event_id")
+        per = cur.execute(f"""select s.kernel_name, d.{order}, e.value from rocpd_pmc_event e
                               join rocpd_info_pmc p on e.pmc_id = p.id
                               join rocpd_kernel_dispatch d on e.event_id = d.event_id
                               join rocpd_info_kernel_symbol s on d.kernel_id = s.id
-                              where p.name = 'FETCH_SIZE' group by s.kernel_name""").fetchall()
+                              where p.name = 'FETCH_SIZE' order by d.{order}""").fetchall()
+        first_name = "frame_begin_batch_kernel" if lanes > 0 else "frame_begin_kernel"
+        rows = frame_rows(per, first_name)
         if lanes > 0:
             frame_kernels = ("gemv_batch", "skinny_gemm_kernel", "attn_pred_batch_kernel", "attn_decode_batch_kernel", "combine_batch_kernel",
                              "sample_pred_batch", "sample_talker_batch", "frame_begin_batch_kernel", "embed_sum_batch_kernel")
@@ -969,6 +989,7 @@ def main():
                 tr, how = measure_frame_traffic(lanes=lanes)
                 if tr is not None:
                     out["roofline"]["traffic"] = float(round(tr))
+                    out["roofline"]["traffic_over_algorithmic"] = round(tr / out["roofline"]["algorithmic_bytes_per_launch"], 3)
                     out["roofline"]["traffic_source"] = f"measured in this run: rocprofv3 --pmc FETCH_SIZE over tools/pmc_workload.py batch {lanes} (own pass, x2 gfx950 correction, {how})"
                 else:
                     out["roofline"]["traffic"] = None
@@ -1096,6 +1117,7 @@ def main():
                 traffic, how = measure_frame_traffic()
             if traffic is not None:
                 rl["traffic"] = float(round(traffic))
+                rl["traffic_over_algorithmic"] = round(traffic / rl["algorithmic_bytes_per_launch"], 3)
                 rl["traffic_source"] = f"measured in this run: rocprofv3 --pmc FETCH_SIZE over tools/pmc_workload.py frames (own pass, x2 gfx950 correction, {how})"
             else:
                 rl["traffic"] = 3.455e9

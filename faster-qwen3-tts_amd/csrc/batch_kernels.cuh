@@ -145,6 +145,10 @@ struct BatchGemvArgs {
     void* const* xn_out;                           // optional per-lane copy of the prepared token (codec_head -> past_hidden): a device table, or null
     int ntiles;                                    // token tiles of 16 lanes (the matrix-core kernels' runtime-count variants, NT = 0)
     void* xn_ws;                                   // [B][K] workspace for pre-normalised tokens (above 32 lanes: rmsnorm_batch_kernel + weight-stationary GEMM), or null
+    // RMSNorm folded into the weight-stationary GEMM pair (round 5, skinny_gemm.cuh): a residual GEMV (o_proj, down) leaves the sum of
+    // squares of every row it stores as N / 16 partials per row in `ssq_out`; the normalising GEMV that reads those rows next takes them as
+    // `ssq_in` (null: the rows came from elsewhere -- layer 0 -- and are normalised by rmsnorm_batch_kernel as before)
+    float* ssq_out; const float* ssq_in;
 };
 
 // One row per wave (4 rows per workgroup), weight rows loaded ONCE; the B <= kMaxLanes tokens pass through LDS in groups of
@@ -327,22 +331,6 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(BatchGemvArgs a) {
 // Columns of tokens >= B hold a duplicate of token B - 1 and are never stored (an MFMA column depends on its own B column only).
 // ---------------------------------------------------------------------------------------------------------------
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
-
-// RMSNorm of 8 values straight to packed bf16: bf16(bf16(x * rs) * w), the two roundings of the reference's norm (and of the loop it
-// replaces: same products, same roundings), in 5 VALU operations per value instead of 8 -- packed fp32 multiplies (v_pk_mul_f32:
-// IEEE products, two per instruction) and no unpack / re-pack round trip after the second rounding.  The normalisation prologue is
-// VALU time every workgroup spends on every token (~1700 instructions per wave at 32 lanes x K = 1024).
-__device__ __forceinline__ u32x4 norm8_pack(const float (&x)[8], float rs, const float (&w)[8]) {
-    uint32_t o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const fq3_f32x2 p = fq3_f32x2{x[2 * i], x[2 * i + 1]} * fq3_f32x2{rs, rs};
-        const uint32_t u = pack_bf16x2(p.x, p.y);
-        const fq3_f32x2 q = fq3_f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)} * fq3_f32x2{w[2 * i], w[2 * i + 1]};
-        o[i] = pack_bf16x2(q.x, q.y);
-    }
-    return u32x4{o[0], o[1], o[2], o[3]};
-}
 
 // Above 32 lanes the normalising GEMVs (qkv, gate | up, heads) stop paying for themselves: every one of their 192-256 workgroups
 // normalises ALL the batch's tokens and walks the token tiles one pair after the other (19.6 / 21.2 us per launch at 128 lanes,

@@ -39,6 +39,9 @@ struct fq3_batch {
     hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr;
     std::vector<void*> allocs;
+    const float* h_ssq = nullptr; // set by run_stack_batch: the partials of what it left in `h` (null: none)
+    float* ssq = nullptr;         // [B][Hm / 16]: sum-of-squares partials of the rows of `h` (written by the o_proj / down epilogues, read by the next normalising GEMM)
+    int norm_fused = 1;           // above norm_skinny_above lanes: the RMSNorm of qkv / gate | up / lm heads inside the weight-stationary GEMM ("norm_fused" 0: rmsnorm_batch_kernel + GEMM, the round-4 form)
     void* xn = nullptr;           // [B][Hm]: pre-normalised tokens of the weight-stationary form of the normalising GEMVs (above 32 lanes)
     int norm_skinny = 1;          // above norm_skinny_above lanes: qkv / gate | up / heads as rmsnorm_batch_kernel + skinny_gemm_kernel ("norm_skinny" 0: the panel kernels at every lane count)
     int norm_skinny_above = 2 * kTokTile;       // measured (profiles/r04_batch_norm_skinny.txt): the panel kernels win up to 32 lanes, the weight-stationary form from 48
@@ -153,7 +156,7 @@ static int poll_prepare(fq3_batch* b);
 // follows the BATCH's lane count, not the group's (a last group of a few lanes must not change its lanes' summation order)
 static void sync_kid_options(fq3_batch* b) {
     for (fq3_batch* k : b->kids) {
-        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma; k->norm_skinny = b->norm_skinny;
+        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma; k->norm_skinny = b->norm_skinny; k->norm_fused = b->norm_fused;
         k->norm_skinny_above = b->B > b->norm_skinny_above ? 0 : (1 << 30);      // the BATCH's lane count decides, as for "skinny"
         k->use_skinny = (b->use_skinny == 1 && b->B > kTokTile) ? 2 : b->use_skinny;
     }
@@ -227,7 +230,7 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
     int r;
     auto A = [&](void** ptr, size_t n) { return bmalloc(b, ptr, n); };
     if ((r = A(&b->h, (size_t)B * b->Hm * esz)) || (r = A(&b->xin, (size_t)B * b->Hm * esz)) ||
-        (r = A(&b->xn, (size_t)B * b->Hm * esz)) || (r = A(&b->qkv, (size_t)B * b->qkvm * esz)) || (r = A(&b->act, (size_t)B * b->Im * esz)) ||
+        (r = A(&b->xn, (size_t)B * b->Hm * esz)) || (r = A((void**)&b->ssq, (size_t)B * (b->Hm / 16 + 4) * sizeof(float))) || (r = A(&b->qkv, (size_t)B * b->qkvm * esz)) || (r = A(&b->act, (size_t)B * b->Im * esz)) ||
         (r = A(&b->attn_out, (size_t)B * b->qkvm * esz)) || (r = A(&b->logits, (size_t)B * Vm * esz)) ||
         (r = A(&b->pred_in, (size_t)B * 2 * t.hidden * esz)) || (r = A(&b->pred_x, (size_t)B * p.hidden * esz)) ||
         (r = A(&b->pred_next, (size_t)B * t.hidden * esz)) || (r = A(&b->plogits, (size_t)B * (G - 1) * p.vocab * esz))) {
@@ -277,6 +280,7 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
 extern "C" int fq3_batch_set_option(fq3_batch* b, const char* key, int value) {
     if (!b || !key) return fq3_fail_(FQ3_EINVAL, "null argument");
     if (std::string(key) == "norm_dual") b->norm_dual = value;
+    else if (std::string(key) == "norm_fused") b->norm_fused = value;     // RMSNorm inside the weight-stationary GEMM (default 1; 0 = the separate normalisation launch of round 4)
     else if (std::string(key) == "norm_skinny_above") b->norm_skinny_above = value;   // the lane count above which "norm_skinny" applies (default 32; measurement switch)
     else if (std::string(key) == "norm_skinny") b->norm_skinny = value;   // above 32 lanes: the normalising GEMVs as pre-normalise + weight-stationary GEMM (default 1)
     else if (std::string(key) == "skinny") b->use_skinny = value;  // o_proj / down of 17..32 lanes on skinny_gemm_kernel (default 1); 0: gemv_batch_mfma_plain_kernel;
@@ -345,6 +349,16 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
     const int n_w = EPI == EPI_SWIGLU ? 2 * a.N : a.N;                  // weight rows: [gate | up] for SwiGLU
     if (g_batch_norm_skinny && a.xn_ws && a.B > g_batch_norm_skinny_above && !a.bias && skinny_k_ok(a.K) && a.K <= 2048 && n_w % 32 == 0 &&
         a.x_stride % 8 == 0 && a.y_stride % 4 == 0 && (EPI == EPI_STORE || EPI == EPI_SWIGLU)) {
+        if (a.ssq_in && !a.xn_out && skinny_norm_ok(a.K, a.B)) {
+            // the rows' sum-of-squares partials came with them (the residual GEMM that stored them): normalise inside the GEMM
+            SkinnyArgs k{};
+            k.X = reinterpret_cast<const bf16_t*>(a.x); k.ldx = a.x_stride; k.M = a.B; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = n_w;
+            k.Y = reinterpret_cast<bf16_t*>(a.y); k.ldy = a.y_stride;
+            k.ssq = a.ssq_in; k.gain = reinterpret_cast<const bf16_t*>(a.norm_w); k.eps = a.eps;
+            if constexpr (EPI == EPI_SWIGLU) skinny_launch<SK_SWIGLU>(k, a.K, s);
+            else skinny_launch<SK_STORE>(k, a.K, s);
+            return 0;
+        }
         bf16_t* xn = reinterpret_cast<bf16_t*>(a.xn_ws);
         const dim3 grid((a.B + 3) / 4);
         if (a.K <= 1024) hipLaunchKernelGGL((rmsnorm_batch_kernel<2>), grid, dim3(256), 0, s, (const bf16_t*)a.x, a.x_stride, (const bf16_t*)a.norm_w, a.eps, a.K, a.B, xn, a.K, a.xn_out);
@@ -399,15 +413,20 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
     }
 }
 static thread_local int g_batch_skinny = 1;      // set per enqueue from fq3_batch::use_skinny
+// does this residual GEMV run on the weight-stationary kernel (whose epilogue can leave the rows' sum-of-squares partials)?
+static bool residual_on_skinny(const BatchGemvArgs& a) {
+    return g_batch_skinny && (a.B > kTokTile || g_batch_skinny >= 2) && !a.bias && skinny_k_ok(a.K) && a.N % 32 == 0 && a.x_stride % 8 == 0 &&
+           a.y_stride % 4 == 0 && a.res_stride % 4 == 0;
+}
 template <int EPI>
 static int launch_gemv_batch_mfma_plain(const BatchGemvArgs& a, hipStream_t s) {
     // 17..32 lanes, residual epilogue (o_proj, down: N = hidden only -- 64 or 128 workgroups of the one-row-block-per-workgroup GEMV, each
     // re-reading every lane's K-long token row): the prefill's weight-stationary kernel splits the two token tiles over workgroups and
     // K over 8 waves with per-wave LDS staging (skinny_gemm.cuh); measured 12.1 -> ~8 us (down) and 9.3 -> ~6.5 us (o_proj) per launch
     if constexpr (EPI == EPI_RESIDUAL) {
-        if (g_batch_skinny && (a.B > kTokTile || g_batch_skinny >= 2) && !a.bias && skinny_k_ok(a.K) && a.N % 32 == 0 && a.x_stride % 8 == 0 && a.y_stride % 4 == 0 &&
-            a.res_stride % 4 == 0) {
+        if (residual_on_skinny(a)) {
             SkinnyArgs k{};
+            k.ssq_out = a.ssq_out; k.ssq_ld = a.N / 16;
             k.X = reinterpret_cast<const bf16_t*>(a.x); k.ldx = a.x_stride; k.M = a.B; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = a.N;
             k.res = reinterpret_cast<const bf16_t*>(a.res); k.ldr = a.res_stride; k.Y = reinterpret_cast<bf16_t*>(a.y); k.ldy = a.y_stride;
             skinny_launch<SK_RESIDUAL>(k, a.K, s);
@@ -464,11 +483,18 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
     const std::vector<fq3_layer_weights>& L = talker ? c->tl : c->pl;
     const int rep = d.n_heads / d.n_kv_heads, B = b->B;
     const int q_dim = d.n_heads * kHeadDim, kv_dim = d.n_kv_heads * kHeadDim;
+    // RMSNorm inside the GEMM pair (the lane counts that take the weight-stationary form of the normalising GEMVs): the residual GEMMs
+    // leave the sum-of-squares partials of the rows of `h`, the next normalising GEMM picks them up
+    const bool fuse = b->norm_fused && g_batch_mfma && c->cfg.dtype == FQ3_BF16 && g_batch_norm_skinny && B > g_batch_norm_skinny_above &&
+                      skinny_norm_ok(d.hidden, B) && b->Hm % 64 == 0;
+    const float* h_ssq = nullptr;                      // partials of the current rows of b->h, or null
+    b->h_ssq = nullptr;
     for (int i = 0; i < d.n_layers; ++i) {
         const fq3_layer_weights& w = L[i];
         const void* xin = i == 0 ? src.x0 : b->h;
         const int xin_stride = i == 0 ? src.x0_stride : b->Hm;
         BatchGemvArgs g{};
+        g.ssq_in = i == 0 ? nullptr : h_ssq;
         g.B = B; g.eps = d.rms_eps; g.W = w.qkv; g.N = q_dim + 2 * kv_dim; g.K = d.hidden; g.x = xin; g.x_stride = xin_stride;
         g.norm_w = w.input_norm; g.y = b->qkv; g.y_stride = b->qkvm; g.xn_ws = b->xn;
         if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, g, s)) return r;
@@ -478,6 +504,8 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
         a.n_kv = d.n_kv_heads; a.scale = 1.0f / sqrtf((float)kHeadDim); a.rep = rep;
         BatchGemvArgs o{};
         o.B = B; o.W = w.o; o.N = d.hidden; o.K = q_dim; o.y = b->h; o.y_stride = b->Hm; o.res = xin; o.res_stride = xin_stride;
+        o.x_stride = b->qkvm;
+        o.ssq_out = fuse && residual_on_skinny(o) ? b->ssq : nullptr;
         if (talker) {
             a.max_seq = c->tk.max_seq; a.part = b->part;
             const dim3 grid(d.n_kv_heads, c->tk.workers, B);
@@ -503,12 +531,16 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
         BatchGemvArgs m{};
         m.B = B; m.eps = d.rms_eps; m.W = w.gate_up; m.N = d.inter; m.K = d.hidden; m.x = b->h; m.x_stride = b->Hm;
         m.norm_w = w.post_norm; m.y = b->act; m.y_stride = b->Im; m.up_off = d.inter; m.xn_ws = b->xn;
+        m.ssq_in = o.ssq_out;
         if (int r = launch_gemv_batch<PRO_NORM, EPI_SWIGLU>(c, m, s)) return r;
         BatchGemvArgs dn{};
         dn.B = B; dn.W = w.down; dn.N = d.hidden; dn.K = d.inter; dn.x = b->act; dn.x_stride = b->Im; dn.y = b->h; dn.y_stride = b->Hm;
         dn.res = b->h; dn.res_stride = b->Hm;
+        dn.ssq_out = fuse && residual_on_skinny(dn) ? b->ssq : nullptr;
         if (int r = launch_gemv_batch<PRO_PLAIN, EPI_RESIDUAL>(c, dn, s)) return r;
+        h_ssq = dn.ssq_out;
     }
+    b->h_ssq = h_ssq;                                  // for the head that reads `h` next
     return 0;
 }
 
@@ -542,6 +574,7 @@ static int enqueue_batch_frame_t(fq3_batch* b, hipStream_t s) {
         BatchGemvArgs hg{};
         hg.B = B; hg.eps = p.rms_eps; hg.W = c->lmh[cb]; hg.N = Vp; hg.K = p.hidden; hg.x = b->h; hg.x_stride = b->Hm;
         hg.norm_w = c->wt.predictor_final_norm; hg.y = lg; hg.y_stride = (int)lstride; hg.xn_ws = b->xn;
+        hg.ssq_in = b->h_ssq;
         if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, hg, s)) return r;
         const T* next_emb = cb + 1 < G - 1 ? (const T*)c->pemb[cb] : nullptr;
         if (Vp <= 2048) hipLaunchKernelGGL((sample_pred_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, tab, lf, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);

@@ -42,6 +42,14 @@ struct SkinnyArgs {
     int nrb;                                // weight-row groups: N / (16 RB)
     int mt;                                 // workgroups per row group; workgroup (rb, j) takes token tiles j, j + mt, ...
     int no_stagger;                         // measurement switch: 1 = every workgroup walks the token tiles from tile 0 (see `rot` below)
+    // ---- RMSNorm folded into the GEMM pair (round 5; the lock-step batch above 32 lanes) ----
+    // producer side (SK_RESIDUAL): per token and 16-column block of Y the sum of squares of the STORED (rounded) values:
+    // ssq_out[token * ssq_ld + column / 16]; null = not wanted
+    float* ssq_out; int ssq_ld;
+    // consumer side (the NORM instantiations of SK_STORE / SK_SWIGLU; X is the raw residual stream): rs = rsqrt(sum / K + eps) from the
+    // K / 16 partials of a row summed in one fixed order, x_n = rnd(rnd(x * rs) * gain) applied on the way from the staging registers
+    // to LDS -- the two roundings of the reference's norm, so only the ORDER of the sum of squares differs from rmsnorm_batch_kernel
+    const float* ssq; const bf16_t* gain; float eps;
 };
 
 // The 27 kernel instantiations live in ONE translation unit of the library (fq3_prefill.hip defines FQ3_SKINNY_DEFINE); the others
@@ -49,6 +57,8 @@ struct SkinnyArgs {
 // standalone tool that includes this header with neither macro gets everything inline.
 // K values served (the talker's hidden / q / intermediate widths at 0.6B and 1.7B)
 inline bool skinny_k_ok(int K) { return K == 1024 || K == 2048 || K == 3072 || K == 6144; }
+// the normalising form (SkinnyArgs::ssq): K = hidden of the 0.6B / 1.7B stacks, every row's 1 / rms in an LDS table
+inline bool skinny_norm_ok(int K, int M) { return (K == 1024 || K == 2048) && M >= 1 && M <= 256; }
 
 #ifdef FQ3_SKINNY_EXTERN
 void skinny_launch_epi(int epi, const SkinnyArgs& a, int K, hipStream_t s, int rb_force);
@@ -63,9 +73,11 @@ constexpr int kSkSlotB = 16 * 256;          // one wave's slot: 16 token rows x 
 constexpr int kSkT = 2;                     // token tiles per reduction group
 constexpr size_t skinny_lds_bytes(int RB) { return (size_t)kSkNW * 2 * kSkSlotB + (size_t)2 * kSkT * kSkNW * RB * 1024; }
 
-template <int K, int RB, int EPI>
+constexpr int kSkNormMaxRows = 256;         // NORM instantiations: rows whose 1 / rms fit the LDS table (two passes of 128 rows, 4 threads per row)
+template <int K, int RB, int EPI, bool NORM = false>
 __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
     typedef bf16_t T_;
+    static_assert(!NORM || EPI != SK_RESIDUAL, "the normalising form feeds qkv / gate | up / heads");
     constexpr int NW = kSkNW, KC = kSkKC, NCH = K / KC, KS = KC / NW / 32, T = kSkT;   // KS = 4 MFMA steps per wave and unit
     static_assert(K % KC == 0 && (T * NCH) % 2 == 0, "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
@@ -117,11 +129,41 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
         }
     };
     const int wr_off = ld_r * 256 + ((ld_c ^ ld_r) & 15) * 16;                  // + p * 1024 + ((4p) swizzle): row 4p + ld_r, chunk c ^ row
-    auto write_unit = [&](const u32x4 (&st)[4], int v) {
+    auto write_unit = [&](const u32x4 (&st)[4], int v, int kcs, const float (*gwp)[8], const float (&rt)[4]) {
         unsigned char* slot = ring + (v & 1) * kSkSlotB;
+        if constexpr (NORM) {
+            // the unit's rows and column chunk (as load_unit resolved them); rows past M took row M - 1's data and take its 1 / rms.
+            // A tile's 16 rows lie in one 64-row block of the table: one register of `rt` (uniform choice), one cross-lane read per row group.
+            const int vv = v < nunits - 1 ? v : nunits - 1;
+            const int i = vv / NCH;
+            const int t0 = __builtin_amdgcn_readfirstlane(tile_t0(i));
+            const int blk = t0 >> 6, last = a.M - 1;
+            // (mask arithmetic, not a select over an array: the latter is turned into an indexed private-memory access = scratch)
+            const uint32_t tvb = (__float_as_uint(rt[0]) & (blk == 0 ? ~0u : 0u)) | (__float_as_uint(rt[1]) & (blk == 1 ? ~0u : 0u)) |
+                                 (__float_as_uint(rt[2]) & (blk == 2 ? ~0u : 0u)) | (__float_as_uint(rt[3]) & (blk == 3 ? ~0u : 0u));
+            float rs4[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)             // row = 4p + ld_r: chunk ^ row = (ld_c ^ ld_r) ^ 4p
-            *reinterpret_cast<u32x4*>(slot + p * 1024 + (wr_off ^ ((4 * p) << 4))) = st[p];
+            for (int p = 0; p < 4; ++p) {           // (all four cross-lane reads go out before the first is needed)
+                int row = t0 + 4 * p + ld_r;
+                row = row < last ? row : last;
+                // a cross-lane read through the LDS crossbar (no LDS memory): the index depends on the lane, so not a DPP pattern
+                rs4[p] = __int_as_float(__builtin_amdgcn_ds_bpermute((row & 63) << 2, (int)tvb));
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                Raw8<T_> xr8; xr8.v = st[p];
+                float x[8];
+                unpack(xr8, x);
+                // kcs = the unit's column chunk v % NCH, a constant at every call site after unrolling (a unit past the end is clamped to
+                // the last one, whose chunk may differ: its values are never used)
+                const u32x4 y = norm8_pack(x, rs4[p], gwp[kcs]);
+                *reinterpret_cast<u32x4*>(slot + p * 1024 + (wr_off ^ ((4 * p) << 4))) = y;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)             // row = 4p + ld_r: chunk ^ row = (ld_c ^ ld_r) ^ 4p
+                *reinterpret_cast<u32x4*>(slot + p * 1024 + (wr_off ^ ((4 * p) << 4))) = st[p];
+        }
     };
     const int fro = fr * 256;
     auto read_frags = [&](sk_bf16x8 (&f)[KS], int v) {
@@ -130,9 +172,34 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
         for (int s = 0; s < KS; ++s) f[s] = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const u32x4*>(slot + (((s * 4 + fq) ^ fr) & 15) * 16));
     };
 
+    // NORM: the rows' sum-of-squares partials (K / 16 per row, written by the producer's epilogue) go out FIRST -- they retire first, so
+    // 1 / rms is formed while the token units and the weights are still in flight.  4 threads per row (a quarter of the partials each,
+    // summed in index order), two passes of 128 rows; rows past M re-read row M - 1.
+    constexpr int NPQ = K / 16 / 4 / 4;                                         // float4 loads per thread and row
+    f32x4 sq[NORM ? 2 : 1][NORM ? NPQ : 1];
+    u32x4 graw[NORM ? NCH : 1];
+    if constexpr (NORM) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            int m = ps * 128 + (tid >> 2);
+            m = m < a.M ? m : a.M - 1;
+            const f32x4* sp = reinterpret_cast<const f32x4*>(a.ssq + (size_t)m * (K / 16) + (tid & 3) * (K / 64));
+#pragma unroll
+            for (int j = 0; j < NPQ; ++j) sq[ps][j] = sp[j];
+        }
+    }
     u32x4 stg[2][4];
     load_unit(stg[0], 0);
     load_unit(stg[1], 1);
+    if constexpr (NORM) {           // this lane's 8 gain columns of every 1024-column chunk (the same columns in every unit)
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc)
+            graw[kc] = *reinterpret_cast<const u32x4*>(a.gain + kc * KC + wave * (KC / NW) + ld_c * 8);
+    }
+    // issue order pinned (round 5): the token-side loads above, THEN the weight rows, then the first arithmetic -- left alone the
+    // scheduler hoisted the first two units' LDS writes (and their full vmcnt wait: one L2 round trip) above the weight loads, i.e. the
+    // HBM stream -- the long pole of the launch -- started a round trip late
+    __builtin_amdgcn_sched_barrier(0);
     // this wave's K share (KS steps in every 1024-column chunk) of the 16 RB weight rows, in A-operand layout
     Raw8<T_> wreg[RB][NCH * KS];
 #pragma unroll
@@ -146,7 +213,36 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) ldraw<false>(wreg[b][kc * KS + s], wp + kc * KC + s * 32);
     }
+    __builtin_amdgcn_sched_barrier(0);
 
+    // NORM: 1 / rms of every row.  The table is built cooperatively in the (still unused) partial-sum area, then every wave takes a
+    // copy into registers -- lane L: rows L, 64 + L, 128 + L, 192 + L -- from which a unit's 16 values come by v_readlane (the RB = 3
+    // instantiations use all 160 KB of LDS already).
+    float gw[NORM ? NCH : 1][8], rtab[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (NORM) {
+        float* tab = red;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            float s4 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NPQ; ++j) { s4 += sq[ps][j].x; s4 += sq[ps][j].y; s4 += sq[ps][j].z; s4 += sq[ps][j].w; }
+            // the four quarters of a row: (q0 + q1) + (q2 + q3) in every lane of the quad (commutative pairings)
+            s4 += dpp_move<kDppXor1, 0xF>(0.f, s4);
+            s4 += dpp_move<kDppXor2, 0xF>(0.f, s4);
+            if ((tid & 3) == 0) tab[ps * 128 + (tid >> 2)] = 1.0f / sqrtf(s4 / (float)K + a.eps);
+        }
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc) {
+            Raw8<T_> g; g.v = graw[kc];
+            unpack(g, gw[kc]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): the table is written
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rtab[j] = tab[j * 64 + lane];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();                                // nobody writes partial sums over the table before everybody has read it
+    }
     // epilogue of row block b of one token tile by the calling wave: the 8 partial products at `rd`, summed in wave order
     auto epilogue = [&](const float* rd, int t0, int b) {
         const int nb = a.M - t0 < 16 ? a.M - t0 : 16;
@@ -182,10 +278,21 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
                 v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
             }
         }
-        if (live) {
-            uint2 o;
-            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(a.Y + (size_t)(t0 + fr) * a.ldy + yc) = o;
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        if (live) *reinterpret_cast<uint2*>(a.Y + (size_t)(t0 + fr) * a.ldy + yc) = o;
+        if constexpr (EPI == SK_RESIDUAL) {
+            // the next RMSNorm's sum of squares, over the values as STORED: this lane's four columns in column order, then the four
+            // column groups of the token's 16-column block (lanes fr, fr + 16, fr + 32, fr + 48) -- one partial per token and block,
+            // summed in block order by the consumer (skinny_gemm_kernel<.., NORM>): deterministic, no atomics
+            if (a.ssq_out) {
+                const float y0 = __uint_as_float(o.x << 16), y1 = __uint_as_float(o.x & 0xffff0000u);
+                const float y2 = __uint_as_float(o.y << 16), y3 = __uint_as_float(o.y & 0xffff0000u);
+                float sq = y0 * y0;
+                sq = fmaf(y1, y1, sq); sq = fmaf(y2, y2, sq); sq = fmaf(y3, y3, sq);
+                sq = xrow_sum(sq);
+                if (live && fq == 0) a.ssq_out[(size_t)(t0 + fr) * a.ssq_ld + (rb * RB + b)] = sq;
+            }
         }
     };
 
@@ -197,9 +304,9 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
     // unit u + 2 going from staging registers to LDS, units u + 3 and u + 4 in flight from L2; the K steps of a unit alternate
     // between two accumulators per row block (two independent MFMA chains).
     sk_bf16x8 fcur[KS], fnext[KS];
-    write_unit(stg[0], 0);
+    write_unit(stg[0], 0, 0, gw, rtab);
     load_unit(stg[0], 2);
-    write_unit(stg[1], 1);
+    write_unit(stg[1], 1, 1 % NCH, gw, rtab);
     load_unit(stg[1], 3);
     read_frags(fcur, 0);
     for (int g = 0; g < ngroups; ++g) {
@@ -224,8 +331,8 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 // unit u + 2 into the slot of unit u (its fragments are in registers, the MFMAs above have read them), then its
                 // staging registers take unit u + 4
-                if (par == 0) { write_unit(stg[0], u + 2); load_unit(stg[0], u + 4); }
-                else { write_unit(stg[1], u + 2); load_unit(stg[1], u + 4); }
+                if (par == 0) { write_unit(stg[0], u + 2, (kc + 2) % NCH, gw, rtab); load_unit(stg[0], u + 4); }
+                else { write_unit(stg[1], u + 2, (kc + 2) % NCH, gw, rtab); load_unit(stg[1], u + 4); }
 #pragma unroll
                 for (int s = 0; s < KS; ++s) fcur[s] = fnext[s];
             }
@@ -248,17 +355,17 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
 
 
 // the kernels need more than the default 64 KB of dynamic LDS: raised once per process and instantiation
-template <int K, int RB, int EPI>
+template <int K, int RB, int EPI, bool NORM = false>
 inline bool skinny_attr() {
     constexpr size_t shm = skinny_lds_bytes(RB);
     static_assert(shm <= 160 * 1024, "LDS");
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<K, RB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess;
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<K, RB, EPI, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess;
     return ok;
 }
-template <int K, int RB, int EPI>
+template <int K, int RB, int EPI, bool NORM = false>
 inline void skinny_go(const SkinnyArgs& a, hipStream_t s) {
-    (void)skinny_attr<K, RB, EPI>();
-    hipLaunchKernelGGL((skinny_gemm_kernel<K, RB, EPI>), dim3(a.nrb * a.mt), dim3(512), skinny_lds_bytes(RB), s, a);
+    (void)skinny_attr<K, RB, EPI, NORM>();
+    hipLaunchKernelGGL((skinny_gemm_kernel<K, RB, EPI, NORM>), dim3(a.nrb * a.mt), dim3(512), skinny_lds_bytes(RB), s, a);
 }
 // Raise the LDS limit of every instantiation of one epilogue NOW: for callers whose first launch could otherwise happen inside a
 // hipGraph stream capture (the batch decode graph).
@@ -270,6 +377,11 @@ inline bool skinny_prepare() {
                       skinny_attr<3072, 1, EPI>(), skinny_attr<3072, 2, EPI>(), skinny_attr<6144, 1, EPI>()};
     bool ok = true;
     for (bool b : r) ok = ok && b;
+    if constexpr (EPI != SK_RESIDUAL) {         // the normalising instantiations (K = hidden: 1024 or 2048)
+        const bool rn[] = {skinny_attr<1024, 1, EPI, true>(), skinny_attr<1024, 2, EPI, true>(), skinny_attr<1024, 3, EPI, true>(),
+                           skinny_attr<2048, 1, EPI, true>(), skinny_attr<2048, 2, EPI, true>(), skinny_attr<2048, 3, EPI, true>()};
+        for (bool b : rn) ok = ok && b;
+    }
     return ok;
 }
 
@@ -291,6 +403,16 @@ inline void skinny_launch(const SkinnyArgs& a0, int K, hipStream_t s, int rb_for
         while (a.nrb * a.mt * 2 <= 256 && a.mt * 2 <= ntiles) a.mt *= 2;      // fill the CUs before deepening the per-workgroup tile walk
     }
     if (a.mt > ntiles) a.mt = ntiles;
+    // the normalising form: a.ssq names the rows' sum-of-squares partials (K / 16 per row); K = hidden = 1024 or 2048, M <= kSkNormMaxRows
+    if constexpr (EPI != SK_RESIDUAL) {
+        if (a.ssq) {
+#define FQ3_SKN(KK) do { if (RB == 3) skinny_go<KK, 3, EPI, true>(a, s); else if (RB == 2) skinny_go<KK, 2, EPI, true>(a, s); \
+                         else skinny_go<KK, 1, EPI, true>(a, s); } while (0)
+            if (K == 1024) FQ3_SKN(1024); else FQ3_SKN(2048);
+#undef FQ3_SKN
+            return;
+        }
+    }
 #define FQ3_SK(KK) do { if constexpr (KK <= 2048) { if (RB == 3) { skinny_go<KK, 3, EPI>(a, s); break; } } \
                         if constexpr (KK <= 3072) { if (RB == 2) { skinny_go<KK, 2, EPI>(a, s); break; } } \
                         skinny_go<KK, 1, EPI>(a, s); } while (0)

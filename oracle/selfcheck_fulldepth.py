@@ -3,6 +3,7 @@
 
     python oracle/selfcheck_fulldepth.py [0p6b|1p7b]      # -> tests/golden/fulldepth_selfcheck.json (minutes on CPU)
     python oracle/selfcheck_fulldepth.py 1p7b_4096        # the configs[4] goldens (tests/golden/longprompt_full.npz; ~15 minutes)
+    python oracle/selfcheck_fulldepth.py 0p6b_alt|1p7b_alt   # the second golden utterance (tests/golden/fulldepth_alt.npz: 137 rows, 16 frames)
 
 The teacher-forced GPU parity tests (tests/test_gpu_fulldepth.py) accept a bf16 mismatch only where the oracle's own top-2 margin
 is a few bf16 ulps, arguing that such a decision is made by the summation order inside dot products and not by the algorithm.
@@ -124,13 +125,18 @@ def main():
     key = sys.argv[1] if len(sys.argv) > 1 else "0p6b"
     size = key.split("_")[0]
     torch.set_num_threads(os.cpu_count() or 1)
-    g = np.load(os.path.join(ROOT, "tests", "golden", "longprompt_full.npz" if key.endswith("_4096") else "fulldepth.npz"))
-    frames, plen, tlen = (int(x) for x in g["meta"])
+    alt = key.endswith("_alt")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "longprompt_full.npz" if key.endswith("_4096") else ("fulldepth_alt.npz" if alt else "fulldepth.npz")))
+    frames, plen, tlen = (int(x) for x in g["meta"][:3])
     case = TF.load_case(g, f"{size}_bf16")
     golden = torch.from_numpy(case["codes"].astype(np.int64))
     cfg = qwen3_tts_0p6b() if size == "0p6b" else qwen3_tts_1p7b()
     W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor"))
-    tie, tam, tth, tpe, _ = synth_prompt(cfg, plen, tlen, 0, dtype=torch.bfloat16)
+    if alt:
+        from oracle.make_golden_fulldepth_alt import alt_prompt
+        tie, tam, tth, tpe, _ = alt_prompt(cfg, torch.bfloat16)
+    else:
+        tie, tam, tth, tpe, _ = synth_prompt(cfg, plen, tlen, 0, dtype=torch.bfloat16)
     out = {}
     for name in ("native_bf16_again", "native_bf16_one_thread", "fp32_operands", "fp32_operands_ksplit8", "fp64_operands"):
         orc = ForcedOracle(cfg, W, max_seq_len=plen + frames + 8)

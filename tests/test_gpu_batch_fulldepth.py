@@ -12,7 +12,7 @@ logit (the largest margin of any mismatch observed on this path: 2 ulps at the 0
 dot products are twice as long), and every lane must reach a FROZEN floor of identical decisions for its utterance: the
 round-3 measurement per shape (profiles/r03_parity_batch_fulldepth.json) minus one decision per lane -- LANE_FLOOR below; it
 replaces the round-3 "matched fraction >= 0.95", which 1.7B / 32 lanes cleared by a hair (0.9547).  K_ULP and the floors do
-not move again.  fp32 (VALU batch GEMVs, 32 lanes, 0.6B) -- every decision identical."""
+not move again.  Above 32 lanes (round 5) the floor comes from the oracle's own self-check, see below.  fp32 (VALU batch GEMVs, 32 lanes, 0.6B) -- every decision identical."""
 import json
 import os
 
@@ -31,9 +31,20 @@ LANE_FLOOR = {("0p6b", 8): (373, 240), ("0p6b", 16): (373, 240), ("0p6b", 32): (
 # floors of that form are its first measurement (378 / 243 and 368 / 248 per lane, at 64 and at 128 lanes alike) minus one decision
 # per lane; the panel kernels' 5..8-tile instantiations are checked separately below against the 32-lane counts, which they must
 # reproduce EXACTLY (a lane's arithmetic does not depend on the number of token tiles of the launch).
-for _n in (64, 128):
-    LANE_FLOOR[("0p6b", _n)] = (377, 242)
-    LANE_FLOOR[("1p7b", _n)] = (367, 247)
+R4_FORM_FLOOR = {"0p6b": (377, 242), "1p7b": (367, 247)}
+# Round 5: above 32 lanes the RMSNorm itself moved INTO the weight-stationary GEMM pair (csrc/skinny_gemm.cuh: the residual GEMM's epilogue
+# leaves sum-of-squares partials, the next GEMM normalises while it stages its token tiles), which changes the fp32 order of the sum of
+# squares.  A form with a summation order of its own does not get a floor cut from its own first measurement (the round-4 review): its
+# floor is the ORACLE's reproducibility floor for the same utterance -- the smallest count any changed-accumulation re-evaluation of the
+# oracle reaches against its own golden ids (tests/golden/fulldepth_selfcheck.json, oracle/selfcheck_fulldepth.py; CPU only) -- minus
+# two.  The round-4 form (`norm_fused` 0: same kernels, separate normalisation launch) is re-run at 64 lanes and must still clear its
+# frozen floors above.
+
+
+def oracle_floor(golden_dir, size):
+    d = json.load(open(os.path.join(golden_dir, "fulldepth_selfcheck.json")))
+    lo = lambda key: min(v["matched_decisions"] for k, v in d[key].items() if k != "native_bf16_again")
+    return (lo(size) - 2, lo(size + "_alt") - 2)
 
 from fq3hip.config import qwen3_tts_0p6b, qwen3_tts_1p7b
 from fq3hip.weights import synth_weights, synth_prompt
@@ -144,6 +155,13 @@ def test_batch_full_depth_bf16_mfma_lanes_vs_oracle(size, golden_dir):
             _note(f"{size}_bf16_mfma_B{B}_panel_kernels", dict(per_lane=got))
             assert all(s["unexplained"] == 0 for s in panel)
             assert got == [per_lane_32[i % len(cases)] for i in range(B)], got
+        if B == 64:
+            # the round-4 form of this lane count (separate normalisation launch): bit-stable, frozen floors
+            old = _run_batch(engines, cfg, cases, B, mfma=1, options=(("norm_fused", 0),))
+            _note(f"{size}_bf16_mfma_B{B}_norm_unfused", dict(per_lane=[s["matched_decisions"] for s in old]))
+            assert all(s["unexplained"] == 0 for s in old)
+            for i, sc in enumerate(old):
+                assert sc["matched_decisions"] >= R4_FORM_FLOOR[size][i % len(cases)], (i, sc)
         scores = _run_batch(engines, cfg, cases, B, mfma=1)
         if B == 32:
             per_lane_32 = [s["matched_decisions"] for s in scores]
@@ -155,8 +173,9 @@ def test_batch_full_depth_bf16_mfma_lanes_vs_oracle(size, golden_dir):
                                               per_lane=[s["matched_decisions"] for s in scores],
                                               unexplained=sum(s["unexplained"] for s in scores)))
         assert all(s["unexplained"] == 0 for s in scores), scores
+        floor = LANE_FLOOR[(size, B)] if (size, B) in LANE_FLOOR else oracle_floor(golden_dir, size)
         for i, sc in enumerate(scores):
-            assert sc["matched_decisions"] >= LANE_FLOOR[(size, B)][i % len(cases)], (i, sc)
+            assert sc["matched_decisions"] >= floor[i % len(cases)], (i, sc, floor)
         # lanes that decode the same utterance must agree with each other exactly (lock-step lanes do not interact)
         for i in range(len(cases), B):
             assert scores[i]["matched_decisions"] == scores[i % len(cases)]["matched_decisions"]

@@ -52,6 +52,12 @@ def main():
             batch.set_option("norm_skinny_above", int(os.environ["FQ3_BENCH_NORM_SKINNY_ABOVE"]))
         if os.environ.get("FQ3_BENCH_NORM_SKINNY") is not None:       # A/B: 0 = the panel kernels above 64 lanes as well
             batch.set_option("norm_skinny", int(os.environ["FQ3_BENCH_NORM_SKINNY"]))
+        if os.environ.get("FQ3_BENCH_NORM_FUSED") is not None:        # A/B: 0 = the separate normalisation launch (round-4 form)
+            batch.set_option("norm_fused", int(os.environ["FQ3_BENCH_NORM_FUSED"]))
+        for kv in os.environ.get("FQ3_BENCH_OPTS", "").split(","):    # further A/B switches: key=value[,key=value]
+            if "=" in kv:
+                k, v = kv.split("=")
+                batch.set_option(k, int(v))
         if graph:
             batch.graph_capture()
         batch.frames(8); torch.cuda.synchronize()
