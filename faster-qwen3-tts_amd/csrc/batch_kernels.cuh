@@ -37,16 +37,16 @@ struct LaneTabs { const int* t[kMaxLanes]; int blk_stride; };     // talker: eve
 template <typename T>
 __global__ __launch_bounds__(256) void frame_begin_batch_kernel(const LaneTab* __restrict__ t, const T* codec_emb, T* pred_in, int H, int G) {
     const int l = blockIdx.x;
-    frame_begin_body<T>(t->st[l], codec_emb, reinterpret_cast<const T*>(t->past_hidden[l]), pred_in + (size_t)l * 2 * H,
-                        t->codes[l], t->seen[l], H, G);
+    frame_begin_body<T>(gptr(t->st[l]), codec_emb, gptr(reinterpret_cast<const T*>(t->past_hidden[l])), pred_in + (size_t)l * 2 * H,
+                        gptr(t->codes[l]), gptr(t->seen[l]), H, G);
 }
 
 template <typename T, int G>
 __global__ __launch_bounds__(256) void embed_sum_batch_kernel(const LaneTab* __restrict__ t, EmbTables tabs, T* x, int H, const float* cos_tab,
                                                               const float* sin_tab, int rope_len, float* rope_now) {
     const int l = blockIdx.x;
-    DecodeState* st = t->st[l];
-    embed_sum_body<T, G>(st, tabs, t->codes[l], x + (size_t)l * H, H, cos_tab, sin_tab, rope_len, st->rope_delta,
+    DecodeState* st = gptr(t->st[l]);
+    embed_sum_body<T, G>(st, tabs, gptr(t->codes[l]), x + (size_t)l * H, H, cos_tab, sin_tab, rope_len, st->rope_delta,
                          rope_now + (size_t)l * kHeadDim);
 }
 
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64) void attn_pred_batch_kernel(AttnArgs a, const L
     const int l = blockIdx.y;
     a.qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)l * qkv_stride;
     a.out = reinterpret_cast<T*>(a.out) + (size_t)l * out_stride;
-    a.kcache = kv->k[l]; a.vcache = kv->v[l];
+    a.kcache = gptr(kv->k[l]); a.vcache = gptr(kv->v[l]);
     attn_pred_body<T>(a);
 }
 
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, cons
     // stale -- the scheduler returns a finished lane's blocks to the pool, and they may already belong to another context -- so the
     // append of the single-stream body would land in somebody else's rows.  It leaves neutral partials ({0, m = 0, l = 1}: the merge
     // yields zeros, not 0 / 0) and exits.
-    const DecodeState* stl = t->st[l];
+    const DecodeState* stl = gptr(t->st[l]);
     const int pos = stl->pos, lane_done = stl->done;
     const bool no_keys = (int)blockIdx.y * kKeysPerTile > pos;
     if (lane_done || no_keys) {
@@ -89,12 +89,230 @@ __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnArgs a, cons
         return;
     }
     a.qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)l * qkv_stride;
-    a.kcache = kv->k[l]; a.vcache = kv->v[l];
-    a.table = tabs->t[l]; a.blk_stride = tabs->blk_stride;
+    a.kcache = gptr(kv->k[l]); a.vcache = gptr(kv->v[l]);
+    a.table = gptr(tabs->t[l]); a.blk_stride = tabs->blk_stride;
     a.pos_ptr = nullptr; a.pos_imm = pos;
     a.n_pad = stl->n_pad;
     a.cos_row = rope_now + (size_t)l * kHeadDim; a.sin_row = a.cos_row + 64;
     attn_decode_body<T, REP, true>(a);
+}
+
+// Talker attention of the lock-step batch from 64 lanes on (round 5): ONE workgroup per (kv head, lane) instead of one per
+// (kv head, 64-key tile, lane) + a merge launch.  At 128 lanes the split kernel is 8 x 8 x 128 = 8192 workgroups of which the ~4100
+// that have keys each repeat the lane's q / k normalisation + RoPE, chase lane state -> block table -> tile before their first K / V
+// byte is requested, and live ~6 us: with 4-5 of them resident per CU the launch is three to four rounds of that latency chain
+// (40.7 us per layer at 128 lanes x ~230 keys, profiles/r04_batch128_kernel_trace.txt, 19 % of the frame), and its partial slots need
+// combine_batch_kernel afterwards.  Here every (kv head, lane) pair is resident at once (8 x 128 = 1024 workgroups of 4 waves), the
+// prologue runs once per pair, wave w walks key tiles w, w + 4, ... in quarter tiles of 16 keys through two alternating register
+// sets (the next quarter's 8 loads are in flight while this one is multiplied; all loads unconditional on clamped steps), the four
+// waves meet once in LDS, and the workgroup writes the FINAL head outputs (fp32 softmax, one rounding to T -- the value
+// combine_batch_kernel produces), so the merge launch disappears.  Only live keys are read; the new token's K / V row is appended by
+// this workgroup (it is the only one that sees the pair); a lane that is done leaves zeros and touches no cache block (its block
+// table may be stale, see attn_decode_batch_kernel).  The order in which keys enter the online softmax differs from the split
+// kernel, so this form has a summation order of its own: it starts at 64 lanes (fq3_batch "attn_lane"), where the parity floors are
+// the oracle-derived ones (tests/test_gpu_batch_fulldepth.py).
+template <typename T, int REP, int NI = 4>
+__global__ __launch_bounds__(256) void attn_decode_lane_kernel(AttnArgs a, const LaneKV* __restrict__ kv, const LaneTabs* __restrict__ tabs,
+                                                               const LaneTab* __restrict__ t, int qkv_stride, const float* rope_now, int out_stride) {
+    constexpr int HD = kHeadDim, KS = kKeysPerTile;
+    constexpr int SPT = KS / (4 * NI);                 // steps per 64-key tile: a step = NI keys for each of the wave's four 16-lane groups
+    static_assert(NI == 4 || NI == 2, "16- or 8-key steps");
+    const int g = blockIdx.x, l = blockIdx.y;
+    __shared__ float qs[REP][HD];
+    __shared__ float knew[HD], vnew[HD];
+    __shared__ float wo[4][REP][HD];
+    __shared__ float wm[4][REP], wl[4][REP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane >> 4, c = lane & 15;
+    const DecodeState* stl = gptr(t->st[l]);
+    const int pos = stl->pos, lane_done = stl->done, n_pad = stl->n_pad;
+    T* out = reinterpret_cast<T*>(a.out) + (size_t)l * out_stride + (size_t)g * REP * HD;
+    if (lane_done) {
+        for (int e = tid; e < REP * HD; e += 256) DT<T>::st(out + e, 0.f);
+        return;
+    }
+    const T* qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)l * qkv_stride;
+    const int q_dim = a.n_kv * REP * HD, kv_dim = a.n_kv * HD;
+    T* kc = gptr(reinterpret_cast<T*>(kv->k[l])) + (size_t)g * KS * HD;        // this kv head's 64 rows inside block 0
+    T* vc = gptr(reinterpret_cast<T*>(kv->v[l])) + (size_t)g * KS * HD;
+    const int* table = gptr(tabs->t[l]);
+    const int blk_stride = tabs->blk_stride;
+    const int t_pos = pos / KS;                                                // the tile the new key falls into (keys < pos are read)
+    // this wave's steps: part q of tile wave + 4 * (j / SPT) is step j; a wave without a tile walks (and discards) tile t_pos
+    const int ntw = wave <= t_pos ? (t_pos - wave) / 4 + 1 : 0;
+    const int nsteps = ntw * SPT;
+    auto step_tile = [&](int j) { j = j < nsteps ? j : nsteps - 1; return ntw ? wave + 4 * (j / SPT) : t_pos; };
+    Raw8<T> ka[NI], va[NI], kb[NI], vb[NI];
+    auto issue = [&](Raw8<T> (&kr)[NI], Raw8<T> (&vr)[NI], int j, int blk) {
+        const int jq = (j < nsteps ? j : nsteps - 1) & (SPT - 1);              // (nsteps = 0: the last part of tile t_pos, discarded)
+        const size_t base = (size_t)blk * blk_stride + (size_t)(jq * 4 * NI + sub) * HD + c * 8;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            ldraw<false>(kr[i], kc + base + (size_t)i * 4 * HD);
+            ldraw<false>(vr[i], vc + base + (size_t)i * 4 * HD);
+        }
+    };
+    int blk_cur = table[step_tile(0)];
+    // ---- token-side loads first (they fly while the table entry arrives), then the first two quarters ----
+    constexpr int NV = (REP + 2 + 3) / 4;
+    float px0[NV], px1[NV], pw0[NV], pw1[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vec = wave + 4 * i < REP + 2 ? wave + 4 * i : REP + 1;
+        const T* src = vec < REP ? qkv + (size_t)(g * REP + vec) * HD
+                     : (vec == REP ? qkv + q_dim + (size_t)g * HD : qkv + q_dim + kv_dim + (size_t)g * HD);
+        px0[i] = DT<T>::ld(src + lane); px1[i] = DT<T>::ld(src + lane + 64);
+        const T* w = reinterpret_cast<const T*>(vec < REP ? a.q_norm_w : a.k_norm_w);
+        pw0[i] = DT<T>::ld(w + lane); pw1[i] = DT<T>::ld(w + lane + 64);
+    }
+    const float* cos_row = rope_now + (size_t)l * kHeadDim;
+    const float cs = cos_row[lane], sn = cos_row[64 + lane];
+    issue(ka, va, 0, blk_cur);
+    issue(kb, vb, 1, blk_cur);
+    int blk_next = table[step_tile(SPT)];                                        // the next tile's entry, one tile ahead
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- prologue: head RMSNorm + RoPE of the q heads and the new k; the new row goes to slot pos % 64 of the block of tile t_pos ----
+    const size_t new_off = (size_t)table[t_pos] * blk_stride + (size_t)(pos - t_pos * KS) * HD;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vec = wave + 4 * i;
+        if (vec >= REP + 2) continue;
+        float x0 = px0[i], x1 = px1[i];
+        if (vec <= REP) {
+            const float ss = wave_sum(fmaf(x0, x0, x1 * x1));
+            const float rs = 1.0f / sqrtf(ss / (float)HD + a.eps);
+            const float n0 = DT<T>::rnd(pw0[i] * DT<T>::rnd(x0 * rs));
+            const float n1 = DT<T>::rnd(pw1[i] * DT<T>::rnd(x1 * rs));
+            x0 = DT<T>::rnd(DT<T>::rnd(n0 * cs) + DT<T>::rnd(-n1 * sn));     // rotate_half: (-x2, x1)
+            x1 = DT<T>::rnd(DT<T>::rnd(n1 * cs) + DT<T>::rnd(n0 * sn));
+        }
+        if (vec < REP) { qs[vec][lane] = x0; qs[vec][lane + 64] = x1; }
+        else {
+            float* dst = vec == REP ? knew : vnew;
+            dst[lane] = x0; dst[lane + 64] = x1;
+            T* cp = (vec == REP ? kc : vc) + new_off;
+            DT<T>::st(cp + lane, x0); DT<T>::st(cp + lane + 64, x1);
+        }
+    }
+    __syncthreads();
+    float qr[REP][8];
+#pragma unroll
+    for (int h = 0; h < REP; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qr[h][i] = qs[h][c * 8 + i];
+    float m[REP], lsum[REP], o[REP][8];
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+        m[h] = -1e30f; lsum[h] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[h][i] = 0.f;
+    }
+    // one step (4 NI keys: this lane's are key0 + 4 i + sub): scores first, then ONE rescale per head
+    auto quarter = [&](const Raw8<T> (&kr)[NI], Raw8<T> (&vr)[NI], int key0) {
+        float sc[REP][NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int key = key0 + i * 4 + sub;
+            const bool ok = key >= n_pad && key < pos;
+            float kf[8];
+            unpack(kr[i], kf);
+            if (!ok) zero(vr[i]);                                              // a dead slot may hold NaN bits: its V row becomes zeros (p is 0 there)
+#pragma unroll
+            for (int h = 0; h < REP; ++h) {
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) s = fmaf(qr[h][d], kf[d], s);
+                s = row16_sum(s);
+                sc[h][i] = ok ? s * a.scale : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            float mn = fmaxf(m[h], fmaxf(sc[h][0], sc[h][1]));
+            if constexpr (NI == 4) mn = fmaxf(mn, fmaxf(sc[h][2], sc[h][3]));
+            const float al = __expf(m[h] - mn);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) sc[h][i] = __expf(sc[h][i] - mn);      // the probabilities (0 for a masked key)
+            float ps = sc[h][0] + sc[h][1];
+            if constexpr (NI == 4) ps += sc[h][2] + sc[h][3];
+            lsum[h] = fmaf(lsum[h], al, ps);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) o[h][d] *= al;
+            m[h] = mn;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float vf[8];
+            unpack(vr[i], vf);
+#pragma unroll
+            for (int h = 0; h < REP; ++h)
+#pragma unroll
+                for (int d = 0; d < 8; ++d) o[h][d] = fmaf(sc[h][i], vf[d], o[h][d]);
+        }
+    };
+    for (int j = 0; j < nsteps; j += 2) {                                      // (uniform per wave; nsteps is a multiple of SPT, SPT is even)
+        const int tile = wave + 4 * (j / SPT);
+        quarter(ka, va, tile * KS + (j & (SPT - 1)) * 4 * NI);
+        // step j + 2: the same tile's next part, or (j + 2 a multiple of SPT) the next tile's first
+        const bool roll = ((j + 2) & (SPT - 1)) == 0;
+        const int blk2 = roll ? blk_next : blk_cur;
+        issue(ka, va, j + 2, j + 2 < nsteps ? blk2 : blk_cur);
+        quarter(kb, vb, tile * KS + ((j + 1) & (SPT - 1)) * 4 * NI);
+        issue(kb, vb, j + 3, j + 3 < nsteps ? blk2 : blk_cur);
+        if (roll) { blk_cur = j + 2 < nsteps ? blk_next : blk_cur; blk_next = table[step_tile(j + 2 + SPT)]; }
+    }
+    {   // the new token's own key / value (LDS), by lane group 0 of wave 0
+        float kf[8], vf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { kf[i] = knew[c * 8 + i]; vf[i] = vnew[c * 8 + i]; }
+        const bool valid = wave == 0 && sub == 0 && pos >= n_pad;
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) s = fmaf(qr[h][d], kf[d], s);
+            s = row16_sum(s);
+            s = valid ? s * a.scale : -INFINITY;
+            const float mn = fmaxf(m[h], s);
+            const float al = __expf(m[h] - mn), p = __expf(s - mn);
+            lsum[h] = fmaf(lsum[h], al, p);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) o[h][d] = fmaf(o[h][d], al, valid ? p * vf[d] : 0.f);
+            m[h] = mn;
+        }
+    }
+    // merge the four 16-lane key groups of the wave, then the four waves (LDS), and write the final head outputs
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+        const float M = xrow_max(m[h]);
+        const float w = __expf(m[h] - M);
+        lsum[h] = xrow_sum(lsum[h] * w);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[h][i] = xrow_sum(o[h][i] * w);
+        m[h] = M;
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wo[wave][h][c * 8 + i] = o[h][i];
+            if (c == 0) { wm[wave][h] = m[h]; wl[wave][h] = lsum[h]; }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < REP * HD; e += 256) {
+        const int h = e / HD, d = e - h * HD;
+        const float M = fmaxf(fmaxf(wm[0][h], wm[1][h]), fmaxf(wm[2][h], wm[3][h]));
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float ww = __expf(wm[w][h] - M);
+            num = fmaf(ww, wo[w][h][d], num);
+            den = fmaf(ww, wl[w][h], den);
+        }
+        DT<T>::st(out + e, num * (1.0f / den));
+    }
 }
 
 // Split-KV merge of the talker attention as its own launch (one thread per 8 head dims per lane, all slot loads in flight
@@ -122,14 +340,14 @@ __global__ __launch_bounds__(256) void sample_pred_batch_kernel(const LaneTab* _
     c.rep_penalty = 1.0f; c.sup_lo = 0; c.sup_hi = 0; c.keep_id = -1; c.sup_extra = -1;
     // NUCLEUS = true: a lane whose policy asks for top_p < 1 takes the LDS sampler (sampler.cuh::sample_core) inside the same
     // launch; the register-resident path of the other lanes is unchanged
-    sample_pred_wave_body<T, NC, true>(t->st[l], logits + (size_t)l * logit_stride, V, cb, c, (const T*)nullptr, t->codes[l], G,
-                                       (int64_t*)nullptr, next_emb, next_in + (size_t)l * H, H, f->tf[l]);
+    sample_pred_wave_body<T, NC, true>(gptr(t->st[l]), logits + (size_t)l * logit_stride, V, cb, c, (const T*)nullptr, gptr(t->codes[l]), G,
+                                       (int64_t*)nullptr, next_emb, next_in + (size_t)l * H, H, gptr(f->tf[l]));
 }
 
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void sample_talker_batch_kernel(const LaneTab* __restrict__ t, const LaneForced* __restrict__ f, const T* logits, int V, int G) {
     const int l = blockIdx.x;
-    sample_talker_wave_body<T, NC, true>(t->st[l], logits + (size_t)l * V, V, t->seen[l], G, f->tf[l]);
+    sample_talker_wave_body<T, NC, true>(gptr(t->st[l]), logits + (size_t)l * V, V, gptr(t->seen[l]), G, gptr(f->tf[l]));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -256,7 +474,7 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(BatchGemvArgs a) {
                 }
             }
             if (m < nb) {
-                T* xo = (blockIdx.x == 0 && a.xn_out) ? reinterpret_cast<T*>(a.xn_out[g0 + m]) : nullptr;
+                T* xo = (blockIdx.x == 0 && a.xn_out) ? gptr(reinterpret_cast<T*>(a.xn_out[g0 + m])) : nullptr;
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     const int off = j * 512 + lane * 8;
@@ -370,7 +588,7 @@ __global__ __launch_bounds__(256) void rmsnorm_batch_kernel(const bf16_t* __rest
         for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
     ss = wave_sum(ss);
     const float rs = 1.0f / sqrtf(ss / (float)K + eps);
-    T* xo = xn_out ? reinterpret_cast<T*>(xn_out[m]) : nullptr;
+    T* xo = xn_out ? gptr(reinterpret_cast<T*>(xn_out[m])) : nullptr;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         float nw[8];
@@ -493,7 +711,7 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                         xn[j] = norm8_pack(xr[j], rs, nw);
                     }
                     if (m < nb) {
-                        T* xo = (blockIdx.x == 0 && a.xn_out) ? reinterpret_cast<T*>(a.xn_out[t0 + m]) : nullptr;
+                        T* xo = (blockIdx.x == 0 && a.xn_out) ? gptr(reinterpret_cast<T*>(a.xn_out[t0 + m])) : nullptr;
 #pragma unroll
                         for (int j = 0; j < NCH; ++j) {
                             const int off = j * 512 + lane * 8;
@@ -596,7 +814,7 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
                 xn[j] = norm8_pack(xr[j], rs, nw);
             }
             if (m < nb) {
-                T* xo = (blockIdx.x == 0 && a.xn_out) ? reinterpret_cast<T*>(a.xn_out[t0 + m]) : nullptr;
+                T* xo = (blockIdx.x == 0 && a.xn_out) ? gptr(reinterpret_cast<T*>(a.xn_out[t0 + m])) : nullptr;
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     const int off = j * 512 + lane * 8;

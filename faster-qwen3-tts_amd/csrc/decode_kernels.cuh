@@ -621,7 +621,7 @@ struct TeacherForcing { const int* forced; int* decisions; };
 // sampler epilogue of the teacher-forcing hook: returns the id the loop continues with (uniform across the block)
 __device__ __forceinline__ int forced_or(const TeacherForcing* tf, int slot, int tok) {
     if (!tf) return tok;
-    const int* forced = tf->forced; int* dec = tf->decisions;
+    const int* forced = gptr(tf->forced); int* dec = gptr(tf->decisions);
     if (dec && threadIdx.x == 0) dec[slot] = tok;
     return forced ? forced[slot] : tok;
 }
@@ -661,8 +661,8 @@ __device__ __forceinline__ void embed_sum_body(DecodeState* st, const EmbTables&
     // one round trip for the state + this frame's 16 ids, one for the 16 embedding rows
     const int done = st->done, frame = st->frame, pos = st->pos, gen_step = st->gen_step;
     const int trailing_len = st->trailing_len, max_seq = st->max_seq;
-    const T* trailing = reinterpret_cast<const T*>(st->trailing_text);
-    const T* pad = reinterpret_cast<const T*>(st->tts_pad);
+    const T* trailing = gptr(reinterpret_cast<const T*>(st->trailing_text));     // (loaded pointers: global memory, fq3_common.cuh::gptr)
+    const T* pad = gptr(reinterpret_cast<const T*>(st->tts_pad));
     if (done) return;
     if (pos >= max_seq - 1) {
         __syncthreads();

@@ -41,7 +41,13 @@ struct fq3_batch {
     std::vector<void*> allocs;
     const float* h_ssq = nullptr; // set by run_stack_batch: the partials of what it left in `h` (null: none)
     float* ssq = nullptr;         // [B][Hm / 16]: sum-of-squares partials of the rows of `h` (written by the o_proj / down epilogues, read by the next normalising GEMM)
-    int norm_fused = 1;           // above norm_skinny_above lanes: the RMSNorm of qkv / gate | up / lm heads inside the weight-stationary GEMM ("norm_fused" 0: rmsnorm_batch_kernel + GEMM, the round-4 form)
+    int norm_fused = 0;           // a MEASURED NEGATIVE (round 5, profiles/r05_normfuse.txt), off: above norm_skinny_above lanes the RMSNorm of qkv / gate | up / lm heads
+                                  // inside the weight-stationary GEMM (sum-of-squares partials from the residual GEMM's epilogue).  It removes the 216 normalisation
+                                  // launches of a frame, but every one of a GEMM's 256 workgroups then normalises every token it stages: +0.3..1.2 us per GEMM at
+                                  // hidden 1024, +3..10 us at 2048, against ~1.5 us for the launch it saves inside a graph ("norm_fused" 1 selects it)
+    int attn_lane = 1;            // talker attention as one workgroup per (kv head, lane), final outputs, no merge launch: 0 never, 1 from attn_lane_from lanes (bf16), 2 always
+    int attn_lane_from = 4 * kTokTile;
+    int attn_lane_keys = 8;       // keys per load step of that kernel: 8 (two register sets of 2 K + 2 V rows per lane group: 122 VGPRs, four workgroups per CU -- measured 29.6 vs 30.6 us per launch at 128 lanes) or 16
     void* xn = nullptr;           // [B][Hm]: pre-normalised tokens of the weight-stationary form of the normalising GEMVs (above 32 lanes)
     int norm_skinny = 1;          // above norm_skinny_above lanes: qkv / gate | up / heads as rmsnorm_batch_kernel + skinny_gemm_kernel ("norm_skinny" 0: the panel kernels at every lane count)
     int norm_skinny_above = 2 * kTokTile;       // measured (profiles/r04_batch_norm_skinny.txt): the panel kernels win up to 32 lanes, the weight-stationary form from 48
@@ -156,7 +162,8 @@ static int poll_prepare(fq3_batch* b);
 // follows the BATCH's lane count, not the group's (a last group of a few lanes must not change its lanes' summation order)
 static void sync_kid_options(fq3_batch* b) {
     for (fq3_batch* k : b->kids) {
-        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma; k->norm_skinny = b->norm_skinny; k->norm_fused = b->norm_fused;
+        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma; k->norm_skinny = b->norm_skinny; k->norm_fused = b->norm_fused; k->attn_lane = b->attn_lane; k->attn_lane_keys = b->attn_lane_keys;
+        k->attn_lane_from = b->B >= b->attn_lane_from ? 0 : (1 << 30);      // the BATCH's lane count decides
         k->norm_skinny_above = b->B > b->norm_skinny_above ? 0 : (1 << 30);      // the BATCH's lane count decides, as for "skinny"
         k->use_skinny = (b->use_skinny == 1 && b->B > kTokTile) ? 2 : b->use_skinny;
     }
@@ -280,7 +287,10 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
 extern "C" int fq3_batch_set_option(fq3_batch* b, const char* key, int value) {
     if (!b || !key) return fq3_fail_(FQ3_EINVAL, "null argument");
     if (std::string(key) == "norm_dual") b->norm_dual = value;
-    else if (std::string(key) == "norm_fused") b->norm_fused = value;     // RMSNorm inside the weight-stationary GEMM (default 1; 0 = the separate normalisation launch of round 4)
+    else if (std::string(key) == "norm_fused") b->norm_fused = value;
+    else if (std::string(key) == "attn_lane") b->attn_lane = value;
+    else if (std::string(key) == "attn_lane_from") b->attn_lane_from = value;
+    else if (std::string(key) == "attn_lane_keys") { if (value != 8 && value != 16) return fq3_fail_(FQ3_EINVAL, "attn_lane_keys must be 8 or 16"); b->attn_lane_keys = value; }     // RMSNorm inside the weight-stationary GEMM (default 1; 0 = the separate normalisation launch of round 4)
     else if (std::string(key) == "norm_skinny_above") b->norm_skinny_above = value;   // the lane count above which "norm_skinny" applies (default 32; measurement switch)
     else if (std::string(key) == "norm_skinny") b->norm_skinny = value;   // above 32 lanes: the normalising GEMVs as pre-normalise + weight-stationary GEMM (default 1)
     else if (std::string(key) == "skinny") b->use_skinny = value;  // o_proj / down of 17..32 lanes on skinny_gemm_kernel (default 1); 0: gemv_batch_mfma_plain_kernel;
@@ -511,6 +521,22 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
             const dim3 grid(d.n_kv_heads, c->tk.workers, B);
             const LaneKV* kvp = b->d_tkv + i;
             const LaneTabs* ttp = b->d_ttab; const LaneTab* tp = b->d_tab;
+            // from 64 lanes (bf16, matrix-core path): one workgroup per (kv head, lane) that writes the final head outputs -- no partial
+            // slots, no merge launch (batch_kernels.cuh::attn_decode_lane_kernel; "attn_lane": 0 = never, 1 = from attn_lane_from lanes, 2 = always)
+            const bool lane_attn = b->attn_lane == 2 || (b->attn_lane == 1 && g_batch_mfma && c->cfg.dtype == FQ3_BF16 && B >= b->attn_lane_from);
+            if (lane_attn) {
+                a.out = b->attn_out;
+                const dim3 lgrid(d.n_kv_heads, B);
+                auto go = [&](auto ni) {
+                    constexpr int NI = decltype(ni)::value;
+                    if (rep == 1) hipLaunchKernelGGL((attn_decode_lane_kernel<T, 1, NI>), lgrid, dim3(256), 0, s, a, kvp, ttp, tp, b->qkvm, b->rope_now, b->qkvm);
+                    else if (rep == 2) hipLaunchKernelGGL((attn_decode_lane_kernel<T, 2, NI>), lgrid, dim3(256), 0, s, a, kvp, ttp, tp, b->qkvm, b->rope_now, b->qkvm);
+                    else hipLaunchKernelGGL((attn_decode_lane_kernel<T, 4, NI>), lgrid, dim3(256), 0, s, a, kvp, ttp, tp, b->qkvm, b->rope_now, b->qkvm);
+                };
+                if (b->attn_lane_keys == 8) go(std::integral_constant<int, 2>{}); else go(std::integral_constant<int, 4>{});
+                o.x = b->attn_out; o.x_stride = b->qkvm;
+                if (int r = launch_gemv_batch<PRO_PLAIN, EPI_RESIDUAL>(c, o, s)) return r;
+            } else {
             if (rep == 1) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 1>), grid, dim3(256), 0, s, a, kvp, ttp, tp, b->qkvm, b->rope_now, b->part_stride);
             else if (rep == 2) hipLaunchKernelGGL((attn_decode_batch_kernel<T, 2>), grid, dim3(256), 0, s, a, kvp, ttp, tp, b->qkvm, b->rope_now, b->part_stride);
             else hipLaunchKernelGGL((attn_decode_batch_kernel<T, 4>), grid, dim3(256), 0, s, a, kvp, ttp, tp, b->qkvm, b->rope_now, b->part_stride);
@@ -518,6 +544,7 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
                                c->tk.workers, rep, q_dim, (T*)b->attn_out, b->qkvm);
             o.x = b->attn_out; o.x_stride = b->qkvm;
             if (int r = launch_gemv_batch<PRO_PLAIN, EPI_RESIDUAL>(c, o, s)) return r;
+            }
         } else {
             int rp = src.pos_imm; const int rl = c->wt.pred_rope_len;
             rp = rp < 0 ? 0 : (rp >= rl ? rl - 1 : rp);

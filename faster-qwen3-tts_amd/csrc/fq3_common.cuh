@@ -61,6 +61,17 @@ template <> struct DT<bfs_t> {
     static __device__ __forceinline__ void st8(bfs_t* p, const float (&f)[8]);
 };
 
+// A pointer that was LOADED from memory (a per-lane pointer table, a field of the on-device loop state) is a generic ("flat") pointer
+// to the compiler: its accesses become flat_load / flat_store, which count against BOTH vmcnt and lgkmcnt and may return out of order
+// between the two paths -- every wait on them is `s_waitcnt vmcnt(0) lgkmcnt(0)`, i.e. the counted, pipelined waits the kernels rely on
+// collapse.  Everything this library points at lives in device global memory: say so (generic -> integer -> address space 1 ->
+// generic; the address-space inference pass then rewrites the accesses to global_load / global_store).
+template <typename U>
+__device__ __forceinline__ U* gptr(U* p) {
+    typedef U __attribute__((address_space(1))) GU;
+    return (U*)reinterpret_cast<GU*>(reinterpret_cast<uintptr_t>(p));
+}
+
 // ---- 8-element (one lane's chunk) raw loads: issue now, convert later ------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

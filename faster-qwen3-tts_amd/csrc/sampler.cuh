@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void sample_pred_kernel(const DecodeState* st,
         c.temperature = st->p_temperature; c.top_k = st->p_top_k; c.top_p = st->p_top_p; c.do_sample = st->p_do_sample;
         frame = st->frame;
         if (st->pred_noise)
-            noise = reinterpret_cast<const T*>(st->pred_noise) + ((size_t)(frame % st->noise_frames) * (G - 1) + cb) * V;
+            noise = gptr(reinterpret_cast<const T*>(st->pred_noise)) + ((size_t)(frame % st->noise_frames) * (G - 1) + cb) * V;
     }
     for (int i = threadIdx.x; i < V; i += 256) sm.vals[i] = DT<T>::ld(logits + i);
     __syncthreads();
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void sample_talker_kernel(DecodeState* st, con
     const int frame = st->frame;
     c.sup_extra = (frame + 1 < st->min_new) ? st->eos_id : -1;      // len(all_codec_ids) < min_new_tokens
     const T* noise = st->talker_noise
-        ? reinterpret_cast<const T*>(st->talker_noise) + (size_t)(frame % st->noise_frames) * V : nullptr;
+        ? gptr(reinterpret_cast<const T*>(st->talker_noise)) + (size_t)(frame % st->noise_frames) * V : nullptr;
     for (int i = threadIdx.x; i < V; i += 256) sm.vals[i] = DT<T>::ld(logits + i);
     __syncthreads();
     int tok = sample_core<T>(sm, V, c, seen, noise);

@@ -207,7 +207,7 @@ __device__ __forceinline__ void sample_pred_wave_body(const DecodeState* st, con
         c.temperature = st->p_temperature; c.top_k = st->p_top_k; c.top_p = st->p_top_p; c.do_sample = st->p_do_sample;
         frame = st->frame;
         if (st->pred_noise)
-            noise = reinterpret_cast<const T*>(st->pred_noise) + ((size_t)(frame % st->noise_frames) * (G - 1) + cb) * V;
+            noise = gptr(reinterpret_cast<const T*>(st->pred_noise)) + ((size_t)(frame % st->noise_frames) * (G - 1) + cb) * V;
     }
     int tok;
     if constexpr (NUCLEUS) {
@@ -255,7 +255,7 @@ __device__ __forceinline__ void sample_talker_wave_body(DecodeState* st, const T
     const int frame = st->frame;
     c.sup_extra = (frame + 1 < st->min_new) ? st->eos_id : -1;
     const T* noise = st->talker_noise
-        ? reinterpret_cast<const T*>(st->talker_noise) + (size_t)(frame % st->noise_frames) * V : nullptr;
+        ? gptr(reinterpret_cast<const T*>(st->talker_noise)) + (size_t)(frame % st->noise_frames) * V : nullptr;
     int tok;
     if constexpr (NUCLEUS) {
         __shared__ SampleSmem big;

@@ -271,6 +271,34 @@ def test_batch_lanes_equal_oracle_fp32():
         assert n == frames and torch.equal(e.decode_codes(0, n).cpu(), r), f"lane {i} differs from the oracle"
 
 
+def test_lane_attention_kernel_fp32_equals_split_kernel_ids():
+    """The talker attention as ONE workgroup per (kv head, lane) with final outputs and no merge launch (attn_decode_lane_kernel; the
+    default from 64 bf16 lanes) against the split-KV kernels + merge: fp32, greedy and sampled lanes of different prompt lengths (one
+    beyond a 64-key tile, one left-padded, one that stops early, one never begun) must produce the same ids, direct launches and graph."""
+    from fq3hip.engine import Fq3Batch
+    dtype = torch.float32
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, dtype)
+    utts = [_utterance(cfg, dtype, 21, 20, 0, 14, 14, True), _utterance(cfg, dtype, 22, 33, 4, 9, 9, True),
+            _utterance(cfg, dtype, 23, 70, 0, 14, 2, False), _utterance(cfg, dtype, 24, 64, 0, 12, 12, False)]
+    lanes = _engines(cfg, W, dtype, 5)
+    got = {}
+    for mode, graph in ((0, False), (2, False), (2, True)):
+        batch = Fq3Batch(lanes)
+        batch.set_option("mfma", 0)
+        batch.set_option("attn_lane", mode)
+        for e, u in zip(lanes, utts):
+            _arm(e, cfg, u)
+        if graph:
+            batch.graph_capture()
+        batch.frames(16)
+        got[(mode, graph)] = [e.decode_codes(0, e.decode_poll()[0]).cpu() for e in lanes[:4]]
+        batch.close()
+    for key in ((2, False), (2, True)):
+        for a, b in zip(got[(0, False)], got[key]):
+            assert a.shape == b.shape and torch.equal(a, b), key
+
+
 @pytest.mark.parametrize("mfma", [0, 1])
 def test_batch_lanes_vs_oracle_bf16_teacher_forced(mfma):
     """bf16, VALU batch GEMVs (mfma=0) and matrix-core batch GEMVs (mfma=1): every lane is teacher-forced with the bf16
@@ -396,6 +424,7 @@ def test_two_panel_normalising_gemv_is_bit_identical_at_32_lanes():
     first27 = None
     for n_lanes, n_armed in ((32, 27), (48, 41), (64, 59), (96, 83), (128, 121)):       # 5..8 tiles: the rolled-loop instantiations (NT = 0)
         batch = Fq3Batch(lanes[:n_lanes])
+        batch.set_option("attn_lane", 0)        # (the property under test belongs to the GEMVs: keep the split-KV attention kernels at every lane count)
         got = []
         for dual in (1, 0):
             batch.set_option("norm_dual", dual)

@@ -32,13 +32,14 @@ LANE_FLOOR = {("0p6b", 8): (373, 240), ("0p6b", 16): (373, 240), ("0p6b", 32): (
 # per lane; the panel kernels' 5..8-tile instantiations are checked separately below against the 32-lane counts, which they must
 # reproduce EXACTLY (a lane's arithmetic does not depend on the number of token tiles of the launch).
 R4_FORM_FLOOR = {"0p6b": (377, 242), "1p7b": (367, 247)}
-# Round 5: above 32 lanes the RMSNorm itself moved INTO the weight-stationary GEMM pair (csrc/skinny_gemm.cuh: the residual GEMM's epilogue
-# leaves sum-of-squares partials, the next GEMM normalises while it stages its token tiles), which changes the fp32 order of the sum of
-# squares.  A form with a summation order of its own does not get a floor cut from its own first measurement (the round-4 review): its
-# floor is the ORACLE's reproducibility floor for the same utterance -- the smallest count any changed-accumulation re-evaluation of the
-# oracle reaches against its own golden ids (tests/golden/fulldepth_selfcheck.json, oracle/selfcheck_fulldepth.py; CPU only) -- minus
-# two.  The round-4 form (`norm_fused` 0: same kernels, separate normalisation launch) is re-run at 64 lanes and must still clear its
-# frozen floors above.
+# Round 5: from 64 lanes the talker attention runs as one workgroup per (kv head, lane) that writes final head outputs
+# (batch_kernels.cuh::attn_decode_lane_kernel: no partial slots, no merge launch), which changes the order in which keys enter the online
+# softmax; and `norm_fused` 1 (a measured negative, off by default) moves the RMSNorm into the weight-stationary GEMM pair, which changes
+# the fp32 order of the sum of squares.  A form with a summation order of its own does not get a floor cut from its own first measurement
+# (the round-4 review): its floor is the ORACLE's reproducibility floor for the same utterance -- the smallest count any
+# changed-accumulation re-evaluation of the oracle reaches against its own golden ids (tests/golden/fulldepth_selfcheck.json,
+# oracle/selfcheck_fulldepth.py; CPU only) -- minus two.  The round-4 form (`attn_lane` 0, `norm_fused` 0) is re-run at 64 lanes and must
+# still clear its frozen floors above.
 
 
 def oracle_floor(golden_dir, size):
@@ -150,18 +151,24 @@ def test_batch_full_depth_bf16_mfma_lanes_vs_oracle(size, golden_dir):
         if B == 128:
             # the panel kernels' rolled-loop instantiations (five to eight tiles) at the real shapes: a lane's arithmetic does not depend on
             # the tile count, so its counts are EXACTLY those it has in the 32-lane batch
-            panel = _run_batch(engines, cfg, cases, B, mfma=1, options=(("norm_skinny", 0),))
+            panel = _run_batch(engines, cfg, cases, B, mfma=1, options=(("norm_skinny", 0), ("attn_lane", 0)))
             got = [s["matched_decisions"] for s in panel]
             _note(f"{size}_bf16_mfma_B{B}_panel_kernels", dict(per_lane=got))
             assert all(s["unexplained"] == 0 for s in panel)
             assert got == [per_lane_32[i % len(cases)] for i in range(B)], got
         if B == 64:
-            # the round-4 form of this lane count (separate normalisation launch): bit-stable, frozen floors
-            old = _run_batch(engines, cfg, cases, B, mfma=1, options=(("norm_fused", 0),))
-            _note(f"{size}_bf16_mfma_B{B}_norm_unfused", dict(per_lane=[s["matched_decisions"] for s in old]))
+            # the round-4 form of this lane count (split-KV attention + merge launch; separate normalisation launch): bit-stable, frozen floors
+            old = _run_batch(engines, cfg, cases, B, mfma=1, options=(("attn_lane", 0), ("norm_fused", 0)))
+            _note(f"{size}_bf16_mfma_B{B}_round4_form", dict(per_lane=[s["matched_decisions"] for s in old]))
             assert all(s["unexplained"] == 0 for s in old)
             for i, sc in enumerate(old):
                 assert sc["matched_decisions"] >= R4_FORM_FLOOR[size][i % len(cases)], (i, sc)
+            # the RMSNorm folded into the GEMM pair (a measured negative, off by default, kept as a switch): correct all the same
+            fused = _run_batch(engines, cfg, cases, B, mfma=1, options=(("norm_fused", 1),))
+            _note(f"{size}_bf16_mfma_B{B}_norm_fused", dict(per_lane=[s["matched_decisions"] for s in fused]))
+            assert all(s["unexplained"] == 0 for s in fused)
+            for i, sc in enumerate(fused):
+                assert sc["matched_decisions"] >= oracle_floor(golden_dir, size)[i % len(cases)], (i, sc)
         scores = _run_batch(engines, cfg, cases, B, mfma=1)
         if B == 32:
             per_lane_32 = [s["matched_decisions"] for s in scores]

@@ -18,6 +18,11 @@ def main():
     graph = (sys.argv[4] if len(sys.argv) > 4 else "1") != "0"
     skinny = int(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] != "-" else None
     groups = [int(x) for x in sys.argv[6].split(",")] if len(sys.argv) > 6 else [None]
+    # FQ3_BENCH_SWEEP="norm_fused=0;norm_fused=1;norm_fused=1,norm_skinny_above=8": option sets measured one after another in this process
+    # (instead of the groups list): every lane count x every set
+    sweep = [v for v in os.environ.get("FQ3_BENCH_SWEEP", "").split(";") if v]
+    if sweep:
+        groups = sweep
     cfg = qwen3_tts_0p6b() if size == "0.6b" else qwen3_tts_1p7b()
     dt = torch.bfloat16
     W = synth_weights(cfg, 0, dt, parts=("talker", "predictor"))
@@ -46,7 +51,11 @@ def main():
         batch = Fq3Batch(lanes[:B])
         if skinny is not None:
             batch.set_option("skinny", skinny)
-        if G is not None:
+        if isinstance(G, str):
+            for kv in G.split(","):
+                k, v = kv.split("=")
+                batch.set_option(k, int(v))
+        elif G is not None:
             batch.set_option("groups", G)
         if os.environ.get("FQ3_BENCH_NORM_SKINNY_ABOVE") is not None:
             batch.set_option("norm_skinny_above", int(os.environ["FQ3_BENCH_NORM_SKINNY_ABOVE"]))
@@ -64,13 +73,13 @@ def main():
         t0 = time.perf_counter(); batch.frames(frames); torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0) / frames
         n = [e.decode_poll()[0] for e in lanes[:B]]
         same = ""
-        if len(groups) > 1:
+        if len(groups) > 1 and not sweep:
             codes = [e.decode_codes(0, min(n)).cpu() for e in lanes[:B]]
             if ref_codes is None:
                 ref_codes = codes
             else:
                 same = f", codes of all {B} lanes == groups={groups[0]}: {all(torch.equal(a, b) for a, b in zip(codes, ref_codes))}"
-        print(f"{size} B={B} graph={int(graph)}{'' if skinny is None else f' skinny={skinny}'}{'' if G is None else f' groups={G}'}: {ms:.3f} ms per lock-step frame -> {B * 80.0 / ms:.1f}x real-time aggregate "
+        print(f"{size} B={B} graph={int(graph)}{'' if skinny is None else f' skinny={skinny}'}{'' if G is None else (f' [{G}]' if isinstance(G, str) else f' groups={G}')}: {ms:.3f} ms per lock-step frame -> {B * 80.0 / ms:.1f}x real-time aggregate "
               f"({80.0 / ms:.1f}x per lane), frames per lane {sorted(set(n))}{same}", flush=True)
         batch.close()
 
