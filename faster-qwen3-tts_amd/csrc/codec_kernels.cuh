@@ -461,14 +461,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a_in) {
 // ---------------------------------------------------------------------------------------------------------------------
 struct ResUnitArgs { GemmArgs c1, c2; };
 
-template <typename T, int C>
+// TE = storage type of the activations: bf16_t, or bfs_t (the bf16 x 2 mode, round 5): conv1 then walks the [rows][2 C] bf16 image of
+// its bfs_t input against the K-duplicated weight (the host doubles lda / Cin as gemm_launch<bfs_t> does), `mid` is parked in LDS as
+// 32-bit (hi | lo) words -- i.e. as the [128][2 C] bf16 image the 1x1 conv's A fragments are read from -- and W2 is the K-duplicated
+// [C][2 C] weight.  Same chains and roundings as the two-GEMM bf16 x 2 path: bit-identical.  C = 96 only (the 192-channel image of
+// `mid` would need 100 KB of static LDS).
+template <typename T, int C, typename TE = T>
 __global__ __launch_bounds__(256) void resunit_kernel(ResUnitArgs u_in) {
-    static_assert(sizeof(T) == 2 && (C == 96 || C == 192), "bf16, 96 or 192 channels");
+    constexpr bool kSplit = std::is_same<TE, bfs_t>::value;
+    constexpr int KM = kSplit ? 2 : 1;                                    // bf16 columns per activation element
+    static_assert(sizeof(T) == 2 && (C == 96 || C == 192) && (!kSplit || C == 96), "bf16 operands, 96 or 192 channels (bf16 x 2: 96)");
     ResUnitArgs u;
-    u.c1 = gemm_segment<T, T>(u_in.c1, (int)blockIdx.y);                     // batched decode: one utterance per blockIdx.y
-    u.c2 = gemm_segment<T, T>(u_in.c2, (int)blockIdx.y);
-    constexpr int BM = 128, BN = C, BK = 32, LD = BK + 8, TM = BM / 32, TN = BN / 32, KS = C / 32;
-    constexpr int MLD = C + 8;                                            // mid tile row (elements): 16-byte rows, bank-spread
+    u.c1 = gemm_segment<T, TE>(u_in.c1, (int)blockIdx.y);                    // batched decode: one utterance per blockIdx.y
+    u.c2 = gemm_segment<T, TE>(u_in.c2, (int)blockIdx.y);
+    constexpr int BM = 128, BN = C, BK = 32, LD = BK + 8, TM = BM / 32, TN = BN / 32, KS = KM * C / 32;
+    constexpr int MLD = KM * C + 8;                                       // mid tile row (bf16 elements): 16-byte rows, bank-spread
     constexpr int kOperandElems = 2 * (BM + BN) * LD, kMidElems = BM * MLD;
     constexpr int kSmemElems = kOperandElems > kMidElems ? kOperandElems : kMidElems;
     __shared__ __attribute__((aligned(16))) T smem[kSmemElems];
@@ -478,31 +485,63 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitArgs u_in) {
     f32x4_t acc[TM][TN];
     conv_gemm_mainloop<T, BM, BN, 2>(u.c1, u_in.c1, smem, acc, m0, 0);   // ends with a barrier: the operand stages are dead
     // ---- mid = SnakeBeta(rnd(acc + b1)) -> LDS, row-major (the C layout holds column fr of rows fq * 4 + r) ----
-    {
-        const T* b1 = reinterpret_cast<const T*>(u.c1.bias);
-        const T* sa = reinterpret_cast<const T*>(u.c1.sn_a);
-        const T* sib = reinterpret_cast<const T*>(u.c1.sn_ib);
+    if constexpr (kSplit) {
+        // bf16 x 2: 48 accurate-sine SnakeBeta evaluations per lane, unrolled over the accumulator registers, are more than the unroller
+        // takes (the accumulators went to scratch).  The raw fp32 tile is parked in LDS instead -- row pitch C + 4 floats, which IS the
+        // pitch of the [128][2 C + 8] bf16 image -- and converted IN PLACE by a rolled loop, four columns per lane.
+        float* park = reinterpret_cast<float*>(smem);
+        constexpr int LDP = MLD / 2;
+        static_assert(LDP == C + 4, "pitch");
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    park[(wr * (BM / 2) + i * 16 + fq * 4 + r) * LDP + wc * (BN / 2) + j * 16 + fr] = acc[i][j][r];
+        __syncthreads();
+        const TE* b1 = reinterpret_cast<const TE*>(u.c1.bias);
+        const TE* sa = reinterpret_cast<const TE*>(u.c1.sn_a);
+        const TE* sib = reinterpret_cast<const TE*>(u.c1.sn_ib);
+        for (int q = tid; q < BM * (C / 4); q += 256) {
+            const int row = q / (C / 4), c4 = (q - row * (C / 4)) * 4;
+            float* pp = park + row * LDP + c4;
+            const f32x4_t av4 = *reinterpret_cast<const f32x4_t*>(pp);
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = c4 + e;
+                const float bv = b1 ? DT<TE>::ld(b1 + n) : 0.f;
+                const float v = DT<TE>::rnd(DT<TE>::rnd(av4[e] + bv));                   // the unfused epilogue rounds twice (idempotent)
+                o[e] = f_to_bfs(snake_apply<TE>(v, DT<TE>::ld(sa + n), DT<TE>::ld(sib + n)));
+            }
+            *reinterpret_cast<u32x4*>(pp) = o;
+        }
+    } else {
+        const TE* b1 = reinterpret_cast<const TE*>(u.c1.bias);
+        const TE* sa = reinterpret_cast<const TE*>(u.c1.sn_a);
+        const TE* sib = reinterpret_cast<const TE*>(u.c1.sn_ib);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = wc * (BN / 2) + j * 16 + fr;
-            const float bv = b1 ? DT<T>::ld(b1 + n) : 0.f, av = DT<T>::ld(sa + n), iv = DT<T>::ld(sib + n);
+            const float bv = b1 ? DT<TE>::ld(b1 + n) : 0.f, av = DT<TE>::ld(sa + n), iv = DT<TE>::ld(sib + n);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = wr * (BM / 2) + i * 16 + fq * 4 + r;
-                    const float v = DT<T>::rnd(DT<T>::rnd(acc[i][j][r] + bv));          // the unfused epilogue rounds twice (idempotent)
-                    DT<T>::st(smem + row * MLD + n, snake_apply<T>(v, av, iv));
+                    const float v = DT<TE>::rnd(DT<TE>::rnd(acc[i][j][r] + bv));         // the unfused epilogue rounds twice (idempotent)
+                    DT<T>::st(smem + row * MLD + n, snake_apply<TE>(v, av, iv));
                 }
         }
     }
     __syncthreads();
     // ---- conv2: acc2 = mid (LDS, A operand) x W2^T (B operand from global: row n = fr, k = ks * 32 + fq * 8) ----
     const T* W2 = reinterpret_cast<const T*>(u.c2.W);
-    const T* wp = W2 + (size_t)(wc * (BN / 2) + fr) * C + fq * 8;
+    const T* wp = W2 + (size_t)(wc * (BN / 2) + fr) * (KM * C) + fq * 8;
     bf16x8_t bfr[2][TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)j * 16 * C);
+    for (int j = 0; j < TN; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)j * 16 * (KM * C));
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -511,7 +550,7 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitArgs u_in) {
     for (int ks = 0; ks < KS; ++ks) {
         if (ks + 1 < KS) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)j * 16 * C + (ks + 1) * 32);
+            for (int j = 0; j < TN; ++j) bfr[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)j * 16 * (KM * C) + (ks + 1) * 32);
         }
         bf16x8_t af[TM];
 #pragma unroll
@@ -524,20 +563,21 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitArgs u_in) {
     }
     __syncthreads();                                                      // everybody is done reading mid: the epilogue parks there
     constexpr int kParkFloats = (int)(sizeof(T) * kSmemElems / sizeof(float));
-    gemm_epilogue_parked<T, BM, BN, TM, TN, kParkFloats>(u.c2, acc, m0, 0, wr, wc, lane, reinterpret_cast<float*>(smem));
+    gemm_epilogue_parked<TE, BM, BN, TM, TN, kParkFloats>(u.c2, acc, m0, 0, wr, wc, lane, reinterpret_cast<float*>(smem));
 }
 
-// can this (conv1, conv2) pair run as one resunit_kernel launch?
+// can this (conv1, conv2) pair run as one resunit_kernel launch?  (arguments in the storage type's own units)
 template <typename T>
 inline bool resunit_ok(const GemmArgs& c1, const GemmArgs& c2) {
     const int C = c1.N;
-    return sizeof(T) == 2 && (C == 96 || C == 192) && c1.n_taps == 7 && c1.Cin == C && c2.N == C && c2.Cin == C && c2.n_taps == 1 && c1.sn_a &&
+    const bool shape = std::is_same<T, bfs_t>::value ? C == 96 : (sizeof(T) == 2 && (C == 96 || C == 192));
+    return shape && c1.n_taps == 7 && c1.Cin == C && c2.N == C && c2.Cin == C && c2.n_taps == 1 && c1.sn_a &&
            c1.sn_ib && c2.Y2 && c2.sn_a && !c2.act2 && !c1.act && !c2.act && !c1.scale && !c2.scale && !c1.res && c2.res && c2.ldr == C &&
            c2.ldy == C && c2.bias_mod == C && c1.bias_mod == C && c1.lda == C;
 }
 template <typename T>
 inline bool resunit_launch(const GemmArgs& c1, const GemmArgs& c2, hipStream_t s) {
-    if constexpr (sizeof(T) != 2) return false;
+    if constexpr (sizeof(T) != 2 && !std::is_same<T, bfs_t>::value) return false;
     else {
         const int rows = c1.M - c1.m_lo, C = c1.N;
         if (!resunit_ok<T>(c1, c2)) return false;
@@ -545,9 +585,16 @@ inline bool resunit_launch(const GemmArgs& c1, const GemmArgs& c2, hipStream_t s
         ResUnitArgs u{c1, c2};
         u.c2.M = c1.M; u.c2.m_lo = c1.m_lo;
         const dim3 grid((rows + 127) / 128, c1.n_seg > 1 ? c1.n_seg : 1);
-        if (C == 96) hipLaunchKernelGGL((resunit_kernel<T, 96>), grid, dim3(256), 0, s, u);
-        else if (C == 192) hipLaunchKernelGGL((resunit_kernel<T, 192>), grid, dim3(256), 0, s, u);
-        else return false;
+        if constexpr (std::is_same<T, bfs_t>::value) {
+            // the [rows][2 C] bf16 image of the bfs_t input against the K-duplicated weights (what gemm_launch<bfs_t> does for a GEMM)
+            u.c1.lda = 2 * c1.lda; u.c1.Cin = 2 * c1.Cin; u.c1.a_seg = 2 * c1.a_seg; u.c1.ws = nullptr;
+            u.c2.Cin = 2 * c2.Cin; u.c2.ws = nullptr;
+            hipLaunchKernelGGL((resunit_kernel<bf16_t, 96, bfs_t>), grid, dim3(256), 0, s, u);
+        } else {
+            if (C == 96) hipLaunchKernelGGL((resunit_kernel<T, 96>), grid, dim3(256), 0, s, u);
+            else if (C == 192) hipLaunchKernelGGL((resunit_kernel<T, 192>), grid, dim3(256), 0, s, u);
+            else return false;
+        }
         return true;
     }
 }

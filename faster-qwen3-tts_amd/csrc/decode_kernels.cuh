@@ -288,6 +288,7 @@ struct AttnArgs {
     void* kcache; void* vcache; int max_seq;          // contiguous: [n_kv][max_seq][128]; paged: the layer's block pool [n_blocks][n_kv][64][128]
     const int* table; int blk_stride;                 // paged: block table of the context, elements per block (n_kv * 64 * 128)
     const int* pos_ptr; int pos_imm; int n_pad;
+    const int* done_ptr;                              // fused loop: the context's DecodeState::done -- a loop that is done never appends (null: API calls)
     int n_kv; float* part; float scale;
     int rep; void* out;                               // attn_pred_kernel: q heads per kv head, final output T[q_dim]
 };
@@ -344,11 +345,17 @@ __device__ __forceinline__ void attn_decode_body(const AttnArgs& a) {
     }
     const float cs = a.cos_row[lane], sn = a.sin_row[lane];
     const int pos = a.pos_ptr ? *a.pos_ptr : a.pos_imm;
+    // A context whose loop is DONE (EOS / limits / cancelled) keeps being launched by frames that were queued ahead; its blocks may have
+    // gone back to the pool (fq3_kv_release, fq3_kv_adopt) and belong to somebody else by now, so it must not append (round-4 advisor;
+    // the lock-step batch has the same guard in attn_decode_batch_kernel).  Branch-free: an unconditional load from a valid address.
+    const int done_word = *(a.done_ptr ? a.done_ptr : reinterpret_cast<const int*>(a.cos_row));
+    const bool loop_done = a.done_ptr != nullptr && done_word != 0;
     if constexpr (PAGED) issue_tile(s, blk);     // after the token-side loads: they flew while the table entry arrived
     __builtin_amdgcn_sched_barrier(0);           // keep every load above the arithmetic (one round trip, not two)
 
     const int t_pos = pos / KS;
     const bool owner = (t_pos % S) == s;
+    const bool may_append = owner && !loop_done;
     // where the new K / V row goes (the owner only): contiguous slot `pos`, or slot pos % 64 of the block of tile t_pos
     size_t new_off = (size_t)pos * HD;
     if constexpr (PAGED) new_off = (size_t)block_of(t_pos) * a.blk_stride + (size_t)(pos - t_pos * KS) * HD;
@@ -369,7 +376,7 @@ __device__ __forceinline__ void attn_decode_body(const AttnArgs& a) {
         else {
             float* dst = vec == REP ? knew : vnew;
             dst[lane] = x0; dst[lane + 64] = x1;
-            if (owner) {
+            if (may_append) {
                 T* cp = (vec == REP ? kc : vc) + new_off;
                 DT<T>::st(cp + lane, x0); DT<T>::st(cp + lane + 64, x1);
             }

@@ -428,6 +428,7 @@ static int run_stack(fq3_ctx* c, bool talker, const StepSrc& src, hipStream_t s)
         a.kcache = kv.k[i]; a.vcache = kv.v[i]; a.max_seq = kv.max_seq;
         a.table = kv.d_table; a.blk_stride = kv.pool ? (int)kv.pool->blk_elems : 0;       // talker: paged; predictor: contiguous (null table)
         a.pos_ptr = src.pos_ptr; a.pos_imm = src.pos_imm;
+        a.done_ptr = src.pos_ptr ? &c->st->done : nullptr;              // the fused loop (device position): a finished loop never appends
         a.n_pad = talker ? c->n_pad : 0;
         a.n_kv = d.n_kv_heads; a.part = c->part;
         a.scale = 1.0f / sqrtf((float)kHeadDim);

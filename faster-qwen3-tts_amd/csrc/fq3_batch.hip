@@ -287,10 +287,10 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
 extern "C" int fq3_batch_set_option(fq3_batch* b, const char* key, int value) {
     if (!b || !key) return fq3_fail_(FQ3_EINVAL, "null argument");
     if (std::string(key) == "norm_dual") b->norm_dual = value;
-    else if (std::string(key) == "norm_fused") b->norm_fused = value;
+    else if (std::string(key) == "norm_fused") b->norm_fused = value;     // RMSNorm inside the weight-stationary GEMM (default 0: a measured negative; 1 selects it)
     else if (std::string(key) == "attn_lane") b->attn_lane = value;
     else if (std::string(key) == "attn_lane_from") b->attn_lane_from = value;
-    else if (std::string(key) == "attn_lane_keys") { if (value != 8 && value != 16) return fq3_fail_(FQ3_EINVAL, "attn_lane_keys must be 8 or 16"); b->attn_lane_keys = value; }     // RMSNorm inside the weight-stationary GEMM (default 1; 0 = the separate normalisation launch of round 4)
+    else if (std::string(key) == "attn_lane_keys") { if (value != 8 && value != 16) return fq3_fail_(FQ3_EINVAL, "attn_lane_keys must be 8 or 16"); b->attn_lane_keys = value; }
     else if (std::string(key) == "norm_skinny_above") b->norm_skinny_above = value;   // the lane count above which "norm_skinny" applies (default 32; measurement switch)
     else if (std::string(key) == "norm_skinny") b->norm_skinny = value;   // above 32 lanes: the normalising GEMVs as pre-normalise + weight-stationary GEMM (default 1)
     else if (std::string(key) == "skinny") b->use_skinny = value;  // o_proj / down of 17..32 lanes on skinny_gemm_kernel (default 1); 0: gemv_batch_mfma_plain_kernel;

@@ -42,8 +42,8 @@ struct fq3_codec {
     std::map<std::string, const void*> w;
     std::map<std::string, int64_t> wn;
     void* buf[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t buf_elems = 0;                         // elements of one utterance's largest activation
-    int batch_cap = 1;                            // utterances the four workspaces hold (grown by fq3_codec_decode_batch)
+    size_t buf_elems = 0;                         // elements each of the four workspaces holds: at first one utterance of max_frames, grown by a
+                                                  // batched decode whose B x elems_for(T) exceeds it (never shrunk)
     void* snake_consts = nullptr;                 // per-channel SnakeBeta constants (a, ib), built at finalize
     std::map<std::string, std::pair<const void*, const void*>> snake;     // "<prefix>" -> (a, ib)
     bool ready = false;
@@ -62,6 +62,17 @@ static int64_t samples_for(const fq3_codec_config& c, int64_t T) {
 
 extern "C" int64_t fq3_codec_num_samples(const fq3_codec* c, int T) { return c ? samples_for(c->cfg, T) : -1; }
 
+// elements of the largest activation of ONE utterance of T frames: walk the stages
+static size_t elems_for(const fq3_codec_config& cfg, int64_t T) {
+    int64_t rows = T, mx = T * std::max(std::max(cfg.latent_dim * 4, 3 * cfg.n_heads * cfg.head_dim), cfg.decoder_dim);
+    mx = std::max(mx, 2 * T * (int64_t)cfg.rvq_dim);                             // the two RVQ sums share a workspace
+    for (int i = 0; i < cfg.n_upsample; ++i) { rows *= cfg.upsampling_ratios[i]; mx = std::max(mx, rows * cfg.latent_dim * 4); }
+    mx = std::max(mx, rows * cfg.decoder_dim);
+    int ch = cfg.decoder_dim;
+    for (int i = 0; i < cfg.n_rates; ++i) { rows = (rows - 1) * cfg.upsample_rates[i]; ch /= 2; mx = std::max(mx, rows * ch); }
+    return (size_t)mx + 64;
+}
+
 extern "C" int fq3_codec_create(const fq3_codec_config* cfg, fq3_codec** out) {
     if (!cfg || !out) return cfail(FQ3_EINVAL, "null argument");
     if (cfg->dtype != FQ3_BF16 && cfg->dtype != FQ3_F32 && cfg->dtype != FQ3_BF16X2) return cfail(FQ3_EINVAL, "dtype");
@@ -78,14 +89,7 @@ extern "C" int fq3_codec_create(const fq3_codec_config* cfg, fq3_codec** out) {
     fq3_codec* c = new fq3_codec();
     c->cfg = *cfg;
     c->esz = cfg->dtype == FQ3_BF16 ? 2 : 4;      // (FQ3_BF16X2: one 32-bit word per element, bf16 high part + bf16 residual)
-    // largest activation: walk the stages
-    const int64_t T = cfg->max_frames;
-    int64_t rows = T, mx = T * std::max(std::max(cfg->latent_dim * 4, 3 * cfg->n_heads * cfg->head_dim), cfg->decoder_dim);
-    for (int i = 0; i < cfg->n_upsample; ++i) { rows *= cfg->upsampling_ratios[i]; mx = std::max(mx, rows * cfg->latent_dim * 4); }
-    mx = std::max(mx, rows * cfg->decoder_dim);
-    ch = cfg->decoder_dim;
-    for (int i = 0; i < cfg->n_rates; ++i) { rows = (rows - 1) * cfg->upsample_rates[i]; ch /= 2; mx = std::max(mx, rows * ch); }
-    c->buf_elems = (size_t)mx + 64;
+    c->buf_elems = elems_for(*cfg, cfg->max_frames);
     for (int i = 0; i < 4; ++i) {
         hipError_t e = hipMalloc(&c->buf[i], c->buf_elems * c->esz);
         if (e != hipSuccess) { for (int j = 0; j < i; ++j) (void)hipFree(c->buf[j]); delete c; return cfail(FQ3_EHIP, "hipMalloc codec workspace"); }
@@ -437,19 +441,23 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int NS, int Tn, int64_t 
     return 0;
 }
 
-// the four activation workspaces hold `n` utterances (grown, never shrunk; a growth waits for the device: it happens on the first
-// batched decode of a new size, outside any graph capture)
-static int reserve_batch(fq3_codec* c, int n) {
-    if (n <= c->batch_cap) return 0;
+// The four activation workspaces must hold n utterances of T frames, compact per tensor: n x elems_for(T) elements -- sized by the T of
+// the CALL (round 5; it used to be n x the max_frames figure: ~24-48 GB pinned by the first 16-way vocode of 8-frame chunks).  The
+// initial allocation (one utterance of max_frames) already covers every batch of short inputs; a growth (never a shrink) waits for the
+// device and happens outside any graph capture.
+static int reserve_batch(fq3_codec* c, int n, int T) {
+    const size_t want = (size_t)n * elems_for(c->cfg, T);
+    if (want <= c->buf_elems) return 0;
     CHIP(hipDeviceSynchronize());
     void* nb[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 4; ++i)
-        if (hipMalloc(&nb[i], c->buf_elems * c->esz * (size_t)n) != hipSuccess) {
+        if (hipMalloc(&nb[i], want * c->esz) != hipSuccess) {
             for (int j = 0; j < i; ++j) (void)hipFree(nb[j]);
-            return cfail(FQ3_EHIP, "codec: workspace for " + std::to_string(n) + " utterances could not be allocated");
+            (void)hipGetLastError();
+            return cfail(FQ3_ENOMEM, "codec: workspace for " + std::to_string(n) + " utterances of " + std::to_string(T) + " frames could not be allocated");
         }
     for (int i = 0; i < 4; ++i) { (void)hipFree(c->buf[i]); c->buf[i] = nb[i]; }
-    c->batch_cap = n;
+    c->buf_elems = want;
     return 0;
 }
 
@@ -460,7 +468,7 @@ static int decode_any(fq3_codec* c, const int64_t* codes, int B, int T, int64_t 
     if (B < 1 || B > 1024) return cfail(FQ3_EINVAL, "codec decode: batch size must be 1..1024");
     if (T > c->cfg.max_frames) return cfail(FQ3_ETOOLONG, "codec decode: " + std::to_string(T) + " frames exceed max_frames=" + std::to_string(c->cfg.max_frames));
     if (first_sample < 0 || first_sample > samples_for(c->cfg, T)) return cfail(FQ3_EINVAL, "first_sample outside the waveform");
-    if (int r = reserve_batch(c, B)) return r;
+    if (int r = reserve_batch(c, B, T)) return r;
     hipStream_t s = (hipStream_t)stream;
     int r;
     switch (c->cfg.dtype) {

@@ -121,6 +121,12 @@ class BatchDecoder:
         # tests/test_gpu_decode.py).  Measured with the workspaces reserved up front (profiles/r03_packed_prefill.txt, 0.6B shapes,
         # 200-row prompts): first-wave TTFA 82.5 -> 63.6 ms at 8 lanes and 125 -> 89 ms at 16, aggregate 153.5 -> 156x / 229 -> 234x.
         self.packed_prefill = bool(packed_prefill)
+        # FIRST WAVE (round 5): how many requests are prepared, prefilled and armed before the first frame is queued (None = one per lane,
+        # the behaviour up to round 4).  With many lanes and many simultaneous requests, preparing all of them first puts every prompt
+        # build and every prefill in front of EVERYBODY's first chunk (128 lanes: first-wave TTFA 348 ms, of which ~250 ms is that
+        # queue); a first wave of 32 starts decoding after 32 of them and the others join at the following frame boundaries, staged
+        # under the running frames (`stage_limit`: up to a quarter of the lanes per poll).
+        self.first_wave: Optional[int] = None
 
     def _group_streams(self):
         """When the batch was told to advance several lane groups concurrently (``fq3_batch_set_option("groups")``, a measurement switch:
@@ -287,6 +293,18 @@ class BatchDecoder:
         ln.t_arm, ln.prefill_ms = st.t0, st.prefill_ms
         st.req, st.kw, st.hidden = None, None, None
 
+    def _drop_blocks(self, x, cancel: bool = False):
+        """Return whatever KV blocks lane / stage ``x`` owns to the pool (a lane's device loop is cancelled first when asked: a lane that
+        was armed must not append to blocks it no longer owns)."""
+        eng = x.engine
+        try:
+            if cancel and getattr(eng, "decode_cancel", None) is not None:
+                eng.decode_cancel()
+            if getattr(eng, "kv_release", None) is not None:
+                eng.kv_release()
+        except Exception:
+            pass
+
     def _fetch(self, ln: _Lane, first: int, count: int, ev_done=None):
         """``(codes LongTensor[count, 16] from frame `first`, event after which they are complete)``.  With look-ahead frames in flight
         (``ev_done``: the event behind the batch that produced them) the read-out runs on the copy stream, beside those frames."""
@@ -358,7 +376,10 @@ class BatchDecoder:
 
         # a previous run() may have been abandoned mid-utterance (a streaming consumer that stopped early, an exception in the
         # caller): no lane carries a tenant, a partial-chunk counter or a staged request over into this one
-        abandoned = [ln for ln in self.lanes if ln.req is not None] + [st for st in self.stages if st.req is not None]
+        def owns(x):
+            blocks = getattr(x.engine, "kv_blocks", None)
+            return blocks is not None and blocks() > 0
+        abandoned = [x for x in list(self.lanes) + list(self.stages) if x.req is not None or owns(x)]
         if abandoned:
             for x in abandoned:
                 cancel = getattr(x.engine, "decode_cancel", None)
@@ -413,7 +434,8 @@ class BatchDecoder:
             # while lanes decode, at most two new requests per frame boundary: whatever the source does to produce one (a
             # model's prompt build, say) runs on the host between two batches of queued frames.  Before anything decodes: only
             # what the first wave can take (one request per lane) -- every further prompt built now would delay the first frame
-            budget = max(0, len(self.lanes) - len(pending) - len(ready)) if not active else max(0, stage_limit() - len(pending))
+            wave = len(self.lanes) if self.first_wave is None else max(1, min(int(self.first_wave), len(self.lanes)))
+            budget = max(0, wave - len(pending) - len(ready)) if not active else max(0, stage_limit() - len(pending))
             while source is not None and budget > 0 and len(pending) < len(self.lanes) + len(self.stages):
                 # with spare contexts the source runs under the PREFILL stream: whatever device work it does to produce a request (a
                 # model's prompt build) neither queues behind the lock-step frames in flight nor -- where it waits for a value --
@@ -480,7 +502,9 @@ class BatchDecoder:
                 idle.appendleft(st)
                 pending.appendleft((req, ev))
 
-        depth = int(self.lookahead) if hasattr(self.batch, "poll_async") else 0
+        # (four poll slots, indexed by the batch number modulo 4: with `depth` batches unread and one being queued, depth <= 3 keeps a slot
+        # from being re-armed before its poll has been read)
+        depth = max(0, min(int(self.lookahead), 3)) if hasattr(self.batch, "poll_async") else 0
         feed_stream = None
         if gpu and self.stages:
             if self._side is None:
@@ -575,6 +599,9 @@ class BatchDecoder:
                     ln.first_batch = batch_no                         # the frames queued from now on are this tenant's
                 except Exception as exc:
                     free.appendleft(ln)
+                    # the lane may already own blocks (the hand-over of a staged request, or its own prefill, came before the step that
+                    # failed -- fq3_decode_begin rejecting a sampling argument, say): it has no tenant, so nothing else would return them
+                    self._drop_blocks(ln, cancel=True)
                     if on_error == "raise":
                         raise
                     self.more_in_poll = 0

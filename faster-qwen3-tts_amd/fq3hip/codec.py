@@ -243,8 +243,16 @@ class HipSpeechTokenizer:
         first_sample = max(0, min(int(first_sample), n))
         pcm = torch.empty(B, n - first_sample, dtype=torch.float32, device=self.device)
         if first_sample < n:
-            L.check(self.lib.fq3_codec_decode_batch(self.h, codes.data_ptr(), int(B), int(Tn), int(first_sample), pcm.data_ptr(),
-                                                    torch.cuda.current_stream(self.device).cuda_stream))
+            rc = self.lib.fq3_codec_decode_batch(self.h, codes.data_ptr(), int(B), int(Tn), int(first_sample), pcm.data_ptr(),
+                                                 torch.cuda.current_stream(self.device).cuda_stream)
+            if rc == L.FQ3_ENOMEM and B > 1:
+                # the workspace for B utterances of this length could not be grown: the same waveforms one utterance at a time (a row of the
+                # batched decode IS the single decode, bit for bit), in the workspace that exists
+                for b in range(B):
+                    L.check(self.lib.fq3_codec_decode_tail(self.h, codes[b].data_ptr(), int(Tn), int(first_sample), pcm[b].data_ptr(),
+                                                           torch.cuda.current_stream(self.device).cuda_stream))
+                return pcm
+            L.check(rc)
         return pcm
 
     def decode_tensor_batch(self, codes: torch.Tensor, first_sample: int = 0) -> torch.Tensor:

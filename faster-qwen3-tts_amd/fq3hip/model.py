@@ -820,7 +820,10 @@ class FasterQwen3TTS:
         ``self.batch_kv_blocks`` (attribute, default ``None``): size of that pool in 64-key blocks.  ``None`` = enough for every
         lane AND every spare context at ``max_seq_len`` (what static caches would reserve; the pool then never runs short).  A
         server that knows its traffic sets less -- e.g. ``(lanes + staging) * ceil((prompt + max_new_tokens + 1) / 64)`` --
-        and a request the pool cannot hold yet waits until finished lanes give blocks back."""
+        and a request the pool cannot hold yet waits until finished lanes give blocks back.  NOTE: a request reserves its WORST case up
+        front (``prompt + max_new_tokens + 1`` key slots, capped at ``max_seq_len``: a short pool must show before any work is queued),
+        so with the default ``max_new_tokens=2048`` at ``max_seq_len=2048`` every request takes a whole context's blocks and a reduced pool
+        merely serialises requests -- size ``batch_kv_blocks`` from the ``max_new_tokens`` the callers really pass."""
         from .batching import BatchDecoder
         from .engine import Fq3Engine, Fq3KvPool
         from .batching import MAX_LANES
@@ -875,7 +878,7 @@ class FasterQwen3TTS:
             self._side_voc_stream = self._vocoder_stream(tok) or concurrent_stream(self.device)
         return _SideVocoder(tok, self.device, getattr(self, "_side_voc_stream", None))
 
-    def _batch_feed(self, prepared, gen_kwargs, lanes: int, meta: dict):
+    def _batch_feed(self, prepared, gen_kwargs, lanes: int, meta: dict, first_wave: Optional[int] = None):
         """``prepared``: an iterable (usually a generator: the prompt of utterance i is built when the scheduler asks for it) of
         ``(talker, config, tie, tam, tth, tpe, ref_codes | None)``.  Returns ``(head, source)`` for ``BatchDecoder.run``: the first
         ``lanes`` requests up front -- the first wave starts decoding before the later prompts exist -- and a ``source`` callback
@@ -892,7 +895,7 @@ class FasterQwen3TTS:
             return BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(gen_kwargs))
 
         head = []
-        for _ in range(max(1, int(lanes))):
+        for _ in range(max(1, int(lanes) if first_wave is None else min(int(lanes), int(first_wave)))):
             r = pull()
             if r is None:
                 break
@@ -905,7 +908,10 @@ class FasterQwen3TTS:
         model.py:927-930).  One ``([waveform], sample_rate)`` per entry, in input order."""
         meta: dict = {}
         dec = self._batch_decoder(lanes)
-        head, source = self._batch_feed(prepared, gen_kwargs, len(dec.lanes), meta)
+        # batch_first_wave (attribute): requests prepared + prefilled + armed before the first frame is queued (BatchDecoder.first_wave);
+        # None = one per lane
+        dec.first_wave = getattr(self, "batch_first_wave", None)
+        head, source = self._batch_feed(prepared, gen_kwargs, len(dec.lanes), meta, dec.first_wave)
         out: List[Optional[Tuple[list, int]]] = [None] * count
         voc = self._side_vocoder()
         # batch_vocode_every (attribute; default 0 = vocode an utterance when it has ended; N > 0 = produce the waveform in slices every N
@@ -946,7 +952,10 @@ class FasterQwen3TTS:
         meta: dict = {}
         vocs, n_chunks = {}, {}
         dec = self._batch_decoder(lanes)
-        head, source = self._batch_feed(prepared, gen_kwargs, len(dec.lanes), meta)
+        # streaming is the latency-oriented entry point: by default at most 32 requests are prepared and prefilled in front of the first
+        # frame (``batch_first_wave_streaming``, attribute); the others join at the following frame boundaries
+        dec.first_wave = getattr(self, "batch_first_wave_streaming", 32)
+        head, source = self._batch_feed(prepared, gen_kwargs, len(dec.lanes), meta, dec.first_wave)
         tok = self.model.model.speech_tokenizer
         side = self._vocoder_stream(tok)
         batched = side is not None and hasattr(tok, "decode_tensor_batch")

@@ -359,3 +359,35 @@ def test_staging_keeps_a_wide_scheduler_full(monkeypatch):
     assert len(out) == waves * n_lanes and set(out.values()) == {frames}
     total = sum(dec.batch.calls)
     assert total <= waves * frames + 2 * 8, total          # three full waves; with two requests per poll this took > 400 frames
+
+
+def test_a_failed_admission_returns_the_lanes_blocks_and_lookahead_is_clamped(sched):
+    """(round-4 advisor) A lane whose arming fails AFTER it took KV blocks (its own prefill, or the hand-over of a staged request, came
+    before the failing step) has no tenant: the scheduler must cancel its loop state and return the blocks itself -- nothing else
+    would.  And a look-ahead depth beyond the four poll slots is clamped to 3."""
+    dec, engines, log, refills = sched
+    held = {e.idx: 0 for e in engines}
+    for e in engines:
+        e.kv_blocks = (lambda e=e: held[e.idx])
+        e.kv_release = (lambda keep=0, e=e: (held.__setitem__(e.idx, 0), log.append(("release", e.idx))))
+        e.decode_cancel = (lambda e=e: log.append(("cancel", e.idx)))
+    bad = _req(7, 16)
+    bad.config.bad = True
+    # the failing arm "took" three blocks before it raised
+    orig = Bt._prefill_and_arm
+
+    def arm_taking_blocks(talker, tie, tam, tth, tpe, config, pg, tg, *a, **kw):
+        held[tg.engine.idx] = 3
+        return orig(talker, tie, tam, tth, tpe, config, pg, tg, *a, **kw)
+
+    Bt._prefill_and_arm = arm_taking_blocks
+    try:
+        dec.lookahead = 9 if dec.lookahead else 0
+        out = {rid: (codes, t) for rid, codes, t in dec.run([_req(0, 12), bad, _req(2, 40)], on_error="yield")}
+    finally:
+        Bt._prefill_and_arm = orig
+    assert out[7][0] is None and "too long" in out[7][1]["error"]
+    assert out[0][0].shape[0] == 12 and out[2][0].shape[0] == 40
+    failed_lane = [e[1] for e in log if e[0] == "cancel"]
+    assert failed_lane and ("release", failed_lane[0]) in log                     # cancelled, then its blocks returned
+    assert all(v == 0 for v in held.values())                                     # finished lanes returned theirs too

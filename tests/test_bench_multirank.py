@@ -41,11 +41,18 @@ def test_bench_two_ranks_gloo_stub():
     c3 = d["config3_sharded_batched"]
     assert c3["utterances"] == 10                     # 5 + 5 lengths came back through the same gather
     assert "stub" in d["data"]
+    # the line proves its own rank count (an all-reduce of ones through the collective backend) and carries every rank's own figures
+    assert d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo"
+    pr = d["per_rank"]
+    assert len(pr["value"]) == 2 and len(pr["ttfa_ms_p50"]) == 2 and all(v > 0 for v in pr["value"]) and all(t > 0 for t in pr["ttfa_ms_p50"])
+    # whole-job value = all ranks' audio over the MAX wall: never above the sum of the ranks' own rates
+    assert d["value"] <= sum(pr["value"]) * 1.001
 
 
 def test_bench_single_rank_stub_has_same_shape():
     d = _run(1, steps=1)
     assert d["n_gpus"] == 1 and d["config3_sharded_batched"]["utterances"] == 10
+    assert d["rccl_ranks"] == 1 and len(d["per_rank"]["value"]) == 1 and abs(d["per_rank"]["value"][0] - d["value"]) <= 0.02 * d["value"]
 
 
 def test_bench_gpus_flag_alone_launches_the_ranks():

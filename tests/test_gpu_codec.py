@@ -162,11 +162,20 @@ def test_codec_high_precision_mode_meets_1e_3(T, golden_dir):
     hp.close(); lo.close()
 
 
-def test_codec_fused_residual_units_are_bit_identical():
+@pytest.mark.parametrize("precision", ["bf16", "bf16x2"])
+def test_codec_fused_residual_units_are_bit_identical(precision):
     """resunit_kernel (blocks with 192 / 96 channels: conv1 k7 -> SnakeBeta -> 1x1 conv -> + skip -> SnakeBeta in one launch, the middle
     tensor in LDS) against the two-GEMM path: the waveform is identical bit for bit, for a full decode (T = 40 and T = 100 > window)
-    and for tail decodes (the row ranges of the fused op follow the conv1 halo)."""
-    cfg, tok = _real_codec(torch.bfloat16)
+    and for tail decodes (the row ranges of the fused op follow the conv1 halo).  bf16 x 2 (round 5): the 96-channel block's units,
+    `mid` parked in LDS as (hi | lo) words (mode 2 then equals mode 1: its 192-channel units stay on two GEMMs)."""
+    from fq3hip.codec import HipSpeechTokenizer
+    from fq3hip.config import qwen3_tts_0p6b
+    if precision == "bf16":
+        cfg, tok = _real_codec(torch.bfloat16)
+    else:
+        cfg = qwen3_tts_0p6b()
+        W = synth_weights(cfg, 0, torch.bfloat16, parts=("codec",), codec_normalized=True)
+        tok = HipSpeechTokenizer(cfg.codec, W, "cuda", torch.bfloat16, max_frames=208, precision="bf16x2")
     g = torch.Generator().manual_seed(11)
     for T in (40, 100):
         codes = torch.randint(0, cfg.codec.codebook_size, (T, cfg.codec.num_quantizers), generator=g).cuda()

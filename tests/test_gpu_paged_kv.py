@@ -177,6 +177,42 @@ def test_pooled_lanes_equal_single_stream_and_finished_lanes_stay_out_of_the_cac
         e.close()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_a_finished_single_stream_loop_stays_out_of_the_cache(graph):
+    """(round-4 advisor) The single-stream fused loop over a POOLED context: once the loop is done (budget reached), frames that were
+    queued ahead keep launching its attention kernels; after fq3_kv_release its blocks may belong to another context, so a done loop
+    must not append K / V rows (attn_decode_kernel reads DecodeState::done).  Another context is prefilled into the returned block and
+    its rows are compared after the idle frames -- direct launches and hipGraph replay."""
+    from fq3hip.engine import Fq3KvPool
+    cfg = tiny_test_config()
+    dtype = torch.float32
+    W = synth_weights(cfg, 0, dtype)
+    private = _mk(cfg, W, dtype)
+    pool = Fq3KvPool(cfg, 4, dtype=dtype)
+    A = _mk(cfg, W, dtype, pool=pool, share=private)
+    u = _utterance(cfg, dtype, 91, 40, 0, 5, 5, True)
+    _arm(A, cfg, u)
+    if graph:
+        A.graph_capture()
+    else:
+        A.graph_reset()
+    A.decode_frames(8)
+    n, d = A.decode_poll()
+    assert n == 5 and d
+    assert A.kv_blocks() == 1
+    A.kv_release()
+    spare = _mk(cfg, W, dtype, pool=pool, share=private)
+    tie, *_ = synth_prompt(cfg, 60, 4, 0, dtype=dtype, seed=78)
+    spare.prefill((tie * 30).to(dtype)[0].cuda().contiguous())      # takes the block A just returned (LIFO free list)
+    k_before, v_before = spare.kv_export(0, 60)
+    A.decode_frames(8)                                              # frames "queued ahead" of a loop that is over
+    torch.cuda.synchronize()
+    k_after, v_after = spare.kv_export(0, 60)
+    assert torch.equal(k_before, k_after) and torch.equal(v_before, v_after), "a finished loop wrote into blocks it no longer owns"
+    for e in (A, spare, private):
+        e.close()
+
+
 def test_scheduler_with_a_short_pool_postpones_requests_and_matches_a_full_pool():
     """BatchDecoder over a pool that cannot hold every request at once: requests wait for blocks instead of failing, every
     utterance completes, with the ids the same scheduler produces over a full-size pool (fp32: lanes are exact)."""

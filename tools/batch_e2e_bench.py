@@ -32,14 +32,17 @@ def main():
         model.batch_groups = G
       if la is not None:
         model.batch_lookahead = la
-      for ev in everys:
+      # FQ3_E2E_FIRST_WAVE="0,32": model.batch_first_wave (requests armed before the first frame is queued; 0 = one per lane)
+      fws = [int(x) for x in os.environ.get("FQ3_E2E_FIRST_WAVE", "0").split(",")]
+      for ev, fw in [(e, f) for e in everys for f in fws]:
         model.batch_vocode_every = ev
+        model.batch_first_wave = fw if fw > 0 else None
         bench.batched_run(model, prompt, lanes, lanes)
         res = [bench.batched_run(model, prompt, 2 * lanes, lanes, seed0=2000 + i) for i in range(runs)]
         host = getattr(model._batch_cache[1], "host_s", None) if getattr(model, "_batch_cache", None) else None
         if host:
             print("  scheduler thread, last run (s): " + ", ".join(f"{k} {v:.3f}" for k, v in host.items()), flush=True)
-        print(f"{size} lanes={lanes} codec={codec} batch_vocode_every={ev}{'' if G is None else f' groups={G}'}{'' if la is None else f' lookahead={la}'}: {[round(a / w, 1) for a, w, _l in res]} x real-time end to end "
+        print(f"{size} lanes={lanes} codec={codec} batch_vocode_every={ev} first_wave={fw}{'' if G is None else f' groups={G}'}{'' if la is None else f' lookahead={la}'}: {[round(a / w, 1) for a, w, _l in res]} x real-time end to end "
               f"({2 * lanes} utterances, wall {[round(w, 3) for _a, w, _l in res]} s)", flush=True)
 
 

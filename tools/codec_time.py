@@ -31,7 +31,7 @@ def main():
     g = torch.Generator().manual_seed(4)
     codes = torch.randint(0, cfg.codec.codebook_size, (370, 16), generator=g).cuda()
     n33 = tok.num_samples_total(33); n178 = tok.num_samples_total(178)
-    for fuse in ((0, 1, 2) if prec == "bf16" else (1,)):
+    for fuse in ((0, 1, 2) if prec == "bf16" else ((0, 1) if prec == "bf16x2" else (1,))):
       tok.set_option("fuse_units", fuse)
       print(f"fused residual units = {fuse}: ", end="")
       print(f"precision {prec}: full 370 frames {timed(lambda: tok.decode_tensor(codes)):.3f} ms | one piece of 300 frames {timed(lambda: tok.decode_tensor(codes[:300].contiguous())):.3f} ms | "
