@@ -125,7 +125,11 @@ class BatchDecoder:
         # the behaviour up to round 4).  With many lanes and many simultaneous requests, preparing all of them first puts every prompt
         # build and every prefill in front of EVERYBODY's first chunk (128 lanes: first-wave TTFA 348 ms, of which ~250 ms is that
         # queue); a first wave of 32 starts decoding after 32 of them and the others join at the following frame boundaries, staged
-        # under the running frames (`stage_limit`: up to a quarter of the lanes per poll).
+        # under the running frames (`stage_limit`: up to a quarter of the lanes per poll).  MEASURED on MI355X (profiles/r05_ttfa_first_wave.txt):
+        # it does not help -- the followers' prefills run beside the first wave's frames and stretch them (128 lanes, wave of 32: first
+        # chunks at 305 .. 513 ms against 340 ms for all 128 at once; end to end 1005x against 1025x) -- so None stays the default and
+        # the knob is a measurement switch.  What the latency of N simultaneous requests is made of: ~35 ms + 2.35 ms per request
+        # (prefill 1.1, first-chunk vocoder 0.6 - 0.7, prompt build 0.33, arming 0.09).
         self.first_wave: Optional[int] = None
 
     def _group_streams(self):

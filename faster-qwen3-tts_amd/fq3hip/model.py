@@ -952,9 +952,11 @@ class FasterQwen3TTS:
         meta: dict = {}
         vocs, n_chunks = {}, {}
         dec = self._batch_decoder(lanes)
-        # streaming is the latency-oriented entry point: by default at most 32 requests are prepared and prefilled in front of the first
-        # frame (``batch_first_wave_streaming``, attribute); the others join at the following frame boundaries
-        dec.first_wave = getattr(self, "batch_first_wave_streaming", 32)
+        # ``batch_first_wave_streaming`` (attribute, default None = one request per lane): requests prepared and prefilled in front of the
+        # first frame, the others joining at the following frame boundaries.  MEASURED (profiles/r05_ttfa_first_wave.txt): a smaller
+        # first wave does not buy its members a lower latency -- the prefills of the followers run beside their first frames and
+        # stretch them (128 lanes: p25 305 ms / p50 395 ms at a wave of 32 against 340 ms for everybody at once) -- so the default stays.
+        dec.first_wave = getattr(self, "batch_first_wave_streaming", None)
         head, source = self._batch_feed(prepared, gen_kwargs, len(dec.lanes), meta, dec.first_wave)
         tok = self.model.model.speech_tokenizer
         side = self._vocoder_stream(tok)
