@@ -259,6 +259,7 @@ extern "C" int fq3_set_option(fq3_ctx* c, const char* key, int value) {
     else if (k == "rows_per_wave_max") c->opt_rmax = value;    // GEMV rows per wave cap (default 2)
     else if (k == "prefill_mode") c->prefill_mode = value;     // 0 matrix-core prefill, 1 token walk
     else if (k == "flash_prefill") c->opt_flash_prefill = value;   // bf16 prefill attention on MFMA (default 1)
+    else if (k == "flash_small") c->opt_flash_small = value;   // <= 256-row prompts: resident key tiles + packed sequences in one launch (default 1; bit-identical to 0)
     else if (k == "skinny_gemm") c->opt_no_skinny = !value;    // weight-stationary short-prompt prefill GEMMs (default 1)
     else return fail(FQ3_EINVAL, "unknown option: " + k);
     fq3_graph_reset(c);

@@ -64,6 +64,7 @@ struct fq3_ctx {
     int opt_pred_attn = 1;        // code predictor: one-wave-per-head register-only attention writing the final head output (FQ3_PRED_ATTN=0: generic split-KV kernel + merge)
     int opt_rmax = 2;             // GEMV rows-per-wave cap
     int opt_flash_prefill = 1;    // bf16 prefill attention on the matrix cores (0: the per-row wave kernel)
+    int opt_flash_small = 1;      // prompts of <= 256 rows: every key tile resident in LDS, the sequences of a packed prefill in one launch (0: the streamed-tile kernel, per prompt)
     int opt_no_skinny = 0;        // 1: short-prompt prefill GEMMs on the tiled / split-K kernels instead of the weight-stationary one (measurement)
     int prefill_mode = 0;         // 0 auto (MFMA), 1 token walk
     bool talker_wave = true;      // talker sampler variant baked into the captured graph

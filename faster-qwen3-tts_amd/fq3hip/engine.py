@@ -303,7 +303,7 @@ class Fq3Engine:
 
     def set_option(self, key: str, value: int):
         """Kernel-variant switch (``fq3_set_option``): weight_nt, pred_m2, pred_attn, rows_per_wave_max, prefill_mode, flash_prefill,
-        skinny_gemm."""
+        flash_small, skinny_gemm."""
         L.check(self.lib.fq3_set_option(self.ctx, key.encode(), int(value)))
 
     def decode_set_forced(self, forced: Optional[torch.Tensor], decisions: Optional[torch.Tensor]):

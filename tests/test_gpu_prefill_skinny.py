@@ -106,3 +106,63 @@ def test_packed_prefill_of_two_short_prompts_through_the_skinny_kernels():
         for i in range(4):
             d = float((got[i] - single[q][i]).abs().max())
             assert d <= 2.0 ** -6 * max(1.0, float(single[q][i].abs().max())), (q, i, d)
+
+
+@pytest.mark.parametrize("L,n_pad", [(200, 0), (37, 0), (256, 0), (16, 0), (200, 5), (130, 70)])
+def test_resident_tile_flash_prefill_is_bit_identical(L, n_pad):
+    """Prompts of <= 256 rows (round 5): flash_prefill_small_kernel keeps every key tile of a query block in LDS (one barrier) instead of
+    streaming them through one stage (two barriers + a global round trip per tile).  Per wave the arithmetic is the same function
+    (flash_tile) over the same tiles in the same order: logits, hidden state and every K / V row are IDENTICAL to the streamed-tile
+    kernel -- whole tiles, a ragged last tile, a single tile, left padding inside the first tile and across a tile boundary."""
+    cfg, W, tie, tam, eng = _setup("0p6b", L)
+    x = tie[0].cuda().contiguous()
+    outs = []
+    for v in (1, 0):
+        eng.set_option("flash_small", v)
+        outs.append(_run(eng, cfg, x, L, n_pad=n_pad))
+    for i, name in enumerate(("logits", "hidden", "K", "V")):
+        assert torch.equal(outs[0][i], outs[1][i]), name
+
+
+def test_packed_prefill_attention_in_one_launch_per_layer():
+    """fq3_prefill_batch over contexts of ONE pool, every prompt <= 256 rows: q / k norm + RoPE + KV write and the causal attention of
+    ALL prompts run as two launches per layer (blockIdx.z = sequence) instead of two per prompt and layer.  Against the per-prompt
+    launches (`flash_small` 0) of the same packed pass: bit-identical (the GEMMs are the same launches either way); against the single
+    prefills: the packed-GEMM tolerance of the test above."""
+    from fq3hip.engine import Fq3Engine, Fq3KvPool
+    cfg = _cfg("0p6b")
+    W = synth_weights(cfg, 0, torch.bfloat16, parts=("talker", "predictor"))
+    first = Fq3Engine(cfg, W, device="cuda", dtype=torch.bfloat16, max_seq_len=512, max_frames=8)
+    pool = Fq3KvPool(cfg, 24, dtype=torch.bfloat16)
+    engs = [Fq3Engine(cfg, W, device="cuda", dtype=torch.bfloat16, max_seq_len=512, max_frames=8, share=first, pool=pool) for _ in range(3)]
+    specs = ((150, 1, 0), (200, 2, 3), (64, 3, 0))
+    xs, pads = [], []
+    for L, seed, n_pad in specs:
+        tie, _, _, _, _ = synth_prompt(cfg, L, 4, seed, dtype=torch.bfloat16)
+        xs.append((tie * 30).to(torch.bfloat16)[0].cuda().contiguous())
+        pads.append(n_pad)
+
+    def snapshot(results):
+        out = []
+        for e, x, p, (lg, hd) in zip(engs, xs, pads, results):
+            k, v = e.kv_export(1, x.shape[0])
+            out.append((lg.float().cpu(), hd.float().cpu(), k.float().cpu()[:, p:], v.float().cpu()[:, p:]))
+        return out
+
+    single = []
+    for e, x, p in zip(engs, xs, pads):
+        e.set_option("flash_small", 0)
+        single.append(e.prefill(x, n_pad=p))
+    single = snapshot(single)
+    packed = {}
+    for mode in (1, 0):
+        for e in engs:
+            e.set_option("flash_small", mode)
+        packed[mode] = snapshot(Fq3Engine.prefill_batch(engs, xs, n_pads=pads))
+    for q in range(3):
+        for i in range(4):
+            assert torch.equal(packed[1][q][i], packed[0][q][i]), (q, i)
+            d = float((packed[1][q][i] - single[q][i]).abs().max())
+            assert d <= 2.0 ** -6 * max(1.0, float(single[q][i].abs().max())), (q, i, d)
+    for e in engs + [first]:
+        e.close()

@@ -49,7 +49,7 @@ def main():
     names = subprocess.run(["c++filt"], input="\n".join(k["name"] for k in ks), capture_output=True, text=True).stdout.split("\n")
     bad = 0
     for k, n in zip(ks, names):
-        n = re.sub(r"\(.*", "", n.replace("fq3::", "").replace("unsigned short", "bf16").replace("void ", ""))
+        n = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("fq3::", "").replace("unsigned short", "bf16").replace("void ", ""))
         if k["scratch"] or "--all" in sys.argv:
             print(f"{n[:90]:90s} scratch={k['scratch']:5d} vgpr={k['vgpr']:3d} agpr={k['agpr']:3d} lds={k['lds']}")
         bad += k["scratch"] > 0
