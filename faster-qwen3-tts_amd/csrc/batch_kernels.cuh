@@ -141,7 +141,10 @@ __global__ __launch_bounds__(256) void attn_decode_lane_kernel(AttnArgs a, const
     const int t_pos = pos / KS;                                                // the tile the new key falls into (keys < pos are read)
     // this wave's steps: part q of tile wave + 4 * (j / SPT) is step j; a wave without a tile walks (and discards) tile t_pos
     const int ntw = wave <= t_pos ? (t_pos - wave) / 4 + 1 : 0;
-    const int nsteps = ntw * SPT;
+    // the tile the new key falls into holds only pos % 64 live keys: its steps beyond them would add exact no-ops (p = 0, rescale by
+    // exp(0)), so the wave that owns it stops there (an even count: the two register sets alternate) -- up to a tile less of K / V per pair
+    const int last_steps = ((pos - t_pos * KS + 4 * NI - 1) / (4 * NI) + 1) & ~1;
+    const int nsteps = (ntw > 0 && (t_pos - wave) % 4 == 0) ? (ntw - 1) * SPT + (last_steps < SPT ? last_steps : SPT) : ntw * SPT;
     auto step_tile = [&](int j) { j = j < nsteps ? j : nsteps - 1; return ntw ? wave + 4 * (j / SPT) : t_pos; };
     Raw8<T> ka[NI], va[NI], kb[NI], vb[NI];
     auto issue = [&](Raw8<T> (&kr)[NI], Raw8<T> (&vr)[NI], int j, int blk) {

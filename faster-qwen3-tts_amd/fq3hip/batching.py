@@ -24,7 +24,8 @@ from typing import Any, Callable, Dict, Iterable, Iterator, List, Optional, Tupl
 import torch
 
 from ._lib import FQ3_ENOMEM
-from .generate import NOISE_RING, _arm_decode, _prefill_and_arm, _prefill_first_token, _prefill_first_tokens_packed, _refill
+from .generate import (NOISE_RING, _arm_decode, _prefill_and_arm, _prefill_first_token, _prefill_first_tokens_launch,
+                       _prefill_first_tokens_packed, _refill)
 from .predictor_graph import PredictorGraph
 from .talker_graph import TalkerGraph
 
@@ -199,10 +200,33 @@ class BatchDecoder:
         main stream -- with lock-step frames already queued -- does not)."""
         self._stage_many([(st, req, req_ready)])
 
-    def _stage_many(self, group):
+    def _stage_sync(self):
+        """The first tokens of every group staged with ``defer=True``: ONE device-to-host copy for all of them, then the stages' fields."""
+        pend, self._unsynced = getattr(self, "_unsynced", []), []
+        if not pend:
+            return
+        flat = [r[0].reshape(()) for _g, _k, res, _t in pend for r in res]
+        if self._side is not None and flat[0].is_cuda:
+            with torch.cuda.stream(self._side):           # the samplers ran on the prefill stream: gather and copy in ITS order
+                toks = torch.stack(flat).cpu().tolist()
+        else:
+            toks = torch.stack(flat).cpu().tolist()
+        i = 0
+        for group, kws, res, t0 in pend:
+            ms = (time.time() - t0) * 1000
+            for (st, req, _ev), kw, (_tok, hidden, n_rows, n_pad) in zip(group, kws, res):
+                st.req, st.kw, st.token, st.hidden, st.n_rows, st.n_pad = req, kw, int(toks[i]), hidden, n_rows, int(n_pad)
+                st.t0, st.prefill_ms = t0, ms
+                i += 1
+
+    def _stage_many(self, group, defer: bool = False):
         """``[(spare context, request, ready event), ...]``: ONE packed prefill for the whole group when it has more than one
-        member (``fq3_prefill_batch``: the layer weights are read once, not once per request)."""
+        member (``fq3_prefill_batch``: the layer weights are read once, not once per request).  ``defer`` (the pipelined first wave,
+        GPU engines with packed prefill only): nothing is waited for -- the left-padding counts of the whole group cost one device
+        round trip up front, the first tokens stay on the device until :meth:`_stage_sync` -- so the host goes on building the next
+        prompts while these prefills run."""
         kws = [self._kwargs(self.lanes[0].predictor_graph, req) for _st, req, _ev in group]
+        defer = bool(defer) and self.packed_prefill and self._on_gpu(group[0][0].engine)
         t0 = time.time()
         items = [(req.talker_input_embeds, req.attention_mask, req.config, kw["min_new_tokens"], kw["temperature"], kw["top_k"],
                   kw["top_p"], kw["do_sample"]) for (_st, req, _ev), kw in zip(group, kws)]
@@ -226,7 +250,28 @@ class BatchDecoder:
                 del taken[:]
                 raise
 
+        def run_deferred():
+            # left padding of every prompt: one stack, one copy (the per-request int() of the synchronous path is a device wait each)
+            masks = [it[1] for it in items]
+            known = [0 if m is None else getattr(m, "fq3_n_pad", None) for m in masks]
+            if all(k is not None for k in known):
+                cnt = [int(k) for k in known]                         # the prompt builder noted them: no device round trip at all
+            else:
+                cnt = torch.stack([(m[0] == 0).sum() if m is not None else torch.zeros((), dtype=torch.long, device=engines[0].device) for m in masks]).cpu().tolist()
+            out, lo, rows = [], 0, 0
+            cap = int(getattr(engines[0], "max_seq_len", 1 << 30))
+            for i, it in enumerate(items):
+                n = int(it[0].shape[1])
+                if i > lo and rows + n > cap:
+                    out += _prefill_first_tokens_launch(engines[lo:i], items[lo:i], cnt[lo:i])
+                    lo, rows = i, 0
+                rows += n
+            out += _prefill_first_tokens_launch(engines[lo:], items[lo:], cnt[lo:])
+            return out
+
         def run():
+            if defer:
+                return run_deferred()
             if len(group) == 1 or not self.packed_prefill:
                 return [_prefill_first_token(e, *it) for e, it in zip(engines, items)]
             # packed prefills share the leading context's workspace (max_seq_len rows): split the group where the rows run out
@@ -271,6 +316,11 @@ class BatchDecoder:
             for e in taken:                                                 # a failed prefill keeps no blocks
                 e.kv_release()
             raise
+        if defer:
+            for (st, req, _ev), kw in zip(group, kws):
+                st.req, st.kw = req, kw                               # (the stage is taken; token / hidden follow in _stage_sync)
+            self._unsynced = getattr(self, "_unsynced", []) + [(group, kws, res, t0)]
+            return
         ms = (time.time() - t0) * 1000
         for (st, req, _ev), kw, (token, hidden, n_rows, n_pad) in zip(group, kws, res):
             st.req, st.kw, st.token, st.hidden, st.n_rows, st.n_pad = req, kw, token, hidden, n_rows, int(n_pad)
@@ -400,6 +450,7 @@ class BatchDecoder:
         for slot in sorted(self._polls):                  # polls an abandoned run queued and never read
             self.batch.poll_wait(slot)
         self._polls.clear()
+        self._unsynced = []                               # (first tokens an abandoned run left on the device: their stages are reset below)
         for ln in self.lanes:
             ln.req, ln.tn, ln.pn, ln.issued, ln.emitted = None, None, None, 0, 0
         for st in self.stages:
@@ -434,17 +485,21 @@ class BatchDecoder:
             need = len(free) + soon + int(finish_rate[0] + 0.999) - len(ready)
             return max(per_poll, min(need, per_poll_cap))
 
-        def pull():
+        def pull(cap: Optional[int] = None, on_main: bool = False):
             # while lanes decode, at most two new requests per frame boundary: whatever the source does to produce one (a
             # model's prompt build, say) runs on the host between two batches of queued frames.  Before anything decodes: only
             # what the first wave can take (one request per lane) -- every further prompt built now would delay the first frame
             wave = len(self.lanes) if self.first_wave is None else max(1, min(int(self.first_wave), len(self.lanes)))
             budget = max(0, wave - len(pending) - len(ready)) if not active else max(0, stage_limit() - len(pending))
+            if cap is not None:
+                budget = min(budget, int(cap))
             while source is not None and budget > 0 and len(pending) < len(self.lanes) + len(self.stages):
                 # with spare contexts the source runs under the PREFILL stream: whatever device work it does to produce a request (a
                 # model's prompt build) neither queues behind the lock-step frames in flight nor -- where it waits for a value --
                 # makes the host wait for them; the staged prefill that consumes it is on that stream anyway
-                if feed_stream is not None:
+                # (first wave, `on_main`: nothing decodes, the MAIN stream is idle -- the builder's host-to-device uploads are synchronous
+                # copies, and on the prefill stream each would wait for the packed prefill queued in front of it)
+                if feed_stream is not None and not on_main:
                     with torch.cuda.stream(feed_stream):
                         r = source()
                         r = None if r is None else stamped(r)
@@ -456,7 +511,7 @@ class BatchDecoder:
                 pending.append(r)
                 budget -= 1
 
-        def stage_ahead(limit: int = 1 << 30):
+        def stage_ahead(limit: int = 1 << 30, defer: bool = False) -> int:
             # while lanes decode, only a couple of prefills per batch of queued frames: the host waits for the staged requests'
             # first tokens, and the main stream must not run dry meanwhile.  Requests staged together are prefilled together.
             group = []
@@ -465,18 +520,18 @@ class BatchDecoder:
                 st, (req, ev) = idle.popleft(), pending.popleft()
                 group.append((st, req, ev))
             if not group:
-                return
+                return 0
             try:
-                self._stage_many(group)
+                self._stage_many(group, defer=defer)
                 ready.extend(st for st, _r, _e in group)
-                return
+                return len(group)
             except Exception as exc:
                 if getattr(exc, "code", None) == FQ3_ENOMEM and (active or ready):
                     # the KV pool is short right now: lanes that finish give blocks back -- keep the requests (in order) for later
                     for st, req, ev in reversed(group):
                         idle.appendleft(st)
                         pending.appendleft((req, ev))
-                    return
+                    return 0
                 if len(group) == 1:
                     st, req, _ev = group[0]
                     idle.appendleft(st)
@@ -484,7 +539,7 @@ class BatchDecoder:
                         raise
                     import sys
                     failed.append((req.rid, {"error": repr(sys.exc_info()[1]), "steps": 0}))
-                    return
+                    return 0
             # a packed group failed (one prompt too long, the pool too short for all of them, ...): stage its members one by one so
             # that only the culprit fails
             postponed = []
@@ -505,6 +560,7 @@ class BatchDecoder:
             for st, req, ev, _exc in reversed(postponed):
                 idle.appendleft(st)
                 pending.appendleft((req, ev))
+            return len(group) - len(postponed)
 
         # (four poll slots, indexed by the batch number modulo 4: with `depth` batches unread and one being queued, depth <= 3 keeps a slot
         # from being re-armed before its poll has been read)
@@ -572,13 +628,23 @@ class BatchDecoder:
             finish_rate[0] = 0.5 * finish_rate[0] + 0.5 * (len(active) - len(still))
             active = still
 
+        # FIRST WAVE, pipelined (round 5): nothing decodes yet, so the critical path to the first frame is "build the prompts (host)" +
+        # "prefill them (GPU)".  They used to run one after the other (128 lanes: 39 ms + 96 ms); now the prompts arrive in slices and
+        # every slice's packed prefill is QUEUED without waiting for its first tokens (`defer`), so the host builds slice k + 1 while the
+        # GPU prefills slice k; one copy fetches all first tokens before the lanes are armed.
+        slice_n = max(1, int(getattr(self, "first_slice", 16)))
         while True:
-            pull()
+            first_wave_phase = bool(self.stages) and not active and not ready and not inflight
+            pull(cap=slice_n if first_wave_phase else None, on_main=first_wave_phase)
             if not (pending or active or ready or failed or inflight):
                 break
             if self.stages and not active and not ready:
                 t_ = clock()
-                stage_ahead()                                         # nothing is decoding: nothing to overlap with
+                while pending:                                        # nothing is decoding: nothing to overlap with but the prompt builds
+                    if stage_ahead(defer=True) == 0:
+                        break
+                    pull(cap=slice_n, on_main=True)
+                self._stage_sync()
                 prof["stage"] += clock() - t_
             while failed:
                 rid, info = failed.pop(0)

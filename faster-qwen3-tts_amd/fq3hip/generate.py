@@ -26,13 +26,22 @@ def _refill(engine, talker_noise, pred_noise):
         pred_noise.exponential_(1)
 
 
+def _n_pad_of(attention_mask) -> int:
+    """Left padding of a prompt (model.py:774-787: the mask's zeros).  The HIP prompt builder notes the count on the mask it creates
+    (``fq3_n_pad``: a single prompt has none); a foreign mask is counted on the device, which is a host wait."""
+    if attention_mask is None:
+        return 0
+    known = getattr(attention_mask, "fq3_n_pad", None)
+    return int(known) if known is not None else int((attention_mask[0] == 0).sum())
+
+
 def _prefill_first_token(eng, talker_input_embeds, attention_mask, config, min_new_tokens, temperature, top_k, top_p, do_sample):
     """=== PREFILL (generate.py:107-134) === on ``eng``: KV rows written, first codebook-0 token sampled.
     Returns (token, past_hidden, prompt_rows, n_pad)."""
     dt, dev = eng.dtype, eng.device
     eos_id = config.codec_eos_token_id
     V = config.vocab_size
-    n_pad = int((attention_mask[0] == 0).sum()) if attention_mask is not None else 0
+    n_pad = _n_pad_of(attention_mask)
     x = talker_input_embeds[0].to(device=dev, dtype=dt).contiguous()
     logits, hidden = eng.prefill(x, n_pad=n_pad)
     first_noise = torch.empty(V, dtype=dt, device=dev).exponential_(1) if do_sample else None
@@ -49,7 +58,7 @@ def _prefill_first_tokens_packed(engines, items):
     from .engine import Fq3Engine
     xs, pads = [], []
     for eng, (tie, tam, _config, *_rest) in zip(engines, items):
-        pads.append(int((tam[0] == 0).sum()) if tam is not None else 0)
+        pads.append(_n_pad_of(tam))
         xs.append(tie[0].to(device=eng.device, dtype=eng.dtype).contiguous())
     outs = Fq3Engine.prefill_batch(engines, xs, pads)
     toks = []
@@ -60,6 +69,25 @@ def _prefill_first_tokens_packed(engines, items):
                                sup_lo=max(0, V - 1024), sup_hi=V, keep_id=config.codec_eos_token_id,
                                suppress_eos=min_new_tokens > 0, noise=first_noise))
     return [(int(t), o[1], int(x.shape[0]), p) for t, o, x, p in zip(toks, outs, xs, pads)]      # the first int() waits for all
+
+
+def _prefill_first_tokens_launch(engines, items, pads):
+    """The LAUNCH half of :func:`_prefill_first_tokens_packed` (the batch scheduler's pipelined first wave): the packed prefill and the
+    first-token samplers are queued on the current stream and nothing is waited for.  ``pads[i]``: the prompt's left padding (the
+    caller counted all of them with one device round trip).  Returns ``[(token TENSOR on the device, past_hidden, prompt_rows, n_pad)]``;
+    the caller turns the tensors into ints when it needs them (one copy for all)."""
+    from .engine import Fq3Engine
+    xs = [tie[0].to(device=eng.device, dtype=eng.dtype).contiguous() for eng, (tie, *_r) in zip(engines, items)]
+    outs = Fq3Engine.prefill_batch(engines, xs, pads)
+    res = []
+    for eng, x, (logits, hidden), p, (tie, tam, config, min_new_tokens, temperature, top_k, top_p, do_sample) in zip(engines, xs, outs, pads, items):
+        V = config.vocab_size
+        first_noise = torch.empty(V, dtype=eng.dtype, device=eng.device).exponential_(1) if do_sample else None
+        tok = eng.sample(logits, temperature=temperature, top_k=top_k, top_p=top_p, do_sample=do_sample,
+                         sup_lo=max(0, V - 1024), sup_hi=V, keep_id=config.codec_eos_token_id,
+                         suppress_eos=min_new_tokens > 0, noise=first_noise)
+        res.append((tok, hidden, int(x.shape[0]), int(p)))
+    return res
 
 
 def _arm_decode(talker, config, token, hidden, n_rows, attention_mask, trailing_text_hiddens, tts_pad_embed, predictor_graph, talker_graph,

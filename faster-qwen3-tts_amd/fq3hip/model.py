@@ -894,8 +894,11 @@ class FasterQwen3TTS:
             meta[i] = rc
             return BatchRequest(i, talker, tie, tam, tth, tpe, config, dict(gen_kwargs))
 
+        # (only the first SLICE of the first wave is built here: the scheduler pulls the rest from `source` in slices and queues every
+        # slice's packed prefill behind the one before, so prompt builds and prefills overlap -- BatchDecoder.run, "first wave, pipelined")
         head = []
-        for _ in range(max(1, int(lanes) if first_wave is None else min(int(lanes), int(first_wave)))):
+        wave = max(1, int(lanes) if first_wave is None else min(int(lanes), int(first_wave)))
+        for _ in range(min(wave, 16)):
             r = pull()
             if r is None:
                 break

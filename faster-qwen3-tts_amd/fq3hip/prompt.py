@@ -122,4 +122,5 @@ def build_talker_inputs_hip(m, input_id: torch.Tensor, ref_id: Optional[torch.Te
     tth = out[L:L + Tt].unsqueeze(0)
     tpe = out[L + Tt:].unsqueeze(0)
     tam = torch.ones(1, L, dtype=torch.long, device=dev)
+    tam.fq3_n_pad = 0               # (host-side note for the prefill: a single prompt is never padded -- saves a device reduction + host wait per request)
     return tie, tam, tth, tpe

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel scratch (private segment) and register use of the BUILT library: unbundles every gfx950 code object embedded in
 libfq3hip.so (clang offload bundles in .hip_fatbin), reads the AMDGPU metadata notes with llvm-readelf and lists every kernel whose
-private segment is not empty (spills / stack arrays).  usage: check_scratch.py [path/to/libfq3hip.so] [--all]
+private segment is not empty (spills / stack arrays).  usage: check_scratch.py [path/to/libfq3hip.so] [--all] [--top N]
+--top N: the N kernels with the most registers (arch + accumulation VGPRs; above 256 a wave64 kernel runs one wave per SIMD).
 Exit code 1 if any kernel uses scratch.  tests/test_abi.py::test_no_kernel_uses_scratch runs it."""
 import os, re, struct, subprocess, sys, tempfile
 
@@ -42,7 +43,7 @@ def kernels(path):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--top"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = args[0] if args else os.path.join(root, "faster-qwen3-tts_amd", "lib", "libfq3hip.so")
     ks = kernels(path)
@@ -53,6 +54,13 @@ def main():
         if k["scratch"] or "--all" in sys.argv:
             print(f"{n[:90]:90s} scratch={k['scratch']:5d} vgpr={k['vgpr']:3d} agpr={k['agpr']:3d} lds={k['lds']}")
         bad += k["scratch"] > 0
+    if "--top" in sys.argv:
+        n_top = int(sys.argv[sys.argv.index("--top") + 1])
+        ranked = sorted(zip(ks, names), key=lambda kn: -(kn[0]["vgpr"] + kn[0]["agpr"]))[:n_top]
+        print(f"top {n_top} register users (arch + acc VGPRs):")
+        for k, n in ranked:
+            n = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("fq3::", "").replace("unsigned short", "bf16").replace("void ", ""))
+            print(f"  {k['vgpr'] + k['agpr']:4d} = {k['vgpr']:3d} + {k['agpr']:3d}  lds={k['lds']:6d}  {n[:100]}")
     print(f"{len(ks)} kernels, {bad} with a non-empty private segment")
     return 1 if bad else 0
 

@@ -139,6 +139,37 @@ __global__ __launch_bounds__(256) void qkv_ticket_only_kernel(GemvArgs a, unsign
 }
 __global__ void empty_kernel(const float* p) { if (p == nullptr) __builtin_trap(); }
 
+// ---- candidate (round 5, the round-4 review's "one bounded single-stream experiment"): the code predictor's attention recomputed
+// redundantly inside its o_proj GEMV.  Every one of the 256 workgroups (here 16 waves: one per q head) runs the one-wave attention body
+// of all 16 heads into LDS (<= 17 keys: ~70 KB of L2 reads per workgroup), one barrier, then the GEMV over the LDS vector (a row's K
+// split over four waves, partial sums through LDS).  Replaces the attn_pred_kernel launch (16 workgroups x 1 wave, 2.75 us in a
+// chain) in front of every predictor o_proj: 75 of the frame's 554 launches -- if the prologue costs less than that launch.
+template <typename T>
+__global__ __launch_bounds__(1024) void oproj_attn_fused_kernel(GemvArgs g, AttnArgs at) {
+    __shared__ __attribute__((aligned(16))) T xs[2048];
+    __shared__ float part[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row = blockIdx.x * 4 + (wave >> 2), kq = wave & 3;
+    Raw8<T> wr;
+    ldraw<false>(wr, reinterpret_cast<const T*>(g.W) + (size_t)row * g.K + kq * 512 + lane * 8);        // the weights first: the long pole
+    const float resv = DT<T>::ld(reinterpret_cast<const T*>(g.res) + blockIdx.x * 4 + (tid & 3));
+    at.out = xs;                                       // (a generic pointer into LDS: the body's stores become flat stores)
+    attn_pred_body<T>(at, wave);                       // head = wave; the group's first head appends K / V (every workgroup: same values)
+    __syncthreads();
+    Raw8<T> xr;
+    xr.v = *reinterpret_cast<const u32x4*>(xs + kq * 512 + lane * 8);
+    float x[8];
+    unpack(xr, x);
+    float sacc = dot8<T>(wr, x, 0.f);
+    sacc = wave_sum(sacc);
+    if (lane == 0) part[wave] = sacc;
+    __syncthreads();
+    if (tid < 4) {
+        const float t = ((part[tid * 4] + part[tid * 4 + 1]) + part[tid * 4 + 2]) + part[tid * 4 + 3];
+        DT<T>::st(reinterpret_cast<T*>(g.y) + blockIdx.x * 4 + tid, DT<T>::rnd(t) + resv);
+    }
+}
+
 int main(int argc, char** argv) {
     const char* only = argc > 1 ? argv[1] : "";
     g_reps = argc > 2 ? atoi(argv[2]) : 20;
@@ -283,6 +314,27 @@ int main(int argc, char** argv) {
         chain("oproj gemv<4,COMBINE,RESID>   N=1024 K=2048 R=1 grid 256, 1 part", N, [&](int i) { gemv<4, PRO_COMBINE, EPI_RESIDUAL, false>(o_args(i, 1), 1); });
         chain("oproj gemv<4,COMBINE,RESID>   N=1024 K=2048 R=1 grid 256, 8 parts", N, [&](int i) { gemv<4, PRO_COMBINE, EPI_RESIDUAL, false>(o_args(i, 8), 1); });
         chain("oproj gemv<4,PLAIN,RESID>     N=1024 K=2048 R=1 grid 256 (no combine)", N, [&](int i) { GemvArgs g = o_args(i, 1); g.x = attn_out; gemv<4, PRO_PLAIN, EPI_RESIDUAL, false>(g, 1); });
+    }
+    if (want("oattn")) {
+        // correctness first: fused == attn_pred_kernel + PLAIN o_proj up to the fp32 order of the K split
+        GemvArgs g0 = o_args(0, 1); g0.x = attn_out;
+        hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(2 * NKV), dim3(64), 0, st, pattn_args(8));
+        gemv<4, PRO_PLAIN, EPI_RESIDUAL, false>(g0, 1); CHK(hipStreamSynchronize(st));
+        auto y_ref = fetch_bf16(g0.y, H);
+        CHK(hipMemset(g0.y, 0, H * 2));
+        hipLaunchKernelGGL((oproj_attn_fused_kernel<bf16_t>), dim3(H / 4), dim3(1024), 0, st, g0, pattn_args(8)); CHK(hipStreamSynchronize(st));
+        auto y_f = fetch_bf16(g0.y, H);
+        double e = 0; for (int r = 0; r < H; ++r) e = fmax(e, fabs(y_f[r] - y_ref[r]) / (1.0 + fabs(y_ref[r])));
+        report("o_proj with the attention recomputed in every workgroup ~ attn + o_proj", e, 2e-2);
+        CHK(hipMemcpy(bufB, bufA, 8192 * 2, hipMemcpyDeviceToDevice));
+        const double t_pair = chain("oattn attn_pred_kernel + gemv<4,PLAIN,RESID> (the product: 2 launches per step, 160 steps)", N, [&](int i) {
+            if (i & 1) { GemvArgs g = o_args(i / 2, 1); g.x = attn_out; gemv<4, PRO_PLAIN, EPI_RESIDUAL, false>(g, 1); }
+            else hipLaunchKernelGGL((attn_pred_kernel<bf16_t>), dim3(2 * NKV), dim3(64), 0, st, pattn_args(8)); });
+        const double t_fused = chain("oattn o_proj with the attention inside (256 WG x 1024 thr: 1 launch per step)", N, [&](int i) {
+            GemvArgs g = o_args(i, 1); g.x = attn_out;
+            hipLaunchKernelGGL((oproj_attn_fused_kernel<bf16_t>), dim3(H / 4), dim3(1024), 0, st, g, pattn_args(8)); });
+        printf("   -> per predictor layer: pair %.2f us, fused %.2f us: %+.2f us (x 75 launches per frame = %+.1f us of ~2060)\n", 2 * t_pair, t_fused, t_fused - 2 * t_pair,
+               75 * (t_fused - 2 * t_pair));
     }
     if (want("gateup")) {
         chain("gateup gemv<2,NORM,SWIGLU>    N=3072 K=1024 R=2 grid 384", N, [&](int i) { gemv<2, PRO_NORM, EPI_SWIGLU, false>(gu_args(i), 2); });
