@@ -45,6 +45,7 @@ struct fq3_batch {
                                   // inside the weight-stationary GEMM (sum-of-squares partials from the residual GEMM's epilogue).  It removes the 216 normalisation
                                   // launches of a frame, but every one of a GEMM's 256 workgroups then normalises every token it stages: +0.3..1.2 us per GEMM at
                                   // hidden 1024, +3..10 us at 2048, against ~1.5 us for the launch it saves inside a graph ("norm_fused" 1 selects it)
+    int pred_pair = 1;            // the predictor's two-token prefill as one pass over 2 B rows where that is bit-identical (see enqueue_batch_frame_t); 0 = two passes
     int attn_lane = 1;            // talker attention as one workgroup per (kv head, lane), final outputs, no merge launch: 0 never, 1 from attn_lane_from lanes (bf16), 2 always
     int attn_lane_from = 4 * kTokTile;
     int attn_lane_keys = 8;       // keys per load step of that kernel: 8 (two register sets of 2 K + 2 V rows per lane group: 122 VGPRs, four workgroups per CU -- measured 29.6 vs 30.6 us per launch at 128 lanes) or 16
@@ -162,7 +163,7 @@ static int poll_prepare(fq3_batch* b);
 // follows the BATCH's lane count, not the group's (a last group of a few lanes must not change its lanes' summation order)
 static void sync_kid_options(fq3_batch* b) {
     for (fq3_batch* k : b->kids) {
-        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma; k->norm_skinny = b->norm_skinny; k->norm_fused = b->norm_fused; k->attn_lane = b->attn_lane; k->attn_lane_keys = b->attn_lane_keys;
+        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma; k->norm_skinny = b->norm_skinny; k->norm_fused = b->norm_fused; k->attn_lane = b->attn_lane; k->attn_lane_keys = b->attn_lane_keys; k->pred_pair = b->pred_pair;
         k->attn_lane_from = b->B >= b->attn_lane_from ? 0 : (1 << 30);      // the BATCH's lane count decides
         k->norm_skinny_above = b->B > b->norm_skinny_above ? 0 : (1 << 30);      // the BATCH's lane count decides, as for "skinny"
         k->use_skinny = (b->use_skinny == 1 && b->B > kTokTile) ? 2 : b->use_skinny;
@@ -236,10 +237,11 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
     const int Vm = std::max(t.vocab, p.vocab);
     int r;
     auto A = [&](void** ptr, size_t n) { return bmalloc(b, ptr, n); };
-    if ((r = A(&b->h, (size_t)B * b->Hm * esz)) || (r = A(&b->xin, (size_t)B * b->Hm * esz)) ||
-        (r = A(&b->xn, (size_t)B * b->Hm * esz)) || (r = A((void**)&b->ssq, (size_t)B * (b->Hm / 16 + 4) * sizeof(float))) || (r = A(&b->qkv, (size_t)B * b->qkvm * esz)) || (r = A(&b->act, (size_t)B * b->Im * esz)) ||
-        (r = A(&b->attn_out, (size_t)B * b->qkvm * esz)) || (r = A(&b->logits, (size_t)B * Vm * esz)) ||
-        (r = A(&b->pred_in, (size_t)B * 2 * t.hidden * esz)) || (r = A(&b->pred_x, (size_t)B * p.hidden * esz)) ||
+    // (h, xn, qkv, act, attn_out, pred_x, ssq hold 2 B rows: the predictor's two-token prefill runs as ONE pass over 2 B token rows)
+    if ((r = A(&b->h, (size_t)2 * B * b->Hm * esz)) || (r = A(&b->xin, (size_t)B * b->Hm * esz)) ||
+        (r = A(&b->xn, (size_t)2 * B * b->Hm * esz)) || (r = A((void**)&b->ssq, (size_t)2 * B * (b->Hm / 16 + 4) * sizeof(float))) || (r = A(&b->qkv, (size_t)2 * B * b->qkvm * esz)) || (r = A(&b->act, (size_t)2 * B * b->Im * esz)) ||
+        (r = A(&b->attn_out, (size_t)2 * B * b->qkvm * esz)) || (r = A(&b->logits, (size_t)B * Vm * esz)) ||
+        (r = A(&b->pred_in, (size_t)B * 2 * t.hidden * esz)) || (r = A(&b->pred_x, (size_t)2 * B * p.hidden * esz)) ||
         (r = A(&b->pred_next, (size_t)B * t.hidden * esz)) || (r = A(&b->plogits, (size_t)B * (G - 1) * p.vocab * esz))) {
         fq3_batch_destroy(b); return r;
     }
@@ -288,6 +290,7 @@ extern "C" int fq3_batch_set_option(fq3_batch* b, const char* key, int value) {
     if (!b || !key) return fq3_fail_(FQ3_EINVAL, "null argument");
     if (std::string(key) == "norm_dual") b->norm_dual = value;
     else if (std::string(key) == "norm_fused") b->norm_fused = value;     // RMSNorm inside the weight-stationary GEMM (default 0: a measured negative; 1 selects it)
+    else if (std::string(key) == "pred_pair") b->pred_pair = value;
     else if (std::string(key) == "attn_lane") b->attn_lane = value;
     else if (std::string(key) == "attn_lane_from") b->attn_lane_from = value;
     else if (std::string(key) == "attn_lane_keys") { if (value != 8 && value != 16) return fq3_fail_(FQ3_EINVAL, "attn_lane_keys must be 8 or 16"); b->attn_lane_keys = value; }
@@ -483,7 +486,11 @@ static int launch_gemv_batch(const fq3_ctx* c, const BatchGemvArgs& a, hipStream
     return c->cfg.dtype == FQ3_BF16 ? launch_gemv_batch_t<bf16_t, PRO, EPI>(a, 2, s) : launch_gemv_batch_t<float, PRO, EPI>(a, 4, s);
 }
 
-struct BatchSrc { const void* x0; int x0_stride; int pos_imm; bool talker; bool kv_only_tail; };
+struct BatchSrc { const void* x0; int x0_stride; int pos_imm; bool talker; bool kv_only_tail; bool pair = false; };
+// `pair` (code predictor only): the stack runs over 2 B token rows -- row 2 l = lane l's token A (cache slot 0), row 2 l + 1 = its token B
+// (slot 1) -- i.e. the two-token prefill of predictor_graph.py:121-128 as ONE pass over the weights, as the single stream does
+// (run_predictor_pair).  Every row's arithmetic is that of the one-row-per-lane passes (the weight-stationary GEMMs and the row kernels
+// do not depend on the row count), so the ids are those of the two-pass form bit for bit.
 
 template <typename T>
 static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
@@ -491,7 +498,8 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
     const bool talker = src.talker;
     const fq3_stack_dims& d = talker ? c->cfg.talker : c->cfg.predictor;
     const std::vector<fq3_layer_weights>& L = talker ? c->tl : c->pl;
-    const int rep = d.n_heads / d.n_kv_heads, B = b->B;
+    const int rep = d.n_heads / d.n_kv_heads;
+    const int B = src.pair ? 2 * b->B : b->B;            // token rows of this pass
     const int q_dim = d.n_heads * kHeadDim, kv_dim = d.n_kv_heads * kHeadDim;
     // RMSNorm inside the GEMM pair (the lane counts that take the weight-stationary form of the normalising GEMVs): the residual GEMMs
     // leave the sum-of-squares partials of the rows of `h`, the next normalising GEMM picks them up
@@ -550,6 +558,17 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
             rp = rp < 0 ? 0 : (rp >= rl ? rl - 1 : rp);
             a.cos_row = c->wt.pred_cos + (size_t)rp * 64; a.sin_row = c->wt.pred_sin + (size_t)rp * 64;
             a.max_seq = c->pk.max_seq; a.pos_ptr = nullptr; a.pos_imm = src.pos_imm; a.n_pad = 0; a.out = b->attn_out;
+            if (src.pair) {
+                // token A (slot 0) of every lane, then token B (slot 1, which attends to A's row just appended): rows 2 l and 2 l + 1
+                for (int m = 0; m < 2; ++m) {
+                    AttnArgs am = a;
+                    am.qkv = (const T*)b->qkv + (size_t)m * b->qkvm; am.out = (T*)b->attn_out + (size_t)m * b->qkvm;
+                    am.pos_imm = m;
+                    const int rm = m < c->wt.pred_rope_len ? m : c->wt.pred_rope_len - 1;
+                    am.cos_row = c->wt.pred_cos + (size_t)rm * 64; am.sin_row = c->wt.pred_sin + (size_t)rm * 64;
+                    hipLaunchKernelGGL((attn_pred_batch_kernel<T>), dim3(d.n_heads, b->B), dim3(64), 0, s, am, (const LaneKV*)(b->d_pkv + i), 2 * b->qkvm, 2 * b->qkvm);
+                }
+            } else
             hipLaunchKernelGGL((attn_pred_batch_kernel<T>), dim3(d.n_heads, B), dim3(64), 0, s, a, (const LaneKV*)(b->d_pkv + i), b->qkvm, b->qkvm);
             if (tail_skip) break;
             o.x = b->attn_out; o.x_stride = b->qkvm;
@@ -581,27 +600,35 @@ static int enqueue_batch_frame_t(fq3_batch* b, hipStream_t s) {
     hipLaunchKernelGGL((frame_begin_batch_kernel<T>), dim3(B), dim3(256), 0, s, tab, (const T*)c->wt.codec_embedding,
                        (T*)b->pred_in, H, G);
     // predictor: token A (past_hidden, slot 0), token B (embed(tok0), slot 1), then 14 single-token passes
+    // the two-token prefill as one pass over 2 B rows ("pred_pair": default from the lane count at which every GEMM of the pass is the
+    // weight-stationary kernel anyway -- above norm_skinny_above lanes, bf16, matrix-core path -- where a row's arithmetic does not
+    // depend on the row count: bit-identical to the two passes; 0 = two passes at every lane count)
+    const bool pair = b->pred_pair && g_batch_mfma && c->cfg.dtype == FQ3_BF16 && g_batch_norm_skinny && g_batch_skinny && B > g_batch_norm_skinny_above &&
+                      2 * B <= kSkinnyMaxRows && skinny_k_ok(p.hidden) && p.hidden <= 2048;
     for (int pass = 0; pass < G; ++pass) {
+        const bool pp = pair && pass == 0;                 // this iteration runs token A and token B together
         const void* x_talker = pass < 2 ? (const void*)((const T*)b->pred_in + (size_t)pass * H) : (const void*)b->pred_next;
-        const int x_stride = pass < 2 ? 2 * H : H;
+        const int x_stride = pp ? H : (pass < 2 ? 2 * H : H);       // (pair: pred_in [B][2 H] read as [2 B][H])
         const void* x0 = x_talker; int x0_stride = x_stride;
         if (c->cfg.has_projection) {                      // small_to_mtp_projection (predictor_graph.py:118,145)
             BatchGemvArgs g{};
-            g.B = B; g.W = c->wt.proj_w; g.bias = c->wt.proj_b; g.N = p.hidden; g.K = H; g.x = x_talker; g.x_stride = x_stride;
+            g.B = pp ? 2 * B : B; g.W = c->wt.proj_w; g.bias = c->wt.proj_b; g.N = p.hidden; g.K = H; g.x = x_talker; g.x_stride = x_stride;
             g.y = b->pred_x; g.y_stride = p.hidden;
             if (int r = launch_gemv_batch<PRO_PLAIN, EPI_STORE>(c, g, s)) return r;
             x0 = b->pred_x; x0_stride = p.hidden;
         }
-        BatchSrc src{x0, x0_stride, pass, false, pass == 0};
+        BatchSrc src{x0, x0_stride, pass, false, pass == 0 && !pp, pp};
         if (int r = run_stack_batch<T>(b, src, s)) return r;
-        if (pass == 0) continue;
+        if (pass == 0 && !pp) continue;
+        if (pp) pass = 1;                                  // token B (slot 1) produces codebook 0 below, from the odd rows of `h`
         const int cb = pass - 1;
         T* lg = (T*)b->plogits + (size_t)cb * Vp;
         const size_t lstride = (size_t)(G - 1) * Vp;
         BatchGemvArgs hg{};
-        hg.B = B; hg.eps = p.rms_eps; hg.W = c->lmh[cb]; hg.N = Vp; hg.K = p.hidden; hg.x = b->h; hg.x_stride = b->Hm;
+        hg.B = B; hg.eps = p.rms_eps; hg.W = c->lmh[cb]; hg.N = Vp; hg.K = p.hidden;
+        hg.x = pp ? (const void*)((const T*)b->h + b->Hm) : (const void*)b->h; hg.x_stride = pp ? 2 * b->Hm : b->Hm;
         hg.norm_w = c->wt.predictor_final_norm; hg.y = lg; hg.y_stride = (int)lstride; hg.xn_ws = b->xn;
-        hg.ssq_in = b->h_ssq;
+        hg.ssq_in = pp ? nullptr : b->h_ssq;              // (the partials are indexed by packed row: the strided read of the pair pass normalises in its own launch)
         if (int r = launch_gemv_batch<PRO_NORM, EPI_STORE>(c, hg, s)) return r;
         const T* next_emb = cb + 1 < G - 1 ? (const T*)c->pemb[cb] : nullptr;
         if (Vp <= 2048) hipLaunchKernelGGL((sample_pred_batch_kernel<T, 1>), dim3(B), dim3(256), 0, s, tab, lf, (const T*)lg, lstride, Vp, cb, G, next_emb, (T*)b->pred_next, H);

@@ -126,7 +126,7 @@ def _run_batch(engines, cfg, cases, B, mfma, graph=True, options=()):
         assert np.array_equal(e.decode_codes(0, N).cpu().numpy(), case["codes"].astype(np.int64)), f"lane {i}: the forced ids were not the ones the loop continued with"
         d = dec.cpu().numpy().astype(np.int64)[:N].copy()
         d[0, 0] = tok0
-        scores.append(TF.score(d, case, K_ULP))
+        scores.append(dict(TF.score(d, case, K_ULP), decisions=d))
         e.decode_set_forced(None, None)
     batch.close()
     return scores
@@ -164,6 +164,12 @@ def test_batch_full_depth_bf16_mfma_lanes_vs_oracle(size, golden_dir):
             for i, sc in enumerate(old):
                 assert sc["matched_decisions"] >= R4_FORM_FLOOR[size][i % len(cases)], (i, sc)
             # the RMSNorm folded into the GEMM pair (a measured negative, off by default, kept as a switch): correct all the same
+            # the predictor's two-token prefill as ONE pass over 2 B rows (the default from 64 lanes) against two passes: every decision of
+            # every lane identical (a row's arithmetic does not depend on the row count of a weight-stationary launch)
+            two = _run_batch(engines, cfg, cases, B, mfma=1, options=(("pred_pair", 0),))
+            one = _run_batch(engines, cfg, cases, B, mfma=1)
+            for i, (a_, b_) in enumerate(zip(two, one)):
+                assert np.array_equal(a_["decisions"], b_["decisions"]), f"lane {i}: the pair pass changed a decision"
             fused = _run_batch(engines, cfg, cases, B, mfma=1, options=(("norm_fused", 1),))
             _note(f"{size}_bf16_mfma_B{B}_norm_fused", dict(per_lane=[s["matched_decisions"] for s in fused]))
             assert all(s["unexplained"] == 0 for s in fused)
