@@ -129,7 +129,9 @@ int fq3_kv_blocks(const fq3_ctx* ctx);
  *   "weight_nt" 0|1|2 (non-temporal weight loads: none | talker | all), "pred_m2" 0|1 (predictor two-token prefill as one
  *   M = 2 pass), "pred_attn" 0|1 (one-wave predictor attention), "rows_per_wave_max" 1|2, "prefill_mode" 0|1,
  *   "flash_prefill" 0|1 (bf16 prefill attention as a flash-style matrix-core kernel), "skinny_gemm" 0|1 (prompts of <= 416 rows:
- *   weight-stationary GEMMs with the SwiGLU fused into the [gate | up] launch; 0 = the tiled / split-K kernels of longer prompts).
+ *   weight-stationary GEMMs with the SwiGLU fused into the [gate | up] launch; 0 = the tiled / split-K kernels of longer prompts),
+ *   "flash_small" 0|1 (round 5; prompts of <= 256 rows: every key tile of a query block resident in LDS, and the prompts of a packed
+ *   fq3_prefill_batch over ONE pool share two attention launches per layer; 0 = the streamed-tile kernel, per prompt; bit-identical).
  * Resets a captured graph. */
 int fq3_set_option(fq3_ctx* ctx, const char* key, int value);
 
@@ -307,6 +309,11 @@ int fq3_batch_poll_wait(fq3_batch* b, int slot, int* n_frames_total, int* done);
  * "norm_skinny" 0|1 (more than 32 lanes): the normalising GEMVs (qkv, gate | up, heads) as ONE normalisation launch + the
  * weight-stationary GEMM kernel (default 1) or as the per-workgroup-panel kernels of the lower lane counts (0);
  * "norm_skinny_above" n moves that lane count (measurement switch).
+ * Round 5: "attn_lane" 0|1|2 -- the talker attention as ONE workgroup per (kv head, lane) that writes the final head outputs (no
+ * partial slots, no merge launch): never | from "attn_lane_from" lanes on (default 64; bf16 matrix-core path) | always; "attn_lane_keys"
+ * 8|16 (keys per load step); "pred_pair" 0|1 -- the predictor's two-token prefill as one pass over 2 B token rows where that is
+ * bit-identical (above 32 lanes; default 1); "norm_fused" 0|1 -- the RMSNorm of qkv / gate | up / lm heads inside the
+ * weight-stationary GEMM, from sum-of-squares partials the residual GEMM's epilogue leaves (measured SLOWER on MI355X: default 0).
  * "groups" 0..4: LANE GROUPS (a measurement switch).  The lanes split into that many independent lock-step chains of whole 16-lane
  * tiles, each with its own frame graph, advanced concurrently on streams the library probes for a hardware queue of their own (they
  * fork from / join `stream` inside fq3_batch_frames, so the caller sees one stream as before); 0 (default) = automatic = ONE chain:
@@ -343,7 +350,10 @@ int fq3_codec_bind(fq3_codec* c, const char* name, const void* ptr, int64_t nume
 /* Kernel-variant switch of the codec decoder (parity tests / measurements): "fuse_units" 1 = the residual units of the
  * 96-channel decoder block (SnakeBeta -> k7 conv -> SnakeBeta -> 1x1 conv -> + skip) run as ONE launch each with the middle
  * tensor kept in LDS (the default: 7.45 vs 7.92 ms per 370-frame decode), 2 = the 192-channel block's too (measured slower:
- * 7.93 ms), 0 = two GEMM launches per unit.  All settings give bit-identical waveforms. */
+ * 7.93 ms), 0 = two GEMM launches per unit.  All settings give bit-identical waveforms.  FQ3_BF16X2 (round 5): the 96-channel block's
+ * units fuse too (the middle tensor parked in LDS as hi | lo words); measured a wash (14.46 -> 14.31 ms per 370-frame decode).
+ * The four activation workspaces follow the CALL: a batched decode needs B x elems(T) elements and grows them when short
+ * (FQ3_ENOMEM when that fails: the Python host then decodes utterance by utterance). */
 int fq3_codec_set_option(fq3_codec* codec, const char* key, int value);
 int fq3_codec_finalize(fq3_codec* c, void* stream);
 /* number of PCM samples produced for T frames (the causal transposed convs trim, so < 1920*T) */
