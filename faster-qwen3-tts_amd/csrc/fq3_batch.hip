@@ -44,7 +44,7 @@ struct fq3_batch {
     int norm_fused = 0;           // a MEASURED NEGATIVE (round 5, profiles/r05_normfuse.txt), off: above norm_skinny_above lanes the RMSNorm of qkv / gate | up / lm heads
                                   // inside the weight-stationary GEMM (sum-of-squares partials from the residual GEMM's epilogue).  It removes the 216 normalisation
                                   // launches of a frame, but every one of a GEMM's 256 workgroups then normalises every token it stages: +0.3..1.2 us per GEMM at
-                                  // hidden 1024, +3..10 us at 2048, against ~1.5 us for the launch it saves inside a graph ("norm_fused" 1 selects it)
+                                  // hidden 1024, +3..10 us at 2048, against 1.9 us for the launch it saves inside a graph ("norm_fused" 1 selects it)
     int pred_pair = 1;            // the predictor's two-token prefill as one pass over 2 B rows where that is bit-identical (see enqueue_batch_frame_t); 0 = two passes
     int attn_lane = 1;            // talker attention as one workgroup per (kv head, lane), final outputs, no merge launch: 0 never, 1 from attn_lane_from lanes (bf16), 2 always
     int attn_lane_from = 4 * kTokTile;

@@ -186,6 +186,10 @@ int main(int argc, char** argv) {
             snprintf(nm, sizeof nm, "%s B=%3d  o_proj alone, without / with the partials", sh.name, B);
             chain(nm, NLAY, 1, [&](int j) { oproj(j % NL, B, false); });
             chain(nm, NLAY, 1, [&](int j) { oproj(j % NL, B, true); });
+            snprintf(nm, sizeof nm, "%s B=%3d  down alone", sh.name, B);
+            chain(nm, NLAY, 1, [&](int j) { down(j % NL, B, false, act_b); });
+            snprintf(nm, sizeof nm, "%s B=%3d  rmsnorm_batch_kernel alone (one wave per token)", sh.name, B);
+            chain(nm, NLAY, 1, [&](int) { rmsnorm_rows(h, H, gain, H, B, xn); });
         }
         for (int l = 0; l < NL; ++l) { CHK(hipFree(Wqkv[l])); CHK(hipFree(Wo[l])); CHK(hipFree(Wgu[l])); CHK(hipFree(Wdn[l])); }
     }
