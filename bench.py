@@ -1012,7 +1012,7 @@ def main():
             except Exception as e:
                 out["streaming"] = {"error": repr(e)}
             # first-chunk latency of SIMULTANEOUS requests at the smaller lane counts too (the bar of the single stream, < 150 ms, holds up
-            # to ~50 simultaneous requests: ~35 ms + ~2 ms per request -- prompt build, packed prefill, first-chunk vocoder; DESIGN.md 4.2)
+            # to ~50 simultaneous requests: ~35 ms + ~2 ms per request -- prompt build, packed prefill, first-chunk vocoder; DESIGN.md 4.3)
             for other in (32, 64):
                 if lanes > other:
                     try:
