@@ -756,6 +756,12 @@ class FasterQwen3TTS:
             # vocoder_stream_priority (attribute, default None = the device default): HIP stream priority of the vocoder
             # stream, larger = lower.  Set it before the first streaming call.
             prio = getattr(self, "vocoder_stream_priority", None)
+            share = getattr(self, "vocoder_cu_share", None)
+            if share:
+                # measurement switch (attribute, default None): the vocoder confined to a share of the CUs (fq3hip/streams.py::cu_masked_stream)
+                from .streams import cu_masked_stream
+                self._voc_stream = cu_masked_stream(dev, float(share))
+                return self._voc_stream
             from .streams import concurrent_stream
             # a stream VERIFIED to execute beside the decode stream: one that shares its hardware queue would hold the first audio chunk
             # back until the next chunk's frames -- queued before it -- have run (fq3hip/streams.py)

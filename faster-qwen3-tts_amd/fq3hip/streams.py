@@ -63,3 +63,29 @@ def _probe(dev, main, others, priority, tries):
         if running[0] and beside_main is None:
             beside_main = cand
     return beside_main if beside_main is not None else cand
+
+
+def cu_masked_stream(device, share: float) -> "torch.cuda.Stream":
+    """A HIP stream whose kernels may only run on a SHARE of the compute units (``hipExtStreamCreateWithCUMask``; a measurement switch,
+    ``FasterQwen3TTS.vocoder_cu_share``).  Idea: the vocoder's full-chip GEMM grids hold every CU for 100-400 us at a time and the
+    latency-bound lock-step frames queue behind them; confined to part of the chip they leave the rest free at all times.  The enabled
+    CUs are chosen by two parity bits of the CU index, so that every XCD / shader engine contributes the same share whichever way the
+    driver maps mask bits to CUs.  ``share`` in {0.25, 0.5, 0.75}."""
+    import ctypes as C
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    n_cu = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    words = (n_cu + 31) // 32
+    quarters = max(1, min(3, int(round(float(share) * 4))))
+    mask = (C.c_uint32 * words)()
+    for b in range(n_cu):
+        h0 = (b ^ (b >> 3) ^ (b >> 6)) & 1
+        h1 = ((b >> 1) ^ (b >> 4) ^ (b >> 7)) & 1
+        if h0 + 2 * h1 < quarters:
+            mask[b // 32] |= 1 << (b % 32)
+    hip = C.CDLL("libamdhip64.so")
+    st = C.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(words), mask)
+    if rc != 0 or not st.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(st.value, device=dev)

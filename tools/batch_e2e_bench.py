@@ -34,7 +34,13 @@ def main():
         model.batch_lookahead = la
       # FQ3_E2E_FIRST_WAVE="0,32": model.batch_first_wave (requests armed before the first frame is queued; 0 = one per lane)
       fws = [int(x) for x in os.environ.get("FQ3_E2E_FIRST_WAVE", "0").split(",")]
-      for ev, fw in [(e, f) for e in everys for f in fws]:
+      # FQ3_E2E_VOC_SHARE="0,0.5,0.75": model.vocoder_cu_share (the vocoder stream confined to a share of the CUs; 0 = the whole chip)
+      shares = [float(x) for x in os.environ.get("FQ3_E2E_VOC_SHARE", "0").split(",")]
+      for ev, fw, sh in [(e, f, s_) for s_ in shares for e in everys for f in fws]:
+        if len(shares) > 1 or sh > 0:
+            model.vocoder_cu_share = sh if sh > 0 else None
+            model._voc_stream = None; model._side_voc_stream = None          # the next run builds its vocoder stream anew
+            print(f"  vocoder_cu_share = {sh}", flush=True)
         model.batch_vocode_every = ev
         model.batch_first_wave = fw if fw > 0 else None
         bench.batched_run(model, prompt, lanes, lanes)
