@@ -60,10 +60,13 @@ int main(int argc, char** argv) {
         // a few bf16 ulps at most) and against a host double dot product on a sample.
         struct SS { const char* name; int M, N, K; int epi; };        // epi: 0 store, 1 residual, 2 [gate|up] + SwiGLU
         std::vector<SS> ss;
-        for (int M : {200, 52, 416}) {
+        // usage: gemm_bench <reps> skinny [M,M,...]   (default 200,52,416: the prefill's row counts; 64,128: the lock-step batch's lane counts)
+        std::vector<int> Ms = {200, 52, 416};
+        if (argc > 3) { Ms.clear(); for (char* t = strtok(argv[3], ","); t; t = strtok(nullptr, ",")) Ms.push_back(atoi(t)); }
+        for (int M : Ms) {
             ss.push_back({"0.6B qkv", M, 4096, 1024, 0}); ss.push_back({"0.6B gate_up+silu", M, 6144, 1024, 2});
             ss.push_back({"0.6B o_proj", M, 1024, 2048, 1}); ss.push_back({"0.6B down", M, 1024, 3072, 1});
-            if (M == 200) {
+            if (M == 200 || argc > 3) {
                 ss.push_back({"1.7B qkv", M, 4096, 2048, 0}); ss.push_back({"1.7B gate_up+silu", M, 12288, 2048, 2});
                 ss.push_back({"1.7B o_proj", M, 2048, 2048, 1}); ss.push_back({"1.7B down", M, 2048, 6144, 1});
             }
