@@ -560,7 +560,7 @@ def measure_frame_traffic(timeout_s=300, lanes=0):
         shutil.rmtree(out, ignore_errors=True)
 
 
-def cpu_baseline(cfg, frames=16, budget_s=45.0):
+def cpu_baseline(cfg, frames=40, budget_s=45.0):
     """CPU oracle ("port") on the host cores: same shapes, fp32 (bf16 matmuls are not accelerated on every host),
     same prompt; a BOUNDED sample: 200-token prefill + up to `frames` generated frames + their vocoding, cut short when
     `budget_s` is exceeded.  RTF with the same definition as the GPU line."""
