@@ -59,6 +59,16 @@ __global__ __launch_bounds__(64) void attn_pred_batch_kernel(AttnArgs a, const L
     a.kcache = gptr(kv->k[l]); a.vcache = gptr(kv->v[l]);
     attn_pred_body<T>(a);
 }
+// the default since round 6: grid (n_kv_heads, B), one wave per (kv group, lane) -- both q heads of a group from one read of the live
+// K / V rows (decode_kernels.cuh::attn_pred_group_body; bit-identical to the per-head form above, which stays as "pred_attn_group" 0)
+template <typename T, int REP>
+__global__ __launch_bounds__(64) void attn_pred_group_batch_kernel(AttnArgs a, const LaneKV* __restrict__ kv, int qkv_stride, int out_stride) {
+    const int l = blockIdx.y;
+    a.qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)l * qkv_stride;
+    a.out = reinterpret_cast<T*>(a.out) + (size_t)l * out_stride;
+    a.kcache = gptr(kv->k[l]); a.vcache = gptr(kv->v[l]);
+    attn_pred_group_body<T, REP>(a, (int)blockIdx.x);
+}
 
 // talker attention: grid (n_kv, workers, B); position, pad count and RoPE row are the lane's own
 template <typename T, int REP>

@@ -47,6 +47,7 @@ struct GemmArgs {
     // reads A + g * a_seg, writes Y / Y2 + g * y_seg, residual res + g * r_seg (strides in ELEMENTS of the respective tensor);
     // rows, taps and zero padding are local to a segment, so utterance g never sees utterance g - 1's rows
     int n_seg; long a_seg, y_seg, r_seg;
+    const void* Wp;                                   // fragment-major copy of W for the weight-stationary kernel (skinny_gemm.cuh), or null
     int no_skinny;                                    // measurement switch: 1 = keep the tiled / split-K kernels where skinny_gemm.cuh would serve
     int epi_legacy;                                   // measurement switch: 1 = the register-layout epilogue (32-byte runs per row) instead of the
                                                       // LDS-parked one (whole tile rows per store instruction); 0 in the product
@@ -1027,6 +1028,7 @@ inline void gemm_launch_te(const GemmArgs& a, hipStream_t s) {
             SkinnyArgs k{};
             k.X = reinterpret_cast<const bf16_t*>(a.A); k.ldx = a.lda; k.M = a.M; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = a.N;
             k.res = reinterpret_cast<const bf16_t*>(a.res); k.ldr = a.ldr; k.Y = reinterpret_cast<bf16_t*>(a.Y); k.ldy = a.ldy;
+            k.Wp = reinterpret_cast<const bf16_t*>(a.Wp);
             if (a.res) skinny_launch<SK_RESIDUAL>(k, a.Cin, s); else skinny_launch<SK_STORE>(k, a.Cin, s);
             return;
         }
@@ -1099,6 +1101,7 @@ inline void gemm_swiglu_halves(const GemmArgs& a, void* y, hipStream_t s) {
             SkinnyArgs k{};
             k.X = reinterpret_cast<const bf16_t*>(a.A); k.ldx = a.lda; k.M = a.M; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = a.N;
             k.Y = reinterpret_cast<bf16_t*>(y); k.ldy = I;
+            k.Wp = reinterpret_cast<const bf16_t*>(a.Wp);
             skinny_launch<SK_SWIGLU>(k, a.Cin, s);
             return;
         }

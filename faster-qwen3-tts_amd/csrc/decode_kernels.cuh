@@ -582,6 +582,120 @@ __device__ __forceinline__ void attn_pred_body(const AttnArgs& a, int head) {
 template <typename T>
 __device__ __forceinline__ void attn_pred_body(const AttnArgs& a) { attn_pred_body<T>(a, (int)blockIdx.x); }
 
+// The same attention for the lock-step batch (round 6): ONE wave per kv group serves the group's REP q heads from ONE read of the
+// group's K / V rows, and only LIVE rows are requested -- a slot >= pos takes slot 0's address (its score is -inf and its V row is
+// zeroed, exactly as for the unclamped read).  With one wave per q head (attn_pred_body) the two heads of a group sit in different
+// workgroups -- on different XCDs -- and every wave requests all 16 slots whatever the position: 18.0 MB per launch at 128 lanes
+// against 8.9 MB of cache and ~4.5 MB of live rows (profiles/r05_pmc_batch128_fetch.txt: 1.44 GB of the 9.9 GB of a frame).
+// Every head keeps the instructions of attn_pred_body in their order (the new key's norm + RoPE is computed once: the same
+// values), so the outputs are bit-identical (tests/test_gpu_batch.py::test_pred_attention_group_form_is_bit_identical).
+template <typename T, int REP>
+__device__ __forceinline__ void attn_pred_group_body(const AttnArgs& a, int g) {
+    constexpr int HD = kHeadDim;
+    const int lane = threadIdx.x & 63, sub = lane >> 4, c = lane & 15;
+    const int pos = a.pos_imm;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    const int q_dim = a.n_kv * REP * HD, kv_dim = a.n_kv * HD;
+    T* kc = reinterpret_cast<T*>(a.kcache) + (size_t)g * a.max_seq * HD;
+    T* vc = reinterpret_cast<T*>(a.vcache) + (size_t)g * a.max_seq * HD;
+    Raw8<T> qraw[REP], knraw, vnraw, qwraw, kwraw, kr[4], vr[4];
+#pragma unroll
+    for (int h = 0; h < REP; ++h) ldraw<false>(qraw[h], qkv + (size_t)(g * REP + h) * HD + c * 8);
+    ldraw<false>(knraw, qkv + q_dim + (size_t)g * HD + c * 8);
+    ldraw<false>(vnraw, qkv + q_dim + kv_dim + (size_t)g * HD + c * 8);
+    ldraw<false>(qwraw, reinterpret_cast<const T*>(a.q_norm_w) + c * 8);
+    ldraw<false>(kwraw, reinterpret_cast<const T*>(a.k_norm_w) + c * 8);
+    const f32x4 cs0 = *reinterpret_cast<const f32x4*>(a.cos_row + ((c * 8) & 63)), cs1 = *reinterpret_cast<const f32x4*>(a.cos_row + ((c * 8 + 4) & 63));
+    const f32x4 sn0 = *reinterpret_cast<const f32x4*>(a.sin_row + ((c * 8) & 63)), sn1 = *reinterpret_cast<const f32x4*>(a.sin_row + ((c * 8 + 4) & 63));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int key = i * 4 + sub;
+        key = key < pos ? key : 0;               // a dead slot: slot 0's line again (no new request), masked below
+        ldraw<false>(kr[i], kc + (size_t)key * HD + c * 8);
+        ldraw<false>(vr[i], vc + (size_t)key * HD + c * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);           // keep every load above the arithmetic (one round trip, not two)
+    const float sgn = c < 8 ? -1.f : 1.f;
+    const float cs[8] = {cs0.x, cs0.y, cs0.z, cs0.w, cs1.x, cs1.y, cs1.z, cs1.w};
+    const float sn[8] = {sgn * sn0.x, sgn * sn0.y, sgn * sn0.z, sgn * sn0.w, sgn * sn1.x, sgn * sn1.y, sgn * sn1.z, sgn * sn1.w};
+    auto norm_rope = [&](const Raw8<T>& raw, const Raw8<T>& wraw, float (&out)[8]) {
+        float x[8], w[8];
+        unpack(raw, x); unpack(wraw, w);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss = fmaf(x[i], x[i], ss);
+        ss = row16_sum(ss);
+        const float rs = 1.0f / sqrtf(ss / (float)HD + a.eps);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            float u = x[i] * rs, v = x[i + 1] * rs;
+            DT<T>::rnd2(u, v);
+            u *= w[i]; v *= w[i + 1];
+            DT<T>::rnd2(u, v);
+            x[i] = u; x[i + 1] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            float a0 = x[i] * cs[i], a1 = x[i + 1] * cs[i + 1];
+            float b0 = row16_xor8(x[i]) * sn[i], b1 = row16_xor8(x[i + 1]) * sn[i + 1];
+            DT<T>::rnd2(a0, a1); DT<T>::rnd2(b0, b1);
+            float r0 = a0 + b0, r1 = a1 + b1;
+            DT<T>::rnd2(r0, r1);
+            out[i] = r0; out[i + 1] = r1;
+        }
+    };
+    float knew[8], vnew[8];
+    norm_rope(knraw, kwraw, knew);
+    unpack(vnraw, vnew);
+    if (sub == 0) {
+        DT<T>::st8(kc + (size_t)pos * HD + c * 8, knew);
+        DT<T>::st8(vc + (size_t)pos * HD + c * 8, vnew);
+    }
+    float kf[4][8], vf[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unpack(kr[i], kf[i]);
+        if (!(i * 4 + sub < pos)) zero(vr[i]);      // dead slots: another row's (or never-written) bits
+        unpack(vr[i], vf[i]);
+    }
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+        float qr[8];
+        norm_rope(qraw[h], qwraw, qr);
+        float sc[5];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) s = fmaf(qr[d], kf[i][d], s);
+            s = row16_sum(s);
+            sc[i] = (i * 4 + sub < pos) ? s * a.scale : -INFINITY;
+        }
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) s = fmaf(qr[d], knew[d], s);
+            s = row16_sum(s);
+            sc[4] = sub == 0 ? s * a.scale : -INFINITY;
+        }
+        const float mx = wave_max(fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), sc[4]));
+        float p[5], lsum = 0.f, o[8];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { p[i] = __expf(sc[i] - mx); lsum += p[i]; }
+        lsum = wave_sum(lsum) * (1.0f / 16.0f);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o[d] = p[4] * vnew[d];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int d = 0; d < 8; ++d) o[d] = fmaf(p[i], vf[i][d], o[d]);
+        const float inv = 1.0f / lsum;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o[d] = xrow_sum(o[d]) * inv;
+        if (sub == 0) DT<T>::st8(reinterpret_cast<T*>(a.out) + (size_t)(g * REP + h) * HD + c * 8, o);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(64) void attn_pred_kernel(AttnArgs a) { attn_pred_body<T>(a); }
 

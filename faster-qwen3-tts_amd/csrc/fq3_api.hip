@@ -1,12 +1,15 @@
 // libfq3hip.so: context, weight binding, launch orchestration and hipGraph capture for the decode path.
 // C ABI declared in include/fq3hip.h (which cites the reference interface each entry replaces).
+#define FQ3_SKINNY_EXTERN           // skinny_gemm.cuh: the kernels (and skinny_pack) are instantiated in fq3_prefill.hip only
 #include "fq3_ctx.h"
 #include "sampler.cuh"
 #include "sampler_wave.cuh"
+#include "skinny_gemm.cuh"
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -260,6 +263,7 @@ extern "C" int fq3_set_option(fq3_ctx* c, const char* key, int value) {
     else if (k == "prefill_mode") c->prefill_mode = value;     // 0 matrix-core prefill, 1 token walk
     else if (k == "flash_prefill") c->opt_flash_prefill = value;   // bf16 prefill attention on MFMA (default 1)
     else if (k == "flash_small") c->opt_flash_small = value;   // <= 256-row prompts: resident key tiles + packed sequences in one launch (default 1; bit-identical to 0)
+    else if (k == "packed_weights") c->opt_packed = value;     // weight-stationary GEMMs on the fragment-major weight copies (default 1; bit-identical)
     else if (k == "skinny_gemm") c->opt_no_skinny = !value;    // weight-stationary short-prompt prefill GEMMs (default 1)
     else return fail(FQ3_EINVAL, "unknown option: " + k);
     fq3_graph_reset(c);
@@ -273,10 +277,73 @@ extern "C" int fq3_graph_reset(fq3_ctx* c) {
     return FQ3_OK;
 }
 
+// ---- fragment-major copies of the layer matrices (fq3_ctx.h) ----
+namespace {
+struct PackedEntry { void* p; int refs; int N, K; };
+std::mutex g_packed_mu;
+std::map<std::pair<const void*, int>, PackedEntry> g_packed;
+}
+const void* fq3_packed_find_(const void* W, int kind) {
+    std::lock_guard<std::mutex> lk(g_packed_mu);
+    auto it = g_packed.find({W, kind});
+    return it == g_packed.end() ? nullptr : it->second.p;
+}
+int fq3_packed_acquire_(const void* W, int N, int K, int kind) {
+    if (!W || !skinny_pack_ok(N, K) || (kind == 1 && (N / 2) % 8)) return FQ3_EUNSUPPORTED;
+    std::lock_guard<std::mutex> lk(g_packed_mu);
+    auto it = g_packed.find({W, kind});
+    if (it != g_packed.end()) {
+        if (it->second.N != N || it->second.K != K) return fail(FQ3_EINVAL, "a matrix is bound with two different shapes");
+        ++it->second.refs;
+        return FQ3_OK;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, (size_t)N * K * 2) != hipSuccess) { (void)hipGetLastError(); return fail(FQ3_ENOMEM, "no device memory for the fragment-major weight copy"); }
+    skinny_pack(reinterpret_cast<const bf16_t*>(W), reinterpret_cast<bf16_t*>(p), N, K, kind == 1 ? N / 2 : 0, nullptr);
+    if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(p); return fail(FQ3_EHIP, "packing a weight matrix failed"); }
+    g_packed[{W, kind}] = PackedEntry{p, 1, N, K};
+    return FQ3_OK;
+}
+void fq3_packed_release_(const void* W, int kind) {
+    std::lock_guard<std::mutex> lk(g_packed_mu);
+    auto it = g_packed.find({W, kind});
+    if (it == g_packed.end()) return;
+    if (--it->second.refs <= 0) { (void)hipFree(it->second.p); g_packed.erase(it); }
+}
+static void packed_release_all(fq3_ctx* c) {
+    for (auto& r : c->packed_refs) fq3_packed_release_(r.first, r.second);
+    c->packed_refs.clear();
+}
+// references for every layer matrix and head of a bf16 context whose shapes the weight-stationary kernels serve (others stay row-major)
+static int packed_acquire_all(fq3_ctx* c) {
+    if (c->cfg.dtype != FQ3_BF16) return FQ3_OK;
+    auto take = [&](const void* W, int N, int K, int kind) -> int {
+        const int r = fq3_packed_acquire_(W, N, K, kind);
+        if (r == FQ3_OK) c->packed_refs.emplace_back(W, kind);
+        return r == FQ3_EUNSUPPORTED ? FQ3_OK : r;
+    };
+    auto stack = [&](const std::vector<fq3_layer_weights>& L, const fq3_stack_dims& d) -> int {
+        const int qd = d.n_heads * kHeadDim, kvd = d.n_kv_heads * kHeadDim;
+        for (const fq3_layer_weights& l : L) {
+            if (int r = take(l.qkv, qd + 2 * kvd, d.hidden, 0)) return r;
+            if (int r = take(l.o, d.hidden, qd, 0)) return r;
+            if (int r = take(l.gate_up, 2 * d.inter, d.hidden, 1)) return r;
+            if (int r = take(l.down, d.hidden, d.inter, 0)) return r;
+        }
+        return FQ3_OK;
+    };
+    if (int r = stack(c->tl, c->cfg.talker)) return r;
+    if (int r = stack(c->pl, c->cfg.predictor)) return r;
+    if (int r = take(c->wt.codec_head, c->cfg.talker.vocab, c->cfg.talker.hidden, 0)) return r;
+    for (const void* h : c->lmh) if (int r = take(h, c->cfg.predictor.vocab, c->cfg.predictor.hidden, 0)) return r;
+    return FQ3_OK;
+}
+
 extern "C" int fq3_ctx_destroy(fq3_ctx* c) {
     if (!c) return FQ3_OK;
     (void)hipDeviceSynchronize();
     fq3_graph_reset(c);
+    packed_release_all(c);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     if (fq3_kv_pool* p = c->tk.pool) {
         (void)fq3_kv_release(c, 0);
@@ -309,6 +376,10 @@ extern "C" int fq3_bind_weights(fq3_ctx* c, const fq3_weight_table* w) {
     for (auto& l : c->pl) if (!l.qkv || !l.o || !l.gate_up || !l.down || !l.input_norm || !l.post_norm || !l.q_norm || !l.k_norm)
         return fail(FQ3_EINVAL, "predictor layer has null weights");
     HIPCHK(hipMemcpy(c->d_pemb, c->pemb.data(), (G - 1) * sizeof(void*), hipMemcpyHostToDevice));
+    // fragment-major copies for the weight-stationary GEMMs (a re-bind first returns the previous table's references)
+    (void)hipDeviceSynchronize();
+    packed_release_all(c);
+    if (int r = packed_acquire_all(c)) { packed_release_all(c); return r; }
     c->bound = true;
     fq3_graph_reset(c);
     return FQ3_OK;

@@ -45,6 +45,8 @@ struct fq3_batch {
                                   // inside the weight-stationary GEMM (sum-of-squares partials from the residual GEMM's epilogue).  It removes the 216 normalisation
                                   // launches of a frame, but every one of a GEMM's 256 workgroups then normalises every token it stages: +0.3..1.2 us per GEMM at
                                   // hidden 1024, +3..10 us at 2048, against 1.9 us for the launch it saves inside a graph ("norm_fused" 1 selects it)
+    int packed = 1;               // the weight-stationary GEMMs read the fragment-major copies of the layer matrices (round 6; bit-identical); 0 = the row-major matrices
+    int pred_attn_group = 1;      // predictor attention: one wave per (kv group, lane), live rows only (round 6; bit-identical); 0 = one wave per (q head, lane), all 16 slots
     int pred_pair = 1;            // the predictor's two-token prefill as one pass over 2 B rows where that is bit-identical (see enqueue_batch_frame_t); 0 = two passes
     int attn_lane = 1;            // talker attention as one workgroup per (kv head, lane), final outputs, no merge launch: 0 never, 1 from attn_lane_from lanes (bf16), 2 always
     int attn_lane_from = 4 * kTokTile;
@@ -163,7 +165,7 @@ static int poll_prepare(fq3_batch* b);
 // follows the BATCH's lane count, not the group's (a last group of a few lanes must not change its lanes' summation order)
 static void sync_kid_options(fq3_batch* b) {
     for (fq3_batch* k : b->kids) {
-        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma; k->norm_skinny = b->norm_skinny; k->norm_fused = b->norm_fused; k->attn_lane = b->attn_lane; k->attn_lane_keys = b->attn_lane_keys; k->pred_pair = b->pred_pair;
+        k->norm_dual = b->norm_dual; k->use_mfma = b->use_mfma; k->norm_skinny = b->norm_skinny; k->norm_fused = b->norm_fused; k->attn_lane = b->attn_lane; k->attn_lane_keys = b->attn_lane_keys; k->pred_pair = b->pred_pair; k->pred_attn_group = b->pred_attn_group; k->packed = b->packed;
         k->attn_lane_from = b->B >= b->attn_lane_from ? 0 : (1 << 30);      // the BATCH's lane count decides
         k->norm_skinny_above = b->B > b->norm_skinny_above ? 0 : (1 << 30);      // the BATCH's lane count decides, as for "skinny"
         k->use_skinny = (b->use_skinny == 1 && b->B > kTokTile) ? 2 : b->use_skinny;
@@ -291,6 +293,8 @@ extern "C" int fq3_batch_set_option(fq3_batch* b, const char* key, int value) {
     if (std::string(key) == "norm_dual") b->norm_dual = value;
     else if (std::string(key) == "norm_fused") b->norm_fused = value;     // RMSNorm inside the weight-stationary GEMM (default 0: a measured negative; 1 selects it)
     else if (std::string(key) == "pred_pair") b->pred_pair = value;
+    else if (std::string(key) == "pred_attn_group") b->pred_attn_group = value;
+    else if (std::string(key) == "packed_weights") b->packed = value;
     else if (std::string(key) == "attn_lane") b->attn_lane = value;
     else if (std::string(key) == "attn_lane_from") b->attn_lane_from = value;
     else if (std::string(key) == "attn_lane_keys") { if (value != 8 && value != 16) return fq3_fail_(FQ3_EINVAL, "attn_lane_keys must be 8 or 16"); b->attn_lane_keys = value; }
@@ -355,6 +359,7 @@ static int launch_gemv_batch_t(BatchGemvArgs a, int esz, hipStream_t s) {
 static thread_local int g_batch_norm_dual = 1;   // set per enqueue from fq3_batch::norm_dual
 static thread_local int g_batch_norm_skinny = 1; // set per enqueue from fq3_batch::norm_skinny
 static thread_local int g_batch_norm_skinny_above = 2 * kTokTile;
+static thread_local int g_batch_packed = 1;      // set per enqueue from fq3_batch::packed (fragment-major weight copies, fq3_ctx.h)
 template <int EPI>
 static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
     if (a.K % 128) return -1000;
@@ -368,6 +373,7 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
             k.X = reinterpret_cast<const bf16_t*>(a.x); k.ldx = a.x_stride; k.M = a.B; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = n_w;
             k.Y = reinterpret_cast<bf16_t*>(a.y); k.ldy = a.y_stride;
             k.ssq = a.ssq_in; k.gain = reinterpret_cast<const bf16_t*>(a.norm_w); k.eps = a.eps;
+            if (g_batch_packed) k.Wp = reinterpret_cast<const bf16_t*>(fq3_packed_find_(a.W, EPI == EPI_SWIGLU ? 1 : 0));
             if constexpr (EPI == EPI_SWIGLU) skinny_launch<SK_SWIGLU>(k, a.K, s);
             else skinny_launch<SK_STORE>(k, a.K, s);
             return 0;
@@ -379,6 +385,7 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
         SkinnyArgs k{};
         k.X = xn; k.ldx = a.K; k.M = a.B; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = n_w;
         k.Y = reinterpret_cast<bf16_t*>(a.y); k.ldy = a.y_stride;
+        if (g_batch_packed) k.Wp = reinterpret_cast<const bf16_t*>(fq3_packed_find_(a.W, EPI == EPI_SWIGLU ? 1 : 0));
         if constexpr (EPI == EPI_SWIGLU) skinny_launch<SK_SWIGLU>(k, a.K, s);
         else skinny_launch<SK_STORE>(k, a.K, s);
         return 0;
@@ -442,6 +449,7 @@ static int launch_gemv_batch_mfma_plain(const BatchGemvArgs& a, hipStream_t s) {
             k.ssq_out = a.ssq_out; k.ssq_ld = a.N / 16;
             k.X = reinterpret_cast<const bf16_t*>(a.x); k.ldx = a.x_stride; k.M = a.B; k.W = reinterpret_cast<const bf16_t*>(a.W); k.N = a.N;
             k.res = reinterpret_cast<const bf16_t*>(a.res); k.ldr = a.res_stride; k.Y = reinterpret_cast<bf16_t*>(a.y); k.ldy = a.y_stride;
+            if (g_batch_packed) k.Wp = reinterpret_cast<const bf16_t*>(fq3_packed_find_(a.W, 0));
             skinny_launch<SK_RESIDUAL>(k, a.K, s);
             return 0;
         }
@@ -558,6 +566,15 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
             rp = rp < 0 ? 0 : (rp >= rl ? rl - 1 : rp);
             a.cos_row = c->wt.pred_cos + (size_t)rp * 64; a.sin_row = c->wt.pred_sin + (size_t)rp * 64;
             a.max_seq = c->pk.max_seq; a.pos_ptr = nullptr; a.pos_imm = src.pos_imm; a.n_pad = 0; a.out = b->attn_out;
+            // one wave per (kv group, lane) serving the group's q heads from one read of the live K / V rows ("pred_attn_group", default 1;
+            // bit-identical to the one-wave-per-q-head form, 0)
+            auto pred_attn = [&](const AttnArgs& aa, int lanes, int stride) {
+                const LaneKV* kvp = b->d_pkv + i;
+                if (b->pred_attn_group && rep == 1) hipLaunchKernelGGL((attn_pred_group_batch_kernel<T, 1>), dim3(d.n_kv_heads, lanes), dim3(64), 0, s, aa, kvp, stride, stride);
+                else if (b->pred_attn_group && rep == 2) hipLaunchKernelGGL((attn_pred_group_batch_kernel<T, 2>), dim3(d.n_kv_heads, lanes), dim3(64), 0, s, aa, kvp, stride, stride);
+                else if (b->pred_attn_group && rep == 4) hipLaunchKernelGGL((attn_pred_group_batch_kernel<T, 4>), dim3(d.n_kv_heads, lanes), dim3(64), 0, s, aa, kvp, stride, stride);
+                else hipLaunchKernelGGL((attn_pred_batch_kernel<T>), dim3(d.n_heads, lanes), dim3(64), 0, s, aa, kvp, stride, stride);
+            };
             if (src.pair) {
                 // token A (slot 0) of every lane, then token B (slot 1, which attends to A's row just appended): rows 2 l and 2 l + 1
                 for (int m = 0; m < 2; ++m) {
@@ -566,10 +583,9 @@ static int run_stack_batch(fq3_batch* b, const BatchSrc& src, hipStream_t s) {
                     am.pos_imm = m;
                     const int rm = m < c->wt.pred_rope_len ? m : c->wt.pred_rope_len - 1;
                     am.cos_row = c->wt.pred_cos + (size_t)rm * 64; am.sin_row = c->wt.pred_sin + (size_t)rm * 64;
-                    hipLaunchKernelGGL((attn_pred_batch_kernel<T>), dim3(d.n_heads, b->B), dim3(64), 0, s, am, (const LaneKV*)(b->d_pkv + i), 2 * b->qkvm, 2 * b->qkvm);
+                    pred_attn(am, b->B, 2 * b->qkvm);
                 }
-            } else
-            hipLaunchKernelGGL((attn_pred_batch_kernel<T>), dim3(d.n_heads, B), dim3(64), 0, s, a, (const LaneKV*)(b->d_pkv + i), b->qkvm, b->qkvm);
+            } else pred_attn(a, B, b->qkvm);
             if (tail_skip) break;
             o.x = b->attn_out; o.x_stride = b->qkvm;
             if (int r = launch_gemv_batch<PRO_PLAIN, EPI_RESIDUAL>(c, o, s)) return r;
@@ -676,6 +692,7 @@ static int enqueue_batch_frame(fq3_batch* b, hipStream_t s) {
     g_batch_norm_dual = b->norm_dual;
     g_batch_norm_skinny = b->norm_skinny;
     g_batch_norm_skinny_above = b->norm_skinny_above;
+    g_batch_packed = b->packed;
     return b->lanes[0]->cfg.dtype == FQ3_BF16 ? enqueue_batch_frame_t<bf16_t>(b, s) : enqueue_batch_frame_t<float>(b, s);
 }
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 // Talker KV cache: PAGED.  A pool holds, per layer, n_blocks blocks of kKeysPerTile = 64 keys ([n_kv][64][128] elements of K, the
@@ -65,6 +66,8 @@ struct fq3_ctx {
     int opt_rmax = 2;             // GEMV rows-per-wave cap
     int opt_flash_prefill = 1;    // bf16 prefill attention on the matrix cores (0: the per-row wave kernel)
     int opt_flash_small = 1;      // prompts of <= 256 rows: every key tile resident in LDS, the sequences of a packed prefill in one launch (0: the streamed-tile kernel, per prompt)
+    int opt_packed = 1;           // weight-stationary GEMMs read the fragment-major copies of the layer matrices (round 6; bit-identical); 0: the row-major matrices
+    std::vector<std::pair<const void*, int>> packed_refs;      // (matrix, kind) references this context holds in the registry
     int opt_no_skinny = 0;        // 1: short-prompt prefill GEMMs on the tiled / split-K kernels instead of the weight-stationary one (measurement)
     int prefill_mode = 0;         // 0 auto (MFMA), 1 token walk
     bool talker_wave = true;      // talker sampler variant baked into the captured graph
@@ -82,6 +85,15 @@ struct fq3_ctx {
     void *pf_x = nullptr, *pf_xn = nullptr, *pf_qkv = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_act = nullptr, *pf_ws = nullptr;
 };
 
+
+// Fragment-major copies of the bf16 layer matrices (skinny_gemm.cuh, SkinnyArgs::Wp): a process-wide, reference-counted registry keyed by
+// the row-major matrix's address.  fq3_bind_weights takes a reference per matrix for the binding context (the first one packs: a few
+// hundred microseconds per matrix, + N K 2 bytes of HBM; every context of the same replica shares the copy), fq3_ctx_destroy / a
+// re-bind returns them; the last reference frees the copy.  kind 0: 16-row blocks; 1: [gate | up] pairs (8 + 8 rows per block).
+// fq3_packed_find_ returns the copy for the weight-stationary GEMM's launchers, or null (not packed: the row-major path).
+const void* fq3_packed_find_(const void* W, int kind);
+int fq3_packed_acquire_(const void* W, int N, int K, int kind);
+void fq3_packed_release_(const void* W, int kind);
 
 int fq3_fail_(int code, const std::string& m);                 // sets the thread-local error string
 // make sure the context owns the blocks of key slots [0, n_pos) (capped at max_seq_len); new table entries are written on `s`.

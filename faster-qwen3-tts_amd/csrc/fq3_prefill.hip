@@ -525,10 +525,13 @@ void rmsnorm_rows(const T* x, const T* w, T* y, int rows, int C, float eps, hipS
 
 constexpr long kPrefillWsFloats = 8L << 20;       // split-K partials of the short-prompt GEMMs (32 MB)
 // every prefill GEMM lends the split-K workspace: that also marks it free to take the weight-stationary kernel (skinny_gemm.cuh)
+// (kind: 0 = a plain matrix, 1 = [gate | up] halves -- which fragment-major copy the weight-stationary kernel would read, fq3_ctx.h)
 template <typename T>
-GemmArgs lin(fq3_ctx* c, const void* A, int M, int K, const void* W, int N, void* Y) {
+GemmArgs lin(fq3_ctx* c, const void* A, int M, int K, const void* W, int N, void* Y, int kind = 0) {
     GemmArgs a{}; a.A = A; a.lda = K; a.M = M; a.a_rows = M; a.n_taps = 1; a.tap_off[0] = 0; a.Cin = K; a.W = W; a.N = N;
-    a.bias_mod = N; a.Y = Y; a.ldy = N; a.ws = (float*)c->pf_ws; a.ws_floats = kPrefillWsFloats; a.no_skinny = c->opt_no_skinny; return a;
+    a.bias_mod = N; a.Y = Y; a.ldy = N; a.ws = (float*)c->pf_ws; a.ws_floats = kPrefillWsFloats; a.no_skinny = c->opt_no_skinny;
+    if (sizeof(T) == 2 && c->opt_packed && M <= kSkinnyMaxRows) a.Wp = fq3_packed_find_(W, kind);
+    return a;
 }
 template <typename T> void gemm(const GemmArgs& a, hipStream_t s) { gemm_launch<T>(a, s); }
 
@@ -555,7 +558,7 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
                 pack_attention_layer(c, i, w, sq1, L, (bf16_t*)QKV, (bf16_t*)ATT, scale, s);
                 { GemmArgs a = lin<T>(c, ATT, L, QD, w.o, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
                 rmsnorm_rows<T>((const T*)X, (const T*)w.post_norm, XN, L, H, d.rms_eps, s);
-                gemm_swiglu_halves<T>(lin<T>(c, XN, L, H, w.gate_up, 2 * I, GU), ACT, s);
+                gemm_swiglu_halves<T>(lin<T>(c, XN, L, H, w.gate_up, 2 * I, GU, 1), ACT, s);
                 { GemmArgs a = lin<T>(c, ACT, L, I, w.down, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
                 continue;
             }
@@ -572,7 +575,7 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
         }
         { GemmArgs a = lin<T>(c, ATT, L, QD, w.o, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
         rmsnorm_rows<T>((const T*)X, (const T*)w.post_norm, XN, L, H, d.rms_eps, s);
-        gemm_swiglu_halves<T>(lin<T>(c, XN, L, H, w.gate_up, 2 * I, GU), ACT, s);
+        gemm_swiglu_halves<T>(lin<T>(c, XN, L, H, w.gate_up, 2 * I, GU, 1), ACT, s);
         { GemmArgs a = lin<T>(c, ACT, L, I, w.down, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
     }
     // final norm of the last row only -> past_hidden; logits through the decode-path head GEMV
@@ -634,7 +637,7 @@ int prefill_batch_t(fq3_ctx* const* cs, int n, const void* const* embeds, const 
         }
         { GemmArgs a = lin<T>(c, ATT, Lt, QD, w.o, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
         rmsnorm_rows<T>((const T*)X, (const T*)w.post_norm, XN, Lt, H, d.rms_eps, s);
-        gemm_swiglu_halves<T>(lin<T>(c, XN, Lt, H, w.gate_up, 2 * I, GU), ACT, s);
+        gemm_swiglu_halves<T>(lin<T>(c, XN, Lt, H, w.gate_up, 2 * I, GU, 1), ACT, s);
         { GemmArgs a = lin<T>(c, ACT, Lt, I, w.down, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
     }
     for (int q = 0; q < n; ++q) {

@@ -42,6 +42,16 @@ struct SkinnyArgs {
     int nrb;                                // weight-row groups: N / (16 RB)
     int mt;                                 // workgroups per row group; workgroup (rb, j) takes token tiles j, j + mt, ...
     int no_stagger;                         // measurement switch: 1 = every workgroup walks the token tiles from tile 0 (see `rot` below)
+    // FRAGMENT-MAJOR copy of W (round 6), or null: P[row block][K / 32 steps][64 lanes][8] -- lane (k group fq, row fr) of step t holds
+    // W[row(block, fr)][32 t + 8 fq .. + 8], i.e. the 1 KB an A-operand load of one wave reads is CONTIGUOUS.  From the row-major
+    // matrix the same load is 16 rows x 64 B -- half cache lines of 16 different rows: measured 40 GB/s per CU against 125-135 for
+    // contiguous kilobytes out of the L2, and 4.3-5.5 against 5.2-6.5 TB/s out of HBM (tools/microbench/l2_rate_bench.hip,
+    // profiles/r06_l2_rate_by_pattern.txt).  Rows of a block: 16 b + fr, or for SK_SWIGLU the 8 gate + 8 up rows the epilogue pairs.
+    // Same values into the same registers: bit-identical.  skinny_pack() builds it.
+    const bf16_t* Wp;
+#ifdef FQ3_SK_TRACE
+    unsigned long long* trace;              // measurement builds only (tools/microbench/skinny_trace.hip): [workgroup][wave][8] time stamps
+#endif
     // ---- RMSNorm folded into the GEMM pair (round 5; the lock-step batch above 32 lanes) ----
     // producer side (SK_RESIDUAL): per token and 16-column block of Y the sum of squares of the STORED (rounded) values:
     // ssq_out[token * ssq_ld + column / 16]; null = not wanted
@@ -60,7 +70,12 @@ inline bool skinny_k_ok(int K) { return K == 1024 || K == 2048 || K == 3072 || K
 // the normalising form (SkinnyArgs::ssq): K = hidden of the 0.6B / 1.7B stacks, every row's 1 / rms in an LDS table
 inline bool skinny_norm_ok(int K, int M) { return (K == 1024 || K == 2048) && M >= 1 && M <= 256; }
 
+// shapes the fragment-major copy serves (the kernels' own: K a multiple of 1024 the kernels are built for, whole 16-row blocks)
+inline bool skinny_pack_ok(int N, int K) { return skinny_k_ok(K) && N % 16 == 0 && N > 0; }
+
 #ifdef FQ3_SKINNY_EXTERN
+void skinny_pack_ext(const bf16_t* W, bf16_t* P, int N, int K, int swiglu_I, hipStream_t s);
+inline void skinny_pack(const bf16_t* W, bf16_t* P, int N, int K, int swiglu_I, hipStream_t s) { skinny_pack_ext(W, P, N, K, swiglu_I, s); }
 void skinny_launch_epi(int epi, const SkinnyArgs& a, int K, hipStream_t s, int rb_force);
 bool skinny_prepare_epi(int epi);
 template <int EPI> inline void skinny_launch(const SkinnyArgs& a, int K, hipStream_t s, int rb_force = 0) { skinny_launch_epi(EPI, a, K, s, rb_force); }
@@ -84,6 +99,14 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
+#ifdef FQ3_SK_TRACE
+    unsigned long long sk_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long sk_w0 = wall_clock64();
+#define FQ3_SK_STAMP(i) sk_t[i] = clock64()
+#else
+#define FQ3_SK_STAMP(i) do {} while (0)
+#endif
+    FQ3_SK_STAMP(0);
     unsigned char* ring = sk_smem + (size_t)wave * (2 * kSkSlotB);              // this wave's [2][16 rows][256 B]
     float* red = reinterpret_cast<float*>(sk_smem + (size_t)NW * 2 * kSkSlotB); // [2][T][NW][RB][64 lanes][4]
     constexpr int kRedTile = NW * RB * 256, kRedBuf = T * kRedTile;             // floats
@@ -207,11 +230,15 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
         int wrow;
         if constexpr (EPI == SK_SWIGLU) { const int j0 = (rb * RB + b) * 8; wrow = fr < 8 ? j0 + fr : (a.N >> 1) + j0 + (fr - 8); }
         else wrow = (rb * RB + b) * 16 + fr;
-        const T_* wp = a.W + (size_t)wrow * K + wave * (KC / NW) + fq * 8;
+        // row-major: row wrow, this wave's 128 columns of every chunk, 8 columns per k group; fragment-major: the wave's KS steps of a
+        // chunk are 4 consecutive kilobytes of row block rb RB + b (uniform choice: one base and two strides)
+        const T_* wp = a.Wp ? a.Wp + ((size_t)(rb * RB + b) * (K / 32) + wave * KS) * 512 + lane * 8
+                            : a.W + (size_t)wrow * K + wave * (KC / NW) + fq * 8;
+        const int st_kc = a.Wp ? (KC / 32) * 512 : KC, st_s = a.Wp ? 512 : 32;
 #pragma unroll
         for (int kc = 0; kc < NCH; ++kc)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) ldraw<false>(wreg[b][kc * KS + s], wp + kc * KC + s * 32);
+            for (int s = 0; s < KS; ++s) ldraw<false>(wreg[b][kc * KS + s], wp + kc * st_kc + s * st_s);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -305,6 +332,7 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
     // between two accumulators per row block (two independent MFMA chains).
     sk_bf16x8 fcur[KS], fnext[KS];
     write_unit(stg[0], 0, 0, gw, rtab);
+    FQ3_SK_STAMP(1);                                                 // token unit 0 has landed
     load_unit(stg[0], 2);
     write_unit(stg[1], 1, 1 % NCH, gw, rtab);
     load_unit(stg[1], 3);
@@ -329,6 +357,7 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
                     for (int b = 0; b < RB; ++b)
                         acc[b][s & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sk_bf16x8, wreg[b][kc * KS + s].v), fcur[s], acc[b][s & 1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (g == 0 && tt == 0 && kc == 0) FQ3_SK_STAMP(2);   // the first unit's MFMAs are issued: its weight fragments have landed
                 // unit u + 2 into the slot of unit u (its fragments are in registers, the MFMAs above have read them), then its
                 // staging registers take unit u + 4
                 if (par == 0) { write_unit(stg[0], u + 2, (kc + 2) % NCH, gw, rtab); load_unit(stg[0], u + 4); }
@@ -340,8 +369,10 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
 #pragma unroll
             for (int b = 0; b < RB; ++b) *reinterpret_cast<f32x4*>(rd + b * 256) = acc[b][0] + acc[b][1];
         }
+        if (g == 0) FQ3_SK_STAMP(3);                                 // the first group's units are multiplied
         __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): my partial sums are written
         __builtin_amdgcn_s_barrier();
+        if (g == 0) FQ3_SK_STAMP(4);
         // the group's T x RB (tile, row block) epilogues go to T x RB different waves (rotating with the group)
 #pragma unroll
         for (int tt = 0; tt < T; ++tt)
@@ -350,7 +381,37 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs a) {
                 const int i = g * T + tt;
                 if (i < nmine && wave == ((g * (T * RB) + tt * RB + b) % NW)) epilogue(rbuf + tt * kRedTile, tile_t0(i), b);
             }
+        if (g == 0) FQ3_SK_STAMP(5);
     }
+#ifdef FQ3_SK_TRACE
+    FQ3_SK_STAMP(6);
+    if (a.trace && lane == 0) {
+        unsigned long long* tr = a.trace + ((size_t)blockIdx.x * NW + wave) * 8;
+        __builtin_amdgcn_s_waitcnt(0);                               // every store of this wave has been issued AND acknowledged
+        const unsigned long long w1 = wall_clock64();
+        for (int i2 = 1; i2 < 7; ++i2) tr[i2] = sk_t[i2] - sk_t[0];   // core cycles since entry
+        tr[0] = sk_w0; tr[7] = w1;                                   // 100 MHz wall clock at entry / exit (shared by every CU)
+    }
+#endif
+#undef FQ3_SK_STAMP
+}
+
+// Row-major [N][K] -> fragment-major (SkinnyArgs::Wp).  swiglu_I > 0: W is [gate | up] = [2 I][K] and row block r holds gate rows
+// 8 r .. 8 r + 7 and up rows I + 8 r .. (the pairing of the SK_SWIGLU epilogue); else row block r = rows 16 r .. 16 r + 15.
+// One thread per 16-byte piece; one-time cost at weight-binding time.
+__global__ __launch_bounds__(256) void skinny_pack_kernel(const bf16_t* __restrict__ W, bf16_t* __restrict__ P, int N, int K, int swiglu_I) {
+    const size_t piece = (size_t)blockIdx.x * 256 + threadIdx.x;            // = (row block * (K / 32) + step) * 64 + lane
+    const size_t total = (size_t)N * K / 8;
+    if (piece >= total) return;
+    const int ln = (int)(piece & 63), fr = ln & 15, fq = ln >> 4;
+    const size_t bs = piece >> 6;
+    const int t = (int)(bs % (size_t)(K / 32)), r = (int)(bs / (size_t)(K / 32));
+    const int row = swiglu_I > 0 ? (fr < 8 ? r * 8 + fr : swiglu_I + r * 8 + (fr - 8)) : r * 16 + fr;
+    *reinterpret_cast<u32x4*>(P + piece * 8) = *reinterpret_cast<const u32x4*>(W + (size_t)row * K + t * 32 + fq * 8);
+}
+inline void skinny_pack(const bf16_t* W, bf16_t* P, int N, int K, int swiglu_I, hipStream_t s) {
+    const size_t total = (size_t)N * K / 8;
+    hipLaunchKernelGGL(skinny_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, P, N, K, swiglu_I);
 }
 
 
@@ -432,6 +493,7 @@ void skinny_launch_epi(int epi, const SkinnyArgs& a, int K, hipStream_t s, int r
     else if (epi == SK_RESIDUAL) skinny_launch<SK_RESIDUAL>(a, K, s, rb_force);
     else skinny_launch<SK_STORE>(a, K, s, rb_force);
 }
+void skinny_pack_ext(const bf16_t* W, bf16_t* P, int N, int K, int swiglu_I, hipStream_t s) { skinny_pack(W, P, N, K, swiglu_I, s); }
 bool skinny_prepare_epi(int epi) {
     return epi == SK_SWIGLU ? skinny_prepare<SK_SWIGLU>() : (epi == SK_RESIDUAL ? skinny_prepare<SK_RESIDUAL>() : skinny_prepare<SK_STORE>());
 }

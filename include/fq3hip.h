@@ -131,11 +131,18 @@ int fq3_kv_blocks(const fq3_ctx* ctx);
  *   "flash_prefill" 0|1 (bf16 prefill attention as a flash-style matrix-core kernel), "skinny_gemm" 0|1 (prompts of <= 416 rows:
  *   weight-stationary GEMMs with the SwiGLU fused into the [gate | up] launch; 0 = the tiled / split-K kernels of longer prompts),
  *   "flash_small" 0|1 (round 5; prompts of <= 256 rows: every key tile of a query block resident in LDS, and the prompts of a packed
- *   fq3_prefill_batch over ONE pool share two attention launches per layer; 0 = the streamed-tile kernel, per prompt; bit-identical).
+ *   fq3_prefill_batch over ONE pool share two attention launches per layer; 0 = the streamed-tile kernel, per prompt; bit-identical),
+ *   "packed_weights" 0|1 (round 6; the weight-stationary GEMMs read the fragment-major copies of the layer matrices; bit-identical).
  * Resets a captured graph. */
 int fq3_set_option(fq3_ctx* ctx, const char* key, int value);
 
-/* Replaces the module references the graph objects keep (predictor_graph.py:52-58, talker_graph.py:40). */
+/* Replaces the module references the graph objects keep (predictor_graph.py:52-58, talker_graph.py:40).
+ * Round 6: for a bf16 context the call also takes a reference on a FRAGMENT-MAJOR copy of every layer matrix and head whose shape the
+ * weight-stationary GEMM serves (K in {1024, 2048, 3072, 6144}, whole 16-row blocks): [row block][K / 32][64 lanes][8] -- the kilobyte one
+ * wave's matrix-core operand load reads is contiguous (from the row-major matrix it is 16 rows x 64 B: 40 GB/s per CU against 125-135
+ * out of the L2).  The first context of a weight replica builds the copies (+ one replica's layer matrices of HBM: 1.0 GB at 0.6B,
+ * 2.8 GB at 1.7B), the others share them; fq3_ctx_destroy / a re-bind returns the references.  The table's matrices must not change
+ * while bound (re-bind after an in-place update). */
 int fq3_bind_weights(fq3_ctx* ctx, const fq3_weight_table* table);
 
 /* ---- talker -------------------------------------------------------------------------------- */
@@ -314,6 +321,10 @@ int fq3_batch_poll_wait(fq3_batch* b, int slot, int* n_frames_total, int* done);
  * 8|16 (keys per load step); "pred_pair" 0|1 -- the predictor's two-token prefill as one pass over 2 B token rows where that is
  * bit-identical (above 32 lanes; default 1); "norm_fused" 0|1 -- the RMSNorm of qkv / gate | up / lm heads inside the
  * weight-stationary GEMM, from sum-of-squares partials the residual GEMM's epilogue leaves (measured SLOWER on MI355X: default 0).
+ * Round 6: "pred_attn_group" 0|1 -- the code predictor's attention as one wave per (kv group, lane) that serves the group's q heads from
+ * one read of the LIVE K / V rows (default 1; bit-identical) or as one wave per (q head, lane) over all 16 slots (0).
+ * "packed_weights" 0|1 -- the weight-stationary GEMMs read the fragment-major copies fq3_bind_weights keeps of the bf16 layer matrices
+ * (default 1; bit-identical) or the row-major matrices (0).
  * "groups" 0..4: LANE GROUPS (a measurement switch).  The lanes split into that many independent lock-step chains of whole 16-lane
  * tiles, each with its own frame graph, advanced concurrently on streams the library probes for a hardware queue of their own (they
  * fork from / join `stream` inside fq3_batch_frames, so the caller sees one stream as before); 0 (default) = automatic = ONE chain:

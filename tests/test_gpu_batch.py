@@ -480,6 +480,41 @@ def test_lane_groups_are_bit_identical():
         e.close()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pred_attention_group_form_is_bit_identical(dtype):
+    """fq3_batch_set_option("pred_attn_group", 1) (the default since round 6): the code predictor's attention as one wave per
+    (kv group, lane) that serves the group's q heads from ONE read of the LIVE K / V rows, against one wave per (q head, lane) reading
+    all 16 slots (0).  Every head keeps its own instructions in their order and a masked row contributes exactly 0, so the ids are
+    identical -- below and above the lane count of the pair pass, sampled and greedy lanes, with and without the frame graph
+    (predictor_graph.py:148-155)."""
+    from fq3hip.engine import Fq3Batch
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, dtype)
+    utts = [_utterance(cfg, dtype, 900 + i, 16 + (5 * i) % 41, (i % 3) * 2, 6 + (i * 5) % 9, 6 + (i * 5) % 9, i % 4 != 1) for i in range(48)]
+    lanes = _engines(cfg, W, dtype, 48)
+    for n_lanes in (5, 16, 48):
+        batch = Fq3Batch(lanes[:n_lanes])
+        ref = None
+        for group, graph in ((0, False), (1, False), (1, True), (0, True)):
+            batch.set_option("pred_attn_group", group)
+            for e, u in zip(lanes[:n_lanes], utts):
+                _arm(e, cfg, u)
+            if graph:
+                batch.graph_capture()
+            batch.frames(16)
+            torch.cuda.synchronize()
+            got = [e.decode_codes(0, e.decode_poll()[0]).cpu() for e in lanes[:n_lanes]]
+            assert all(g.shape[0] > 0 for g in got)
+            if ref is None:
+                ref = got
+            else:
+                for i, (a, b) in enumerate(zip(ref, got)):
+                    assert a.shape == b.shape and torch.equal(a, b), (n_lanes, group, graph, i)
+        batch.close()
+    for e in lanes:
+        e.close()
+
+
 def test_batch_incremental_vocoding_is_exact():
     """generate_voice_clone_batch produces an utterance's waveform in slices while it still decodes (every `batch_vocode_every` frames,
     all lanes that reached the boundary as one batched codec launch set; _SideVocoder.inc_add).  ICL prompts (reference frames in front,

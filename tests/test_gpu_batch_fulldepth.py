@@ -170,6 +170,14 @@ def test_batch_full_depth_bf16_mfma_lanes_vs_oracle(size, golden_dir):
             one = _run_batch(engines, cfg, cases, B, mfma=1)
             for i, (a_, b_) in enumerate(zip(two, one)):
                 assert np.array_equal(a_["decisions"], b_["decisions"]), f"lane {i}: the pair pass changed a decision"
+            # the predictor attention per (kv group, lane) with live rows only (round 6 default) against per (q head, lane): bit-identical
+            perhead = _run_batch(engines, cfg, cases, B, mfma=1, options=(("pred_attn_group", 0),))
+            for i, (a_, b_) in enumerate(zip(perhead, one)):
+                assert np.array_equal(a_["decisions"], b_["decisions"]), f"lane {i}: the group form of the predictor attention changed a decision"
+            # the weight-stationary GEMMs on the fragment-major weight copies (round 6 default) against the row-major matrices: bit-identical
+            rowmajor = _run_batch(engines, cfg, cases, B, mfma=1, options=(("packed_weights", 0),))
+            for i, (a_, b_) in enumerate(zip(rowmajor, one)):
+                assert np.array_equal(a_["decisions"], b_["decisions"]), f"lane {i}: the fragment-major weight copies changed a decision"
             fused = _run_batch(engines, cfg, cases, B, mfma=1, options=(("norm_fused", 1),))
             _note(f"{size}_bf16_mfma_B{B}_norm_fused", dict(per_lane=[s["matched_decisions"] for s in fused]))
             assert all(s["unexplained"] == 0 for s in fused)

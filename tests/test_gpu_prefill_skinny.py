@@ -68,6 +68,24 @@ def test_skinny_prefill_matches_oracle_and_tiled_kernels(size, L):
           f"{float((ref[1] - ho).abs().max()):.4f}), skinny vs tiled {float((got[1] - ref[1]).abs().max()):.4f}")
 
 
+@pytest.mark.parametrize("size", ["0p6b", "1p7b"])
+@pytest.mark.parametrize("L", [200, 37])
+def test_fragment_major_weight_copies_are_bit_identical(size, L):
+    """Round 6: fq3_bind_weights keeps a FRAGMENT-MAJOR copy of every bf16 layer matrix (the kilobyte an A-operand load of one wave
+    reads is contiguous; csrc/skinny_gemm.cuh, SkinnyArgs::Wp) and the weight-stationary GEMMs read it ("packed_weights", default 1).
+    The same values reach the same registers, so the prefill's logits, hidden state and K / V rows are those of the row-major
+    matrices bit for bit -- plain 16-row blocks (qkv, o_proj, down) and the [gate | up] pairing alike."""
+    cfg, W, tie, tam, eng = _setup(size, L)
+    x = tie[0].cuda().contiguous()
+    eng.set_option("packed_weights", 1)
+    got = _run(eng, cfg, x, L)
+    eng.set_option("packed_weights", 0)
+    ref = _run(eng, cfg, x, L)
+    for i, name in enumerate(("logits", "hidden", "K of the last layer", "V of the last layer")):
+        assert torch.equal(got[i], ref[i]), name
+    assert float(got[3].abs().amax(dim=(0, 2)).min()) > 0
+
+
 def test_skinny_prefill_left_padded():
     L, n_pad = 200, 5
     cfg, W, tie, tam, eng = _setup("0p6b", L)

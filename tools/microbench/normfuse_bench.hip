@@ -38,6 +38,7 @@ static std::vector<float> fetch_f32(const void* d, size_t n) { std::vector<float
 static hipStream_t st;
 static hipEvent_t e0, e1;
 static int g_reps = 20, g_fail = 0;
+static int g_packed = 0;       // 1 = the launches below read the fragment-major weight copies (SkinnyArgs::Wp, round 6)
 static void report(const char* what, double err, double tol) {
     printf("check %-72s %.3e (tol %.1e) %s\n", what, err, tol, err <= tol ? "ok" : "FAIL");
     if (!(err <= tol)) ++g_fail;
@@ -84,6 +85,13 @@ int main(int argc, char** argv) {
             Wgu[l] = dev_bf16((size_t)2 * I * H, 1.f / sqrtf((float)H));
             Wdn[l] = dev_bf16((size_t)H * I, 1.f / sqrtf((float)I));
         }
+        void *Pqkv[NL], *Po[NL], *Pgu[NL], *Pdn[NL];
+        for (int l = 0; l < NL; ++l) {
+            CHK(hipMalloc(&Pqkv[l], (size_t)NQKV * H * 2)); CHK(hipMalloc(&Po[l], (size_t)H * QD * 2)); CHK(hipMalloc(&Pgu[l], (size_t)2 * I * H * 2)); CHK(hipMalloc(&Pdn[l], (size_t)H * I * 2));
+            skinny_pack((const bf16_t*)Wqkv[l], (bf16_t*)Pqkv[l], NQKV, H, 0, st); skinny_pack((const bf16_t*)Wo[l], (bf16_t*)Po[l], H, QD, 0, st);
+            skinny_pack((const bf16_t*)Wgu[l], (bf16_t*)Pgu[l], 2 * I, H, I, st); skinny_pack((const bf16_t*)Wdn[l], (bf16_t*)Pdn[l], H, I, 0, st);
+        }
+        CHK(hipStreamSynchronize(st));
         void* gain = dev_bf16(H, 0.05f, 1.f);
         void* attn = dev_bf16((size_t)MB * QD, 1.f);             // o_proj input
         void* res = dev_bf16((size_t)MB * H, 1.f);               // residual stream before o_proj
@@ -97,27 +105,27 @@ int main(int argc, char** argv) {
             SkinnyArgs k{};
             k.X = (const bf16_t*)attn; k.ldx = QD; k.M = B; k.W = (const bf16_t*)Wo[l]; k.N = H; k.res = (const bf16_t*)res; k.ldr = H;
             k.Y = (bf16_t*)h; k.ldy = H; if (with_ssq) { k.ssq_out = ssq; k.ssq_ld = H / 16; }
-            skinny_launch<SK_RESIDUAL>(k, QD, st);
+            if (g_packed) k.Wp = (const bf16_t*)Po[l]; skinny_launch<SK_RESIDUAL>(k, QD, st);
         };
         auto down = [&](int l, int B, bool with_ssq, const void* a) {
             SkinnyArgs k{};
             k.X = (const bf16_t*)a; k.ldx = I; k.M = B; k.W = (const bf16_t*)Wdn[l]; k.N = H; k.res = (const bf16_t*)h; k.ldr = H;
             k.Y = (bf16_t*)h; k.ldy = H; if (with_ssq) { k.ssq_out = ssq; k.ssq_ld = H / 16; }
-            skinny_launch<SK_RESIDUAL>(k, I, st);
+            if (g_packed) k.Wp = (const bf16_t*)Pdn[l]; skinny_launch<SK_RESIDUAL>(k, I, st);
         };
         auto qkvg = [&](int l, int B, bool fused, void* y) {
             SkinnyArgs k{};
             k.M = B; k.W = (const bf16_t*)Wqkv[l]; k.N = NQKV; k.Y = (bf16_t*)y; k.ldy = NQKV;
             if (fused) { k.X = (const bf16_t*)h; k.ldx = H; k.ssq = ssq; k.gain = (const bf16_t*)gain; k.eps = 1e-6f; }
             else { rmsnorm_rows(h, H, gain, H, B, xn); k.X = (const bf16_t*)xn; k.ldx = H; }
-            skinny_launch<SK_STORE>(k, H, st);
+            if (g_packed) k.Wp = (const bf16_t*)Pqkv[l]; skinny_launch<SK_STORE>(k, H, st);
         };
         auto gateup = [&](int l, int B, bool fused, void* y) {
             SkinnyArgs k{};
             k.M = B; k.W = (const bf16_t*)Wgu[l]; k.N = 2 * I; k.Y = (bf16_t*)y; k.ldy = I;
             if (fused) { k.X = (const bf16_t*)h; k.ldx = H; k.ssq = ssq; k.gain = (const bf16_t*)gain; k.eps = 1e-6f; }
             else { rmsnorm_rows(h, H, gain, H, B, xn); k.X = (const bf16_t*)xn; k.ldx = H; }
-            skinny_launch<SK_SWIGLU>(k, H, st);
+            if (g_packed) k.Wp = (const bf16_t*)Pgu[l]; skinny_launch<SK_SWIGLU>(k, H, st);
         };
 
         // ---- 1. checks ----
@@ -166,10 +174,49 @@ int main(int argc, char** argv) {
             snprintf(nm, sizeof nm, "%s B=%d: normalising gate|up + SwiGLU vs the two-launch form (max abs diff)", sh.name, B); report(nm, dmax, 3e-2);
             snprintf(nm, sizeof nm, "%s B=%d: ... share of elements that differ", sh.name, B); report(nm, (double)ndiff / ga.size(), 0.05);
         }
+        // ---- 1b. fragment-major weight copies against the row-major matrices: the same values into the same registers -> bit for bit ----
+        for (int B : {1, 16, 33, 48, 64, 128, 200, 256}) {
+            size_t bad = 0;
+            auto snap = [&](const void* d, size_t n) { std::vector<unsigned short> v(n); CHK(hipMemcpy(v.data(), d, n * 2, hipMemcpyDeviceToHost)); return v; };
+            std::vector<unsigned short> ref[6], got[6];
+            for (int pk : {0, 1}) {
+                g_packed = pk;
+                std::vector<unsigned short>* out = pk ? got : ref;
+                CHK(hipMemcpy(h, res, (size_t)MB * H * 2, hipMemcpyDeviceToDevice));
+                CHK(hipMemset(ssq, 0, (size_t)MB * (H / 16) * 4));
+                oproj(2, B, true); CHK(hipStreamSynchronize(st)); out[0] = snap(h, (size_t)B * H);
+                qkvg(2, B, false, qkv_a); CHK(hipStreamSynchronize(st)); out[1] = snap(qkv_a, (size_t)B * NQKV);
+                qkvg(2, B, true, qkv_a); CHK(hipStreamSynchronize(st)); out[2] = snap(qkv_a, (size_t)B * NQKV);       // (the normalising form)
+                gateup(2, B, false, act_a); CHK(hipStreamSynchronize(st)); out[3] = snap(act_a, (size_t)B * I);
+                gateup(2, B, true, act_b); CHK(hipStreamSynchronize(st)); out[4] = snap(act_b, (size_t)B * I);
+                down(2, B, false, act_a); CHK(hipStreamSynchronize(st)); out[5] = snap(h, (size_t)B * H);             // (in place: res = Y = h)
+            }
+            for (int q = 0; q < 6; ++q) for (size_t i = 0; i < ref[q].size(); ++i) bad += ref[q][i] != got[q][i];
+            char nm[160];
+            snprintf(nm, sizeof nm, "%s B=%d: fragment-major == row-major weights, o_proj / qkv / gate|up / down (elements that differ)", sh.name, B); report(nm, (double)bad, 0.5);
+            g_packed = 0;
+        }
         // ---- 2. chains: one layer = qkv, o_proj, gate | up, down ----
         const int NLAY = 40;
         for (int B : {32, 64, 128}) {
             char nm[160];
+            double tp[2] = {0, 0};
+            for (int pk : {0, 1}) {
+                g_packed = pk;
+                const char* wn = pk ? "fragment-major" : "row-major     ";
+                snprintf(nm, sizeof nm, "%s B=%3d  %s: norm + qkv, o_proj, norm + gate|up, down (6 launches)", sh.name, B, wn);
+                tp[pk] = chain(nm, NLAY, 1, [&](int j) { const int l = j % NL; qkvg(l, B, false, qkv_b); oproj(l, B, false); gateup(l, B, false, act_b); down(l, B, false, act_b); });
+                snprintf(nm, sizeof nm, "%s B=%3d  %s: qkv alone: norm + GEMM", sh.name, B, wn);
+                chain(nm, NLAY, 1, [&](int j) { qkvg(j % NL, B, false, qkv_b); });
+                snprintf(nm, sizeof nm, "%s B=%3d  %s: o_proj alone", sh.name, B, wn);
+                chain(nm, NLAY, 1, [&](int j) { oproj(j % NL, B, false); });
+                snprintf(nm, sizeof nm, "%s B=%3d  %s: gate|up alone: norm + GEMM", sh.name, B, wn);
+                chain(nm, NLAY, 1, [&](int j) { gateup(j % NL, B, false, act_b); });
+                snprintf(nm, sizeof nm, "%s B=%3d  %s: down alone", sh.name, B, wn);
+                chain(nm, NLAY, 1, [&](int j) { down(j % NL, B, false, act_b); });
+            }
+            printf("   -> fragment-major weights save %.2f us per layer (%.1f %%)\n", tp[0] - tp[1], 100.0 * (tp[0] - tp[1]) / tp[0]);
+            g_packed = 0;
             snprintf(nm, sizeof nm, "%s B=%3d  round-4 form: norm + qkv, o_proj, norm + gate|up, down (6 launches)", sh.name, B);
             const double t0 = chain(nm, NLAY, 1, [&](int j) { const int l = j % NL; qkvg(l, B, false, qkv_b); oproj(l, B, false); gateup(l, B, false, act_b); down(l, B, false, act_b); });
             snprintf(nm, sizeof nm, "%s B=%3d  fused form:   qkv(norm), o_proj(+ssq), gate|up(norm), down(+ssq) (4 launches)", sh.name, B);
@@ -191,7 +238,7 @@ int main(int argc, char** argv) {
             snprintf(nm, sizeof nm, "%s B=%3d  rmsnorm_batch_kernel alone (one wave per token)", sh.name, B);
             chain(nm, NLAY, 1, [&](int) { rmsnorm_rows(h, H, gain, H, B, xn); });
         }
-        for (int l = 0; l < NL; ++l) { CHK(hipFree(Wqkv[l])); CHK(hipFree(Wo[l])); CHK(hipFree(Wgu[l])); CHK(hipFree(Wdn[l])); }
+        for (int l = 0; l < NL; ++l) { CHK(hipFree(Wqkv[l])); CHK(hipFree(Wo[l])); CHK(hipFree(Wgu[l])); CHK(hipFree(Wdn[l])); CHK(hipFree(Pqkv[l])); CHK(hipFree(Po[l])); CHK(hipFree(Pgu[l])); CHK(hipFree(Pdn[l])); }
     }
     printf("%s\n", g_fail ? "SELF-CHECK FAILED" : "self-checks ok");
     return g_fail ? 1 : 0;
