@@ -1113,8 +1113,8 @@ inline void gemm_swiglu_halves(const GemmArgs& a, void* y, hipStream_t s) {
 // ---- RVQ: sequential (rounded) sum of codebook rows; one block per frame ------------------------------
 struct RvqArgs { const void* books[32]; int nq; int n_first; int dim; };
 template <typename T>
-__global__ void rvq_gather_kernel(RvqArgs a, const int64_t* codes, T* first, T* rest, int Tn) {
-    const int t = blockIdx.x;
+__global__ void rvq_gather_kernel(RvqArgs a, const int64_t* codes, T* first, T* rest, int Tn, int row_lo) {
+    const int t = row_lo + blockIdx.x;               // rows [row_lo, Tn): a decode behind a cached reference prefix starts at its first new frame
     {   // batched decode: utterance blockIdx.y (tensors compact per utterance: Tn rows each)
         const size_t g = blockIdx.y;
         codes += g * Tn * a.nq; first += g * Tn * a.dim; rest += g * Tn * a.dim;
@@ -1130,6 +1130,23 @@ __global__ void rvq_gather_kernel(RvqArgs a, const int64_t* codes, T* first, T* 
         DT<T>::st(first + (size_t)t * a.dim + d, f);
         DT<T>::st(rest + (size_t)t * a.dim + d, r);
     }
+}
+
+// ---- cached reference-prefix rows -> an utterance's workspace (fq3_codec.hip: fq3_codec_prefix) -----------------
+// utterance u = blockIdx.y: n_rows rows of n_cols elements from src[u] (+ src_off, leading dimension src_ld) to rows dst_row0 .. of the
+// utterance's [rows_per_utt][dst_ld] tensor, columns dst_col0 ..; 16-byte pieces (n_cols, the offsets and leading dimensions are multiples of 16 bytes)
+struct PrefixSrc { const void* p[128]; };
+template <typename T>
+__global__ __launch_bounds__(256) void prefix_rows_kernel(PrefixSrc src, size_t src_off, int src_ld, T* dst, size_t dst_seg, int dst_ld,
+                                                          int dst_row0, int dst_col0, int n_rows, int n_cols) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int cpr = n_cols / EPC;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_rows * cpr) return;
+    const int r = e / cpr, c = (e - r * cpr) * EPC;
+    const T* sp = reinterpret_cast<const T*>(src.p[blockIdx.y]) + src_off + (size_t)r * src_ld + c;
+    T* dp = dst + (size_t)blockIdx.y * dst_seg + (size_t)(dst_row0 + r) * dst_ld + dst_col0 + c;
+    *reinterpret_cast<u32x4*>(dp) = *reinterpret_cast<const u32x4*>(sp);
 }
 
 // ---- row norms: one wave per row, rows [row_lo, rows) ---------------------------------------------------
@@ -1190,12 +1207,12 @@ __global__ void silu_mul_kernel(const T* gu, T* y, int rows, int I) {     // gu 
 
 // RoPE on the q and k thirds of qkv [rows][3*QD], head_dim HD (rotate_half convention), position = row
 template <typename T>
-__global__ void rope_rows_kernel(T* qkv, const float* cos_tab, const float* sin_tab, int rows, int QD, int HD) {
+__global__ void rope_rows_kernel(T* qkv, const float* cos_tab, const float* sin_tab, int rows, int QD, int HD, int row_lo) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int half = HD / 2, per_row = 2 * (QD / HD) * half;
-    if (i >= (size_t)rows * per_row) return;
+    if (i >= (size_t)(rows - row_lo) * per_row) return;
     qkv += (size_t)blockIdx.y * rows * 3 * QD;                                     // batched decode: utterance blockIdx.y (positions restart at 0)
-    const int t = (int)(i / per_row), r = (int)(i % per_row);
+    const int t = row_lo + (int)(i / per_row), r = (int)(i % per_row);            // rows [row_lo, rows); position = absolute row
     const int head = r / half, j = r % half;              // heads 0..QD/HD-1 = q, then k
     T* p = qkv + (size_t)t * 3 * QD + (size_t)head * HD;
     const float cs = cos_tab[(size_t)t * half + j], sn = sin_tab[(size_t)t * half + j];
@@ -1209,11 +1226,11 @@ __global__ void rope_rows_kernel(T* qkv, const float* cos_tab, const float* sin_
 // softmax across lanes; P.V: one (or two) head dims per lane, looping over the window with the probability broadcast by
 // v_readlane.  ~8x fewer instructions than a wave-wide reduction per key.
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void swa_attn_kernel(const T* qkv, T* out, int Tn, int NH, int window, float scale) {
+__global__ __launch_bounds__(256) void swa_attn_kernel(const T* qkv, T* out, int Tn, int NH, int window, float scale, int row_lo) {
     constexpr int NCH = HD / 8;
     __shared__ float qs[4][HD];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + wave, h = blockIdx.y;
+    const int q = row_lo + blockIdx.x * 4 + wave, h = blockIdx.y;      // queries [row_lo, Tn) (their keys reach back to row q - window + 1)
     const int QD = NH * HD;
     qkv += (size_t)blockIdx.z * Tn * 3 * QD; out += (size_t)blockIdx.z * Tn * QD;  // batched decode: utterance blockIdx.z
     const bool live = q < Tn;

@@ -53,6 +53,21 @@ struct fq3_codec {
                                                   // 256 x 256 ring tile the k7 conv otherwise gets than the saved `mid` round trip brings
 };
 
+// State of the frame-level front end over a REFERENCE PREFIX (round 6; SURVEY section 7 step 9, the call sites model.py:1085-1115 and
+// :919-937 re-decode `ref_codes + everything so far` for every phase-1 chunk and for every utterance of a voice): what rows >= ref_len
+// of a later decode read from rows < ref_len --
+//   pre   the RVQ projection sum of the last 2 rows (the k = 3 causal pre_conv's left context)
+//   kv    per transformer layer the post-RoPE k | v rows of the last (sliding_window - 1) rows
+//   out   the front end's output rows of the last kPrefixOutRows rows (the conv stack's halo reaches ~13 frames back)
+// Every value is what a full decode computes for that row (the front end is causal and a row's arithmetic does not depend on the row
+// count), so a decode that starts at row ref_len on top of this state is bit-identical to the full one.
+constexpr int kPrefixOutRows = 48;
+struct fq3_codec_prefix {
+    fq3_codec* owner = nullptr;
+    int ref_len = 0, n_pre = 0, n_kv = 0, n_out = 0;
+    void *pre = nullptr, *kv = nullptr, *out = nullptr;       // [n_pre][codebook_dim], [n_layers][n_kv][2 QD], [n_out][latent_dim] in the codec's element type
+};
+
 static int64_t samples_for(const fq3_codec_config& c, int64_t T) {
     int64_t n = T;
     for (int i = 0; i < c.n_upsample; ++i) n *= c.upsampling_ratios[i];
@@ -225,10 +240,18 @@ static GemmArgs segmented(GemmArgs a, int NS) {
 // is laid out [utterance][rows][C], every launch carries the utterance in a grid dimension, rows / taps / causal padding are
 // local to an utterance.  Per utterance the arithmetic is that of a single decode (same tiles per row and column, same chains):
 // bit-identical PCM.
+// pfx (or null): NS prefix states of one ref_len -- the front end runs over rows [ref_len, Tn) only; when the requested samples reach
+// further back than the cached output rows the call returns kPrefixTooShort and the caller takes the full path.
+// cap (or null; NS = 1, front end only): the call fills this prefix state from a decode of the Tn = ref_len reference rows.
+constexpr int kPrefixTooShort = -1000;
 template <typename T>
-static int decode_t(fq3_codec* c, const int64_t* codes, int NS, int Tn, int64_t first_sample, float* pcm, hipStream_t s) {
+static int decode_t(fq3_codec* c, const int64_t* codes, int NS, int Tn, int64_t first_sample, float* pcm, hipStream_t s,
+                    const fq3_codec_prefix* const* pfx = nullptr, fq3_codec_prefix* cap = nullptr) {
     const auto& g = c->cfg;
     int err = 0;
+    const int f0 = pfx ? pfx[0]->ref_len : 0;          // first row the front end computes
+    PrefixSrc src_pre{}, src_kv{}, src_out{};
+    if (pfx) for (int u = 0; u < NS; ++u) { src_pre.p[u] = pfx[u]->pre; src_kv.p[u] = pfx[u]->kv; src_out.p[u] = pfx[u]->out; }
     auto W = [&](const std::string& n) -> const void* { const void* p = nullptr; if (!err) err = need(c, n, 0, &p); return p; };
     auto SN = [&](const std::string& prefix) -> std::pair<const void*, const void*> {
         auto it = c->snake.find(prefix);
@@ -238,7 +261,7 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int NS, int Tn, int64_t 
     T* B0 = (T*)c->buf[0]; T* B1 = (T*)c->buf[1]; T* B2 = (T*)c->buf[2]; T* B3 = (T*)c->buf[3];
     const std::string D = "decoder.";
     auto el = [&](size_t n) { return dim3((unsigned)((n + 255) / 256), (unsigned)NS); };      // elementwise launches: utterance = blockIdx.y
-    const dim3 rows4((Tn + 3) / 4, NS);                                                        // one wave per row of the frame-level front end
+    const dim3 rows4((Tn - f0 + 3) / 4, NS);                                                   // one wave per (new) row of the frame-level front end
     Plan P;
     auto gemm_op = [&](GemmArgs a, int out, int out2, std::vector<Dep> in, int unit = 1) {
         Op o; o.out = out; o.out2 = out2; o.in = std::move(in); o.unit = unit;
@@ -246,7 +269,19 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int NS, int Tn, int64_t 
         o.run = [a, s](int lo) mutable { a.m_lo = lo; gemm_launch<T>(a, s); };
         P.add(std::move(o));
     };
-    auto G = [&](GemmArgs a) { gemm_launch<T>(segmented(a, NS), s); };
+    auto G = [&](GemmArgs a) { a.m_lo = f0; gemm_launch<T>(segmented(a, NS), s); };             // (front end: rows [f0, Tn))
+    // cached prefix rows -> every utterance's copy of a front-end tensor (rows [f0 - n, f0)); the reverse copy fills `cap`
+    auto put_rows = [&](const PrefixSrc& src, size_t src_off, int src_ld, T* dst, int dst_ld, int dst_col0, int n_rows, int n_cols) {
+        if (n_rows <= 0) return;
+        constexpr int EPC = 16 / (int)sizeof(T);
+        hipLaunchKernelGGL((prefix_rows_kernel<T>), dim3((n_rows * (n_cols / EPC) + 255) / 256, NS), dim3(256), 0, s, src, src_off, src_ld, dst,
+                           (size_t)Tn * dst_ld, dst_ld, f0 - n_rows, dst_col0, n_rows, n_cols);
+    };
+    auto keep_rows = [&](void* dst, size_t dst_off, int dst_ld, const T* src, int src_ld, int src_col0, int n_rows, int n_cols) {
+        if (n_rows <= 0) return;
+        (void)hipMemcpy2DAsync((T*)dst + dst_off, (size_t)dst_ld * sizeof(T), src + (size_t)(Tn - n_rows) * src_ld + src_col0, (size_t)src_ld * sizeof(T),
+                               (size_t)n_cols * sizeof(T), n_rows, hipMemcpyDeviceToDevice, s);
+    };
 
     // ---- frame-level front end: RVQ, pre_conv, transformer (all T rows: the attention stack sees the whole prefix) ----
     RvqArgs ra{}; ra.nq = g.num_quantizers; ra.n_first = g.num_semantic; ra.dim = g.rvq_dim;
@@ -279,31 +314,42 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int NS, int Tn, int64_t 
         if (err) return err;
         o.run = [=](int) {
             T* qf = B1; T* qr = B1 + (size_t)NS * Tn * g.rvq_dim;
-            hipLaunchKernelGGL((rvq_gather_kernel<T>), dim3(Tn, NS), dim3(256), 0, s, ra, codes, qf, qr, Tn);
+            hipLaunchKernelGGL((rvq_gather_kernel<T>), dim3(Tn - f0, NS), dim3(256), 0, s, ra, codes, qf, qr, Tn, f0);
             G(lin<T>(qf, Tn, g.rvq_dim, w_first, g.codebook_dim, nullptr, B0));
             { GemmArgs a = lin<T>(qr, Tn, g.rvq_dim, w_rest, g.codebook_dim, nullptr, B0); a.res = B0; a.ldr = g.codebook_dim; G(a); }
+            if (pfx) put_rows(src_pre, 0, g.codebook_dim, B0, g.codebook_dim, 0, pfx[0]->n_pre, g.codebook_dim);      // the k = 3 pre_conv's left context
+            if (cap) keep_rows(cap->pre, 0, g.codebook_dim, B0, g.codebook_dim, 0, cap->n_pre, g.codebook_dim);
             G(conv(B0, Tn, g.codebook_dim, w_pre, g.latent_dim, b_pre, B1, 3, 1));
             G(lin<T>(B1, Tn, g.latent_dim, w_in, g.hidden, b_in, B0));                     // x = B0
             for (int i = 0; i < g.n_layers; ++i) {
                 const LayerW& w = LW[i];
-                hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), rows4, dim3(256), 0, s, (const T*)B0, (const T*)w.ln1, B1, 0, Tn, g.hidden, g.rms_eps);
+                hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), rows4, dim3(256), 0, s, (const T*)B0, (const T*)w.ln1, B1, f0, Tn, g.hidden, g.rms_eps);
                 G(lin<T>(B1, Tn, g.hidden, w.qkv, 3 * QD, nullptr, B2));
-                hipLaunchKernelGGL((rope_rows_kernel<T>), el((size_t)Tn * 2 * g.n_heads * (g.head_dim / 2)), dim3(256), 0, s, B2, cosT, sinT, Tn, QD, g.head_dim);
-                const dim3 ag((Tn + 3) / 4, g.n_heads, NS);
+                hipLaunchKernelGGL((rope_rows_kernel<T>), el((size_t)(Tn - f0) * 2 * g.n_heads * (g.head_dim / 2)), dim3(256), 0, s, B2, cosT, sinT, Tn, QD, g.head_dim, f0);
+                // the layer's cached post-RoPE k | v of the last window - 1 prefix rows, in front of the new rows
+                if (pfx) put_rows(src_kv, (size_t)i * pfx[0]->n_kv * 2 * QD, 2 * QD, B2, 3 * QD, QD, pfx[0]->n_kv, 2 * QD);
+                if (cap) keep_rows(cap->kv, (size_t)i * cap->n_kv * 2 * QD, 2 * QD, B2, 3 * QD, QD, cap->n_kv, 2 * QD);
+                const dim3 ag((Tn - f0 + 3) / 4, g.n_heads, NS);
                 const float sc = 1.0f / sqrtf((float)g.head_dim);
-                if (g.head_dim == 32) hipLaunchKernelGGL((swa_attn_kernel<T, 32>), ag, dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.sliding_window, sc);
-                else if (g.head_dim == 64) hipLaunchKernelGGL((swa_attn_kernel<T, 64>), ag, dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.sliding_window, sc);
-                else hipLaunchKernelGGL((swa_attn_kernel<T, 128>), ag, dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.sliding_window, sc);
+                if (g.head_dim == 32) hipLaunchKernelGGL((swa_attn_kernel<T, 32>), ag, dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.sliding_window, sc, f0);
+                else if (g.head_dim == 64) hipLaunchKernelGGL((swa_attn_kernel<T, 64>), ag, dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.sliding_window, sc, f0);
+                else hipLaunchKernelGGL((swa_attn_kernel<T, 128>), ag, dim3(256), 0, s, (const T*)B2, B1, Tn, g.n_heads, g.sliding_window, sc, f0);
                 { GemmArgs a = lin<T>(B1, Tn, QD, w.o, g.hidden, nullptr, B0); a.scale = w.ls1; a.res = B0; a.ldr = g.hidden; G(a); }
-                hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), rows4, dim3(256), 0, s, (const T*)B0, (const T*)w.ln2, B1, 0, Tn, g.hidden, g.rms_eps);
+                hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), rows4, dim3(256), 0, s, (const T*)B0, (const T*)w.ln2, B1, f0, Tn, g.hidden, g.rms_eps);
                 { GemmArgs a = lin<T>(B1, Tn, g.hidden, w.gu, 2 * g.inter, nullptr, B2); a.act = 2; a.ldy = g.inter; G(a); }     // SwiGLU epilogue
                 { GemmArgs a = lin<T>(B2, Tn, g.inter, w.down, g.hidden, nullptr, B0); a.scale = w.ls2; a.res = B0; a.ldr = g.hidden; G(a); }
             }
-            hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), rows4, dim3(256), 0, s, (const T*)B0, (const T*)w_norm, B1, 0, Tn, g.hidden, g.rms_eps);
+            hipLaunchKernelGGL((rmsnorm_rows_kernel<T>), rows4, dim3(256), 0, s, (const T*)B0, (const T*)w_norm, B1, f0, Tn, g.hidden, g.rms_eps);
             G(lin<T>(B1, Tn, g.hidden, w_out, g.latent_dim, b_out, B0));                    // h = B0 [T, latent]
+            if (pfx) put_rows(src_out, 0, g.latent_dim, B0, g.latent_dim, 0, pfx[0]->n_out, g.latent_dim);           // the conv stack's halo rows
+            if (cap) keep_rows(cap->out, 0, g.latent_dim, B0, g.latent_dim, 0, cap->n_out, g.latent_dim);
         };
+        if (cap) { o.run(0); return err; }                     // (fq3_codec_prefix_create: the front end over the reference rows, nothing else)
         P.add(std::move(o));
     }
+    // consumers of the front end's output: all of its rows exist in a full decode; behind a prefix state only rows >= ref_len - n_out do,
+    // so there the true first row needed is propagated (and checked below)
+    const int kFrontSame = pfx ? DEP_SAME : DEP_ALL, kFrontBack = pfx ? DEP_BACK : DEP_ALL;
     // ---- upsample: transposed conv (k = stride) + ConvNeXt ------------------------------------------------------------
     int rows = Tn;
     const int Lc = g.latent_dim;
@@ -313,7 +359,7 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int NS, int Tn, int64_t 
         const std::string U = D + "upsample." + std::to_string(i) + ".";
         const int t_up = P.tensor(), t_dw = P.tensor(), t_ln = P.tensor(), t_pw = P.tensor(), t_o = P.tensor();
         { GemmArgs a = lin<T>(B0, rows, Lc, W(U + "0.conv.weight"), f * Lc, W(U + "0.conv.bias"), B1); a.bias_mod = Lc;
-          gemm_op(a, t_up, -1, {{t_h, t_h == t_front ? DEP_ALL : DEP_SAME, 0}}, f); }
+          gemm_op(a, t_up, -1, {{t_h, t_h == t_front ? kFrontSame : DEP_SAME, 0}}, f); }
         rows *= f;                                                                      // B1 = [rows, Lc]
         {
             const int R = rows;
@@ -342,7 +388,7 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int NS, int Tn, int64_t 
         auto sn = SN(DD + "1.block.0.");
         GemmArgs a = conv(B0, rows, Lc, W(DD + "0.conv.weight"), ch, W(DD + "0.conv.bias"), nullptr, 7, 1);
         a.sn_a = sn.first; a.sn_ib = sn.second; a.Y2 = bufS;
-        gemm_op(a, -1, t_s, {{t_h, t_h == t_front ? DEP_ALL : DEP_BACK, 6}});
+        gemm_op(a, -1, t_s, {{t_h, t_h == t_front ? kFrontBack : DEP_BACK, 6}});
     }
     for (int i = 0; i < g.n_rates && !err; ++i) {
         const int r = g.upsample_rates[i], co = ch / 2;
@@ -436,6 +482,7 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int NS, int Tn, int64_t 
             need_from[d.t] = std::min(need_from[d.t], std::max(0L, v));
         }
     }
+    if (pfx && need_from[t_front] < (long)(f0 - pfx[0]->n_out)) return kPrefixTooShort;       // nothing was launched: the caller decodes in full
     for (size_t i = 0; i < P.ops.size(); ++i)
         if (lo_of[i] >= 0) P.ops[i].run(lo_of[i]);
     return 0;
@@ -461,8 +508,17 @@ static int reserve_batch(fq3_codec* c, int n, int T) {
     return 0;
 }
 
-static int decode_any(fq3_codec* c, const int64_t* codes, int B, int T, int64_t first_sample, float* pcm, void* stream) {
+static int decode_any(fq3_codec* c, const int64_t* codes, int B, int T, int64_t first_sample, float* pcm, void* stream,
+                      const fq3_codec_prefix* const* pfx = nullptr) {
     if (!c || !codes || !pcm) return cfail(FQ3_EINVAL, "null argument");
+    if (pfx) {
+        if (B > 128) return cfail(FQ3_EINVAL, "codec decode behind prefix states: at most 128 utterances per call");
+        for (int u = 0; u < B; ++u) {
+            if (!pfx[u] || pfx[u]->owner != c) return cfail(FQ3_EINVAL, "prefix state is null or belongs to another codec");
+            if (pfx[u]->ref_len != pfx[0]->ref_len) return cfail(FQ3_EINVAL, "the prefix states of one call must cover the same number of frames");
+        }
+        if (pfx[0]->ref_len >= T) return cfail(FQ3_EINVAL, "a decode behind a prefix state needs at least one frame after the prefix");
+    }
     if (!c->ready) return cfail(FQ3_ESTATE, "codec weights not finalized");
     if (T < 1) return cfail(FQ3_EINVAL, "need at least 1 frame");
     if (B < 1 || B > 1024) return cfail(FQ3_EINVAL, "codec decode: batch size must be 1..1024");
@@ -471,10 +527,14 @@ static int decode_any(fq3_codec* c, const int64_t* codes, int B, int T, int64_t 
     if (int r = reserve_batch(c, B, T)) return r;
     hipStream_t s = (hipStream_t)stream;
     int r;
-    switch (c->cfg.dtype) {
-        case FQ3_BF16: r = decode_t<bf16_t>(c, codes, B, T, first_sample, pcm, s); break;
-        case FQ3_BF16X2: r = decode_t<bfs_t>(c, codes, B, T, first_sample, pcm, s); break;
-        default: r = decode_t<float>(c, codes, B, T, first_sample, pcm, s); break;
+    for (int pass = 0; pass < 2; ++pass) {
+        switch (c->cfg.dtype) {
+            case FQ3_BF16: r = decode_t<bf16_t>(c, codes, B, T, first_sample, pcm, s, pfx); break;
+            case FQ3_BF16X2: r = decode_t<bfs_t>(c, codes, B, T, first_sample, pcm, s, pfx); break;
+            default: r = decode_t<float>(c, codes, B, T, first_sample, pcm, s, pfx); break;
+        }
+        if (r != kPrefixTooShort) break;
+        pfx = nullptr;                                         // the samples reach further back than the cached rows: the full decode
     }
     if (r) return r;
     CHIP(hipGetLastError());
@@ -491,4 +551,52 @@ extern "C" int fq3_codec_decode_tail(fq3_codec* c, const int64_t* codes, int T, 
 
 extern "C" int fq3_codec_decode_batch(fq3_codec* c, const int64_t* codes, int B, int T, int64_t first_sample, float* pcm, void* stream) {
     return decode_any(c, codes, B, T, first_sample, pcm, stream);
+}
+
+// ---- reference-prefix state (see fq3_codec_prefix above) ---------------------------------------------------------------------------
+extern "C" int fq3_codec_prefix_destroy(fq3_codec_prefix* p) {
+    if (!p) return FQ3_OK;
+    (void)hipDeviceSynchronize();
+    if (p->pre) (void)hipFree(p->pre);
+    if (p->kv) (void)hipFree(p->kv);
+    if (p->out) (void)hipFree(p->out);
+    delete p;
+    return FQ3_OK;
+}
+
+extern "C" int fq3_codec_prefix_create(fq3_codec* c, const int64_t* ref_codes, int ref_len, fq3_codec_prefix** out, void* stream) {
+    if (!c || !ref_codes || !out) return cfail(FQ3_EINVAL, "null argument");
+    if (!c->ready) return cfail(FQ3_ESTATE, "codec weights not finalized");
+    if (ref_len < 1 || ref_len >= c->cfg.max_frames) return cfail(FQ3_EINVAL, "prefix length must be in 1 .. max_frames - 1");
+    if (int r = reserve_batch(c, 1, ref_len)) return r;
+    const auto& g = c->cfg;
+    const int QD = g.n_heads * g.head_dim;
+    fq3_codec_prefix* p = new fq3_codec_prefix();
+    p->owner = c; p->ref_len = ref_len;
+    p->n_pre = std::min(ref_len, 2); p->n_kv = std::min(ref_len, g.sliding_window - 1); p->n_out = std::min(ref_len, kPrefixOutRows);
+    const size_t esz = c->esz;
+    if (hipMalloc(&p->pre, std::max<size_t>(16, (size_t)p->n_pre * g.codebook_dim * esz)) != hipSuccess ||
+        hipMalloc(&p->kv, std::max<size_t>(16, (size_t)g.n_layers * p->n_kv * 2 * QD * esz)) != hipSuccess ||
+        hipMalloc(&p->out, std::max<size_t>(16, (size_t)p->n_out * g.latent_dim * esz)) != hipSuccess) {
+        (void)hipGetLastError(); fq3_codec_prefix_destroy(p); return cfail(FQ3_ENOMEM, "codec prefix state: out of device memory");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int r;
+    switch (g.dtype) {
+        case FQ3_BF16: r = decode_t<bf16_t>(c, ref_codes, 1, ref_len, 0, nullptr, s, nullptr, p); break;
+        case FQ3_BF16X2: r = decode_t<bfs_t>(c, ref_codes, 1, ref_len, 0, nullptr, s, nullptr, p); break;
+        default: r = decode_t<float>(c, ref_codes, 1, ref_len, 0, nullptr, s, nullptr, p); break;
+    }
+    if (r == FQ3_OK && hipGetLastError() != hipSuccess) r = cfail(FQ3_EHIP, "codec prefix state: a launch failed");
+    if (r) { fq3_codec_prefix_destroy(p); return r; }
+    *out = p;
+    return FQ3_OK;
+}
+
+extern "C" int fq3_codec_prefix_frames(const fq3_codec_prefix* p) { return p ? p->ref_len : -1; }
+
+extern "C" int fq3_codec_decode_batch_prefix(fq3_codec* c, const fq3_codec_prefix* const* prefixes, const int64_t* codes, int B, int T,
+                                             int64_t first_sample, float* pcm, void* stream) {
+    if (!prefixes) return cfail(FQ3_EINVAL, "null argument");
+    return decode_any(c, codes, B, T, first_sample, pcm, stream, prefixes);
 }

@@ -265,7 +265,7 @@ extern "C" int fq3_refenc_encode(fq3_refenc* r, const float* pcm, int64_t n, int
         if (err) return err;
         hipLaunchKernelGGL((layernorm_rows_kernel<float>), dim3((Tt + 3) / 4), dim3(256), 0, s, (const float*)X, ln1w, ln1b, N1, 0, Tt, Hd, g.norm_eps);
         gemm_launch<float>(gemm(N1, Hd, Tt, Tt, Hd, wqkv, 3 * QD, nullptr, QKV, 3 * QD), s);
-        hipLaunchKernelGGL((rope_rows_kernel<float>), el((size_t)Tt * 2 * g.n_heads * (g.head_dim / 2)), dim3(256), 0, s, QKV, cosT, sinT, Tt, QD, g.head_dim);
+        hipLaunchKernelGGL((rope_rows_kernel<float>), el((size_t)Tt * 2 * g.n_heads * (g.head_dim / 2)), dim3(256), 0, s, QKV, cosT, sinT, Tt, QD, g.head_dim, 0);
         const dim3 ag((Tt + 3) / 4, g.n_heads);
         const float sc = 1.0f / sqrtf((float)g.head_dim);
 #define FQ3_WIN_ATTN(HD, NPV) hipLaunchKernelGGL((win_attn_kernel<HD, NPV>), ag, dim3(256), 0, s, (const float*)QKV, AT, Tt, g.n_heads, g.sliding_window, sc)

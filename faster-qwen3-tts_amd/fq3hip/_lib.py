@@ -142,6 +142,10 @@ SIGNATURES = {
     "fq3_codec_decode": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "fq3_codec_decode_tail": (C.c_int, [vp, vp, C.c_int, C.c_int64, vp, vp]),
     "fq3_codec_decode_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int64, vp, vp]),
+    "fq3_codec_prefix_create": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp), vp]),
+    "fq3_codec_prefix_destroy": (C.c_int, [vp]),
+    "fq3_codec_prefix_frames": (C.c_int, [vp]),
+    "fq3_codec_decode_batch_prefix": (C.c_int, [vp, C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int64, vp, vp]),
     "fq3_refenc_create": (C.c_int, [C.POINTER(RefEncConfig), C.POINTER(vp)]),
     "fq3_refenc_destroy": (C.c_int, [vp]),
     "fq3_refenc_bind": (C.c_int, [vp, C.c_char_p, vp, C.c_int64]),
@@ -175,7 +179,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = ABI drift; let it surface
         fn.restype = res
         fn.argtypes = args
-    if lib.fq3_abi_version() != 4:
+    if lib.fq3_abi_version() != 5:
         raise ImportError("libfq3hip ABI version mismatch")
     _lib = lib
     return lib

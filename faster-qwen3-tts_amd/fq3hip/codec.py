@@ -188,8 +188,69 @@ class HipSpeechTokenizer:
     CHUNK_FRAMES = 300
     LEFT_CONTEXT = 25
 
-    def _decode_piece(self, codes: torch.Tensor, first_sample: int = 0) -> torch.Tensor:
+    # ---- reference-prefix states (``fq3_codec_prefix_*``, round 6) -------------------------------------------------------------
+    # The ICL call sites decode ``ref_codes + generated codes`` (model.py:919-937; every phase-1 streaming chunk again, :1085-1115).
+    # ``prefix_for(ref_codes)`` runs the frame-level front end over the reference frames ONCE per voice and keeps what later rows
+    # read of them; ``decode_tensor(..., prefix=...)`` / ``decode_tensor_batch(..., prefixes=...)`` then compute the front end over
+    # the new rows only.  Bit-identical to the full decode (tests/test_gpu_codec.py).  ``use_prefix = False`` turns it off.
+    use_prefix = True
+    PREFIX_CACHE = 64           # voices kept (least recently used first out)
+
+    class Prefix:
+        """Owner of one ``fq3_codec_prefix`` handle (destroyed with the object or by ``HipSpeechTokenizer.close``)."""
+
+        def __init__(self, tok, handle, ref_len: int, keep):
+            self.tok, self.h, self.ref_len, self._keep = tok, handle, int(ref_len), keep
+
+        def close(self):
+            if getattr(self, "h", None) is not None and self.h.value:
+                self.tok.lib.fq3_codec_prefix_destroy(self.h)
+                self.h = L.vp()
+
+        def __del__(self):
+            try:
+                self.close()
+            except Exception:
+                pass
+
+    def prefix_for(self, ref_codes, stream=None):
+        """The (cached) prefix state of ``ref_codes`` LongTensor[ref_len, 16], or None (no reference / switched off / not applicable).
+        A device tensor is recognised by identity (address, shape, version counter -- the entry keeps it alive), a host tensor by
+        its content.  The state is built on ``stream`` (a ``torch.cuda.Stream``; default: the current one): use the stream the
+        decodes run on -- the codec's workspaces are shared by everything that goes through this tokenizer."""
+        if not self.use_prefix or ref_codes is None or not hasattr(ref_codes, "shape") or ref_codes.dim() != 2:
+            return None
+        n = int(ref_codes.shape[0])
+        if n < 1 or n >= min(self.CHUNK_FRAMES, self.max_frames):
+            return None
+        if ref_codes.device.type == "cpu":
+            import hashlib
+            key = ("host", n, hashlib.blake2b(ref_codes.contiguous().numpy().tobytes(), digest_size=16).digest())
+        else:
+            key = ("dev", int(ref_codes.data_ptr()), tuple(ref_codes.shape), str(ref_codes.dtype), int(ref_codes._version))
+        cache = self.__dict__.setdefault("_prefixes", {})
+        hit = cache.pop(key, None)
+        if hit is not None:
+            cache[key] = hit                                       # most recently used last
+            return hit
+        codes = ref_codes.to(device=self.device, dtype=torch.long).contiguous()
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream(self.device))
+            codes.record_stream(stream)
+        h = L.vp()
+        with torch.cuda.stream(st):
+            L.check(self.lib.fq3_codec_prefix_create(self.h, codes.data_ptr(), n, C.byref(h), st.cuda_stream))
+        pf = HipSpeechTokenizer.Prefix(self, h, n, (ref_codes, codes))
+        cache[key] = pf
+        while len(cache) > self.PREFIX_CACHE:
+            cache.pop(next(iter(cache)))                           # (dropped states die with their last user)
+        return pf
+
+    def _decode_piece(self, codes: torch.Tensor, first_sample: int = 0, prefix=None) -> torch.Tensor:
         """One decoder pass over codes [T <= max_frames, 16]; returns samples [first_sample, num_samples(T))."""
+        if prefix is not None and prefix.ref_len < codes.shape[0]:
+            return self._decode_piece_batch(codes.unsqueeze(0), first_sample, [prefix])[0]
         Tn = codes.shape[0]
         n = self.num_samples(Tn)
         first_sample = max(0, min(int(first_sample), n))
@@ -216,12 +277,15 @@ class HipSpeechTokenizer:
             start = end
         return out
 
-    def decode_tensor(self, codes: torch.Tensor, first_sample: int = 0) -> torch.Tensor:
+    def decode_tensor(self, codes: torch.Tensor, first_sample: int = 0, prefix=None) -> torch.Tensor:
         """codes LongTensor[T, 16] -> float32 waveform tensor on the device.  Any T: inputs longer than the chunk size
         are decoded piecewise with a 25-frame left context, as upstream ``chunked_decode`` does.
 
         ``first_sample`` > 0 returns ``decode_tensor(codes)[first_sample:]`` (bit-identical) while recomputing only the
-        rows those samples depend on -- what the streaming call sites keep of each re-decode."""
+        rows those samples depend on -- what the streaming call sites keep of each re-decode.
+
+        ``prefix`` (``prefix_for(ref_codes)``): ``codes`` starts with that reference; the front end then runs over the rows behind it only
+        (the piece that starts at frame 0 -- later pieces of a long input begin behind the reference anyway)."""
         codes = codes.to(device=self.device, dtype=torch.long).contiguous()
         Tn = codes.shape[0]
         up = self.cfg.total_upsample
@@ -230,18 +294,28 @@ class HipSpeechTokenizer:
             n_piece = self.num_samples(end - start + ctx) - ctx * up
             if pos + n_piece > first_sample:
                 skip = ctx * up + max(0, first_sample - pos)
-                wavs.append(self._decode_piece(codes[start - ctx:end].contiguous(), skip))
+                wavs.append(self._decode_piece(codes[start - ctx:end].contiguous(), skip, prefix if start == 0 else None))
             pos += n_piece
         if not wavs:
             return torch.empty(0, dtype=torch.float32, device=self.device)
         return torch.cat(wavs) if len(wavs) != 1 else wavs[0]
 
-    def _decode_piece_batch(self, codes: torch.Tensor, first_sample: int = 0) -> torch.Tensor:
-        """One decoder pass over codes [B, T <= max_frames, 16] (``fq3_codec_decode_batch``): [B, num_samples(T) - first_sample]."""
+    def _decode_piece_batch(self, codes: torch.Tensor, first_sample: int = 0, prefixes=None) -> torch.Tensor:
+        """One decoder pass over codes [B, T <= max_frames, 16] (``fq3_codec_decode_batch``): [B, num_samples(T) - first_sample].
+        ``prefixes``: B prefix states of one length that the utterances start with (``fq3_codec_decode_batch_prefix``), or None."""
         B, Tn = codes.shape[0], codes.shape[1]
         n = self.num_samples(Tn)
         first_sample = max(0, min(int(first_sample), n))
         pcm = torch.empty(B, n - first_sample, dtype=torch.float32, device=self.device)
+        if prefixes is not None and (len(prefixes) != B or B > 128 or any(p is None or p.ref_len != prefixes[0].ref_len for p in prefixes)
+                                     or prefixes[0].ref_len >= Tn):
+            prefixes = None
+        if first_sample < n and prefixes is not None:
+            codes = codes.contiguous()
+            arr = (L.vp * B)(*[p.h for p in prefixes])
+            L.check(self.lib.fq3_codec_decode_batch_prefix(self.h, arr, codes.data_ptr(), int(B), int(Tn), int(first_sample), pcm.data_ptr(),
+                                                           torch.cuda.current_stream(self.device).cuda_stream))
+            return pcm
         if first_sample < n:
             rc = self.lib.fq3_codec_decode_batch(self.h, codes.data_ptr(), int(B), int(Tn), int(first_sample), pcm.data_ptr(),
                                                  torch.cuda.current_stream(self.device).cuda_stream)
@@ -255,7 +329,7 @@ class HipSpeechTokenizer:
             L.check(rc)
         return pcm
 
-    def decode_tensor_batch(self, codes: torch.Tensor, first_sample: int = 0) -> torch.Tensor:
+    def decode_tensor_batch(self, codes: torch.Tensor, first_sample: int = 0, prefixes=None) -> torch.Tensor:
         """codes LongTensor[B, T, 16] -> float32 [B, samples] on the device: row b is, bit for bit, ``decode_tensor(codes[b],
         first_sample)``, but the B utterances share every launch (one ``[B, T, 16]`` vocoder call as the reference's interface takes it,
         model.py:924).  Utterances of different lengths: pad to the longest with valid ids and keep ``num_samples_total(T_b)`` samples
@@ -270,7 +344,7 @@ class HipSpeechTokenizer:
             n_piece = self.num_samples(end - start + ctx) - ctx * up
             if pos + n_piece > first_sample:
                 skip = ctx * up + max(0, first_sample - pos)
-                wavs.append(self._decode_piece_batch(codes[:, start - ctx:end].contiguous(), skip))
+                wavs.append(self._decode_piece_batch(codes[:, start - ctx:end].contiguous(), skip, prefixes if start == 0 else None))
             pos += n_piece
         if not wavs:
             return torch.empty(B, 0, dtype=torch.float32, device=self.device)
@@ -291,6 +365,9 @@ class HipSpeechTokenizer:
         return [wav[b] for b in range(wav.shape[0])], self.sample_rate
 
     def close(self):
+        for pf in list(self.__dict__.get("_prefixes", {}).values()):
+            pf.close()                                            # a prefix state must not outlive its codec
+        self.__dict__["_prefixes"] = {}
         if getattr(self, "h", None) and self.h.value:
             self.lib.fq3_codec_destroy(self.h)
             self.h = L.vp()

@@ -44,9 +44,16 @@ class _SideVocoder:
         self.stream = stream if self.async_ok else None
         self.items: list = []
 
-    def submit(self, key, codes: torch.Tensor, ref_len: int = 0) -> None:
+    def _prefix(self, ref):
+        """the tokenizer's cached front-end state of an ICL reference (built on the vocoder stream), or None"""
+        if ref is None or not hasattr(self.tok, "prefix_for"):
+            return None
+        return self.tok.prefix_for(ref, self.stream)
+
+    def submit(self, key, codes: torch.Tensor, ref_len: int = 0, ref=None) -> None:
         """``ref_len`` > 0: the first ``ref_len`` frames are the ICL reference; only the waveform after their share
-        (``int(ref_len / T * n_samples)``, model.py:927-930) is produced."""
+        (``int(ref_len / T * n_samples)``, model.py:927-930) is produced.  ``ref``: that reference's own tensor (its cached
+        front-end state then serves every utterance of the voice)."""
         if not self.async_ok or not hasattr(self.tok, "num_samples_total"):
             lst, _rate = self.tok.decode({"audio_codes": codes.unsqueeze(0)})
             a = _to_numpy(lst[0])
@@ -55,8 +62,9 @@ class _SideVocoder:
         cut = int(ref_len / max(codes.shape[0], 1) * self.tok.num_samples_total(codes.shape[0])) if ref_len > 0 else 0
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         codes.record_stream(self.stream)
+        pf = self._prefix(ref) if ref_len > 0 else None
         with torch.cuda.stream(self.stream):
-            pcm = self.tok.decode_tensor(codes, cut)
+            pcm = self.tok.decode_tensor(codes, cut, prefix=pf) if pf is not None else self.tok.decode_tensor(codes, cut)
             host = torch.empty(pcm.shape, dtype=torch.float32, pin_memory=True)
             host.copy_(pcm, non_blocking=True)
             ev = torch.cuda.Event()
@@ -65,12 +73,12 @@ class _SideVocoder:
 
     MAX_GROUP = 16          # utterances per batched codec launch set (the workspace grows with it; the gain saturates well before)
 
-    def add(self, key, codes: torch.Tensor, ref_len: int = 0, more: int = 0) -> None:
+    def add(self, key, codes: torch.Tensor, ref_len: int = 0, more: int = 0, ref=None) -> None:
         """Grouped form of ``submit``: utterances that finished in the same poll of the lock-step decode (``more`` = how many more of
         that poll follow, ``timing["more_in_poll"]``) are held back and vocoded TOGETHER -- utterances of equal length through one
         batched launch set (``decode_tensor_batch``: the [B, T, 16] form of the vocoder interface, model.py:924)."""
         self._held = getattr(self, "_held", [])
-        self._held.append((key, codes, ref_len))
+        self._held.append((key, codes, ref_len, ref))
         if more <= 0:
             held, self._held = self._held, []
             self.submit_many(held)
@@ -82,29 +90,33 @@ class _SideVocoder:
 
     def submit_many(self, group) -> None:
         if not self.async_ok or not hasattr(self.tok, "decode_tensor_batch") or not hasattr(self.tok, "num_samples_total"):
-            for key, codes, ref_len in group:
-                self.submit(key, codes, ref_len)
+            for key, codes, ref_len, ref in group:
+                self.submit(key, codes, ref_len, ref)
             return
         classes: Dict[Any, list] = {}
-        for key, codes, ref_len in group:
-            classes.setdefault((int(codes.shape[0]), int(ref_len)), []).append((key, codes))
+        for key, codes, ref_len, ref in group:
+            classes.setdefault((int(codes.shape[0]), int(ref_len)), []).append((key, codes, ref))
         for (T, ref_len), members in classes.items():
             for i in range(0, len(members), self.MAX_GROUP):
                 part = members[i:i + self.MAX_GROUP]
                 if len(part) == 1:
-                    self.submit(part[0][0], part[0][1], ref_len)
+                    self.submit(part[0][0], part[0][1], ref_len, part[0][2])
                     continue
                 cut = int(ref_len / max(T, 1) * self.tok.num_samples_total(T)) if ref_len > 0 else 0
                 self.stream.wait_stream(torch.cuda.current_stream(self.dev))
-                for _k, c in part:
+                for _k, c, _r in part:
                     c.record_stream(self.stream)
+                pfs = [self._prefix(r) for _k, _c, r in part] if ref_len > 0 else None
+                if pfs is not None and any(p is None for p in pfs):
+                    pfs = None
                 with torch.cuda.stream(self.stream):
-                    pcm = self.tok.decode_tensor_batch(torch.stack([c for _k, c in part]), cut)
+                    stacked = torch.stack([c for _k, c, _r in part])
+                    pcm = self.tok.decode_tensor_batch(stacked, cut, prefixes=pfs) if pfs is not None else self.tok.decode_tensor_batch(stacked, cut)
                     host = torch.empty(pcm.shape, dtype=torch.float32, pin_memory=True)
                     host.copy_(pcm, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(self.stream)
-                for j, (key, _c) in enumerate(part):
+                for j, (key, _c, _r) in enumerate(part):
                     self.items.append((key, host[j], ev, pcm))
 
     # ---- incremental (exact) vocoding of utterances that are still decoding ------------------------------------------------
@@ -223,8 +235,13 @@ class StreamingVocoder:
         self.min_cal = max(self.CONTEXT_FRAMES, int(chunk_size))
         self.all_codes: List[torch.Tensor] = []
         self.prev_len, self.spf = 0, None
+        # phase 1 decodes ``ref_codes + everything so far`` for every chunk: with the tokenizer's cached front-end state of the
+        # reference (built once per voice, on the vocoder stream) only the rows behind it are computed -- bit-identical
+        self.prefix = (tok.prefix_for(ref_codes, side_stream) if side_stream is not None and ref_codes is not None and hasattr(tok, "prefix_for")
+                       else None)
+        self.last_prefix = None          # the prefix the decode returned by the last ``prepare`` may use (None in phase 2)
 
-    def _vocode(self, codes_in, first_sample, ev):
+    def _vocode(self, codes_in, first_sample, ev, prefix=None):
         """waveform[first_sample:] of codes_in (host array)."""
         if self.side is None:
             lst, rate = self.tok.decode({"audio_codes": codes_in.unsqueeze(0)})
@@ -234,7 +251,8 @@ class StreamingVocoder:
         else:
             self.side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.side):
-            out = _to_numpy(self.tok.decode_tensor(codes_in, first_sample))      # .cpu() synchronises the side stream only
+            # (.cpu() synchronises the side stream only)
+            out = _to_numpy(self.tok.decode_tensor(codes_in, first_sample, prefix=prefix) if prefix is not None else self.tok.decode_tensor(codes_in, first_sample))
         return out, self.tok.sample_rate
 
     def _cat(self, parts, ev):
@@ -267,17 +285,19 @@ class StreamingVocoder:
             self.prev_len = n_audio - cut
             if n_total >= self.min_cal:
                 self.spf = self.prev_len / n_total
+            self.last_prefix = self.prefix if ref_len else None
             return inp, first
         start = max(0, n_total - n_new - self.CONTEXT_FRAMES)
         window = flat[start:]
         n_ctx = window.shape[0] - n_new
+        self.last_prefix = None
         return window, (int(round(n_ctx * self.spf)) if n_ctx > 0 else 0)
 
     def push(self, chunk: torch.Tensor, ready_event=None):
         """``chunk`` LongTensor[n_new, 16] (device) -> (new audio as a host array, sample_rate)."""
         if self.side is not None:
             inp, first = self.prepare(chunk, ready_event)
-            return self._vocode(inp, first, ready_event)
+            return self._vocode(inp, first, ready_event, self.last_prefix)
         self.all_codes.append(chunk)
         n_new = chunk.shape[0]
         flat = self._cat(self.all_codes, ready_event)
@@ -730,7 +750,8 @@ class FasterQwen3TTS:
             # the reference decodes ref + generated frames and cuts the reference's share (model.py:927-930); the HIP
             # decoder produces only that tail (bit-identical to the slice, fq3_codec_decode_tail)
             cut = int(ref_len / max(codes.shape[0], 1) * tok.num_samples_total(codes.shape[0]))
-            out, sr = [_to_numpy(tok.decode_tensor(codes, cut))], tok.sample_rate
+            pf = tok.prefix_for(ref_codes) if hasattr(tok, "prefix_for") else None          # the voice's cached front-end state
+            out, sr = [_to_numpy(tok.decode_tensor(codes, cut, prefix=pf) if pf is not None else tok.decode_tensor(codes, cut))], tok.sample_rate
         else:
             audio_list, sr = tok.decode({"audio_codes": codes.unsqueeze(0)})
             out = []
@@ -948,7 +969,7 @@ class FasterQwen3TTS:
             codes = torch.cat([rc.to(codec_ids.device), codec_ids], dim=0) if rc is not None else codec_ids
             # side stream; the next frames of the other lanes are not held up.  Utterances that finished in the same poll are vocoded
             # together (equal lengths: one batched launch set)
-            voc.add(rid, codes, ref_len=rc.shape[0] if rc is not None else 0, more=more)
+            voc.add(rid, codes, ref_len=rc.shape[0] if rc is not None else 0, more=more, ref=rc)
         voc.add_flush()
         for rid, a in voc.collect():
             out[rid] = ([a], voc.sample_rate)
@@ -978,8 +999,9 @@ class FasterQwen3TTS:
             classes: Dict[Any, list] = {}
             for j in jobs:
                 if j[3] is not None:
-                    classes.setdefault((int(j[3][0].shape[0]), int(j[3][1])), []).append(j)
-            for (_T, first), members in classes.items():
+                    pf = j[3][3] if len(j[3]) > 3 else None
+                    classes.setdefault((int(j[3][0].shape[0]), int(j[3][1]), pf.ref_len if pf is not None else 0), []).append(j)
+            for (_T, first, pf_len), members in classes.items():
                 for i in range(0, len(members), _SideVocoder.MAX_GROUP):
                     part = members[i:i + _SideVocoder.MAX_GROUP]
                     for j in part:
@@ -988,10 +1010,12 @@ class FasterQwen3TTS:
                         else:
                             side.wait_stream(torch.cuda.current_stream(torch.device(self.device)))
                     with torch.cuda.stream(side):
+                        pfs = [j[3][3] for j in part] if pf_len > 0 else None      # (phase 1 behind ICL references: the voices' cached front-end states)
                         if len(part) == 1:
-                            part[0][2] = _to_numpy(tok.decode_tensor(part[0][3][0], first))
+                            part[0][2] = _to_numpy(tok.decode_tensor(part[0][3][0], first, prefix=pfs[0]) if pfs else tok.decode_tensor(part[0][3][0], first))
                         else:
-                            wav = tok.decode_tensor_batch(torch.stack([j[3][0] for j in part]), first).cpu().numpy()
+                            stacked = torch.stack([j[3][0] for j in part])
+                            wav = (tok.decode_tensor_batch(stacked, first, prefixes=pfs) if pfs else tok.decode_tensor_batch(stacked, first)).cpu().numpy()
                             for k, j in enumerate(part):
                                 j[2] = wav[k]
             done, jobs[:] = list(jobs), []
@@ -1008,7 +1032,7 @@ class FasterQwen3TTS:
             if codes is not None and codes.shape[0] > 0:
                 if batched:
                     inp, first = vocs[rid].prepare(codes, ev)
-                    jobs.append([rid, out_meta, None, (inp, first, ev)])
+                    jobs.append([rid, out_meta, None, (inp, first, ev, vocs[rid].last_prefix)])
                 else:
                     audio, _sr = vocs[rid].push(codes, ev)
                     jobs.append([rid, out_meta, audio, None])

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FQ3_ABI_VERSION 4
+#define FQ3_ABI_VERSION 5
 
 enum { FQ3_BF16 = 0, FQ3_F32 = 1,
        FQ3_BF16X2 = 2 };   /* codec decoder only: activations kept as a bf16 high part + a bf16 residual (16 mantissa bits), products of the
@@ -385,6 +385,22 @@ int fq3_codec_decode_tail(fq3_codec* c, const int64_t* codes, int T, int64_t fir
  * prefix of the codes gives the same prefix of the waveform -- and keep num_samples(T_b) samples of each.  The workspace grows to
  * B utterances on first use (a device synchronisation; not inside a graph capture). */
 int fq3_codec_decode_batch(fq3_codec* c, const int64_t* codes, int B, int T, int64_t first_sample, float* pcm, void* stream);
+/* Reference-prefix state (round 6).  The ICL call sites decode `ref_codes + generated codes` and cut the reference part off
+ * (model.py:919-937; every phase-1 chunk of the streaming path again, model.py:1085-1115): the frame-level front end -- RVQ sums,
+ * pre_conv, the sliding-window transformer -- re-runs over the same reference frames for every chunk and every utterance of a voice.
+ * fq3_codec_prefix_create runs it ONCE over ref_codes int64[ref_len][16] (device) and keeps what later rows read from the prefix: the
+ * pre_conv's two context rows, every layer's post-RoPE K / V of the last sliding_window - 1 rows, the last 48 output rows (the conv
+ * stack's halo).  fq3_codec_decode_batch_prefix is fq3_codec_decode_batch for codes whose first fq3_codec_prefix_frames(prefix) frames
+ * of utterance b ARE that prefix's codes (prefixes: HOST array of B states of one length, B <= 128; the same state may repeat): the
+ * front end computes rows [ref_len, T) only.  The waveform is bit-identical to the full decode's (the front end is causal and a row's
+ * arithmetic does not depend on the row count); a first_sample that reaches further back than the cached rows silently takes the full
+ * path.  A state belongs to the codec that made it and must be destroyed before it. */
+typedef struct fq3_codec_prefix fq3_codec_prefix;
+int fq3_codec_prefix_create(fq3_codec* c, const int64_t* ref_codes, int ref_len, fq3_codec_prefix** out, void* stream);
+int fq3_codec_prefix_destroy(fq3_codec_prefix* prefix);
+int fq3_codec_prefix_frames(const fq3_codec_prefix* prefix);
+int fq3_codec_decode_batch_prefix(fq3_codec* c, const fq3_codec_prefix* const* prefixes, const int64_t* codes, int B, int T,
+                                  int64_t first_sample, float* pcm, void* stream);
 
 /* ---- reference-audio analysis (create_voice_clone_prompt, model.py:415-463 -> upstream qwen_tts) -----------------------
  * What the reference runs once per new (ref_audio, ref_text) pair and then caches (model.py:424-463):

@@ -38,7 +38,7 @@ def test_binding_table_matches_header():
 
 def test_abi_version_and_error_string(lib):
     lib.fq3_abi_version.restype = ctypes.c_int
-    assert lib.fq3_abi_version() == 4
+    assert lib.fq3_abi_version() == 5
     lib.fq3_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.fq3_last_error(), bytes)
 

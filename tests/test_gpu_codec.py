@@ -249,6 +249,89 @@ def test_codec_tail_decode_is_bit_identical_real_shapes():
     tok.close()
 
 
+# ---- reference-prefix states (fq3_codec_prefix_*, round 6) -------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["bf16", "bf16x2", "fp32"])
+def test_codec_prefix_state_is_bit_identical_real_shapes(precision):
+    """The ICL call sites decode `reference codes + generated codes` (model.py:919-937; every phase-1 streaming chunk again,
+    :1085-1115).  A prefix state (``tok.prefix_for(ref)``: the pre_conv context rows, every layer's post-RoPE K / V of the last 71
+    reference rows, the last 48 output rows) lets the front end run over the rows BEHIND the reference only.  At the benchmark's
+    shapes -- 170 reference frames + 8 .. 32 generated frames (phase 1, the last 8 frames' samples kept), + 130 / 200 generated
+    frames with the reference's share cut off (non-streaming; 370 frames = two pieces) -- the waveform must equal the full decode's
+    bit for bit, single and batched (different voices in one call), in all three precisions; a cut that reaches further back than the
+    cached rows silently takes the full path; a reference shorter than the attention window / the cached output rows works too."""
+    from fq3hip.codec import HipSpeechTokenizer
+    from fq3hip.config import qwen3_tts_0p6b
+    cfg = qwen3_tts_0p6b()
+    dt = torch.float32 if precision == "fp32" else torch.bfloat16
+    W = synth_weights(cfg, 0, dt, parts=("codec",), codec_normalized=True)
+    tok = HipSpeechTokenizer(cfg.codec, W, "cuda", max_frames=400, precision=precision)
+    g = torch.Generator().manual_seed(11)
+    nq, cb = cfg.codec.num_quantizers, cfg.codec.codebook_size
+    refs = [torch.randint(0, cb, (170, nq), generator=g).cuda() for _ in range(3)]
+    gens = [torch.randint(0, cb, (200, nq), generator=g).cuda() for _ in range(3)]
+    tok.use_prefix = True
+    pfs = [tok.prefix_for(r) for r in refs]
+    assert all(p is not None and p.ref_len == 170 for p in pfs)
+    assert tok.prefix_for(refs[0]) is pfs[0]                                   # cached by identity
+    assert tok.prefix_for(refs[0].cpu()) is tok.prefix_for(refs[0].cpu().clone())       # host tensors: by content
+    for n_gen, keep in ((8, 8), (16, 8), (32, 8), (130, None), (200, None)):
+        T = 170 + n_gen
+        fulls = [torch.cat([r, gcodes[:n_gen]]) for r, gcodes in zip(refs, gens)]
+        n = tok.num_samples_total(T)
+        first = n - keep * 1920 - 37 if keep else int(170 / T * n)
+        want = [tok.decode_tensor(f, first) for f in fulls]
+        got = [tok.decode_tensor(f, first, prefix=p) for f, p in zip(fulls, pfs)]
+        for i, (a, b) in enumerate(zip(want, got)):
+            assert a.shape == b.shape and torch.equal(a, b), (precision, n_gen, "single", i)
+        gotb = tok.decode_tensor_batch(torch.stack(fulls), first, prefixes=pfs)
+        for i in range(3):
+            assert torch.equal(gotb[i], want[i]), (precision, n_gen, "batched", i)
+    # samples of the reference part itself: further back than the cached rows -> the full path, same values
+    f = torch.cat([refs[0], gens[0][:8]])
+    assert torch.equal(tok.decode_tensor(f, 100 * 1920, prefix=pfs[0]), tok.decode_tensor(f, 100 * 1920))
+    assert torch.equal(tok.decode_tensor(f, 0, prefix=pfs[0]), tok.decode_tensor(f, 0))
+    # short references: fewer rows than the attention window (71) / than the cached output rows (48) / than the pre_conv context (2)
+    for rl in (1, 2, 30, 60):
+        r = torch.randint(0, cb, (rl, nq), generator=g).cuda()
+        f = torch.cat([r, gens[1][:24]])
+        p = tok.prefix_for(r)
+        n = tok.num_samples_total(rl + 24)
+        for first in (int(rl / (rl + 24) * n), n - 8 * 1920):
+            assert torch.equal(tok.decode_tensor(f, first, prefix=p), tok.decode_tensor(f, first)), (rl, first)
+    tok.close()
+
+
+def test_codec_prefix_state_tiny_decoder_and_streaming_vocoder():
+    """The same property on the tiny test decoder (head_dim 32, window 8, other channel counts), and end to end through the
+    streaming windowing state machine: the chunks StreamingVocoder produces with the tokenizer's prefix states switched on are those it
+    produces with them switched off, bit for bit (phase 1 behind the reference, phase 2 without it)."""
+    from fq3hip.codec import HipSpeechTokenizer
+    from fq3hip.model import StreamingVocoder
+    from fq3hip.streams import concurrent_stream
+    cfg = tiny_test_config()
+    W = synth_weights(cfg, 0, torch.float32, parts=("codec",))
+    tok = HipSpeechTokenizer(cfg.codec, W, "cuda", max_frames=128)
+    g = torch.Generator().manual_seed(3)
+    nq, cb = cfg.codec.num_quantizers, cfg.codec.codebook_size
+    ref = torch.randint(0, cb, (21, nq), generator=g).cuda()
+    gen = torch.randint(0, cb, (56, nq), generator=g).cuda()
+    side = concurrent_stream(torch.device("cuda"))
+    outs = []
+    for use in (False, True):
+        tok.use_prefix = use
+        voc = StreamingVocoder(tok, ref, 8, "cuda", side)
+        assert (voc.prefix is not None) == use
+        chunks = []
+        for i in range(0, 56, 8):
+            a, _sr = voc.push(gen[i:i + 8].contiguous())
+            chunks.append(np.asarray(a).copy())
+        outs.append(chunks)
+    assert len(outs[0]) == len(outs[1]) == 7
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert a.shape == b.shape and np.array_equal(a, b), i
+    tok.close()
+
+
 # ---- the bf16 x 2 high-precision mode (FQ3_BF16X2) and the batched decode (fq3_codec_decode_batch) --------------------------
 @pytest.mark.parametrize("T", [40, 100])
 def test_codec_bf16x2_mode_meets_1e_3_at_real_shapes(T, golden_dir):

@@ -39,12 +39,25 @@ def main():
           f"first chunk 170+8 frames (tail of 8) {timed(lambda: tok.decode_tensor(codes[:178].contiguous(), n178 - 8 * 1920), 10):.3f} ms", flush=True)
     tok.set_option("fuse_units", 1)
     cut = int(170 / 370 * tok.num_samples_total(370))
+    # the same decodes behind the reference's cached front-end state (fq3_codec_prefix_*, round 6): bit-identical waveforms
+    pf = tok.prefix_for(codes[:170].contiguous())
+    print(f"precision {prec} with the prefix state of the 170 reference frames: first chunk 170+8 (tail of 8) "
+          f"{timed(lambda: tok.decode_tensor(codes[:178].contiguous(), n178 - 8 * 1920, prefix=pf), 10):.3f} ms | 170+32 (tail of 8) "
+          f"{timed(lambda: tok.decode_tensor(codes[:202].contiguous(), tok.num_samples_total(202) - 8 * 1920, prefix=pf), 10):.3f} ms "
+          f"(without: {timed(lambda: tok.decode_tensor(codes[:202].contiguous(), tok.num_samples_total(202) - 8 * 1920), 10):.3f}) | "
+          f"370 frames, tail after the reference {timed(lambda: tok.decode_tensor(codes, cut, prefix=pf)):.3f} ms "
+          f"(without: {timed(lambda: tok.decode_tensor(codes, cut)):.3f})", flush=True)
     for B in Bs:
         cb = torch.randint(0, cfg.codec.codebook_size, (B, 370, 16), generator=g).cuda()
         full = timed(lambda: tok.decode_tensor_batch(cb), 3)
         tail = timed(lambda: tok.decode_tensor_batch(cb, cut), 3)
         first = timed(lambda: tok.decode_tensor_batch(cb[:, :178].contiguous(), n178 - 8 * 1920), 5)
         ch = timed(lambda: tok.decode_tensor_batch(cb[:, :33].contiguous(), n33 - 8 * 1920), 5)
+        pfs = [tok.prefix_for(cb[b, :170].contiguous()) for b in range(B)]
+        tail_p = timed(lambda: tok.decode_tensor_batch(cb, cut, prefixes=pfs), 3)
+        first_p = timed(lambda: tok.decode_tensor_batch(cb[:, :178].contiguous(), n178 - 8 * 1920, prefixes=pfs), 5)
+        print(f"precision {prec} BATCH of {B} with prefix states: tail after 170 reference frames {tail_p:.3f} ms = {tail_p / B:.3f} per utterance "
+              f"(without {tail / B:.3f}) | first chunks 170+8 {first_p:.3f} ms = {first_p / B:.3f} each (without {first / B:.3f})", flush=True)
         print(f"precision {prec} BATCH of {B}: full 370 frames {full:.3f} ms = {full / B:.3f} per utterance | tail after 170 reference frames "
               f"{tail:.3f} ms = {tail / B:.3f} per utterance | first chunks 170+8 (tail of 8) {first:.3f} ms = {first / B:.3f} each | "
               f"chunks 25+8 {ch:.3f} ms = {ch / B:.3f} each", flush=True)
