@@ -636,6 +636,11 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
     constexpr int K = KSTEPS * 128, KP = K + 8;                 // padded LDS row: 16 tokens x same k would share a bank
     constexpr int NCH = (K + 511) / 512;
     constexpr int TPW = kTokTile / 4;
+    // K = 2048 with the two weight-row halves of SwiGLU (1.7B gate | up at <= 32 lanes): 128 registers of weight fragments + the raw
+    // rows of four tokens (64) + gains do not fit 256 VGPRs (272-294: one wave per SIMD, i.e. one workgroup per CU for a grid of 384).
+    // There a wave's four tokens are fetched and normalised in TWO rounds of two through the same registers (TPI tokens per round); the
+    // second round's L2 round trip lies behind the weight rows that are in flight anyway.  Per token the same instructions: bit-identical.
+    constexpr int TPI = (KSTEPS >= 16 && NR == 2) ? TPW / 2 : TPW, NRND = TPW / TPI;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NPANEL = DUAL ? 2 : 1;
     T* xs = reinterpret_cast<T*>(smem_raw);                     // [NPANEL][16][KP]
@@ -646,14 +651,15 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
     const int row0 = blockIdx.x * 16;
 
     // ---- 1. token loads of the first token tile (lanes 0..15 of the batch), and of the second when it fits ----
-    Raw8<T> xraw[NXR][TPW][NCH], nraw[NCH];
-    auto issue_tokens = [&](int slot, int t0, int nb) {
+    Raw8<T> xraw[NXR][TPI][NCH], nraw[NCH];
+    auto issue_tokens = [&](int slot, int t0, int nb, int rnd = 0) {       // tokens wave + 4 (rnd TPI + t), t < TPI, of the tile at t0
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int off = j * 512 + lane * 8, offc = off < K ? off : 0;
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int m = t0 + (wave + 4 * t < nb ? wave + 4 * t : nb - 1);
+            for (int t = 0; t < TPI; ++t) {
+                const int tk = wave + 4 * (rnd * TPI + t);
+                const int m = t0 + (tk < nb ? tk : nb - 1);
                 ldraw<false>(xraw[slot][t][j], reinterpret_cast<const T*>(a.x) + (size_t)m * a.x_stride + offc);
             }
         }
@@ -804,8 +810,10 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
         if (tt > 0 && !PRE2) issue_tokens(0, t0, nb);           // one exposed round trip; the weights are already here
         // ---- 3. prepare the tile's tokens (the first tile: while the weights fly) ----
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            const int m = wave + 4 * t;
+        for (int tq = 0; tq < TPW; ++tq) {
+            const int t = tq % TPI;                             // the register set of token tq
+            if (NRND > 1 && tq > 0 && t == 0) issue_tokens(slot, t0, nb, tq / TPI);      // the next round of tokens through the same registers
+            const int m = wave + 4 * tq;
             float xr[NCH][8];
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {

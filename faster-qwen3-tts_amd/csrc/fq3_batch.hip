@@ -47,6 +47,7 @@ struct fq3_batch {
                                   // hidden 1024, +3..10 us at 2048, against 1.9 us for the launch it saves inside a graph ("norm_fused" 1 selects it)
     int packed = 1;               // the weight-stationary GEMMs read the fragment-major copies of the layer matrices (round 6; bit-identical); 0 = the row-major matrices
     int pred_attn_group = 1;      // predictor attention: one wave per (kv group, lane), live rows only (round 6; bit-identical); 0 = one wave per (q head, lane), all 16 slots
+    int rows2 = 1;                // 2: the activation buffers hold 2 B rows (the pair pass can engage), 1: B rows
     int pred_pair = 1;            // the predictor's two-token prefill as one pass over 2 B rows where that is bit-identical (see enqueue_batch_frame_t); 0 = two passes
     int attn_lane = 1;            // talker attention as one workgroup per (kv head, lane), final outputs, no merge launch: 0 never, 1 from attn_lane_from lanes (bf16), 2 always
     int attn_lane_from = 4 * kTokTile;
@@ -239,11 +240,15 @@ static int batch_create_(fq3_ctx* const* lanes, int n_lanes, fq3_batch** out, bo
     const int Vm = std::max(t.vocab, p.vocab);
     int r;
     auto A = [&](void** ptr, size_t n) { return bmalloc(b, ptr, n); };
-    // (h, xn, qkv, act, attn_out, pred_x, ssq hold 2 B rows: the predictor's two-token prefill runs as ONE pass over 2 B token rows)
-    if ((r = A(&b->h, (size_t)2 * B * b->Hm * esz)) || (r = A(&b->xin, (size_t)B * b->Hm * esz)) ||
-        (r = A(&b->xn, (size_t)2 * B * b->Hm * esz)) || (r = A((void**)&b->ssq, (size_t)2 * B * (b->Hm / 16 + 4) * sizeof(float))) || (r = A(&b->qkv, (size_t)2 * B * b->qkvm * esz)) || (r = A(&b->act, (size_t)2 * B * b->Im * esz)) ||
-        (r = A(&b->attn_out, (size_t)2 * B * b->qkvm * esz)) || (r = A(&b->logits, (size_t)B * Vm * esz)) ||
-        (r = A(&b->pred_in, (size_t)B * 2 * t.hidden * esz)) || (r = A(&b->pred_x, (size_t)2 * B * p.hidden * esz)) ||
+    // h, xn, qkv, act, attn_out, pred_x, ssq hold 2 B rows where the predictor's two-token prefill can run as ONE pass over 2 B token rows
+    // (bf16, more than norm_skinny_above lanes at the default setting, 2 B rows within the weight-stationary kernel's range -- see `pair` in
+    // enqueue_batch_frame_t); smaller, fp32 and lane-group batches take one row per lane (round-5 advisor)
+    const size_t R2 = (c0->cfg.dtype == FQ3_BF16 && B > 2 * kTokTile && 2 * B <= kSkinnyMaxRows) ? 2 : 1;
+    b->rows2 = (int)R2;
+    if ((r = A(&b->h, R2 * B * b->Hm * esz)) || (r = A(&b->xin, (size_t)B * b->Hm * esz)) ||
+        (r = A(&b->xn, R2 * B * b->Hm * esz)) || (r = A((void**)&b->ssq, R2 * B * (b->Hm / 16 + 4) * sizeof(float))) || (r = A(&b->qkv, R2 * B * b->qkvm * esz)) || (r = A(&b->act, R2 * B * b->Im * esz)) ||
+        (r = A(&b->attn_out, R2 * B * b->qkvm * esz)) || (r = A(&b->logits, (size_t)B * Vm * esz)) ||
+        (r = A(&b->pred_in, (size_t)B * 2 * t.hidden * esz)) || (r = A(&b->pred_x, R2 * B * p.hidden * esz)) ||
         (r = A(&b->pred_next, (size_t)B * t.hidden * esz)) || (r = A(&b->plogits, (size_t)B * (G - 1) * p.vocab * esz))) {
         fq3_batch_destroy(b); return r;
     }
@@ -619,7 +624,7 @@ static int enqueue_batch_frame_t(fq3_batch* b, hipStream_t s) {
     // the two-token prefill as one pass over 2 B rows ("pred_pair": default from the lane count at which every GEMM of the pass is the
     // weight-stationary kernel anyway -- above norm_skinny_above lanes, bf16, matrix-core path -- where a row's arithmetic does not
     // depend on the row count: bit-identical to the two passes; 0 = two passes at every lane count)
-    const bool pair = b->pred_pair && g_batch_mfma && c->cfg.dtype == FQ3_BF16 && g_batch_norm_skinny && g_batch_skinny && B > g_batch_norm_skinny_above &&
+    const bool pair = b->pred_pair && b->rows2 == 2 && g_batch_mfma && c->cfg.dtype == FQ3_BF16 && g_batch_norm_skinny && g_batch_skinny && B > g_batch_norm_skinny_above &&
                       2 * B <= kSkinnyMaxRows && skinny_k_ok(p.hidden) && p.hidden <= 2048;
     for (int pass = 0; pass < G; ++pass) {
         const bool pp = pair && pass == 0;                 // this iteration runs token A and token B together

@@ -435,10 +435,15 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kv_pack_kernel(T* qkv, const
     DT<T>::st(dst + lane + 64, x1);
 }
 
+// (the LDS limit of a kernel is a per-DEVICE setting: remembered per device, for a process that drives more than one)
 static bool flash_small_prepare() {
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_prefill_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)kFsLdsBytes) == hipSuccess;
-    return ok;
+    static int state[kSkMaxDevices] = {};                 // 0 = not asked yet, 1 = raised, -1 = failed
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kSkMaxDevices) return false;
+    if (!state[dev])
+        state[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_prefill_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)kFsLdsBytes) == hipSuccess ? 1 : -1;
+    return state[dev] > 0;
 }
 // every sequence short enough, one pool, bf16: the packed attention kernels take the whole group (false: the per-prompt launches)
 static bool pack_attention_ok(fq3_ctx* const* cs, int n, const int* L) {
@@ -456,7 +461,7 @@ static PackSeq pack_seq(fq3_ctx* const* cs, int n, const int* L, const int* n_pa
     return sq;
 }
 // one layer's q / k norm + RoPE + KV write and causal attention for every sequence of the pack: two launches
-static void pack_attention_layer(fq3_ctx* c0, int layer, const fq3_layer_weights& w, const PackSeq& sq, int Lmax, bf16_t* QKV, bf16_t* ATT,
+static bool pack_attention_layer(fq3_ctx* c0, int layer, const fq3_layer_weights& w, const PackSeq& sq, int Lmax, bf16_t* QKV, bf16_t* ATT,
                                  float scale, hipStream_t s) {
     const fq3_stack_dims& d = c0->cfg.talker;
     const int NH = d.n_heads, NKV = d.n_kv_heads, Lt = sq.off[sq.n];
@@ -465,6 +470,7 @@ static void pack_attention_layer(fq3_ctx* c0, int layer, const fq3_layer_weights
                        (const bf16_t*)w.k_norm, d.rms_eps, c0->wt.talker_cos, c0->wt.talker_sin, c0->wt.talker_rope_len, kv, sq, NH, NKV);
     hipLaunchKernelGGL(flash_prefill_small_kernel, dim3((Lmax + kFaQ - 1) / kFaQ, NH, sq.n), dim3(256), kFsLdsBytes, s, (const bf16_t*)QKV, kv, ATT, sq,
                        NH, NKV, scale);
+    return hipGetLastError() == hipSuccess;                // a refused launch (e.g. the 158 KB of LDS) must not leave ATT stale silently
 }
 
 // shape choice: short prompts keep 64-query blocks, one per workgroup (parallelism first); from 1024 tokens the blocks are paired
@@ -555,7 +561,7 @@ int prefill_t(fq3_ctx* c, const void* embeds, int L, int n_pad, void* out_logits
         gemm<T>(lin<T>(c, XN, L, H, w.qkv, per, QKV), s);
         if constexpr (sizeof(T) == 2) {
             if (small) {
-                pack_attention_layer(c, i, w, sq1, L, (bf16_t*)QKV, (bf16_t*)ATT, scale, s);
+                if (!pack_attention_layer(c, i, w, sq1, L, (bf16_t*)QKV, (bf16_t*)ATT, scale, s)) return fq3_fail_(FQ3_EHIP, "prefill: the packed attention launch failed");
                 { GemmArgs a = lin<T>(c, ATT, L, QD, w.o, H, X); a.res = X; a.ldr = H; gemm<T>(a, s); }
                 rmsnorm_rows<T>((const T*)X, (const T*)w.post_norm, XN, L, H, d.rms_eps, s);
                 gemm_swiglu_halves<T>(lin<T>(c, XN, L, H, w.gate_up, 2 * I, GU, 1), ACT, s);
@@ -616,7 +622,8 @@ int prefill_batch_t(fq3_ctx* const* cs, int n, const void* const* embeds, const 
         rmsnorm_rows<T>((const T*)X, (const T*)w.input_norm, XN, Lt, H, d.rms_eps, s);
         gemm<T>(lin<T>(c, XN, Lt, H, w.qkv, per, QKV), s);
         if constexpr (sizeof(T) == 2) {
-            if (small) pack_attention_layer(c, i, w, sqn, Lmax, (bf16_t*)QKV, (bf16_t*)ATT, scale, s);
+            if (small && !pack_attention_layer(c, i, w, sqn, Lmax, (bf16_t*)QKV, (bf16_t*)ATT, scale, s))
+                return fq3_fail_(FQ3_EHIP, "prefill: the packed attention launch failed");
         }
         for (int q = 0; q < n && !small; ++q) {
             fq3_ctx* cq = cs[q];

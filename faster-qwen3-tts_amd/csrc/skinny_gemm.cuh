@@ -71,6 +71,7 @@ inline bool skinny_k_ok(int K) { return K == 1024 || K == 2048 || K == 3072 || K
 inline bool skinny_norm_ok(int K, int M) { return (K == 1024 || K == 2048) && M >= 1 && M <= 256; }
 
 // shapes the fragment-major copy serves (the kernels' own: K a multiple of 1024 the kernels are built for, whole 16-row blocks)
+constexpr int kSkMaxDevices = 16;           // devices a process may drive (the LDS limit of a kernel is a per-device setting)
 inline bool skinny_pack_ok(int N, int K) { return skinny_k_ok(K) && N % 16 == 0 && N > 0; }
 
 #ifdef FQ3_SKINNY_EXTERN
@@ -420,8 +421,12 @@ template <int K, int RB, int EPI, bool NORM = false>
 inline bool skinny_attr() {
     constexpr size_t shm = skinny_lds_bytes(RB);
     static_assert(shm <= 160 * 1024, "LDS");
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<K, RB, EPI, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess;
-    return ok;
+    static int state[kSkMaxDevices] = {};                 // per device: 0 = not asked yet, 1 = raised, -1 = failed
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kSkMaxDevices) return false;
+    if (!state[dev])
+        state[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<K, RB, EPI, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess ? 1 : -1;
+    return state[dev] > 0;
 }
 template <int K, int RB, int EPI, bool NORM = false>
 inline void skinny_go(const SkinnyArgs& a, hipStream_t s) {

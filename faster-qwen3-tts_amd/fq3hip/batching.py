@@ -253,7 +253,8 @@ class BatchDecoder:
         def run_deferred():
             # left padding of every prompt: one stack, one copy (the per-request int() of the synchronous path is a device wait each)
             masks = [it[1] for it in items]
-            known = [0 if m is None else getattr(m, "fq3_n_pad", None) for m in masks]
+            from .generate import noted_n_pad
+            known = [0 if m is None else noted_n_pad(m) for m in masks]
             if all(k is not None for k in known):
                 cnt = [int(k) for k in known]                         # the prompt builder noted them: no device round trip at all
             else:
@@ -640,11 +641,15 @@ class BatchDecoder:
                 break
             if self.stages and not active and not ready:
                 t_ = clock()
-                while pending:                                        # nothing is decoding: nothing to overlap with but the prompt builds
-                    if stage_ahead(defer=True) == 0:
-                        break
-                    pull(cap=slice_n, on_main=True)
-                self._stage_sync()
+                try:
+                    while pending:                                    # nothing is decoding: nothing to overlap with but the prompt builds
+                        if stage_ahead(defer=True) == 0:
+                            break
+                        pull(cap=slice_n, on_main=True)
+                finally:
+                    # the deferred stages hold a request but not yet its first token / hidden state: complete them even when the
+                    # interleaved pull() (the caller's source) raised, so that no stage is left half-filled for the cleanup to find
+                    self._stage_sync()
                 prof["stage"] += clock() - t_
             while failed:
                 rid, info = failed.pop(0)

@@ -227,7 +227,9 @@ class HipSpeechTokenizer:
             import hashlib
             key = ("host", n, hashlib.blake2b(ref_codes.contiguous().numpy().tobytes(), digest_size=16).digest())
         else:
-            key = ("dev", int(ref_codes.data_ptr()), tuple(ref_codes.shape), str(ref_codes.dtype), int(ref_codes._version))
+            # (a tensor made under torch.inference_mode() has no version counter: -1)
+            key = ("dev", int(ref_codes.data_ptr()), tuple(ref_codes.shape), str(ref_codes.dtype),
+                   -1 if ref_codes.is_inference() else int(ref_codes._version))
         cache = self.__dict__.setdefault("_prefixes", {})
         hit = cache.pop(key, None)
         if hit is not None:

@@ -31,8 +31,21 @@ def _n_pad_of(attention_mask) -> int:
     (``fq3_n_pad``: a single prompt has none); a foreign mask is counted on the device, which is a host wait."""
     if attention_mask is None:
         return 0
-    known = getattr(attention_mask, "fq3_n_pad", None)
-    return int(known) if known is not None else int((attention_mask[0] == 0).sum())
+    known = noted_n_pad(attention_mask)
+    return known if known is not None else int((attention_mask[0] == 0).sum())
+
+
+def noted_n_pad(attention_mask):
+    """The padding count the prompt builder noted on a mask it created -- valid only while the mask has not been written to since
+    (the note carries the tensor's version counter) -- or None."""
+    note = getattr(attention_mask, "fq3_n_pad", None)
+    if not (isinstance(note, tuple) and len(note) == 2):
+        return None
+    if note[1] is None:                               # noted on an inference-mode tensor (no version counter)
+        return int(note[0])
+    if attention_mask.is_inference() or note[1] != attention_mask._version:
+        return None
+    return int(note[0])
 
 
 def _prefill_first_token(eng, talker_input_embeds, attention_mask, config, min_new_tokens, temperature, top_k, top_p, do_sample):

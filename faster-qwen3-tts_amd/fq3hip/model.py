@@ -72,6 +72,8 @@ class _SideVocoder:
         self.items.append((key, host, ev, pcm))          # pcm kept alive until its copy has completed
 
     MAX_GROUP = 16          # utterances per batched codec launch set (the workspace grows with it; the gain saturates well before)
+    STREAM_GROUP = 32       # streaming CHUNKS per launch set (short inputs: 178-202 frames behind a reference, 33 in phase 2): measured per chunk
+                            # 0.42 / 0.35 / 0.31 ms at 16 / 32 / 64 (profiles/r06_codec_time_bf16x2_groups.txt); 32 keeps the workspace at ~17 GB
 
     def add(self, key, codes: torch.Tensor, ref_len: int = 0, more: int = 0, ref=None) -> None:
         """Grouped form of ``submit``: utterances that finished in the same poll of the lock-step decode (``more`` = how many more of
@@ -1002,8 +1004,8 @@ class FasterQwen3TTS:
                     pf = j[3][3] if len(j[3]) > 3 else None
                     classes.setdefault((int(j[3][0].shape[0]), int(j[3][1]), pf.ref_len if pf is not None else 0), []).append(j)
             for (_T, first, pf_len), members in classes.items():
-                for i in range(0, len(members), _SideVocoder.MAX_GROUP):
-                    part = members[i:i + _SideVocoder.MAX_GROUP]
+                for i in range(0, len(members), _SideVocoder.STREAM_GROUP):
+                    part = members[i:i + _SideVocoder.STREAM_GROUP]
                     for j in part:
                         if j[3][2] is not None:
                             side.wait_event(j[3][2])

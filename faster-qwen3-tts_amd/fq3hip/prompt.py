@@ -122,5 +122,8 @@ def build_talker_inputs_hip(m, input_id: torch.Tensor, ref_id: Optional[torch.Te
     tth = out[L:L + Tt].unsqueeze(0)
     tpe = out[L + Tt:].unsqueeze(0)
     tam = torch.ones(1, L, dtype=torch.long, device=dev)
-    tam.fq3_n_pad = 0               # (host-side note for the prefill: a single prompt is never padded -- saves a device reduction + host wait per request)
+    # host-side note for the prefill: a single prompt is never padded -- saves a device reduction + host wait per request.  The note
+    # carries the tensor's version counter: an in-place edit of the mask afterwards voids it (generate._n_pad_of counts again)
+    # (a tensor created under torch.inference_mode() has no version counter: its note is taken as it is)
+    tam.fq3_n_pad = (0, None if tam.is_inference() else tam._version)
     return tie, tam, tth, tpe

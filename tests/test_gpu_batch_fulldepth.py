@@ -12,7 +12,8 @@ logit (the largest margin of any mismatch observed on this path: 2 ulps at the 0
 dot products are twice as long), and every lane must reach a FROZEN floor of identical decisions for its utterance: the
 round-3 measurement per shape (profiles/r03_parity_batch_fulldepth.json) minus one decision per lane -- LANE_FLOOR below; it
 replaces the round-3 "matched fraction >= 0.95", which 1.7B / 32 lanes cleared by a hair (0.9547).  K_ULP and the floors do
-not move again.  Above 32 lanes (round 5) the floor comes from the oracle's own self-check, see below.  fp32 (VALU batch GEMVs, 32 lanes, 0.6B) -- every decision identical."""
+not move again.  Above 32 lanes (round 5) the floor of a NEW summation order comes from the oracle's own self-check, see below; the default
+form's measured counts are frozen since round 6 (DEFAULT_FORM_FLOOR).  fp32 (VALU batch GEMVs, 32 lanes, 0.6B) -- every decision identical."""
 import json
 import os
 
@@ -40,6 +41,15 @@ R4_FORM_FLOOR = {"0p6b": (377, 242), "1p7b": (367, 247)}
 # changed-accumulation re-evaluation of the oracle reaches against its own golden ids (tests/golden/fulldepth_selfcheck.json,
 # oracle/selfcheck_fulldepth.py; CPU only) -- minus two.  The round-4 form (`attn_lane` 0, `norm_fused` 0) is re-run at 64 lanes and must
 # still clear its frozen floors above.
+
+
+# Round 6 (round-5 advisor): the DEFAULT path of 64 and 128 lanes (weight-stationary normalising GEMMs, lane attention, pair pass) has now
+# been measured in two rounds with identical counts -- 373 / 245 (0.6B) and 366 / 248 (1.7B) per lane at 64 and at 128 lanes alike
+# (profiles/r05_parity_batch_fulldepth.json, profiles/r06_parity_batch_fulldepth.json); every change of round 6 on that path (fragment-major
+# weight copies, the group form of the predictor attention) is bit-identical by construction and asserted so decision by decision below.
+# Those counts are FROZEN here, like the <= 32-lane ones: the default path must reach them exactly minus one decision per lane (and, as
+# before, the oracle-derived floor, which a NEW summation order would be held to instead).
+DEFAULT_FORM_FLOOR = {"0p6b": (372, 244), "1p7b": (365, 247)}
 
 
 def oracle_floor(golden_dir, size):
@@ -194,7 +204,7 @@ def test_batch_full_depth_bf16_mfma_lanes_vs_oracle(size, golden_dir):
                                               per_lane=[s["matched_decisions"] for s in scores],
                                               unexplained=sum(s["unexplained"] for s in scores)))
         assert all(s["unexplained"] == 0 for s in scores), scores
-        floor = LANE_FLOOR[(size, B)] if (size, B) in LANE_FLOOR else oracle_floor(golden_dir, size)
+        floor = LANE_FLOOR[(size, B)] if (size, B) in LANE_FLOOR else tuple(max(a_, b_) for a_, b_ in zip(DEFAULT_FORM_FLOOR[size], oracle_floor(golden_dir, size)))
         for i, sc in enumerate(scores):
             assert sc["matched_decisions"] >= floor[i % len(cases)], (i, sc, floor)
         # lanes that decode the same utterance must agree with each other exactly (lock-step lanes do not interact)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# round-6 GPU call 8: first-wave TTFA with prefix states + chunk groups of 32; the whole GPU suite; bench line (mid-round)
+cd $GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out/r6; mkdir -p $O
+timeout 900 python tools/batch_ttfa_probe.py 32,64,128 0 > $O/c8_ttfa_probe.txt 2>&1; grep "^{" $O/c8_ttfa_probe.txt
+timeout 2400 python -m pytest tests -q -m gpu -x > $O/c8_tests.log 2>&1; echo "tests rc=$?"; tail -6 $O/c8_tests.log
+cp gpurun_out/parity_batch_fulldepth.json $O/c8_parity_batch_fulldepth.json 2>/dev/null; cp gpurun_out/parity_fulldepth.json $O/c8_parity_fulldepth.json 2>/dev/null
+timeout 900 python bench.py --steps 5 --warmup 1 > $O/c8_bench.json 2> $O/c8_bench.err; echo "bench rc=$?"; tail -2 $O/c8_bench.err
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r6/c8_bench.json").read().strip().splitlines()[-1])
+b=d.get("batched_decode_one_gpu",{})
+print({k:d.get(k) for k in ("value","ttfa_ms_p50","decode_ms_per_frame","rccl_ranks")}, "frac", d.get("roofline",{}).get("frac"), "traffic x", d.get("roofline",{}).get("traffic_over_algorithmic"))
+print("batched", {k:b.get(k) for k in ("value","ms_per_lockstep_frame","decode_only_value","end_to_end_over_decode_only")}, "frac", b.get("roofline",{}).get("frac"), "traffic x", b.get("roofline",{}).get("traffic_over_algorithmic"))
+for k in ("streaming","streaming_64_lanes","streaming_32_lanes"): print(k, {kk:(b.get(k) or {}).get(kk) for kk in ("value","ttfa_ms_first_wave_p50","ttfa_ms_first_wave_max","error")})
+print("lanes", {k:b.get(k) for k in ("lanes_16","lanes_32","lanes_64")})
+print("config3", (d.get("config3_sharded_batched") or {}).get("value"))
+m=d.get("model_1p7b",{}); print("1p7b", {k:m.get(k) for k in ("rtf","ttfa_ms_p50","decode_ms_per_frame","error")}, {k:(m.get(k) or {}).get("ms_per_lockstep_frame") for k in ("batched_b32","batched_b64","batched_b128")}, "config4", {k:(m.get("config4_voice_design_4k") or {}).get(k) for k in ("rtf","ttfa_ms_p50")})
+print("mfma", d.get("roofline_mfma"))
+print("cpu", d.get("cpu_baseline"))
+PY

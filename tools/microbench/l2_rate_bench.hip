@@ -5,6 +5,7 @@
 //   pattern 1  token rows      one instruction = 4 rows x 256 B, row stride 2 KB                   (skinny_gemm_kernel's token units)
 //   pattern 2  operand rows    one instruction = 16 rows x 64 B, row stride 2 KB (K = 1024)        (skinny_gemm_kernel's weight fragments)
 //   pattern 3  operand rows, row stride 6 KB (K = 3072)
+//   pattern 4  8 rows x 128 B (whole cache lines; a K step of 64)      pattern 5  16 rows x 64 B, both halves of a line by the same wave back to back
 //   source  0  shared: every workgroup reads the SAME region (tokens: L2 hits after the first touch per XCD)
 //           1  private: every workgroup its own region of a buffer much larger than the caches, rotating (weights: HBM)
 // Prints GB/s per CU and TB/s aggregate.   usage: l2_rate_bench [KB per workgroup = 128] [NL = 8] [reps = 50]
@@ -30,7 +31,12 @@ __global__ __launch_bounds__(512) void pull_kernel(const unsigned char* base, si
             if (PAT == 0) off = (size_t)q * 1024 + lane * 16;
             else if (PAT == 1) off = (size_t)(q >> 3) * (4 * 2048) + (size_t)(lane >> 4) * 2048 + (q & 7) * 256 + (lane & 15) * 16;     // 4 rows x 256 B
             else if (PAT == 2) off = (size_t)(q >> 5) * (16 * 2048) + (size_t)(lane & 15) * 2048 + (q & 31) * 64 + (lane >> 4) * 16;  // 16 rows x 64 B
-            else off = (size_t)(q / 96) * (16 * 6144) + (size_t)(lane & 15) * 6144 + (q % 96) * 64 + (lane >> 4) * 16;
+            else if (PAT == 3) off = (size_t)(q / 96) * (16 * 6144) + (size_t)(lane & 15) * 6144 + (q % 96) * 64 + (lane >> 4) * 16;
+            else if (PAT == 4) off = (size_t)(q >> 4) * (8 * 2048) + (size_t)(lane >> 3) * 2048 + (q & 15) * 128 + (lane & 7) * 16;   // 8 rows x 128 B (whole lines)
+            else {  // PAT 5: 16 rows x 64 B, the SAME wave takes both halves of a line in consecutive instructions
+                const int pr = r * NL + i, qq = (pr >> 1) * 8 + wave;                     // the pair's index; i even / odd = first / second half
+                off = (size_t)(qq >> 4) * (16 * 2048) + (size_t)(lane & 15) * 2048 + (qq & 15) * 128 + (pr & 1) * 64 + (lane >> 4) * 16;
+            }
             v[i] = *reinterpret_cast<const u32x4*>(p + off);
         }
 #pragma unroll
@@ -78,6 +84,8 @@ int main(int argc, char** argv) {
         run<1, 8>("token rows", src, kb, reps, buf, buf_bytes, sink, st);
         run<2, 8>("operand rows 2K", src, kb, reps, buf, buf_bytes, sink, st);
         run<3, 8>("operand rows 6K", src, kb, reps, buf, buf_bytes, sink, st);
+        run<4, 8>("8 rows x 128 B", src, kb, reps, buf, buf_bytes, sink, st);
+        run<5, 8>("16 x 64 B paired", src, kb, reps, buf, buf_bytes, sink, st);
         run<0, 16>("contiguous", src, kb, reps, buf, buf_bytes, sink, st);
         run<1, 16>("token rows", src, kb, reps, buf, buf_bytes, sink, st);
         run<2, 16>("operand rows 2K", src, kb, reps, buf, buf_bytes, sink, st);
