@@ -47,6 +47,9 @@ struct GemmArgs {
     // reads A + g * a_seg, writes Y / Y2 + g * y_seg, residual res + g * r_seg (strides in ELEMENTS of the respective tensor);
     // rows, taps and zero padding are local to a segment, so utterance g never sees utterance g - 1's rows
     int n_seg; long a_seg, y_seg, r_seg;
+    int glds_min_wgs;                                 // 0 = default: the LDS-DMA 128 x 64 tile from this many workgroups on (measurement hook of gemm_bench)
+    int big_pair;                                     // 256-wide ring tiles: 0 = whole cache lines per row (two K steps per copy group: PAIR, round 6) where Cin % 64 == 0,
+                                                      // -1 = the half-line ring of four K steps (measurement switch)
     const void* Wp;                                   // fragment-major copy of W for the weight-stationary kernel (skinny_gemm.cuh), or null
     int no_skinny;                                    // measurement switch: 1 = keep the tiled / split-K kernels where skinny_gemm.cuh would serve
     int epi_legacy;                                   // measurement switch: 1 = the register-layout epilogue (32-byte runs per row) instead of the
@@ -724,9 +727,21 @@ inline void glds_go(const GemmArgs& a, hipStream_t s) {
 // the workgroups of one XCD (every 8th id) cover a compact range of tiles (shared A / W panels stay in that XCD's L2).
 // Per output element the same ascending chain of 32-wide MFMA products as conv_gemm_kernel: bit-identical results.
 constexpr int kBigBM = 256, kBigBN = 256, kBigBK = 32, kBigStages = 4;
+// workgroups from which gemm_launch takes the LDS-DMA 128 x 64 tile (below: the register-prefetch tiles).  512 until round 5; measured in
+// round 6 (profiles/r06_gemm_shapes.txt): from ~150 workgroups on the LDS-DMA tile (whole 128-byte lines per row, K steps of 64) is never
+// slower than the 64 x 64 register-prefetch tile (half lines) and wins 8-10 % on the packed prefill's o_proj / down (M = 1200-2000, N = 1024)
+// and 25 % on the codec's dec.0 (M = 1480, N = 1536, K = 7168).  All tile families agree bit for bit.
+constexpr int kGldsMinWgs = 150;
 // Batched decode: the grid holds n_seg x (tiles of one segment) workgroups; the XCD-aware remap runs over ALL of them (so that the
 // tiles of one utterance that share A / W panels stay on one XCD), then tile / tiles_seg selects the segment.
-template <int ST, bool TR, int BN, typename TE = bf16_t>
+// PAIR (round 6): the operand copies move WHOLE 128-byte lines -- 8 lanes per row, two K steps (64 columns) per copy group -- into two
+// buffers of 64-column rows (the same LDS bytes as the ring of four 32-column stages).  A copy of 16 rows x 64 B (half lines) is served at
+// 40 GB/s per CU out of the L2, whole lines at 148 (tools/microbench/l2_rate_bench.hip, profiles/r06_l2_rate_by_pattern.txt): at 32 KB per
+// K step that is 0.8 us against 0.43 us of MFMA time for the 256 x 256 tile -- the ring was memory-bound at ~half the matrix-core peak.
+// Buffer d & 1 holds K steps 2 d and 2 d + 1; pair d + 1 is copied while pair d is multiplied (one barrier per pair).  LDS chunk c of row
+// r holds global chunk c ^ ((r >> 1) & 7) of the row's 128 B: the 16 rows of a fragment read cover all 64 banks.  Per output element the
+// MFMA products are issued in the same ascending order over the K steps: bit-identical to the ring of four (and to conv_gemm_kernel).
+template <int ST, bool TR, int BN, typename TE = bf16_t, bool PAIR = false>
 __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a_in, int tiles_x, int tiles_seg, int tiles_total) {
     typedef bf16_t T;
     static_assert(!TR || std::is_same<TE, bf16_t>::value, "the register-layout (TR) epilogue stores bf16");
@@ -757,15 +772,17 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a_in, int tiles_
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // copy slots: slot = p * 512 + tid -> row = slot >> 2, LDS chunk = slot & 3, source chunk = chunk ^ swz(row)
-    int arow[2], asrc[2];
-    const T* wsrc[NPB];
+    // (PAIR: row = slot >> 3, chunk = slot & 7 of the row's 128 bytes, swz(row) = (row >> 1) & 7; twice the slots per copy group)
+    constexpr int NPA = PAIR ? 4 : 2, NPW = PAIR ? 2 * NPB : NPB;
+    int arow[NPA], asrc[NPA];
+    const T* wsrc[NPW];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int slot = p * 512 + tid, r = slot >> 2, c = slot & 3;
-        const int sc = (c ^ ((0 - (r >> 2)) & 3)) * 8;
+    for (int p = 0; p < NPA; ++p) {
+        const int slot = p * 512 + tid, r = PAIR ? slot >> 3 : slot >> 2, c = PAIR ? slot & 7 : slot & 3;
+        const int sc = PAIR ? (c ^ ((r >> 1) & 7)) * 8 : (c ^ ((0 - (r >> 2)) & 3)) * 8;
         arow[p] = m0 + r;
         asrc[p] = sc;
-        if (p < NPB) {
+        if (p < NPW) {
             int n = n0 + r;
             n = n < a.N ? n : a.N - 1;
             wsrc[p] = W + (size_t)n * K + sc;
@@ -773,21 +790,67 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a_in, int tiles_
     }
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    // (PAIR: `step` counts copy groups of 64 columns, a buffer holds BM x 64 | BN x 64 elements; a group never straddles a tap: Cin % 64 == 0)
+    constexpr int GK = PAIR ? 2 * BK : BK;                       // columns per copy group
     auto issue = [&](int step, int buf) {
-        const int k0 = step * BK;
+        const int k0 = step * GK;
         const int tap = k0 / a.Cin, ci = k0 - tap * a.Cin;
         const int toff = a_in.tap_off[tap];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < NPA; ++p) {
             const int ar = arow[p] + toff;
             const bool ok = arow[p] < a.M && ar >= 0 && ar < a.a_rows;
             const T* src = ok ? A + (size_t)ar * a.lda + ci + asrc[p] : zero;
-            __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(As + buf * BM * BK + (p * 512 + wave * 64) * 8), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(As + buf * BM * GK + (p * 512 + wave * 64) * 8), 16, 0, 0);
         }
 #pragma unroll
-        for (int p = 0; p < NPB; ++p)
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(wsrc[p] + k0), (lds_ptr)(Bs + buf * BN * BK + (p * 512 + wave * 64) * 8), 16, 0, 0);
+        for (int p = 0; p < NPW; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(wsrc[p] + k0), (lds_ptr)(Bs + buf * BN * GK + (p * 512 + wave * 64) * 8), 16, 0, 0);
     };
+    if constexpr (PAIR) {
+        // ---- two buffers of 64-column rows: pair d = K steps 2 d, 2 d + 1 ----
+        const int npairs = nsteps >> 1;                              // (K % 64 == 0: the host's condition for this form)
+        const int swz8 = (fr >> 1) & 7;
+        const int a_off8 = (wr * 128 + fr) * GK, b_off8 = (wc * WN + fr) * GK;
+        bf16x8_t fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        auto load_frags8 = [&](bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN], int buf, int sub) {
+            const int ch = ((sub * 4 + fq) ^ swz8) * 8;
+            const T* as = As + buf * BM * GK + a_off8 + ch;
+            const T* bs = Bs + buf * BN * GK + b_off8 + ch;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(bs + j * 16 * GK);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(as + i * 16 * GK);
+        };
+        auto mfmas = [&](bf16x8_t (&ca)[TM], bf16x8_t (&cb)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[j], ca[i], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+        };
+        issue(0, 0);
+        for (int d = 0; d < npairs; ++d) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): my copies of pair d (nothing else is in flight)
+            __builtin_amdgcn_s_barrier();                            // pair d is published; everybody is done reading pair d - 1's buffer
+            issue(d + 1 < npairs ? d + 1 : npairs - 1, (d + 1) & 1); // (past the end: a redundant re-copy into the free buffer, never read)
+            load_frags8(fa0, fb0, d & 1, 0);
+            load_frags8(fa1, fb1, d & 1, 1);                         // the second step's fragments are read under the first step's MFMAs
+            mfmas(fa0, fb0);
+            mfmas(fa1, fb1);
+            constexpr int PER = (TM * TN) / (TM + TN);
+            __builtin_amdgcn_sched_group_barrier(0x020, NPA + NPW, 0);               // the copies first
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);                 // the first step's fragment reads
+#pragma unroll
+            for (int k = 0; k < TM + TN; ++k) {                                      // the second step's reads between the first step's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN - PER * (TM + TN), 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);                          // the tail's redundant copy must not outlive the workgroup's LDS
+    } else {
 #pragma unroll
     for (int d = 0; d < ST - 1; ++d) issue(d < nsteps ? d : nsteps - 1, d);          // a short K re-copies its last step (never read)
     const int swz = ((0 - (fr >> 2)) & 3);
@@ -839,6 +902,7 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a_in, int tiles_
         if (s + 1 < nsteps) body(fa1, fb1, fa0, fb0, s + 1);
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);                  // the tail's redundant copies must not outlive the workgroup's LDS
+    }
     if constexpr (TR) {
     // Variant TR (wide, PLAIN outputs only -- bias at most; the prefill's qkv / gate_up / o / down: gemm_launch never sends anything
     // else here): the MFMAs ran with swapped operands, so each accumulator tile is the TRANSPOSE of the usual layout: a lane holds 4
@@ -953,6 +1017,14 @@ inline void big_go_t(const GemmArgs& a, hipStream_t s) {
     const int rows = a.M - a.m_lo, nseg = a.n_seg > 1 ? a.n_seg : 1;
     const int tx = (a.N + BN - 1) / BN, ty = (rows + kBigBM - 1) / kBigBM;
     const size_t shm = (size_t)kBigStages * (kBigBM + BN) * kBigBK * 2;
+    // whole-line copies (PAIR) wherever a group of 64 columns stays inside one tap; the half-line ring of four otherwise (Cin = 96, 160, ...)
+    if (a.big_pair >= 0 && a.Cin % 64 == 0) {
+        static bool attr_p = false;
+        auto kern = big_gemm_kernel<kBigStages, TR, BN, TE, true>;
+        if (!attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_p = true; }
+        hipLaunchKernelGGL(kern, dim3(tx * ty * nseg), dim3(512), shm, s, a, tx, tx * ty, tx * ty * nseg);
+        return;
+    }
     static bool attr = false;
     auto kern = big_gemm_kernel<kBigStages, TR, BN, TE>;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = true; }
@@ -1065,7 +1137,7 @@ inline void gemm_launch_te(const GemmArgs& a, hipStream_t s) {
                 return;
             }
         }
-        if (a.N % 64 == 0 && a.Cin % 64 == 0 && wgs(128, 64) >= 512) {
+        if (a.N % 64 == 0 && a.Cin % 64 == 0 && wgs(128, 64) >= (a.glds_min_wgs > 0 ? a.glds_min_wgs : kGldsMinWgs)) {
             glds_go<64, 2, TE>(a, s);
         } else if (n64 && wgs(128, 64) >= 512) gemm_go<T, 128, 64, TE>(a, s);
         else if (a.act != 2 && !n64 && a.N % 96 == 0 && wgs(128, 96) >= 256) gemm_go<T, 128, 96, TE>(a, s);      // N = 96 / 288 (codec block 4): 3x fewer reads of the A tile than 32-wide tiles

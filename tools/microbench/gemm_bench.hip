@@ -24,6 +24,14 @@ int main(int argc, char** argv) {
         {"prefill4k gate_up", 4096, 12288, 2048, 1, 1},
         {"prefill4k down", 4096, 2048, 6144, 1, 1},
         {"prefill4k o_proj", 4096, 2048, 2048, 1, 1},
+        {"packed10 qkv (0.6B)", 2000, 4096, 1024, 1, 1},
+        {"packed10 gate_up", 2000, 6144, 1024, 1, 1},
+        {"packed10 o_proj", 2000, 1024, 2048, 1, 1},
+        {"packed10 down", 2000, 1024, 3072, 1, 1},
+        {"packed6 o_proj", 1200, 1024, 2048, 1, 1},
+        {"packed6 down", 1200, 1024, 3072, 1, 1},
+        {"packed10 o_proj (1.7B)", 2000, 2048, 2048, 1, 1},
+        {"packed10 down (1.7B)", 2000, 2048, 6144, 1, 1},
         {"prefill200 qkv (0.6B)", 200, 4096, 1024, 1, 1},
         {"prefill200 gate_up", 200, 6144, 1024, 1, 1},
         {"prefill200 down", 200, 1024, 3072, 1, 1},
@@ -264,12 +272,28 @@ int main(int argc, char** argv) {
                 printf("big 256x128 vs glds 128x64 on random operands: %zu / %zu elements differ%s\n", bad2, y1.size(), bad2 ? "  <-- MISMATCH" : " (bit-identical)");
             }
             (void)hipFree(Y2);
-            rung("big 256x128 ring-4 (random)", big_go_t<true, 128>);
-            rung("big 256x256 ring-4 (random)", big_go<bf16_t>);
+            rung("big 256x128 whole lines (random)", big_go_t<true, 128>);
+            rung("big 256x256 whole lines (random)", big_go<bf16_t>);
+            a.big_pair = -1;
+            rung("big 256x128 ring-4 half lines (random)", big_go_t<true, 128>);
+            rung("big 256x256 ring-4 half lines (random)", big_go<bf16_t>);
+            {   // the two copy forms of the big tile against each other
+                GemmArgs c2 = a; void* Y3; (void)hipMalloc(&Y3, (size_t)M * N * 2); c2.Y = Y3;
+                big_go(c2, s); c2.big_pair = 0; c2.Y = Y; big_go(c2, s); (void)hipStreamSynchronize(s);
+                std::vector<uint16_t> q1((size_t)M * N), q2((size_t)M * N);
+                (void)hipMemcpy(q1.data(), Y, q1.size() * 2, hipMemcpyDeviceToHost); (void)hipMemcpy(q2.data(), Y3, q2.size() * 2, hipMemcpyDeviceToHost);
+                size_t bd = 0; for (size_t i = 0; i < q1.size(); ++i) bd += q1[i] != q2[i];
+                printf("big 256x256 whole lines vs half lines: %zu elements differ%s\n", bd, bd ? "  <-- MISMATCH" : " (bit-identical)");
+                (void)hipFree(Y3);
+            }
+            a.big_pair = 0;
             rung("glds 128x64 2 st (random)", glds_go<64, 2>);
             (void)hipMemset(A, 0x3c, (size_t)M * K * 2); (void)hipMemset(W, 0x3c, (size_t)N * K * 2);
         }
-        rung("big 256x256 ring-4", big_go<bf16_t>);
+        rung("big 256x256 whole lines", big_go<bf16_t>);
+        a.big_pair = -1;
+        rung("big 256x256 ring-4 half lines", big_go<bf16_t>);
+        a.big_pair = 0;
         rung("glds 128x64 2 stages", glds_go<64, 2>);
         rung("glds 128x64 3 stages", glds_go<64, 3>);
         rung("glds 128x128 2 stages", glds_go<128, 2>);
@@ -300,6 +324,18 @@ int main(int argc, char** argv) {
         a.bias_mod = sh.N; a.Y = Y; a.ldy = sh.N;
         void* ws = nullptr;
         if (sh.ws) { (void)hipMalloc(&ws, (size_t)(8 << 20) * 4); a.ws = (float*)ws; a.ws_floats = 8 << 20; }
+        // the half-line ring of four first (where the big tile is chosen at all), its output kept for the comparison
+        float ms_half = 0; std::vector<uint16_t> hy_half(ny);
+        {
+            GemmArgs h = a; h.big_pair = -1;
+            gemm_launch<bf16_t>(h, s); (void)hipStreamSynchronize(s);
+            (void)hipEventRecord(e0, s);
+            for (int r = 0; r < reps; ++r) gemm_launch<bf16_t>(h, s);
+            (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+            (void)hipEventElapsedTime(&ms_half, e0, e1); ms_half /= reps;
+            (void)hipMemcpy(hy_half.data(), Y, ny * 2, hipMemcpyDeviceToHost);
+            (void)hipMemset(Y, 0, ny * 2);
+        }
         gemm_launch<bf16_t>(a, s);
         (void)hipStreamSynchronize(s);
         (void)hipEventRecord(e0, s);
@@ -324,8 +360,22 @@ int main(int argc, char** argv) {
             if (err > maxerr) maxerr = err;
         }
         const double fl = 2.0 * sh.M * sh.N * K;
-        printf("%-24s M=%7d N=%5d K=%5zu  %9.3f us  %8.1f TFLOP/s  check %.2e %s\n", sh.name, sh.M, sh.N, K, ms * 1e3, fl / (ms * 1e-3) / 1e12,
-               maxerr, maxerr < 2e-2 ? "ok" : "MISMATCH");
+        float ms_g = 0; size_t ndg = 0;
+        {   // the LDS-DMA 128 x 64 tile already from 100 workgroups on (default: 512)
+            GemmArgs h = a; h.glds_min_wgs = 100;
+            (void)hipMemset(Y, 0, ny * 2);
+            gemm_launch<bf16_t>(h, s); (void)hipStreamSynchronize(s);
+            (void)hipEventRecord(e0, s);
+            for (int r = 0; r < reps; ++r) gemm_launch<bf16_t>(h, s);
+            (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+            (void)hipEventElapsedTime(&ms_g, e0, e1); ms_g /= reps;
+            std::vector<uint16_t> hg(ny); (void)hipMemcpy(hg.data(), Y, ny * 2, hipMemcpyDeviceToHost);
+            if (!sh.ws) for (size_t i = 0; i < ny; ++i) ndg += hy[i] != hg[i];
+        }
+        size_t nd = 0; for (size_t i = 0; i < ny; ++i) nd += hy[i] != hy_half[i];
+        printf("%-24s M=%7d N=%5d K=%5zu  %9.3f us  %8.1f TFLOP/s  check %.2e %s | big tile on half lines: %9.3f us (%+.1f %%), outputs %s\n", sh.name, sh.M, sh.N, K, ms * 1e3,
+               fl / (ms * 1e-3) / 1e12, maxerr, maxerr < 2e-2 ? "ok" : "MISMATCH", ms_half * 1e3, 100.0 * (ms_half - ms) / ms_half, nd ? "DIFFER <-- MISMATCH" : "bit-identical");
+        printf("%-24s    glds tile from 100 workgroups: %9.3f us (%+.1f %%), outputs %s\n", "", ms_g * 1e3, 100.0 * (ms - ms_g) / ms, ndg ? "DIFFER" : "bit-identical");
         (void)hipFree(A); (void)hipFree(W); (void)hipFree(Y); if (ws) (void)hipFree(ws);
     }
     return 0;

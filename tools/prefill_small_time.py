@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times the 200-token prefill with the resident-tile attention kernel on / off (`fq3_set_option("flash_small", v)`; bit-identical
 outputs) and a PACKED prefill of 10 such prompts over one KV pool (the staged admission of the batch scheduler: `fq3_prefill_batch`).
-usage: prefill_small_time.py [0p6b|1p7b]      (development aid; bench.py is the contract)"""
+usage: prefill_small_time.py [0p6b|1p7b] [prompts per packed prefill = 10]      (development aid; bench.py is the contract)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -37,9 +37,11 @@ def main():
         outs[v] = (lg.float().clone(), hd.float().clone())
         print(f"{size} prefill of {x.shape[0]} tokens, flash_small={v}: {ms:.3f} ms", flush=True)
     print("identical logits / hidden:", bool(torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])))
-    n = 10
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 10          # prompts per packed prefill (the scheduler's first wave stages slices of 16)
     pool = Fq3KvPool(eng.cfg, n * 5, device=dev, dtype=eng.dtype)
-    engs = [Fq3Engine(eng.cfg, eng.weights, device=dev, dtype=eng.dtype, max_seq_len=eng.max_seq_len, max_frames=8, share=eng, pool=pool) for _ in range(n)]
+    # (the packed rows of all prompts go through the FIRST context's prefill workspaces: sized by its max_seq_len)
+    msl = max(int(eng.max_seq_len), n * int(x.shape[0]) + 8)
+    engs = [Fq3Engine(eng.cfg, eng.weights, device=dev, dtype=eng.dtype, max_seq_len=msl, max_frames=8, share=eng, pool=pool) for _ in range(n)]
     engs[0].prefill_reserve()
     xs = [x] * n
     for v in (0, 1, 0, 1):
