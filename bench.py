@@ -250,6 +250,32 @@ def measure_mfma(cfg, model, prompt):
     out["prefill_200"] = {"tokens": int(x.shape[0]), "ms": round(ms, 3), "gemm_tflop": round(fl / 1e12, 3),
                           "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "bound": "mfma"}
+    # the PACKED prefill of the batch scheduler's staged admission (fq3_prefill_batch: the rows of several prompts through one pass over
+    # the weights; a pack holds as many prompts as fit the leading context's max_seq_len rows -- 10 x 200 at 2048)
+    try:
+        from fq3hip.engine import Fq3Engine, Fq3KvPool
+        n = max(1, min(10, int(eng.max_seq_len) // int(x.shape[0])))
+        device = eng.device
+        pool = Fq3KvPool(eng.cfg, n * 5, device=device, dtype=eng.dtype)
+        engs = [Fq3Engine(eng.cfg, eng.weights, device=device, dtype=eng.dtype, max_seq_len=eng.max_seq_len, max_frames=8, share=eng, pool=pool)
+                for _ in range(n)]
+        engs[0].prefill_reserve()
+        xs = [x] * n
+        for _ in range(3):
+            Fq3Engine.prefill_batch(engs, xs)
+        torch.cuda.synchronize(device)
+        e0.record()
+        for _ in range(10):
+            Fq3Engine.prefill_batch(engs, xs)
+        e1.record(); torch.cuda.synchronize(device)
+        msp = e0.elapsed_time(e1) / 10
+        out[f"packed_prefill_{n}x{int(x.shape[0])}"] = {"prompts": n, "tokens_each": int(x.shape[0]), "ms": round(msp, 3), "ms_per_prompt": round(msp / n, 3),
+                                                         "gemm_tflop": round(n * fl / 1e12, 3), "achieved": round(n * fl / (msp * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                                         "unit": "TFLOP/s", "frac": round(n * fl / (msp * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "bound": "mfma"}
+        for e in engs:
+            e.close()
+    except Exception as exc:                  # a measurement row, never a reason to lose the line
+        out["packed_prefill"] = {"error": repr(exc)}
     return out
 
 

@@ -107,7 +107,9 @@ def figures_table(ev, src):
             f"| MFMA rooflines (`roofline_mfma`) | codec 370 frames {fig((rm.get('codec_full_decode') or {}).get('ms'), 2)} ms = {fig((rm.get('codec_full_decode') or {}).get('achieved'), 0)} TFLOP/s "
             f"({fig(100 * ((rm.get('codec_full_decode') or {}).get('frac') or 0), 1)} %); prefill-200 {fig((rm.get('prefill_200') or {}).get('ms'), 3)} ms = "
             f"{fig((rm.get('prefill_200') or {}).get('achieved'), 0)} TFLOP/s ({fig(100 * ((rm.get('prefill_200') or {}).get('frac') or 0), 1)} %); prefill-4096 "
-            f"{fig((m.get('prefill_4096') or {}).get('ms'), 2)} ms = {fig((m.get('prefill_4096') or {}).get('achieved'), 0)} TFLOP/s ({fig(100 * ((m.get('prefill_4096') or {}).get('frac') or 0), 1)} %) |",
+            f"{fig((m.get('prefill_4096') or {}).get('ms'), 2)} ms = {fig((m.get('prefill_4096') or {}).get('achieved'), 0)} TFLOP/s ({fig(100 * ((m.get('prefill_4096') or {}).get('frac') or 0), 1)} %)"
+            + "".join(f"; {k.replace('_', ' ')} {fig(v.get('ms'), 2)} ms = {fig(v.get('ms_per_prompt'), 3)} ms per prompt ({fig(100 * (v.get('frac') or 0), 1)} %)"
+                      for k, v in sorted(rm.items()) if k.startswith('packed_prefill_') and isinstance(v, dict) and 'ms' in v) + " |",
             f"| `parity_bf16_frames` | {pf.get('matched_decisions')} / {pf.get('decisions')} decisions, {pf.get('matched_frames')} / {pf.get('frames')} whole frames, worst "
             f"{fig(pf.get('worst_mismatch_margin_bf16_ulp'), 0)} ulps, unexplained {pf.get('unexplained')} |",
             f"| `parity_pcm` (vs the fp32-arithmetic oracle) | bf16x2 {fig((pp.get('bf16x2') or {}).get('pcm_rms_vs_fp32_oracle'), 7)}; bf16 {fig((pp.get('bf16') or {}).get('pcm_rms_vs_fp32_oracle'), 5)}; "
