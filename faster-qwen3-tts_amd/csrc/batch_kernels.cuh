@@ -380,6 +380,10 @@ struct BatchGemvArgs {
     // squares of every row it stores as N / 16 partials per row in `ssq_out`; the normalising GEMV that reads those rows next takes them as
     // `ssq_in` (null: the rows came from elsewhere -- layer 0 -- and are normalised by rmsnorm_batch_kernel as before)
     float* ssq_out; const float* ssq_in;
+    // fragment-major copy of W in 16-row blocks (skinny_gemm.cuh: SkinnyArgs::Wp, kind 0), or null: the matrix-core GEMVs' A-operand
+    // loads then read contiguous kilobytes instead of 16 rows x 64 B (round 6; every byte comes from HBM here, where half lines cost
+    // 15-30 %, tools/microbench/l2_rate_bench.hip).  Needs N % 16 == 0 (and up_off % 16 == 0).  Same values, same registers: bit-identical.
+    const void* Wp;
 };
 
 // One row per wave (4 rows per workgroup), weight rows loaded ONCE; the B <= kMaxLanes tokens pass through LDS in groups of
@@ -676,11 +680,16 @@ __global__ __launch_bounds__(256) void gemv_batch_mfma_norm_kernel(BatchGemvArgs
     // ---- 2. this wave's K quarter of the 16 (x NR) weight rows, in A-operand layout: loaded ONCE, kept for every token tile ----
     Raw8<T> wreg[NR][KSTEPS];
     const int rowc = row0 + fr < a.N ? row0 + fr : a.N - 1;
+    const T* Wp = reinterpret_cast<const T*>(a.Wp);
 #pragma unroll
-    for (int h = 0; h < NR; ++h)
+    for (int h = 0; h < NR; ++h) {
+        // row-major: row rowc (+ the up half), this wave's K quarter; fragment-major: block row0 / 16 (+ up_off / 16), K steps wave * KSTEPS + s
+        const T* wp = Wp ? Wp + ((size_t)(blockIdx.x + h * (a.up_off >> 4)) * (K / 32) + wave * KSTEPS) * 512 + lane * 8
+                         : W + (size_t)(rowc + h * a.up_off) * K + wave * (K / 4) + fq * 8;
+        const int st_s = Wp ? 512 : 32;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
-            ldraw<false>(wreg[h][s], W + (size_t)(rowc + h * a.up_off) * K + wave * (K / 4) + s * 32 + fq * 8);
+        for (int s = 0; s < KSTEPS; ++s) ldraw<false>(wreg[h][s], wp + s * st_s);
+    }
     // epilogue operands of wave 0: token = fr, rows row0 + fq * 4 + i
     float biasv[4];
 #pragma unroll
@@ -920,9 +929,12 @@ __global__ __launch_bounds__(64 * NW) void gemv_batch_mfma_plain_kernel(BatchGem
     if constexpr (PRE2) issue_tokens(1, kTokTile, B - kTokTile, 0);
     __builtin_amdgcn_sched_barrier(0);
     const int rowc = row0 + fr < a.N ? row0 + fr : a.N - 1;
-    const T* wp = W + (size_t)rowc * K + wave * (K / NW) + fq * 8;
+    const T* Wpk = reinterpret_cast<const T*>(a.Wp);
+    const T* wp = Wpk ? Wpk + ((size_t)blockIdx.x * (K / 32) + wave * KSTEPS) * 512 + lane * 8        // fragment-major: block row0 / 16, K steps wave * KSTEPS + s
+                      : W + (size_t)rowc * K + wave * (K / NW) + fq * 8;
+    const int st_s = Wpk ? 512 : 32;
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) ldraw<false>(wreg[s], wp + s * 32);
+    for (int s = 0; s < KSTEPS; ++s) ldraw<false>(wreg[s], wp + s * st_s);
     // epilogue operands (bias, residual): issued up front so that they fly with the weights -- except in the longest variant
     // (K = 6144: 48 operand registers per K step pair already fill the 256-VGPR budget), where wave 0 fetches them at the end
     constexpr bool kHoist = KSTEPS <= 16;

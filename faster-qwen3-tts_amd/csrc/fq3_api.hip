@@ -327,7 +327,8 @@ static int packed_acquire_all(fq3_ctx* c) {
         for (const fq3_layer_weights& l : L) {
             if (int r = take(l.qkv, qd + 2 * kvd, d.hidden, 0)) return r;
             if (int r = take(l.o, d.hidden, qd, 0)) return r;
-            if (int r = take(l.gate_up, 2 * d.inter, d.hidden, 1)) return r;
+            if (int r = take(l.gate_up, 2 * d.inter, d.hidden, 1)) return r;       // the 8 + 8 pairing of the weight-stationary SwiGLU GEMM (> 32 lanes, prefill)
+            if (int r = take(l.gate_up, 2 * d.inter, d.hidden, 0)) return r;       // 16-row blocks for the panel kernels of <= 32 lanes
             if (int r = take(l.down, d.hidden, d.inter, 0)) return r;
         }
         return FQ3_OK;

@@ -366,8 +366,9 @@ static thread_local int g_batch_norm_skinny = 1; // set per enqueue from fq3_bat
 static thread_local int g_batch_norm_skinny_above = 2 * kTokTile;
 static thread_local int g_batch_packed = 1;      // set per enqueue from fq3_batch::packed (fragment-major weight copies, fq3_ctx.h)
 template <int EPI>
-static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
-    if (a.K % 128) return -1000;
+static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a0, hipStream_t s) {
+    if (a0.K % 128) return -1000;
+    BatchGemvArgs a = a0;                                          // (a copy: the panel path below adds the fragment-major weight pointer)
     // above 32 lanes (three token tiles and more): normalise once, then the weight-stationary GEMM (batch_kernels.cuh::rmsnorm_batch_kernel)
     const int n_w = EPI == EPI_SWIGLU ? 2 * a.N : a.N;                  // weight rows: [gate | up] for SwiGLU
     if (g_batch_norm_skinny && a.xn_ws && a.B > g_batch_norm_skinny_above && !a.bias && skinny_k_ok(a.K) && a.K <= 2048 && n_w % 32 == 0 &&
@@ -399,6 +400,8 @@ static int launch_gemv_batch_mfma_norm(const BatchGemvArgs& a, hipStream_t s) {
     constexpr int NR = EPI == EPI_SWIGLU ? 2 : 1;
     const size_t shm = (((size_t)kTokTile * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * NR * 256 * sizeof(float);
     const int nt = (a.B + kTokTile - 1) / kTokTile;            // token tiles: 1..4
+    // the panel kernels' weight fragments from the fragment-major copy in 16-row blocks (kind 0), where the shape has whole blocks
+    a.Wp = (g_batch_packed && a.N % 16 == 0 && (EPI != EPI_SWIGLU || a.up_off % 16 == 0)) ? fq3_packed_find_(a.W, 0) : nullptr;
     auto go = [&](auto ks) -> int {
         constexpr int KS = decltype(ks)::value;
         if constexpr (KS <= 8) {
@@ -463,6 +466,7 @@ static int launch_gemv_batch_mfma_plain(const BatchGemvArgs& a, hipStream_t s) {
     auto go = [&](auto ks, auto nw) -> int {
         constexpr int KS = decltype(ks)::value, NW = decltype(nw)::value;
         BatchGemvArgs an = a;
+        an.Wp = (g_batch_packed && a.N % 16 == 0) ? fq3_packed_find_(a.W, 0) : nullptr;      // fragment-major copy in 16-row blocks, where there is one
         an.ntiles = (a.B + kTokTile - 1) / kTokTile;         // token tiles
         switch (an.ntiles) {
             case 1: hipLaunchKernelGGL((gemv_batch_mfma_plain_kernel<KS, NW, EPI, 1>), dim3(grid), dim3(64 * NW), 0, s, an); break;
