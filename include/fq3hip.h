@@ -140,8 +140,8 @@ int fq3_set_option(fq3_ctx* ctx, const char* key, int value);
  * Round 6: for a bf16 context the call also takes a reference on a FRAGMENT-MAJOR copy of every layer matrix and head whose shape the
  * weight-stationary GEMM serves (K in {1024, 2048, 3072, 6144}, whole 16-row blocks): [row block][K / 32][64 lanes][8] -- the kilobyte one
  * wave's matrix-core operand load reads is contiguous (from the row-major matrix it is 16 rows x 64 B: 40 GB/s per CU against 125-135
- * out of the L2).  The first context of a weight replica builds the copies (+ one replica's layer matrices of HBM: 1.0 GB at 0.6B,
- * 2.8 GB at 1.7B), the others share them; fq3_ctx_destroy / a re-bind returns the references.  The table's matrices must not change
+ * out of the L2).  The first context of a weight replica builds the copies (+ one replica's layer matrices of HBM, gate | up in two blockings: 1.5 GB
+ * at 0.6B, 3.9 GB at 1.7B), the others share them; fq3_ctx_destroy / a re-bind returns the references.  The table's matrices must not change
  * while bound (re-bind after an in-place update). */
 int fq3_bind_weights(fq3_ctx* ctx, const fq3_weight_table* table);
 
