@@ -52,9 +52,30 @@ struct GemmArgs {
                                                       // -1 = the half-line ring of four K steps (measurement switch)
     const void* Wp;                                   // fragment-major copy of W for the weight-stationary kernel (skinny_gemm.cuh), or null
     int no_skinny;                                    // measurement switch: 1 = keep the tiled / split-K kernels where skinny_gemm.cuh would serve
+    int glds_waves;                                   // 0 = the LDS-DMA tile by eight waves where the grid is at most ~one round of tiles (round 6), -1 = always four (measurement switch)
+    int xcd_map;                                      // 0 = XCD-aware tile order of the (N tiles x M tiles) grids (round 6), -1 = the plain blockIdx order (measurement switch)
     int epi_legacy;                                   // measurement switch: 1 = the register-layout epilogue (32-byte runs per row) instead of the
                                                       // LDS-parked one (whole tile rows per store instruction); 0 in the product
 };
+
+// XCD-aware tile order of a (gx = N tiles) x (gy = M tiles) grid (round 6).  The dispatcher deals workgroups to the 8 XCDs round robin
+// in linear order (x fastest), so with the plain order the N tiles of one M tile -- which read the same A rows -- sit on different
+// XCDs and every A line crosses the fabric once per XCD that asks: M = 2000, N = 1024, K = 2048 on 128 x 64 tiles moved 8 x 8 MB of A
+// through 4-MB L2s for 12 MB of operands, at the SAME 0.9 us per K step whatever the ring depth (profiles/r06_glds_depth.txt).  Here
+// XCD x takes a contiguous range of tile ids (bijective also when the count is not a multiple of 8) and ids walk PANELS of four M
+// tiles, M fastest: the ~32 workgroups an XCD runs at a time cover 4 M tiles x 8 N tiles -- every A line serves 8 CUs, every W line 4,
+// and the operands of the range fit the L2.  Pure relabelling of which workgroup computes which tile: results are unchanged.
+__device__ __forceinline__ void xcd_tile(int bx, int by, int gx, int gy, bool plain, int& tn, int& tm) {
+    if (plain) { tn = bx; tm = by; return; }
+    const int orig = bx + gx * by, total = gx * gy;
+    const int xcd = orig & 7, q = total >> 3, r8 = total & 7;
+    const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    constexpr int PH = 4;
+    const int p = id / (PH * gx), rem = id - p * (PH * gx);
+    const int left = gy - p * PH, h = left < PH ? left : PH;
+    tn = rem / h;
+    tm = p * PH + (rem - tn * h);
+}
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
@@ -436,7 +457,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a_in) {
     __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LD];          // operand stages; the epilogue parks the tile here
     const GemmArgs a = gemm_segment<T, TE>(a_in, a_in.n_seg > 1 ? (int)blockIdx.z : 0);      // (blockIdx.z is the K slice of a split-K launch: n_seg <= 1 there)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m0 = a.m_lo + blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int tile_n, tile_m;
+    xcd_tile((int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, a_in.xcd_map < 0, tile_n, tile_m);
+    const int m0 = a.m_lo + tile_m * BM, n0 = tile_n * BN;
     const int wr = wave >> 1, wc = wave & 1;
     f32x4_t acc[TM][TN];
     conv_gemm_mainloop<T, BM, BN, PF>(a, a_in, smem, acc, m0, n0);
@@ -613,19 +636,34 @@ inline bool resunit_launch(const GemmArgs& c1, const GemmArgs& c2, hipStream_t s
 // Requires Cin % 64 == 0 (a K step never straddles a tap).
 static __device__ u32x4 g_gemm_zero_page[8];      // 128 zero bytes (one copy per translation unit)
 
-template <int BN, int STAGES, typename TE = bf16_t>
-__global__ __launch_bounds__(256) void glds_gemm_kernel(GemmArgs a_in) {
-    static_assert(STAGES == 2 || STAGES == 3, "two or three LDS stages");
+// s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8)
+constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
+
+// NT = 512 (round 6): the same tile by EIGHT waves as 2 (M) x 4 (N), each a 64 x (BN / 4) block.  A wave takes delivery of ~3.6 B/clk out
+// of the L2 however many loads it keeps in flight and whichever way they travel (tools/microbench/dma_rate_bench.hip,
+// profiles/r06_dma_rate.txt: one workgroup of 4 / 8 / 16 waves per CU: 35 / 64 / 78 GB/s), so a grid that gives every CU ONE tile -- the
+// packed prefill's o_proj / down: M = 2000, N = 1024 -- moves its operands at the rate of four waves per CU and spends 0.9 us per K
+// step of 64 whatever the ring depth (profiles/r06_glds_depth.txt).  Eight waves share the same copies (half as many per thread); the
+// MFMA chain per output element is unchanged (bit-identical); only the LDS-parked epilogue is served (gemm_launch checks).
+template <int BN, int STAGES, typename TE = bf16_t, int NT = 256>
+__global__ __launch_bounds__(NT) void glds_gemm_kernel(GemmArgs a_in) {
+    static_assert(STAGES >= 2 && STAGES <= 6, "two to six LDS stages");
+    static_assert(NT == 256 || NT == 512, "four or eight waves");
     typedef bf16_t T;
     const GemmArgs a = gemm_segment<T, TE>(a_in, (int)blockIdx.z);
-    constexpr int BM = 128, BK = 64, TM = 4, TN = BN / 32, NPB = BN / 32;     // NPB: 16-byte copy slots per thread for the B tile
+    constexpr int WCOLS = NT == 256 ? 2 : 4;                                  // waves across the tile's columns (two wave rows of 64 rows each)
+    constexpr int BM = 128, BK = 64, TM = 4, TN = BN / (16 * WCOLS);
+    constexpr int NPA = BM * 8 / NT, NPB = BN * 8 / NT;                       // 16-byte copy slots per thread and stage: A tile, B tile
+    static_assert(TN >= 1 && NPB >= 1, "tile too narrow for the wave layout");
     extern __shared__ __attribute__((aligned(128))) unsigned char glds_smem[];
     T* As = reinterpret_cast<T*>(glds_smem);                                  // [STAGES][BM * BK]
     T* Bs = As + STAGES * BM * BK;                                            // [STAGES][BN * BK]
     const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = a.m_lo + blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int wr = wave >> 1, wc = wave & 1;
+    int tile_n, tile_m;
+    xcd_tile((int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, a_in.xcd_map < 0, tile_n, tile_m);
+    const int m0 = a.m_lo + tile_m * BM, n0 = tile_n * BN;
+    const int wr = NT == 256 ? wave >> 1 : wave >> 2, wc = NT == 256 ? wave & 1 : wave & 3;
     const int K = a.n_taps * a.Cin, nsteps = K / BK;
     const T* A = reinterpret_cast<const T*>(a.A);
     const T* W = reinterpret_cast<const T*>(a.W);
@@ -635,18 +673,18 @@ __global__ __launch_bounds__(256) void glds_gemm_kernel(GemmArgs a_in) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    // this thread's copy slots: slot = p * 256 + tid -> row = slot >> 3, LDS chunk = slot & 7, source chunk = chunk ^ swz(row)
-    int arow[4], asrc[4];
+    // this thread's copy slots: slot = p * NT + tid -> row = slot >> 3, LDS chunk = slot & 7, source chunk = chunk ^ swz(row)
+    int arow[NPA], asrc[NPA];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int slot = p * 256 + tid, r = slot >> 3, c = slot & 7;
+    for (int p = 0; p < NPA; ++p) {
+        const int slot = p * NT + tid, r = slot >> 3, c = slot & 7;
         arow[p] = m0 + r;
         asrc[p] = (c ^ ((r >> 1) & 7)) * 8;
     }
     const T* wsrc[NPB];
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {
-        const int slot = p * 256 + tid, r = slot >> 3, c = slot & 7;
+        const int slot = p * NT + tid, r = slot >> 3, c = slot & 7;
         int n = n0 + r;
         n = n < a.N ? n : a.N - 1;
         wsrc[p] = W + (size_t)n * K + (c ^ ((r >> 1) & 7)) * 8;
@@ -658,24 +696,30 @@ __global__ __launch_bounds__(256) void glds_gemm_kernel(GemmArgs a_in) {
         const int tap = k0 / a.Cin, ci = k0 - tap * a.Cin;
         const int toff = a_in.tap_off[tap];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NPA; ++p) {
             const int ar = arow[p] + toff;
             const bool ok = arow[p] < a.M && ar >= 0 && ar < a.a_rows;
             const T* src = ok ? A + (size_t)ar * a.lda + ci + asrc[p] : zero;
-            __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(As + buf * BM * BK + (p * 256 + wave * 64) * 8), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(As + buf * BM * BK + (p * NT + wave * 64) * 8), 16, 0, 0);
         }
 #pragma unroll
         for (int p = 0; p < NPB; ++p)
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(wsrc[p] + k0), (lds_ptr)(Bs + buf * BN * BK + (p * 256 + wave * 64) * 8), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(wsrc[p] + k0), (lds_ptr)(Bs + buf * BN * BK + (p * NT + wave * 64) * 8), 16, 0, 0);
     };
     issue(0, 0);
-    if (STAGES == 3 && nsteps > 1) issue(1, 1);
+#pragma unroll
+    for (int d = 1; d < STAGES - 1; ++d)
+        if (d < nsteps) issue(d, d);
     int buf = 0;
+    constexpr int CPS = NPA + NPB;                       // copies per thread and stage
     for (int s = 0; s < nsteps; ++s) {
-        // this wave's copies of stage s have landed (with three stages the copies of stage s + 1 may stay in flight)
-        if (STAGES == 3 && s + 1 < nsteps) {
-            if constexpr (BN == 64) __builtin_amdgcn_s_waitcnt(0x0f76); else __builtin_amdgcn_s_waitcnt(0x0f78);       // vmcnt(6) | vmcnt(8)
-        } else __builtin_amdgcn_s_waitcnt(0x0f70);                                                                    // vmcnt(0)
+        // this wave's copies of stage s have landed; the copies of the (up to STAGES - 2) stages behind it may stay in flight
+        const int rem = nsteps - 1 - s;
+        if (STAGES >= 6 && rem >= 4) __builtin_amdgcn_s_waitcnt(vmcnt_imm(4 * CPS));
+        else if (STAGES >= 5 && rem >= 3) __builtin_amdgcn_s_waitcnt(vmcnt_imm(3 * CPS));
+        else if (STAGES >= 4 && rem >= 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * CPS));
+        else if (STAGES >= 3 && rem >= 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(CPS));
+        else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
         __builtin_amdgcn_s_barrier();                    // ... and everybody's; everybody is also done reading the stage refilled next
         if (s + STAGES - 1 < nsteps) issue(s + STAGES - 1, (buf + STAGES - 1) % STAGES);       // flies under this step's MFMAs
         const T* as = As + buf * BM * BK;
@@ -690,7 +734,7 @@ __global__ __launch_bounds__(256) void glds_gemm_kernel(GemmArgs a_in) {
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int r = wc * (BN / 2) + j * 16 + fr;
+                const int r = wc * (BN / WCOLS) + j * 16 + fr;
                 bfr[j] = *reinterpret_cast<const bf16x8_t*>(bs + r * BK + (((ks * 4 + fq) ^ ((r >> 1) & 7)) * 8));
             }
 #pragma unroll
@@ -702,19 +746,21 @@ __global__ __launch_bounds__(256) void glds_gemm_kernel(GemmArgs a_in) {
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
     constexpr int kParkFloats = STAGES * (BM + BN) * BK * 2 / 4;
-    if (epi_can_park(a)) {
+    if (NT == 512 || epi_can_park(a)) {
         __syncthreads();                                 // everybody is done reading the last stage
-        gemm_epilogue_parked<TE, BM, BN, TM, TN, kParkFloats>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(glds_smem));
-    } else gemm_epilogue<TE, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
+        gemm_epilogue_parked<TE, BM, BN, TM, TN, kParkFloats, WCOLS, NT>(a, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(glds_smem));
+    } else {
+        if constexpr (NT == 256) gemm_epilogue<TE, BM, BN, TM, TN>(a, acc, m0, n0, wr, wc, lane);
+    }
 }
 
-template <int BN, int STAGES, typename TE = bf16_t>
+template <int BN, int STAGES, typename TE = bf16_t, int NT = 256>
 inline void glds_go(const GemmArgs& a, hipStream_t s) {
     const int rows = a.M - a.m_lo;
     const size_t shm = (size_t)STAGES * (128 + BN) * 64 * 2;
-    auto kern = glds_gemm_kernel<BN, STAGES, TE>;
+    auto kern = glds_gemm_kernel<BN, STAGES, TE, NT>;
     if (shm > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, (rows + 127) / 128, a.n_seg > 1 ? a.n_seg : 1), dim3(256), shm, s, a);
+    hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, (rows + 127) / 128, a.n_seg > 1 ? a.n_seg : 1), dim3(NT), shm, s, a);
 }
 
 // Largest-M variant (bf16): 256 x 256 tile, 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 block of 8 x 4 MFMA tiles
@@ -1138,7 +1184,14 @@ inline void gemm_launch_te(const GemmArgs& a, hipStream_t s) {
             }
         }
         if (a.N % 64 == 0 && a.Cin % 64 == 0 && wgs(128, 64) >= (a.glds_min_wgs > 0 ? a.glds_min_wgs : kGldsMinWgs)) {
-            glds_go<64, 2, TE>(a, s);
+            // at most ~one round of tiles: eight waves per tile (a wave takes delivery of ~3.6 B/clk, so a CU with one 4-wave tile starves:
+            // profiles/r06_dma_rate.txt); measured per shape in profiles/r06_glds_8waves.txt (-16 .. -27 %), bit-identical
+            const long t64 = wgs(128, 64), t128 = wgs(128, 128);
+            const bool parks = a.act != 2 && a.ksplit <= 1 && !a.epi_legacy && a.glds_waves >= 0;
+            if (parks && a.N % 128 == 0 && t128 >= 140 && t128 <= 256) glds_go<128, 3, TE, 512>(a, s);
+            else if (parks && t64 <= 256) glds_go<64, 3, TE, 512>(a, s);
+            else if (parks && t64 <= 512) glds_go<64, 2, TE, 512>(a, s);
+            else glds_go<64, 2, TE>(a, s);
         } else if (n64 && wgs(128, 64) >= 512) gemm_go<T, 128, 64, TE>(a, s);
         else if (a.act != 2 && !n64 && a.N % 96 == 0 && wgs(128, 96) >= 256) gemm_go<T, 128, 96, TE>(a, s);      // N = 96 / 288 (codec block 4): 3x fewer reads of the A tile than 32-wide tiles
         else if (a.act != 2 && !n64 && wgs(128, 32) >= 256) gemm_go<T, 128, 32, TE>(a, s);

@@ -220,6 +220,53 @@ int main(int argc, char** argv) {
         printf("one pass over the 12 decoder-block convs of a 300-frame piece (x1; each residual unit runs 3x): parked %.3f ms, register-layout %.3f ms\n", tot_new, tot_old);
         return 0;
     }
+    if (argc > 2 && !strcmp(argv[2], "glds")) {
+        // LDS-DMA 128 x 64 tile by ring depth on one shape (random operands; every depth must agree bit for bit with two stages)
+        // usage: gemm_bench <reps> glds <M> <N> <K>
+        const int M = atoi(argv[3]), N = atoi(argv[4]), K = atoi(argv[5]);
+        std::vector<uint16_t> ha((size_t)M * K), hw((size_t)N * K);
+        uint32_t x = 4242;
+        auto rnd = [&]() { x = x * 1664525u + 1013904223u; return x >> 16; };
+        for (auto& v : ha) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 128.f);
+        for (auto& v : hw) v = f_to_bf16_host((float)((int)(rnd() & 0xff) - 128) / 1024.f);
+        void *A, *W, *Y;
+        (void)hipMalloc(&A, ha.size() * 2); (void)hipMalloc(&W, hw.size() * 2); (void)hipMalloc(&Y, (size_t)M * N * 2);
+        (void)hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice); (void)hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+        GemmArgs a{};
+        a.A = A; a.lda = K; a.M = M; a.a_rows = M; a.n_taps = 1; a.Cin = K; a.W = W; a.N = N; a.bias_mod = N; a.Y = Y; a.ldy = N;
+        std::vector<uint16_t> y0((size_t)M * N), y1((size_t)M * N);
+        auto rung = [&](const char* name, auto go, bool ref) {
+            (void)hipMemset(Y, 0, (size_t)M * N * 2);
+            go(a, s); (void)hipStreamSynchronize(s);
+            (void)hipMemcpy((ref ? y0 : y1).data(), Y, y0.size() * 2, hipMemcpyDeviceToHost);
+            size_t bad = 0; if (!ref) for (size_t i = 0; i < y0.size(); ++i) bad += y0[i] != y1[i];
+            (void)hipEventRecord(e0, s);
+            for (int r = 0; r < reps; ++r) go(a, s);
+            (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+            printf("M=%d N=%d K=%d  %-26s %9.3f us  %8.1f TFLOP/s  %s\n", M, N, K, name, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12,
+                   ref ? "(reference)" : bad ? "DIFFERS  <-- MISMATCH" : "bit-identical");
+        };
+        a.xcd_map = -1;
+        rung("glds 128x64 2 st, plain order", glds_go<64, 2>, true);
+        rung("glds 128x64 3 st, plain order", glds_go<64, 3>, false);
+        rung("glds 128x64 4 st, plain order", glds_go<64, 4>, false);
+        rung("glds 128x64 6 st, plain order", glds_go<64, 6>, false);
+        rung("64x64 PF=4, plain order", gemm_go<bf16_t, 64, 64>, false);
+        rung("gemm_launch, plain order", gemm_launch<bf16_t>, false);
+        a.xcd_map = 0;
+        rung("glds 128x64 2 st, XCD order", glds_go<64, 2>, false);
+        rung("glds 128x64 3 st, XCD order", glds_go<64, 3>, false);
+        rung("glds 128x64 4 st, XCD order", glds_go<64, 4>, false);
+        rung("glds 128x64 6 st, XCD order", glds_go<64, 6>, false);
+        rung("glds 128x64 8 waves 2 st", glds_go<64, 2, bf16_t, 512>, false);
+        rung("glds 128x64 8 waves 3 st", glds_go<64, 3, bf16_t, 512>, false);
+        rung("glds 128x64 8 waves 4 st", glds_go<64, 4, bf16_t, 512>, false);
+        rung("glds 128x128 8 waves 3 st", glds_go<128, 3, bf16_t, 512>, false);
+        rung("64x64 PF=4, XCD order", gemm_go<bf16_t, 64, 64>, false);
+        rung("gemm_launch, XCD order", gemm_launch<bf16_t>, false);
+        return 0;
+    }
     if (argc > 2) {        // variant sweep on 4096 x 4096 x 4096: tile shape x prefetch depth
         const int M = 4096, N = 4096, K = 4096;
         void *A, *W, *Y;
@@ -361,8 +408,8 @@ int main(int argc, char** argv) {
         }
         const double fl = 2.0 * sh.M * sh.N * K;
         float ms_g = 0; size_t ndg = 0;
-        {   // the LDS-DMA 128 x 64 tile already from 100 workgroups on (default: 512)
-            GemmArgs h = a; h.glds_min_wgs = 100;
+        {   // round 5's choices: the plain blockIdx order of the (N tiles x M tiles) grids, the LDS-DMA tile by four waves whatever the grid
+            GemmArgs h = a; h.xcd_map = -1; h.glds_waves = -1;
             (void)hipMemset(Y, 0, ny * 2);
             gemm_launch<bf16_t>(h, s); (void)hipStreamSynchronize(s);
             (void)hipEventRecord(e0, s);
@@ -375,7 +422,7 @@ int main(int argc, char** argv) {
         size_t nd = 0; for (size_t i = 0; i < ny; ++i) nd += hy[i] != hy_half[i];
         printf("%-24s M=%7d N=%5d K=%5zu  %9.3f us  %8.1f TFLOP/s  check %.2e %s | big tile on half lines: %9.3f us (%+.1f %%), outputs %s\n", sh.name, sh.M, sh.N, K, ms * 1e3,
                fl / (ms * 1e-3) / 1e12, maxerr, maxerr < 2e-2 ? "ok" : "MISMATCH", ms_half * 1e3, 100.0 * (ms_half - ms) / ms_half, nd ? "DIFFER <-- MISMATCH" : "bit-identical");
-        printf("%-24s    glds tile from 100 workgroups: %9.3f us (%+.1f %%), outputs %s\n", "", ms_g * 1e3, 100.0 * (ms - ms_g) / ms, ndg ? "DIFFER" : "bit-identical");
+        printf("%-24s    plain tile order, 4-wave tiles : %9.3f us (%+.1f %%), outputs %s\n", "", ms_g * 1e3, 100.0 * (ms_g - ms) / ms_g, ndg ? "DIFFER" : "bit-identical");
         (void)hipFree(A); (void)hipFree(W); (void)hipFree(Y); if (ws) (void)hipFree(ws);
     }
     return 0;
