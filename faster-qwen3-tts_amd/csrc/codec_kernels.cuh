@@ -1183,15 +1183,18 @@ inline void gemm_launch_te(const GemmArgs& a, hipStream_t s) {
                 return;
             }
         }
-        if (a.N % 64 == 0 && a.Cin % 64 == 0 && wgs(128, 64) >= (a.glds_min_wgs > 0 ? a.glds_min_wgs : kGldsMinWgs)) {
-            // at most ~one round of tiles: eight waves per tile (a wave takes delivery of ~3.6 B/clk, so a CU with one 4-wave tile starves:
-            // profiles/r06_dma_rate.txt); measured per shape in profiles/r06_glds_8waves.txt (-16 .. -27 %), bit-identical
-            const long t64 = wgs(128, 64), t128 = wgs(128, 128);
-            const bool parks = a.act != 2 && a.ksplit <= 1 && !a.epi_legacy && a.glds_waves >= 0;
-            if (parks && a.N % 128 == 0 && t128 >= 140 && t128 <= 256) glds_go<128, 3, TE, 512>(a, s);
-            else if (parks && t64 <= 256) glds_go<64, 3, TE, 512>(a, s);
-            else if (parks && t64 <= 512) glds_go<64, 2, TE, 512>(a, s);
-            else glds_go<64, 2, TE>(a, s);
+        // LDS-DMA 128 x 64 tile.  Up to ~two rounds of tiles: by EIGHT waves (a wave takes delivery of ~3.6 B/clk, so a CU with one 4-wave
+        // tile starves: profiles/r06_dma_rate.txt) -- also for the few-row GEMMs of a streaming chunk (M = 52 .. 2080 against K = 5376 ..
+        // 14336: -25 .. -34 % against the register-prefetch tiles, profiles/r06_glds_8waves.txt, r06_glds_few_rows.txt).  Bit-identical.
+        const long t64 = wgs(128, 64), t128 = wgs(128, 128);
+        const bool glds_shape = a.N % 64 == 0 && a.Cin % 64 == 0;
+        const bool parks = a.act != 2 && a.ksplit <= 1 && !a.epi_legacy && a.glds_waves >= 0;
+        if (glds_shape && parks && t64 <= 512 && (long)a.n_taps * a.Cin >= 512) {
+            if (a.N % 128 == 0 && t128 >= 140 && t128 <= 256) glds_go<128, 3, TE, 512>(a, s);
+            else if (t64 <= 256) glds_go<64, 3, TE, 512>(a, s);
+            else glds_go<64, 2, TE, 512>(a, s);
+        } else if (glds_shape && t64 >= (a.glds_min_wgs > 0 ? a.glds_min_wgs : kGldsMinWgs)) {
+            glds_go<64, 2, TE>(a, s);
         } else if (n64 && wgs(128, 64) >= 512) gemm_go<T, 128, 64, TE>(a, s);
         else if (a.act != 2 && !n64 && a.N % 96 == 0 && wgs(128, 96) >= 256) gemm_go<T, 128, 96, TE>(a, s);      // N = 96 / 288 (codec block 4): 3x fewer reads of the A tile than 32-wide tiles
         else if (a.act != 2 && !n64 && wgs(128, 32) >= 256) gemm_go<T, 128, 32, TE>(a, s);
