@@ -52,6 +52,7 @@ struct GemmArgs {
                                                       // -1 = the half-line ring of four K steps (measurement switch)
     const void* Wp;                                   // fragment-major copy of W for the weight-stationary kernel (skinny_gemm.cuh), or null
     int no_skinny;                                    // measurement switch: 1 = keep the tiled / split-K kernels where skinny_gemm.cuh would serve
+    int chain;                                        // 0 = the chain kernel for a handful of output tiles against a long K (round 6), -1 = never (measurement switch)
     int glds_waves;                                   // 0 = the LDS-DMA tile by eight waves where the grid is at most ~one round of tiles (round 6), -1 = always four (measurement switch)
     int xcd_map;                                      // 0 = XCD-aware tile order of the (N tiles x M tiles) grids (round 6), -1 = the plain blockIdx order (measurement switch)
     int epi_legacy;                                   // measurement switch: 1 = the register-layout epilogue (32-byte runs per row) instead of the
@@ -763,6 +764,107 @@ inline void glds_go(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, (rows + 127) / 128, a.n_seg > 1 ? a.n_seg : 1), dim3(NT), shm, s, a);
 }
 
+// Chain GEMM (round 6): FEW rows against a LONG K -- the convs of a streaming chunk (M = 52 .. 416 rows, K = 5376 .. 14336) -- bit-identical
+// to the tile families.  Those GEMMs have a handful of output tiles (19 workgroups on average for a 25 + 8-frame chunk), and splitting K
+// over workgroups is not open to them: a tail decode must equal the full decode bit for bit, so every output element keeps ONE ascending
+// chain of 32-wide MFMA products.  What bounds them is the rate at which a WAVE takes delivery of its operands (~3.6 B/clk,
+// profiles/r06_dma_rate.txt), not the matrix cores.  So: a workgroup of NW waves owns ONE 32 x 32 output tile, the K steps are dealt to the
+// waves in chunks of CH (chunk c belongs to wave c % NW), every wave keeps its next chunk's operand fragments in flight -- straight from
+// global memory in operand layout, no LDS staging -- and the ACCUMULATORS travel: the owner of chunk c takes the tile's partial sums from
+// LDS, appends its CH x 4 products in ascending K order, puts them back, and the workgroup meets at a barrier (lgkmcnt only: the loads stay
+// in flight).  NW waves deliver in parallel; the arithmetic is the serial chain it always was (4 MFMAs per K step: ~1 % of the time).
+// The LDS image of the accumulators is the parked tile of gemm_epilogue_parked: the epilogue walks it with four columns per lane.
+template <int NW, int CH, typename TE = bf16_t>
+__global__ __launch_bounds__(NW * 64) void chain_gemm_kernel(GemmArgs a_in) {
+    typedef bf16_t T;
+    constexpr int BM = 32, BN = 32, TM = 2, TN = 2, LDP = BN + 4, NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) float park[BM * LDP];
+    const GemmArgs a = gemm_segment<T, TE>(a_in, (int)blockIdx.z);
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = a.m_lo + blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int K = a.n_taps * a.Cin, nsteps = K / 32, nchunks = (nsteps + CH - 1) / CH;
+    const T* A = reinterpret_cast<const T*>(a.A);
+    const T* zero = reinterpret_cast<const T*>(g_gemm_zero_page) + fq * 8;
+    int am[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { const int m = m0 + i * 16 + fr; am[i] = m < a.M ? m : -(1 << 28); }      // rows past M: out of every tap's range
+    const T* wrow[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int n = n0 + j * 16 + fr;
+        n = n < a.N ? n : a.N - 1;                                   // columns past N are computed on row N - 1 and never stored
+        wrow[j] = reinterpret_cast<const T*>(a.W) + (size_t)n * K + fq * 8;
+    }
+    u32x4 ar[CH][TM], wr[CH][TN];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            int t = c * CH + s;
+            t = t < nsteps ? t : nsteps - 1;                         // the last chunk's spare steps reload the last step (never multiplied)
+            const int k0 = t * 32, tap = k0 / a.Cin, ci = k0 - tap * a.Cin;
+            const int toff = a_in.tap_off[tap];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = am[i] + toff;
+                const T* src = (r >= 0 && r < a.a_rows) ? A + (size_t)r * a.lda + ci + fq * 8 : zero;
+                ar[s][i] = *reinterpret_cast<const u32x4*>(src);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wr[s][j] = *reinterpret_cast<const u32x4*>(wrow[j] + k0);
+        }
+    };
+    if (wave < nchunks) load_chunk(wave);
+    for (int c = 0; c < nchunks; ++c) {
+        if (wave == (c % NW)) {
+            f32x4_t acc[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = c ? park[(i * 16 + fq * 4 + r) * LDP + j * 16 + fr] : 0.f;
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                if (c * CH + s < nsteps) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ar[s][i]), __builtin_bit_cast(bf16x8_t, wr[s][j]), acc[i][j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) park[(i * 16 + fq * 4 + r) * LDP + j * 16 + fr] = acc[i][j][r];
+            if (c + NW < nchunks) load_chunk(c + NW);                // in flight over the next NW - 1 chunks of the chain
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): the partial sums are in LDS (the operand loads stay in flight)
+        __builtin_amdgcn_s_barrier();
+    }
+    const EpiQ e = epiq_of(a);
+    const bool quads = epi_quads_ok(a);
+    for (int q = tid; q < BM * (BN / 4); q += NT) {
+        const int row = q / (BN / 4), c4 = (q - row * (BN / 4)) * 4;
+        const int m = m0 + row, n = n0 + c4;
+        if (m >= a.M || n >= a.N) continue;
+        if (quads) epi_quad<TE>(e, *reinterpret_cast<const f32x4_t*>(park + row * LDP + c4), m, n);
+        else for (int cc = 0; cc < 4 && n + cc < a.N; ++cc) epilogue_elem<TE>(a, park[row * LDP + c4 + cc], m, n + cc);
+    }
+}
+template <int NW, int CH, typename TE = bf16_t>
+inline void chain_go(const GemmArgs& a, hipStream_t s) {
+    const int rows = a.M - a.m_lo;
+    hipLaunchKernelGGL((chain_gemm_kernel<NW, CH, TE>), dim3((a.N + 31) / 32, (rows + 31) / 32, a.n_seg > 1 ? a.n_seg : 1), dim3(NW * 64), 0, s, a);
+}
+// shapes the chain kernel serves: a K step never straddles a tap, the per-element epilogue is the parked one (no split-K, no SwiGLU pairing)
+inline bool chain_ok(const GemmArgs& a) {
+    return a.Cin % 32 == 0 && a.act != 2 && a.ksplit <= 1 && !a.epi_legacy && a.lda % 8 == 0;
+}
+
 // Largest-M variant (bf16): 256 x 256 tile, 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 block of 8 x 4 MFMA tiles
 // (one LDS byte feeds 2.7x the arithmetic of the 128 x 64 tile), K step 32, operands by global_load_lds into a RING OF FOUR
 // 32 KB stages: the copies of K steps t + 1 .. t + 3 are in flight while step t is multiplied, the wait before a step is
@@ -1189,6 +1291,11 @@ inline void gemm_launch_te(const GemmArgs& a, hipStream_t s) {
         const long t64 = wgs(128, 64), t128 = wgs(128, 128);
         const bool glds_shape = a.N % 64 == 0 && a.Cin % 64 == 0;
         const bool parks = a.act != 2 && a.ksplit <= 1 && !a.epi_legacy && a.glds_waves >= 0;
+        // a handful of output tiles against a long K (a streaming chunk's dec.0, the frame-level transformer's GEMMs): the chain kernel --
+        // NW waves deliver the operands of ONE 32 x 32 tile, the accumulators travel (-20 .. -40 % against the eight-wave tile up to ~200
+        // tiles, slower beyond: profiles/r06_chain_gemm.txt, r06_chain_small.txt, r06_chain_taps.txt).  Bit-identical.
+        const long t32 = wgs(32, 32);
+        if (a.chain >= 0 && chain_ok(a) && t32 <= 224 && (long)a.n_taps * a.Cin >= 512) { chain_go<8, 8, TE>(a, s); return; }
         if (glds_shape && parks && t64 <= 512 && (long)a.n_taps * a.Cin >= 512) {
             if (a.N % 128 == 0 && t128 >= 140 && t128 <= 256) glds_go<128, 3, TE, 512>(a, s);
             else if (t64 <= 256) glds_go<64, 3, TE, 512>(a, s);

@@ -45,6 +45,11 @@ int main(int argc, char** argv) {
         {"codec370 b4 conv2 k1", 709845, 96, 96, 1, 1},
         {"chunk13 dec.0 k7", 52, 1536, 1024, 7, 1},
         {"chunk13 b1 conv1 k7", 416, 768, 768, 7, 1},
+        {"chunk13 dec.0 as ONE tap", 52, 1536, 7168, 1, 1},
+        {"chunk13 dec.0 k7 bf16x2", 52, 1536, 2048, 7, 1},
+        {"chunk13 b1 conv1 bf16x2", 416, 768, 1536, 7, 3},
+        {"chunk13 b1 up k2 bf16x2", 52, 6144, 3072, 2, 1},
+        {"chunk front GEMM", 33, 512, 2048, 1, 1},
         {"chunk13 b4 conv1 k7", 24960, 96, 96, 7, 1},
     };
     hipStream_t s; (void)hipStreamCreate(&s);
@@ -263,6 +268,10 @@ int main(int argc, char** argv) {
         rung("glds 128x64 8 waves 3 st", glds_go<64, 3, bf16_t, 512>, false);
         rung("glds 128x64 8 waves 4 st", glds_go<64, 4, bf16_t, 512>, false);
         rung("glds 128x128 8 waves 3 st", glds_go<128, 3, bf16_t, 512>, false);
+        rung("chain 32x32, 8 waves x 8 steps", chain_go<8, 8>, false);
+        rung("chain 32x32, 16 waves x 4 steps", chain_go<16, 4>, false);
+        rung("chain 32x32, 8 waves x 4 steps", chain_go<8, 4>, false);
+        rung("chain 32x32, 4 waves x 8 steps", chain_go<4, 8>, false);
         rung("64x64 PF=4, XCD order", gemm_go<bf16_t, 64, 64>, false);
         rung("gemm_launch, XCD order", gemm_launch<bf16_t>, false);
         return 0;
@@ -409,7 +418,7 @@ int main(int argc, char** argv) {
         const double fl = 2.0 * sh.M * sh.N * K;
         float ms_g = 0; size_t ndg = 0;
         {   // round 5's choices: the plain blockIdx order of the (N tiles x M tiles) grids, the LDS-DMA tile by four waves whatever the grid
-            GemmArgs h = a; h.xcd_map = -1; h.glds_waves = -1;
+            GemmArgs h = a; h.xcd_map = -1; h.glds_waves = -1; h.chain = -1;
             (void)hipMemset(Y, 0, ny * 2);
             gemm_launch<bf16_t>(h, s); (void)hipStreamSynchronize(s);
             (void)hipEventRecord(e0, s);
@@ -419,10 +428,25 @@ int main(int argc, char** argv) {
             std::vector<uint16_t> hg(ny); (void)hipMemcpy(hg.data(), Y, ny * 2, hipMemcpyDeviceToHost);
             if (!sh.ws) for (size_t i = 0; i < ny; ++i) ndg += hy[i] != hg[i];
         }
+        if (sh.M <= 2100 && !sh.ws && chain_ok(a)) {   // the chain kernel on the few-row shapes (taps and dilations included): must agree bit for bit
+            for (int form = 0; form < 2; ++form) {
+                (void)hipMemset(Y, 0, ny * 2);
+                auto go = [&]() { if (form) chain_go<16, 4>(a, s); else chain_go<8, 8>(a, s); };
+                go(); (void)hipStreamSynchronize(s);
+                (void)hipEventRecord(e0, s);
+                for (int r = 0; r < reps; ++r) go();
+                (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+                float ms_c; (void)hipEventElapsedTime(&ms_c, e0, e1); ms_c /= reps;
+                std::vector<uint16_t> hc(ny); (void)hipMemcpy(hc.data(), Y, ny * 2, hipMemcpyDeviceToHost);
+                size_t ndc = 0; for (size_t i = 0; i < ny; ++i) ndc += hy[i] != hc[i];
+                printf("%-24s    chain kernel, %s: %9.3f us (%+.1f %%), outputs %s\n", "", form ? "16 waves x 4 steps" : " 8 waves x 8 steps", ms_c * 1e3,
+                       100.0 * (ms - ms_c) / ms, ndc ? "DIFFER <-- MISMATCH" : "bit-identical");
+            }
+        }
         size_t nd = 0; for (size_t i = 0; i < ny; ++i) nd += hy[i] != hy_half[i];
         printf("%-24s M=%7d N=%5d K=%5zu  %9.3f us  %8.1f TFLOP/s  check %.2e %s | big tile on half lines: %9.3f us (%+.1f %%), outputs %s\n", sh.name, sh.M, sh.N, K, ms * 1e3,
                fl / (ms * 1e-3) / 1e12, maxerr, maxerr < 2e-2 ? "ok" : "MISMATCH", ms_half * 1e3, 100.0 * (ms_half - ms) / ms_half, nd ? "DIFFER <-- MISMATCH" : "bit-identical");
-        printf("%-24s    plain tile order, 4-wave tiles : %9.3f us (%+.1f %%), outputs %s\n", "", ms_g * 1e3, 100.0 * (ms_g - ms) / ms_g, ndg ? "DIFFER" : "bit-identical");
+        printf("%-24s    round 5's choices (see source) : %9.3f us (%+.1f %%), outputs %s\n", "", ms_g * 1e3, 100.0 * (ms_g - ms) / ms_g, ndg ? "DIFFER" : "bit-identical");
         (void)hipFree(A); (void)hipFree(W); (void)hipFree(Y); if (ws) (void)hipFree(ws);
     }
     return 0;
