@@ -200,24 +200,27 @@ class BatchDecoder:
         main stream -- with lock-step frames already queued -- does not)."""
         self._stage_many([(st, req, req_ready)])
 
-    def _stage_sync(self):
-        """The first tokens of every group staged with ``defer=True``: ONE device-to-host copy for all of them, then the stages' fields."""
-        pend, self._unsynced = getattr(self, "_unsynced", []), []
-        if not pend:
-            return
-        flat = [r[0].reshape(()) for _g, _k, res, _t in pend for r in res]
-        if self._side is not None and flat[0].is_cuda:
-            with torch.cuda.stream(self._side):           # the samplers ran on the prefill stream: gather and copy in ITS order
-                toks = torch.stack(flat).cpu().tolist()
-        else:
-            toks = torch.stack(flat).cpu().tolist()
-        i = 0
-        for group, kws, res, t0 in pend:
+    def _stage_sync(self, upto=None):
+        """The first tokens of the groups staged with ``defer=True``, oldest first: every group's tokens were copied to pinned host
+        memory right behind its prefill (stream order), so reading group g waits for ITS prefill only -- the groups behind it keep the
+        GPU busy while the host arms group g's lanes (round 6; until then ONE copy fetched all first tokens, and the GPU idled through
+        the arming of a whole wave: 14 ms at 128 lanes).  ``upto``: stop once this stage's fields are complete (None = all groups)."""
+        pend = getattr(self, "_unsynced", [])
+        while pend:
+            group, kws, res, t0, host, done = pend.pop(0)
+            if done is not None:
+                done.synchronize()                                    # this group's prefill + its token copy; later groups still run
+                toks = host.tolist()
+            else:
+                toks = torch.stack([r[0].reshape(()) for r in res]).cpu().tolist()
             ms = (time.time() - t0) * 1000
-            for (st, req, _ev), kw, (_tok, hidden, n_rows, n_pad) in zip(group, kws, res):
-                st.req, st.kw, st.token, st.hidden, st.n_rows, st.n_pad = req, kw, int(toks[i]), hidden, n_rows, int(n_pad)
+            hit = False
+            for (st, req, _ev), kw, (_tok, hidden, n_rows, n_pad), tok in zip(group, kws, res, toks):
+                st.req, st.kw, st.token, st.hidden, st.n_rows, st.n_pad = req, kw, int(tok), hidden, n_rows, int(n_pad)
                 st.t0, st.prefill_ms = t0, ms
-                i += 1
+                hit = hit or st is upto
+            if hit:
+                break
 
     def _stage_many(self, group, defer: bool = False):
         """``[(spare context, request, ready event), ...]``: ONE packed prefill for the whole group when it has more than one
@@ -232,6 +235,7 @@ class BatchDecoder:
                   kw["top_p"], kw["do_sample"]) for (_st, req, _ev), kw in zip(group, kws)]
         engines = [st.engine for st, _req, _ev in group]
         taken = []
+        host_toks = None
 
         def reserve_all():
             # the KV blocks of every member's whole utterance (prompt + max_new_tokens + 1 slots, capped at max_seq_len) are taken
@@ -306,6 +310,11 @@ class BatchDecoder:
                             self._side.wait_event(st.released)              # the previous tenant's hand-over has been queued
                     reserve_all()
                     res = run()
+                    if defer:
+                        # the group's first tokens go to pinned host memory right behind its prefill: no wait here
+                        flat = torch.stack([r[0].reshape(()) for r in res])
+                        host_toks = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+                        host_toks.copy_(flat, non_blocking=True)
                     done = torch.cuda.Event()
                     done.record(self._side)
                 for st, _req, _ev in group:
@@ -319,8 +328,8 @@ class BatchDecoder:
             raise
         if defer:
             for (st, req, _ev), kw in zip(group, kws):
-                st.req, st.kw = req, kw                               # (the stage is taken; token / hidden follow in _stage_sync)
-            self._unsynced = getattr(self, "_unsynced", []) + [(group, kws, res, t0)]
+                st.req, st.kw, st.token = req, kw, None               # (the stage is taken; token / hidden follow in _stage_sync)
+            self._unsynced = getattr(self, "_unsynced", []) + [(group, kws, res, t0, host_toks, group[0][0].ready if host_toks is not None else None)]
             return
         ms = (time.time() - t0) * 1000
         for (st, req, _ev), kw, (token, hidden, n_rows, n_pad) in zip(group, kws, res):
@@ -646,10 +655,13 @@ class BatchDecoder:
                         if stage_ahead(defer=True) == 0:
                             break
                         pull(cap=slice_n, on_main=True)
-                finally:
-                    # the deferred stages hold a request but not yet its first token / hidden state: complete them even when the
-                    # interleaved pull() (the caller's source) raised, so that no stage is left half-filled for the cleanup to find
+                except BaseException:
+                    # the deferred stages hold a request but not yet its first token / hidden state: complete them when the interleaved
+                    # pull() (the caller's source) raised, so that no stage is left half-filled for the cleanup to find
                     self._stage_sync()
+                    raise
+                # (no wait here: the admission loop below reads each group's first tokens when it reaches the group's first stage, and
+                # arms its lanes while the groups behind it are still being prefilled)
                 prof["stage"] += clock() - t_
             while failed:
                 rid, info = failed.pop(0)
@@ -664,6 +676,8 @@ class BatchDecoder:
                         st = ready.popleft()
                         rid = st.req.rid
                         try:
+                            if st.token is None:
+                                self._stage_sync(upto=st)             # a deferred group: its first tokens (and only its) are waited for
                             self._admit(ln, st)
                         finally:
                             idle.append(st)

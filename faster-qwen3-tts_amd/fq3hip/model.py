@@ -257,6 +257,21 @@ class StreamingVocoder:
             out = _to_numpy(self.tok.decode_tensor(codes_in, first_sample, prefix=prefix) if prefix is not None else self.tok.decode_tensor(codes_in, first_sample))
         return out, self.tok.sample_rate
 
+    def _ref_on(self, device):
+        """The reference codes on ``device``.  A host tensor is uploaded ONCE per tensor object and device (noted on the object: the
+        streams of one voice share the prompt's tensor), not once per chunk of every stream (a synchronous copy each)."""
+        rc = self.ref_codes
+        if rc.device == device:
+            return rc
+        note = getattr(rc, "fq3_on_device", None)
+        if not (isinstance(note, tuple) and note[0] == device and (note[2] is None or (not rc.is_inference() and note[2] == rc._version))):
+            note = (device, rc.to(device), None if rc.is_inference() else rc._version)
+            try:
+                rc.fq3_on_device = note
+            except Exception:
+                pass
+        return note[1]
+
     def _cat(self, parts, ev):
         if self.side is None:
             return torch.cat(parts, dim=0)
@@ -279,7 +294,7 @@ class StreamingVocoder:
         n_total = flat.shape[0]
         if self.spf is None:
             rc = self.ref_codes
-            inp = self._cat([rc.to(flat.device), flat], ready_event) if rc is not None else flat
+            inp = self._cat([self._ref_on(flat.device), flat], ready_event) if rc is not None else flat
             ref_len = rc.shape[0] if rc is not None else 0
             n_audio = self.tok.num_samples_total(inp.shape[0])
             cut = int(ref_len / max(inp.shape[0], 1) * n_audio) if ref_len else 0
@@ -306,7 +321,7 @@ class StreamingVocoder:
         n_total = flat.shape[0]
         if self.spf is None:
             rc = self.ref_codes
-            inp = self._cat([rc.to(flat.device), flat], ready_event) if rc is not None else flat
+            inp = self._cat([self._ref_on(flat.device), flat], ready_event) if rc is not None else flat
             ref_len = rc.shape[0] if rc is not None else 0
             if self.side is not None:
                 # model.py:1095-1100 without materialising what is thrown away: audio[cut:][prev_len:]
@@ -995,33 +1010,64 @@ class FasterQwen3TTS:
         batched = side is not None and hasattr(tok, "decode_tensor_batch")
         jobs: list = []                                  # the events of one poll, in order: [rid, meta, audio | None, (codes_in, first, ev) | None]
 
-        def flush():
-            # chunks of different utterances that need the SAME decode shape (the first chunks of lanes that started together:
-            # reference + 8 frames in, the last 8 frames' samples out) go through one batched launch set on the vocoder stream
-            classes: Dict[Any, list] = {}
-            for j in jobs:
-                if j[3] is not None:
-                    pf = j[3][3] if len(j[3]) > 3 else None
-                    classes.setdefault((int(j[3][0].shape[0]), int(j[3][1]), pf.ref_len if pf is not None else 0), []).append(j)
-            for (_T, first, pf_len), members in classes.items():
+        # chunks of different utterances that need the SAME decode shape (the first chunks of lanes that started together: reference + 8
+        # frames in, the last 8 frames' samples out) go through one batched launch set on the vocoder stream, STREAM_GROUP at a time.
+        # Round 6: a group is LAUNCHED as soon as it is full -- while the host still prepares the next group's inputs -- every group's
+        # waveform goes to pinned host memory behind its launch set, and the groups are handed out one by one as their copies land: a
+        # wave of 128 first chunks (four groups of 32) used to be prepared as a whole, launched group by group with a host wait after
+        # each, and reached the caller all at once after the last group.  Per utterance the order of the events is unchanged: groups are
+        # handed out in launch order, a launch takes every open class in order of first appearance, markers without audio come last.
+        open_classes: Dict[Any, list] = {}
+        queued: list = []                               # (jobs of the group, pinned waveforms, event, device waveforms kept alive)
+
+        def launch(key, part):
+            _T, first, pf_len = key
+            for j in part:
+                if j[3][2] is not None:
+                    side.wait_event(j[3][2])
+                else:
+                    side.wait_stream(torch.cuda.current_stream(torch.device(self.device)))
+            with torch.cuda.stream(side):
+                pfs = [j[3][3] for j in part] if pf_len > 0 else None      # (phase 1 behind ICL references: the voices' cached front-end states)
+                if len(part) == 1:
+                    wav = (tok.decode_tensor(part[0][3][0], first, prefix=pfs[0]) if pfs else tok.decode_tensor(part[0][3][0], first)).reshape(1, -1)
+                else:
+                    stacked = torch.stack([j[3][0] for j in part])
+                    wav = tok.decode_tensor_batch(stacked, first, prefixes=pfs) if pfs else tok.decode_tensor_batch(stacked, first)
+                wav = wav.float()
+                host = torch.empty(wav.shape, dtype=wav.dtype, pin_memory=True)
+                host.copy_(wav, non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(side)
+            queued.append((part, host, landed, wav))
+
+        def launch_open():
+            for key in list(open_classes):
+                members = open_classes.pop(key)
                 for i in range(0, len(members), _SideVocoder.STREAM_GROUP):
-                    part = members[i:i + _SideVocoder.STREAM_GROUP]
-                    for j in part:
-                        if j[3][2] is not None:
-                            side.wait_event(j[3][2])
-                        else:
-                            side.wait_stream(torch.cuda.current_stream(torch.device(self.device)))
-                    with torch.cuda.stream(side):
-                        pfs = [j[3][3] for j in part] if pf_len > 0 else None      # (phase 1 behind ICL references: the voices' cached front-end states)
-                        if len(part) == 1:
-                            part[0][2] = _to_numpy(tok.decode_tensor(part[0][3][0], first, prefix=pfs[0]) if pfs else tok.decode_tensor(part[0][3][0], first))
-                        else:
-                            stacked = torch.stack([j[3][0] for j in part])
-                            wav = (tok.decode_tensor_batch(stacked, first, prefixes=pfs) if pfs else tok.decode_tensor_batch(stacked, first)).cpu().numpy()
-                            for k, j in enumerate(part):
-                                j[2] = wav[k]
-            done, jobs[:] = list(jobs), []
-            return done
+                    launch(key, members[i:i + _SideVocoder.STREAM_GROUP])
+
+        def add_job(j):
+            jobs.append(j)
+            if j[3] is not None:
+                pf = j[3][3] if len(j[3]) > 3 else None
+                key = (int(j[3][0].shape[0]), int(j[3][1]), pf.ref_len if pf is not None else 0)
+                open_classes.setdefault(key, []).append(j)
+                if len(open_classes[key]) >= _SideVocoder.STREAM_GROUP:
+                    launch_open()
+
+        def flush():
+            launch_open()
+            plain = [j for j in jobs if j[3] is None]
+            jobs[:] = []
+            groups, queued[:] = list(queued), []
+            for part, host, landed, _wav in groups:
+                landed.synchronize()
+                arr = host.numpy()
+                for k, j in enumerate(part):
+                    j[2] = arr[k]
+                yield from part
+            yield from plain
 
         for rid, codes, info in dec.run(head, source=source, chunk_frames=chunk_size):
             if rid not in vocs:
@@ -1034,13 +1080,13 @@ class FasterQwen3TTS:
             if codes is not None and codes.shape[0] > 0:
                 if batched:
                     inp, first = vocs[rid].prepare(codes, ev)
-                    jobs.append([rid, out_meta, None, (inp, first, ev, vocs[rid].last_prefix)])
+                    add_job([rid, out_meta, None, (inp, first, ev, vocs[rid].last_prefix)])
                 else:
                     audio, _sr = vocs[rid].push(codes, ev)
-                    jobs.append([rid, out_meta, audio, None])
+                    add_job([rid, out_meta, audio, None])
                 n_chunks[rid] += 1
             elif final:
-                jobs.append([rid, out_meta, np.zeros(1 if codes is None else 0, dtype=np.float32), None])
+                add_job([rid, out_meta, np.zeros(1 if codes is None else 0, dtype=np.float32), None])
                 n_chunks[rid] += 1
             if more <= 0:
                 for r, m, audio, _job in flush():

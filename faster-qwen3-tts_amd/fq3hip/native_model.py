@@ -216,7 +216,10 @@ class NativeQwen3TTS:
             else:
                 ids = self.tokenizer(t)["input_ids"] if not callable(getattr(self.tokenizer, "encode", None)) \
                     else self.tokenizer.encode(t)
-            out.append(torch.tensor([ids], dtype=torch.long, device=self.device))
+            tt = torch.tensor([ids], dtype=torch.long, device=self.device)
+            # the list just uploaded, noted for the prompt builder (prompt.host_ids): valid while the tensor is not written to
+            tt.fq3_host_ids = (list(ids), None if tt.is_inference() else tt._version)
+            out.append(tt)
         return out
 
     # ---- validation -------------------------------------------------------------------------------------
