@@ -646,14 +646,15 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 // packed prefill's o_proj / down: M = 2000, N = 1024 -- moves its operands at the rate of four waves per CU and spends 0.9 us per K
 // step of 64 whatever the ring depth (profiles/r06_glds_depth.txt).  Eight waves share the same copies (half as many per thread); the
 // MFMA chain per output element is unchanged (bit-identical); only the LDS-parked epilogue is served (gemm_launch checks).
-template <int BN, int STAGES, typename TE = bf16_t, int NT = 256>
+template <int BN, int STAGES, typename TE = bf16_t, int NT = 256, int BM = 128>
 __global__ __launch_bounds__(NT) void glds_gemm_kernel(GemmArgs a_in) {
     static_assert(STAGES >= 2 && STAGES <= 6, "two to six LDS stages");
     static_assert(NT == 256 || NT == 512, "four or eight waves");
     typedef bf16_t T;
     const GemmArgs a = gemm_segment<T, TE>(a_in, (int)blockIdx.z);
     constexpr int WCOLS = NT == 256 ? 2 : 4;                                  // waves across the tile's columns (two wave rows of 64 rows each)
-    constexpr int BM = 128, BK = 64, TM = 4, TN = BN / (16 * WCOLS);
+    constexpr int BK = 64, TM = BM / 32, TN = BN / (16 * WCOLS);            // BM = 64 (eight waves only): half-height tiles where 128-row tiles would leave most CUs idle
+    static_assert(BM == 128 || (BM == 64 && NT == 512), "128-row tiles, or 64-row tiles by eight waves");
     constexpr int NPA = BM * 8 / NT, NPB = BN * 8 / NT;                       // 16-byte copy slots per thread and stage: A tile, B tile
     static_assert(TN >= 1 && NPB >= 1, "tile too narrow for the wave layout");
     extern __shared__ __attribute__((aligned(128))) unsigned char glds_smem[];
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(NT) void glds_gemm_kernel(GemmArgs a_in) {
             bf16x8_t af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int r = wr * 64 + i * 16 + fr;
+                const int r = wr * (BM / 2) + i * 16 + fr;
                 af[i] = *reinterpret_cast<const bf16x8_t*>(as + r * BK + (((ks * 4 + fq) ^ ((r >> 1) & 7)) * 8));
             }
 #pragma unroll
@@ -755,13 +756,13 @@ __global__ __launch_bounds__(NT) void glds_gemm_kernel(GemmArgs a_in) {
     }
 }
 
-template <int BN, int STAGES, typename TE = bf16_t, int NT = 256>
+template <int BN, int STAGES, typename TE = bf16_t, int NT = 256, int BM = 128>
 inline void glds_go(const GemmArgs& a, hipStream_t s) {
     const int rows = a.M - a.m_lo;
-    const size_t shm = (size_t)STAGES * (128 + BN) * 64 * 2;
-    auto kern = glds_gemm_kernel<BN, STAGES, TE, NT>;
+    const size_t shm = (size_t)STAGES * (BM + BN) * 64 * 2;
+    auto kern = glds_gemm_kernel<BN, STAGES, TE, NT, BM>;
     if (shm > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, (rows + 127) / 128, a.n_seg > 1 ? a.n_seg : 1), dim3(NT), shm, s, a);
+    hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, (rows + BM - 1) / BM, a.n_seg > 1 ? a.n_seg : 1), dim3(NT), shm, s, a);
 }
 
 // Chain GEMM (round 6): FEW rows against a LONG K -- the convs of a streaming chunk (M = 52 .. 416 rows, K = 5376 .. 14336) -- bit-identical
@@ -1288,7 +1289,7 @@ inline void gemm_launch_te(const GemmArgs& a, hipStream_t s) {
         // LDS-DMA 128 x 64 tile.  Up to ~two rounds of tiles: by EIGHT waves (a wave takes delivery of ~3.6 B/clk, so a CU with one 4-wave
         // tile starves: profiles/r06_dma_rate.txt) -- also for the few-row GEMMs of a streaming chunk (M = 52 .. 2080 against K = 5376 ..
         // 14336: -25 .. -34 % against the register-prefetch tiles, profiles/r06_glds_8waves.txt, r06_glds_few_rows.txt).  Bit-identical.
-        const long t64 = wgs(128, 64), t128 = wgs(128, 128);
+        const long t64 = wgs(128, 64);
         const bool glds_shape = a.N % 64 == 0 && a.Cin % 64 == 0;
         const bool parks = a.act != 2 && a.ksplit <= 1 && !a.epi_legacy && a.glds_waves >= 0;
         // a handful of output tiles against a long K (a streaming chunk's dec.0, the frame-level transformer's GEMMs): the chain kernel --
@@ -1297,7 +1298,11 @@ inline void gemm_launch_te(const GemmArgs& a, hipStream_t s) {
         const long t32 = wgs(32, 32);
         if (a.chain >= 0 && chain_ok(a) && t32 <= 224 && (long)a.n_taps * a.Cin >= 512) { chain_go<8, 8, TE>(a, s); return; }
         if (glds_shape && parks && t64 <= 512 && (long)a.n_taps * a.Cin >= 512) {
-            if (a.N % 128 == 0 && t128 >= 140 && t128 <= 256) glds_go<128, 3, TE, 512>(a, s);
+            // which eight-wave tile: 64-row tiles put twice the workgroups on the chip (profiles/r06_glds_64rows.txt): 64 x 128 where that
+            // fills 140 .. 512 CUs' worth, 64 x 64 for the smaller grids, 128 x 64 where 64-row tiles would run to several rounds
+            const long ta = a.N % 128 == 0 ? wgs(64, 128) : 0, tb = wgs(64, 64);
+            if (ta >= 140 && ta <= 512) glds_go<128, 3, TE, 512, 64>(a, s);
+            else if (tb <= 256) glds_go<64, 3, TE, 512, 64>(a, s);
             else if (t64 <= 256) glds_go<64, 3, TE, 512>(a, s);
             else glds_go<64, 2, TE, 512>(a, s);
         } else if (glds_shape && t64 >= (a.glds_min_wgs > 0 ? a.glds_min_wgs : kGldsMinWgs)) {

@@ -268,6 +268,9 @@ int main(int argc, char** argv) {
         rung("glds 128x64 8 waves 3 st", glds_go<64, 3, bf16_t, 512>, false);
         rung("glds 128x64 8 waves 4 st", glds_go<64, 4, bf16_t, 512>, false);
         rung("glds 128x128 8 waves 3 st", glds_go<128, 3, bf16_t, 512>, false);
+        rung("glds 64x64 8 waves 3 st", glds_go<64, 3, bf16_t, 512, 64>, false);
+        rung("glds 64x64 8 waves 4 st", glds_go<64, 4, bf16_t, 512, 64>, false);
+        rung("glds 64x128 8 waves 3 st", glds_go<128, 3, bf16_t, 512, 64>, false);
         rung("chain 32x32, 8 waves x 8 steps", chain_go<8, 8>, false);
         rung("chain 32x32, 16 waves x 4 steps", chain_go<16, 4>, false);
         rung("chain 32x32, 8 waves x 4 steps", chain_go<8, 4>, false);
