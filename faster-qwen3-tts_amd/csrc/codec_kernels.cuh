@@ -51,6 +51,8 @@ struct GemmArgs {
     int big_pair;                                     // 256-wide ring tiles: 0 = whole cache lines per row (two K steps per copy group: PAIR, round 6) where Cin % 64 == 0,
                                                       // -1 = the half-line ring of four K steps (measurement switch)
     const void* Wp;                                   // fragment-major copy of W for the weight-stationary kernel (skinny_gemm.cuh), or null
+    const void* Wi;                                   // [gate | up] weights only: row-major copy with the halves interleaved in 16-row blocks (fq3_ctx.h kind 2), or null:
+                                                      // gemm_swiglu_halves runs the 256-wide ring tile over it with SwiGLU in the epilogue (round 6)
     int no_skinny;                                    // measurement switch: 1 = keep the tiled / split-K kernels where skinny_gemm.cuh would serve
     int chain;                                        // 0 = the chain kernel for a handful of output tiles against a long K (round 6), -1 = never (measurement switch)
     int glds_waves;                                   // 0 = the LDS-DMA tile by eight waves where the grid is at most ~one round of tiles (round 6), -1 = always four (measurement switch)
@@ -1062,6 +1064,23 @@ __global__ __launch_bounds__(512) void big_gemm_kernel(GemmArgs a_in, int tiles_
         for (int j = 0; j < TN; ++j) {
             const int m = m0 + wr * 128 + i * 16 + fr, n = n0 + wc * WN + j * 16 + fq * 4;
             if (m >= a.M || n >= a.N) continue;
+            if (a.act == 2) {
+                // SwiGLU over a 16-row-interleaved [gate | up] weight (GemmArgs::Wi): tile j even = gate columns, j + 1 = the matching up
+                // columns, in the same lane and register.  y = rnd(rnd(silu(rnd(g))) * rnd(u)): the values of the GEMM + silu_mul_kernel pair
+                if constexpr (TN >= 2) {
+                    if ((j & 1) == 0) {
+                        const int no = (n0 + wc * WN + j * 16) / 2 + fq * 4;      // logical output column of this lane's four values
+                        float y[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float g = DT<T>::rnd(acc[i][j][c]), u = DT<T>::rnd(acc[i][j + 1 < TN ? j + 1 : j][c]);
+                            y[c] = DT<T>::rnd(g / (1.0f + expf(-g))) * u;
+                        }
+                        *reinterpret_cast<uint2*>(reinterpret_cast<T*>(a.Y) + (size_t)m * a.ldy + no) = uint2{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+                    }
+                }
+                continue;
+            }
             f32x4_t t = acc[i][j];
             const int ch = n % a.bias_mod;
             if (n + 3 < a.N && (a.ldy & 3) == 0 && (a.bias_mod & 3) == 0) {
@@ -1296,7 +1315,9 @@ inline void gemm_launch_te(const GemmArgs& a, hipStream_t s) {
         // NW waves deliver the operands of ONE 32 x 32 tile, the accumulators travel (-20 .. -40 % against the eight-wave tile up to ~200
         // tiles, slower beyond: profiles/r06_chain_gemm.txt, r06_chain_small.txt, r06_chain_taps.txt).  Bit-identical.
         const long t32 = wgs(32, 32);
-        if (a.chain >= 0 && chain_ok(a) && t32 <= 224 && (long)a.n_taps * a.Cin >= 512) { chain_go<8, 8, TE>(a, s); return; }
+        // (K <= 4096: behind that the 64 x 64 eight-wave tile is ahead again -- dec.0 at 52 rows, K = 14336: 84 against 94 us,
+        // profiles/r06_chain_vs_64rows.txt)
+        if (a.chain >= 0 && chain_ok(a) && t32 <= 224 && (long)a.n_taps * a.Cin >= 512 && (long)a.n_taps * a.Cin <= 4096) { chain_go<8, 8, TE>(a, s); return; }
         if (glds_shape && parks && t64 <= 512 && (long)a.n_taps * a.Cin >= 512) {
             // which eight-wave tile: 64-row tiles put twice the workgroups on the chip (profiles/r06_glds_64rows.txt): 64 x 128 where that
             // fills 140 .. 512 CUs' worth, 64 x 64 for the smaller grids, 128 x 64 where 64-row tiles would run to several rounds
@@ -1343,6 +1364,18 @@ inline void gemm_swiglu_halves(const GemmArgs& a, void* y, hipStream_t s) {
             k.Y = reinterpret_cast<bf16_t*>(y); k.ldy = I;
             k.Wp = reinterpret_cast<const bf16_t*>(a.Wp);
             skinny_launch<SK_SWIGLU>(k, a.Cin, s);
+            return;
+        }
+    }
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        // many rows (packed prefills, long prompts): the 256-wide ring tile over the 16-row-interleaved copy, SwiGLU in its epilogue -- the
+        // [M][2I] image is never written and the elementwise launch (13 us per layer of a 10 x 200 pack) is gone.  Bit-identical to the pair.
+        const int rows = a.M - a.m_lo;
+        if (a.Wi && !a.res && !a.bias && !a.scale && a.n_taps == 1 && a.N % 512 == 0 && a.Cin % 32 == 0 && a.n_seg <= 1 && I % 4 == 0 &&
+            big_tiling_pays(rows, a.N, kBigBN, 1)) {
+            GemmArgs b = a;
+            b.W = a.Wi; b.act = 2; b.Y = y; b.ldy = I;
+            big_go_t<true, kBigBN>(b, s);
             return;
         }
     }

@@ -263,6 +263,7 @@ extern "C" int fq3_set_option(fq3_ctx* c, const char* key, int value) {
     else if (k == "prefill_mode") c->prefill_mode = value;     // 0 matrix-core prefill, 1 token walk
     else if (k == "flash_prefill") c->opt_flash_prefill = value;   // bf16 prefill attention on MFMA (default 1)
     else if (k == "flash_small") c->opt_flash_small = value;   // <= 256-row prompts: resident key tiles + packed sequences in one launch (default 1; bit-identical to 0)
+    else if (k == "swiglu_tile") c->opt_swiglu_tile = value;   // many-row prefills: SwiGLU in the ring tile's epilogue over the interleaved gate | up copy (default 1; bit-identical)
     else if (k == "packed_weights") c->opt_packed = value;     // weight-stationary GEMMs on the fragment-major weight copies (default 1; bit-identical)
     else if (k == "skinny_gemm") c->opt_no_skinny = !value;    // weight-stationary short-prompt prefill GEMMs (default 1)
     else return fail(FQ3_EINVAL, "unknown option: " + k);
@@ -289,7 +290,7 @@ const void* fq3_packed_find_(const void* W, int kind) {
     return it == g_packed.end() ? nullptr : it->second.p;
 }
 int fq3_packed_acquire_(const void* W, int N, int K, int kind) {
-    if (!W || !skinny_pack_ok(N, K) || (kind == 1 && (N / 2) % 8)) return FQ3_EUNSUPPORTED;
+    if (!W || !skinny_pack_ok(N, K) || (kind == 1 && (N / 2) % 8) || (kind == 2 && N % 512)) return FQ3_EUNSUPPORTED;
     std::lock_guard<std::mutex> lk(g_packed_mu);
     auto it = g_packed.find({W, kind});
     if (it != g_packed.end()) {
@@ -299,7 +300,8 @@ int fq3_packed_acquire_(const void* W, int N, int K, int kind) {
     }
     void* p = nullptr;
     if (hipMalloc(&p, (size_t)N * K * 2) != hipSuccess) { (void)hipGetLastError(); return fail(FQ3_ENOMEM, "no device memory for the fragment-major weight copy"); }
-    skinny_pack(reinterpret_cast<const bf16_t*>(W), reinterpret_cast<bf16_t*>(p), N, K, kind == 1 ? N / 2 : 0, nullptr);
+    // kind 0: fragment-major 16-row blocks; 1: fragment-major 8 gate + 8 up rows; 2: ROW-major, [gate | up] interleaved in 16-row blocks
+    skinny_pack(reinterpret_cast<const bf16_t*>(W), reinterpret_cast<bf16_t*>(p), N, K, kind == 1 ? N / 2 : (kind == 2 ? -(N / 2) : 0), nullptr);
     if (hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(p); return fail(FQ3_EHIP, "packing a weight matrix failed"); }
     g_packed[{W, kind}] = PackedEntry{p, 1, N, K};
     return FQ3_OK;
@@ -335,6 +337,8 @@ static int packed_acquire_all(fq3_ctx* c) {
     };
     if (int r = stack(c->tl, c->cfg.talker)) return r;
     if (int r = stack(c->pl, c->cfg.predictor)) return r;
+    // the talker's gate | up once more, row-major with the halves interleaved: the many-row prefill's ring tile with SwiGLU in its epilogue
+    for (const fq3_layer_weights& l : c->tl) if (int r = take(l.gate_up, 2 * c->cfg.talker.inter, c->cfg.talker.hidden, 2)) return r;
     if (int r = take(c->wt.codec_head, c->cfg.talker.vocab, c->cfg.talker.hidden, 0)) return r;
     for (const void* h : c->lmh) if (int r = take(h, c->cfg.predictor.vocab, c->cfg.predictor.hidden, 0)) return r;
     return FQ3_OK;

@@ -66,6 +66,7 @@ struct fq3_ctx {
     int opt_rmax = 2;             // GEMV rows-per-wave cap
     int opt_flash_prefill = 1;    // bf16 prefill attention on the matrix cores (0: the per-row wave kernel)
     int opt_flash_small = 1;      // prompts of <= 256 rows: every key tile resident in LDS, the sequences of a packed prefill in one launch (0: the streamed-tile kernel, per prompt)
+    int opt_swiglu_tile = 1;      // many-row prefills: gate | up on the ring tile over the 16-row-interleaved copy with SwiGLU in the epilogue (round 6; bit-identical); 0: GEMM + silu_mul
     int opt_packed = 1;           // weight-stationary GEMMs read the fragment-major copies of the layer matrices (round 6; bit-identical); 0: the row-major matrices
     std::vector<std::pair<const void*, int>> packed_refs;      // (matrix, kind) references this context holds in the registry
     int opt_no_skinny = 0;        // 1: short-prompt prefill GEMMs on the tiled / split-K kernels instead of the weight-stationary one (measurement)

@@ -537,6 +537,7 @@ GemmArgs lin(fq3_ctx* c, const void* A, int M, int K, const void* W, int N, void
     GemmArgs a{}; a.A = A; a.lda = K; a.M = M; a.a_rows = M; a.n_taps = 1; a.tap_off[0] = 0; a.Cin = K; a.W = W; a.N = N;
     a.bias_mod = N; a.Y = Y; a.ldy = N; a.ws = (float*)c->pf_ws; a.ws_floats = kPrefillWsFloats; a.no_skinny = c->opt_no_skinny;
     if (sizeof(T) == 2 && c->opt_packed && M <= kSkinnyMaxRows) a.Wp = fq3_packed_find_(W, kind);
+    if (sizeof(T) == 2 && kind == 1 && c->opt_swiglu_tile && M > kSkinnyMaxRows) a.Wi = fq3_packed_find_(W, 2);
     return a;
 }
 template <typename T> void gemm(const GemmArgs& a, hipStream_t s) { gemm_launch<T>(a, s); }

@@ -404,6 +404,16 @@ __global__ __launch_bounds__(256) void skinny_pack_kernel(const bf16_t* __restri
     const size_t piece = (size_t)blockIdx.x * 256 + threadIdx.x;            // = (row block * (K / 32) + step) * 64 + lane
     const size_t total = (size_t)N * K / 8;
     if (piece >= total) return;
+    if (swiglu_I < 0) {
+        // ROW-MAJOR copy of a [gate | up] matrix with the halves interleaved in blocks of 16 rows (gate rows 16 b .., then up rows I + 16 b ..):
+        // the layout whose 256-wide ring tiles hold both factors of an output in one wave's accumulators (codec_kernels.cuh, TR epilogue)
+        const int I = -swiglu_I, ppr = K / 8;
+        const int orow = (int)(piece / (size_t)ppr), cp = (int)(piece % (size_t)ppr);
+        const int blk = orow >> 5, w = orow & 31;
+        const int srow = w < 16 ? blk * 16 + w : I + blk * 16 + (w - 16);
+        *reinterpret_cast<u32x4*>(P + piece * 8) = *reinterpret_cast<const u32x4*>(W + (size_t)srow * K + cp * 8);
+        return;
+    }
     const int ln = (int)(piece & 63), fr = ln & 15, fq = ln >> 4;
     const size_t bs = piece >> 6;
     const int t = (int)(bs % (size_t)(K / 32)), r = (int)(bs / (size_t)(K / 32));

@@ -132,7 +132,9 @@ int fq3_kv_blocks(const fq3_ctx* ctx);
  *   weight-stationary GEMMs with the SwiGLU fused into the [gate | up] launch; 0 = the tiled / split-K kernels of longer prompts),
  *   "flash_small" 0|1 (round 5; prompts of <= 256 rows: every key tile of a query block resident in LDS, and the prompts of a packed
  *   fq3_prefill_batch over ONE pool share two attention launches per layer; 0 = the streamed-tile kernel, per prompt; bit-identical),
- *   "packed_weights" 0|1 (round 6; the weight-stationary GEMMs read the fragment-major copies of the layer matrices; bit-identical).
+ *   "packed_weights" 0|1 (round 6; the weight-stationary GEMMs read the fragment-major copies of the layer matrices; bit-identical),
+ *   "swiglu_tile" 0|1 (round 6; prefills of more than 416 rows run gate | up on the ring tile over a 16-row-interleaved copy of the
+ *   weight with SwiGLU in the epilogue instead of GEMM + elementwise pass; bit-identical).
  * Resets a captured graph. */
 int fq3_set_option(fq3_ctx* ctx, const char* key, int value);
 

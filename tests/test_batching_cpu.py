@@ -391,3 +391,23 @@ def test_a_failed_admission_returns_the_lanes_blocks_and_lookahead_is_clamped(sc
     failed_lane = [e[1] for e in log if e[0] == "cancel"]
     assert failed_lane and ("release", failed_lane[0]) in log                     # cancelled, then its blocks returned
     assert all(v == 0 for v in held.values())                                     # finished lanes returned theirs too
+
+
+def test_deferred_first_tokens_are_read_group_by_group():
+    """_stage_sync (round 6): the groups staged with defer=True are completed oldest first, and ``upto`` stops at the group that holds the
+    stage the admission loop has reached -- the groups behind it stay deferred (their prefills keep the GPU busy meanwhile)."""
+    dec = Bt.BatchDecoder.__new__(Bt.BatchDecoder)
+    st = [Bt._Stage(engine=None) for _ in range(5)]
+    for s in st:
+        s.token = None
+    reqs = [object() for _ in range(5)]
+    mk = lambda idx: ([(st[i], reqs[i], None) for i in idx], [{} for _ in idx],
+                      [(torch.tensor([100 + i]), f"hidden{i}", 7 + i, 0) for i in idx], 0.0, None, None)
+    dec._unsynced = [mk([0, 1]), mk([2, 3]), mk([4])]
+    dec._stage_sync(upto=st[0])
+    assert [s.token for s in st] == [100, 101, None, None, None] and len(dec._unsynced) == 2
+    dec._stage_sync(upto=st[3])
+    assert [s.token for s in st] == [100, 101, 102, 103, None] and st[3].hidden == "hidden3" and st[3].n_rows == 10
+    dec._stage_sync()                                                 # no stage named: every remaining group
+    assert st[4].token == 104 and st[4].req is reqs[4] and dec._unsynced == []
+    dec._stage_sync()                                                 # nothing deferred: a no-op

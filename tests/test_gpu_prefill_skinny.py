@@ -184,3 +184,21 @@ def test_packed_prefill_attention_in_one_launch_per_layer():
             assert d <= 2.0 ** -6 * max(1.0, float(single[q][i].abs().max())), (q, i, d)
     for e in engs + [first]:
         e.close()
+
+
+@pytest.mark.parametrize("size", ["0p6b", "1p7b"])
+@pytest.mark.parametrize("L", [1000, 517])
+def test_swiglu_in_the_ring_tile_is_bit_identical(size, L):
+    """Round 6: a many-row prefill (> 416 rows: packed prefills, long prompts) runs gate | up on the 256-wide ring tile over a copy of the
+    weight whose halves are interleaved in 16-row blocks, with SwiGLU in the tile's epilogue ("swiglu_tile", default 1; GemmArgs::Wi) --
+    the [M][2I] image and the elementwise launch are gone.  y = rnd(rnd(silu(rnd(g))) * rnd(u)) either way: logits, hidden state and the
+    K / V rows of the last layer equal those of the GEMM + silu_mul pair bit for bit (1000 rows: whole tiles; 517: a ragged last tile)."""
+    cfg, W, tie, tam, eng = _setup(size, L)
+    x = tie[0].cuda().contiguous()
+    eng.set_option("swiglu_tile", 1)
+    got = _run(eng, cfg, x, L)
+    eng.set_option("swiglu_tile", 0)
+    ref = _run(eng, cfg, x, L)
+    for i, name in enumerate(("logits", "hidden", "K of the last layer", "V of the last layer")):
+        assert torch.equal(got[i], ref[i]), name
+    assert float(got[3].abs().amax(dim=(0, 2)).min()) > 0

@@ -66,3 +66,33 @@ def test_row_programs_reproduce_the_reference_prompt(tag, dtype, golden_dir):
             tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
             assert (v.float() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max())), (name, k)
         assert int(tam.sum()) == tie.shape[1]
+
+
+def test_host_ids_note_is_used_and_voided_by_a_write():
+    """prompt.host_ids (round 6): the tokenising step notes the id list it uploaded on the tensor, the prompt builder reads the note
+    instead of copying the tensor back -- and a tensor written to since (or from anywhere else) is read back."""
+    from fq3hip.prompt import host_ids
+    t = torch.tensor([[5, 6, 7]], dtype=torch.long)
+    assert host_ids(t) == [5, 6, 7]                                   # no note: read back
+    t.fq3_host_ids = ([5, 6, 7], t._version)
+    t_data = t.clone()
+    assert host_ids(t) == [5, 6, 7]
+    t.fq3_host_ids = ([9, 9, 9], t._version)                          # (a note that differs from the data proves the note is what is read)
+    assert host_ids(t) == [9, 9, 9]
+    t[0, 0] = 1                                                       # an in-place write bumps the version: the note is void
+    assert host_ids(t) == [1, 6, 7]
+    with torch.inference_mode():
+        u = torch.tensor([[2, 3]], dtype=torch.long)
+    u.fq3_host_ids = ([2, 3], None)                                   # inference-mode tensors carry no version counter: taken as noted
+    assert host_ids(u) == [2, 3]
+    assert t_data.tolist() == [[5, 6, 7]]
+
+
+def test_tokenize_texts_notes_the_ids_it_uploads():
+    from fq3hip.native_model import ByteTokenizer, NativeQwen3TTS
+    from fq3hip.prompt import host_ids
+    m = NativeQwen3TTS.__new__(NativeQwen3TTS)
+    m.tokenizer, m.device = ByteTokenizer(4096), torch.device("cpu")
+    (t,) = m._tokenize_texts(["<|im_start|>assistant\nhello<|im_end|>\n<|im_start|>assistant\n"])
+    assert isinstance(getattr(t, "fq3_host_ids", None), tuple)
+    assert host_ids(t) == [int(x) for x in t.reshape(-1).tolist()]
