@@ -648,7 +648,9 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 // packed prefill's o_proj / down: M = 2000, N = 1024 -- moves its operands at the rate of four waves per CU and spends 0.9 us per K
 // step of 64 whatever the ring depth (profiles/r06_glds_depth.txt).  Eight waves share the same copies (half as many per thread); the
 // MFMA chain per output element is unchanged (bit-identical); only the LDS-parked epilogue is served (gemm_launch checks).
-template <int BN, int STAGES, typename TE = bf16_t, int NT = 256, int BM = 128>
+// DBG (measurement builds of tools/microbench/gemm_bench.hip only; 0 in the library): 1 = no MFMAs (the fragment reads stay), 2 = no
+// fragment reads either (copies + barriers only), 3 = copies only (no barrier): where does a K step's time go?
+template <int BN, int STAGES, typename TE = bf16_t, int NT = 256, int BM = 128, int DBG = 0>
 __global__ __launch_bounds__(NT) void glds_gemm_kernel(GemmArgs a_in) {
     static_assert(STAGES >= 2 && STAGES <= 6, "two to six LDS stages");
     static_assert(NT == 256 || NT == 512, "four or eight waves");
@@ -724,12 +726,12 @@ __global__ __launch_bounds__(NT) void glds_gemm_kernel(GemmArgs a_in) {
         else if (STAGES >= 4 && rem >= 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * CPS));
         else if (STAGES >= 3 && rem >= 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(CPS));
         else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
-        __builtin_amdgcn_s_barrier();                    // ... and everybody's; everybody is also done reading the stage refilled next
+        if constexpr (DBG != 3) __builtin_amdgcn_s_barrier();                    // ... and everybody's; everybody is also done reading the stage refilled next
         if (s + STAGES - 1 < nsteps) issue(s + STAGES - 1, (buf + STAGES - 1) % STAGES);       // flies under this step's MFMAs
         const T* as = As + buf * BM * BK;
         const T* bs = Bs + buf * BN * BK;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < (DBG >= 2 ? 0 : 2); ++ks) {
             bf16x8_t af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -744,8 +746,10 @@ __global__ __launch_bounds__(NT) void glds_gemm_kernel(GemmArgs a_in) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (DBG == 1) { acc[i][j][0] += (float)af[i][0] + (float)bfr[j][0]; }      // (keeps the reads alive)
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
         }
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
@@ -758,12 +762,21 @@ __global__ __launch_bounds__(NT) void glds_gemm_kernel(GemmArgs a_in) {
     }
 }
 
-template <int BN, int STAGES, typename TE = bf16_t, int NT = 256, int BM = 128>
+template <int BN, int STAGES, typename TE = bf16_t, int NT = 256, int BM = 128, int DBG = 0>
 inline void glds_go(const GemmArgs& a, hipStream_t s) {
     const int rows = a.M - a.m_lo;
     const size_t shm = (size_t)STAGES * (BM + BN) * 64 * 2;
-    auto kern = glds_gemm_kernel<BN, STAGES, TE, NT, BM>;
-    if (shm > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    auto kern = glds_gemm_kernel<BN, STAGES, TE, NT, BM, DBG>;
+    if (shm > 48 * 1024) {
+        // the LDS limit of a kernel is a per-device setting: raised once per instantiation AND device (a process may drive several)
+        static bool raised[16] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+        if (dev < 0 || !raised[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            if (dev >= 0) raised[dev] = true;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3((a.N + BN - 1) / BN, (rows + BM - 1) / BM, a.n_seg > 1 ? a.n_seg : 1), dim3(NT), shm, s, a);
 }
 

@@ -271,6 +271,12 @@ int main(int argc, char** argv) {
         rung("glds 64x64 8 waves 3 st", glds_go<64, 3, bf16_t, 512, 64>, false);
         rung("glds 64x64 8 waves 4 st", glds_go<64, 4, bf16_t, 512, 64>, false);
         rung("glds 64x128 8 waves 3 st", glds_go<128, 3, bf16_t, 512, 64>, false);
+        rung("dbg 64x128 8w: no MFMAs", glds_go<128, 3, bf16_t, 512, 64, 1>, false);
+        rung("dbg 64x128 8w: copies + barriers", glds_go<128, 3, bf16_t, 512, 64, 2>, false);
+        rung("dbg 64x128 8w: copies only", glds_go<128, 3, bf16_t, 512, 64, 3>, false);
+        rung("dbg 64x128 8w 4st: copies+barriers", glds_go<128, 4, bf16_t, 512, 64, 2>, false);
+        rung("dbg 128x64 4w 2st: copies+barriers", glds_go<64, 2, bf16_t, 256, 128, 2>, false);
+        rung("dbg 128x64 4w 2st: no MFMAs", glds_go<64, 2, bf16_t, 256, 128, 1>, false);
         rung("chain 32x32, 8 waves x 8 steps", chain_go<8, 8>, false);
         rung("chain 32x32, 16 waves x 4 steps", chain_go<16, 4>, false);
         rung("chain 32x32, 8 waves x 4 steps", chain_go<8, 4>, false);
