@@ -7,7 +7,9 @@
 // L2) in steps of `step_kb` (one "K step" of a tile), `iters` steps per launch (long enough that the launch cost vanishes), with
 // DEPTH steps in flight.  Access pattern: 8 lanes per 128-byte row (whole cache lines), rows `row_stride` bytes apart -- a K step of 64
 // bf16 columns of a row-major operand; with --half: 4 lanes per 64-byte half row, 16 rows per wave instruction (a K step of 32).
-// usage: dma_rate_bench [threads = 256] [step_kb = 24] [iters = 4000] [row_stride = 4096]
+// Workgroups of 4 / 8 / 16 waves, one to four per CU.  Result on MI355X (profiles/r06_dma_rate.txt): ~3.6 B/clk per WAVE whatever the path
+// and the depth; a CU saturates near 80-90 GB/s from 16 waves on.
+// usage: dma_rate_bench [iters = 4000] [row_stride = 4096] [window_kb = 1024]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
