@@ -54,6 +54,7 @@ struct GemmArgs {
     const void* Wi;                                   // [gate | up] weights only: row-major copy with the halves interleaved in 16-row blocks (fq3_ctx.h kind 2), or null:
                                                       // gemm_swiglu_halves runs the 256-wide ring tile over it with SwiGLU in the epilogue (round 6)
     int no_skinny;                                    // measurement switch: 1 = keep the tiled / split-K kernels where skinny_gemm.cuh would serve
+    int glds_cap8;                                    // measurement hook: bf16 x 2 outputs take the eight-wave LDS-DMA tiles up to this many 128 x 64 tiles (0 = default)
     int chain;                                        // 0 = the chain kernel for a handful of output tiles against a long K (round 6), -1 = never (measurement switch)
     int glds_waves;                                   // 0 = the LDS-DMA tile by eight waves where the grid is at most ~one round of tiles (round 6), -1 = always four (measurement switch)
     int xcd_map;                                      // 0 = XCD-aware tile order of the (N tiles x M tiles) grids (round 6), -1 = the plain blockIdx order (measurement switch)
@@ -1331,11 +1332,15 @@ inline void gemm_launch_te(const GemmArgs& a, hipStream_t s) {
         // (K <= 4096: behind that the 64 x 64 eight-wave tile is ahead again -- dec.0 at 52 rows, K = 14336: 84 against 94 us,
         // profiles/r06_chain_vs_64rows.txt)
         if (a.chain >= 0 && chain_ok(a) && t32 <= 224 && (long)a.n_taps * a.Cin >= 512 && (long)a.n_taps * a.Cin <= 4096) { chain_go<8, 8, TE>(a, s); return; }
-        if (glds_shape && parks && t64 <= 512 && (long)a.n_taps * a.Cin >= 512) {
+        // (bf16 x 2 outputs: the four-wave tile's epilogue needs 224 registers -- two workgroups = eight waves per CU whatever the grid -- so the
+        // eight-wave tiles (74 .. 82 registers, two or three workgroups per CU) serve the large grids too: a group of 32 first chunks 0.327 ->
+        // 0.275 ms each, 370 frames 12.4 -> 12.0 ms, profiles/r06_codec_time_bf16x2_cap8.txt)
+        const long cap8 = std::is_same<TE, bfs_t>::value ? (a.glds_cap8 > 0 ? a.glds_cap8 : (1L << 30)) : 512;
+        if (glds_shape && parks && t64 <= cap8 && (long)a.n_taps * a.Cin >= 512) {
             // which eight-wave tile: 64-row tiles put twice the workgroups on the chip (profiles/r06_glds_64rows.txt): 64 x 128 where that
             // fills 140 .. 512 CUs' worth, 64 x 64 for the smaller grids, 128 x 64 where 64-row tiles would run to several rounds
             const long ta = a.N % 128 == 0 ? wgs(64, 128) : 0, tb = wgs(64, 64);
-            if (ta >= 140 && ta <= 512) glds_go<128, 3, TE, 512, 64>(a, s);
+            if (ta >= 140 && ta <= cap8) glds_go<128, 3, TE, 512, 64>(a, s);
             else if (tb <= 256) glds_go<64, 3, TE, 512, 64>(a, s);
             else if (t64 <= 256) glds_go<64, 3, TE, 512>(a, s);
             else glds_go<64, 2, TE, 512>(a, s);

@@ -47,6 +47,7 @@ struct fq3_codec {
     void* snake_consts = nullptr;                 // per-channel SnakeBeta constants (a, ib), built at finalize
     std::map<std::string, std::pair<const void*, const void*>> snake;     // "<prefix>" -> (a, ib)
     bool ready = false;
+    int glds_cap8 = 0;                            // measurement hook ("glds_cap8"): bf16 x 2 GEMMs take the eight-wave LDS-DMA tiles up to this many 128 x 64 tiles (0 = the launcher's default)
     int fuse_units = 1;                           // 1 (default): residual units of the 96-channel block as one launch each (resunit_kernel), 2: the
                                                   // 192-channel block too, 0: two GEMMs per unit.  Bit-identical; measured per 370-frame decode on
                                                   // MI355X: 7.92 (0) / 7.45 (1) / 7.93 ms (2) -- at 192 channels the 128 x C tile loses more against the
@@ -124,7 +125,8 @@ extern "C" int fq3_codec_destroy(fq3_codec* c) {
 
 extern "C" int fq3_codec_set_option(fq3_codec* c, const char* key, int value) {
     if (!c || !key) return cfail(FQ3_EINVAL, "null argument");
-    if (std::string(key) == "fuse_units") c->fuse_units = value;      // 0: two GEMMs per residual unit; 1 (default): 96-channel units fused; 2: 192 too
+    if (std::string(key) == "glds_cap8") c->glds_cap8 = value;
+    else if (std::string(key) == "fuse_units") c->fuse_units = value;      // 0: two GEMMs per residual unit; 1 (default): 96-channel units fused; 2: 192 too
     else return cfail(FQ3_EINVAL, std::string("unknown codec option: ") + key);
     return FQ3_OK;
 }
@@ -266,10 +268,11 @@ static int decode_t(fq3_codec* c, const int64_t* codes, int NS, int Tn, int64_t 
     auto gemm_op = [&](GemmArgs a, int out, int out2, std::vector<Dep> in, int unit = 1) {
         Op o; o.out = out; o.out2 = out2; o.in = std::move(in); o.unit = unit;
         a = segmented(a, NS);
+        a.glds_cap8 = c->glds_cap8;
         o.run = [a, s](int lo) mutable { a.m_lo = lo; gemm_launch<T>(a, s); };
         P.add(std::move(o));
     };
-    auto G = [&](GemmArgs a) { a.m_lo = f0; gemm_launch<T>(segmented(a, NS), s); };             // (front end: rows [f0, Tn))
+    auto G = [&](GemmArgs a) { a.m_lo = f0; a.glds_cap8 = c->glds_cap8; gemm_launch<T>(segmented(a, NS), s); };             // (front end: rows [f0, Tn))
     // cached prefix rows -> every utterance's copy of a front-end tensor (rows [f0 - n, f0)); the reverse copy fills `cap`
     auto put_rows = [&](const PrefixSrc& src, size_t src_off, int src_ld, T* dst, int dst_ld, int dst_col0, int n_rows, int n_cols) {
         if (n_rows <= 0) return;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Workload for a kernel trace of ONE shape of the codec decoder (development aid): the streaming phase-2 chunk (25 context + 8 new
 frames, tail decode) by default, or the 200-frame tail of a batch behind prefix states.
-usage: codec_chunk_trace.py [bf16|bf16x2] [chunk|first|tail16] [reps]"""
+usage: codec_chunk_trace.py [bf16|bf16x2] [chunk|first|first32|tail16] [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "faster-qwen3-tts_amd"))
@@ -20,7 +20,13 @@ def main():
     tok = HipSpeechTokenizer(cfg.codec, W, "cuda", max_frames=400, precision=prec)
     g = torch.Generator().manual_seed(4)
     codes = torch.randint(0, cfg.codec.codebook_size, (370, 16), generator=g).cuda()
-    if what == "tail16":
+    if what == "first32":
+        B = 32
+        cb = codes[:178].unsqueeze(0).repeat(B, 1, 1).contiguous()
+        pf = tok.prefix_for(codes[:170].contiguous())
+        first = tok.num_samples_total(178) - 8 * 1920
+        fn = lambda: tok.decode_tensor_batch(cb, first, prefixes=[pf] * B)
+    elif what == "tail16":
         B = 16
         cb = codes.unsqueeze(0).repeat(B, 1, 1).contiguous()
         first = tok.num_samples_total(370) - 200 * 1920

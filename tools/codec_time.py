@@ -25,9 +25,13 @@ def timed(fn, reps=5):
 def main():
     prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
     Bs = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "4,16").split(",")]
+    cap8 = int(sys.argv[3]) if len(sys.argv) > 3 else 0             # measurement hook: fq3_codec_set_option("glds_cap8")
     cfg = qwen3_tts_0p6b()
     W = synth_weights(cfg, 0, torch.bfloat16, parts=("codec",), codec_normalized=True)
     tok = HipSpeechTokenizer(cfg.codec, W, "cuda", max_frames=400, precision=prec)
+    if cap8:
+        tok.set_option("glds_cap8", cap8)
+        print(f"glds_cap8 = {cap8}")
     g = torch.Generator().manual_seed(4)
     codes = torch.randint(0, cfg.codec.codebook_size, (370, 16), generator=g).cuda()
     n33 = tok.num_samples_total(33); n178 = tok.num_samples_total(178)
