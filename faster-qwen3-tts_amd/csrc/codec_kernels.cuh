@@ -454,7 +454,7 @@ __device__ __forceinline__ void conv_gemm_mainloop(const GemmArgs& a, const Gemm
 // T = operand type (bf16 | fp32), TE = storage type of the outputs / residual / per-column vectors (T itself, or bfs_t over bf16
 // operands: the bf16 x 2 mode, whose A operand is the [rows][2 Cin] bf16 image of a bfs_t tensor).
 template <typename T, int BM, int BN, int PF, typename TE = T>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a_in) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 2 && BM == 128 && BN == 96) ? 3 : 1, 8))) void conv_gemm_kernel(GemmArgs a_in) {
     constexpr int BK = 32;
     constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 4);
     constexpr int TM = BM / 32, TN = BN / 32;
@@ -498,7 +498,7 @@ struct ResUnitArgs { GemmArgs c1, c2; };
 // [C][2 C] weight.  Same chains and roundings as the two-GEMM bf16 x 2 path: bit-identical.  C = 96 only (the 192-channel image of
 // `mid` would need 100 KB of static LDS).
 template <typename T, int C, typename TE = T>
-__global__ __launch_bounds__(256) void resunit_kernel(ResUnitArgs u_in) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 96 ? 3 : 1, 4))) void resunit_kernel(ResUnitArgs u_in) {
     constexpr bool kSplit = std::is_same<TE, bfs_t>::value;
     constexpr int KM = kSplit ? 2 : 1;                                    // bf16 columns per activation element
     static_assert(sizeof(T) == 2 && (C == 96 || C == 192) && (!kSplit || C == 96), "bf16 operands, 96 or 192 channels (bf16 x 2: 96)");
