@@ -177,7 +177,8 @@ class HipSpeechTokenizer:
 
     def set_option(self, key: str, value: int):
         """``fq3_codec_set_option``: "fuse_units" 0|1|2 (two GEMMs per residual unit | the 96-channel block's units fused into one launch
-        each, the default | the 192-channel block's too); all settings give bit-identical waveforms."""
+        each, the default | the 192-channel block's too); "glds_cap8" n (measurement hook: bf16x2 GEMMs on the eight-wave LDS-DMA tiles up
+        to n tiles; 0 = always); all settings give bit-identical waveforms."""
         L.check(self.lib.fq3_codec_set_option(self.h, key.encode(), int(value)))
 
     def num_samples(self, n_frames: int) -> int:

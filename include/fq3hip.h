@@ -365,6 +365,8 @@ int fq3_codec_bind(fq3_codec* c, const char* name, const void* ptr, int64_t nume
  * tensor kept in LDS (the default: 7.45 vs 7.92 ms per 370-frame decode), 2 = the 192-channel block's too (measured slower:
  * 7.93 ms), 0 = two GEMM launches per unit.  All settings give bit-identical waveforms.  FQ3_BF16X2 (round 5): the 96-channel block's
  * units fuse too (the middle tensor parked in LDS as hi | lo words); measured a wash (14.46 -> 14.31 ms per 370-frame decode).
+ * "glds_cap8" n (round 6, measurement hook): FQ3_BF16X2 GEMMs take the eight-wave LDS-DMA tiles up to n tiles of 128 x 64 (0 = the
+ * launcher's default: whatever the grid); bit-identical.
  * The four activation workspaces follow the CALL: a batched decode needs B x elems(T) elements and grows them when short
  * (FQ3_ENOMEM when that fails: the Python host then decodes utterance by utterance). */
 int fq3_codec_set_option(fq3_codec* codec, const char* key, int value);
